@@ -1,0 +1,67 @@
+/*
+ * rectdetect-mi355x: entry points beyond the reference's own headers.  Plain C ABI (pointers and sizes only).
+ *
+ * The reference API (oclrect.h) takes HOST frames, so each call pays a PCIe upload.  The rd_* functions below let a
+ * caller keep frames resident in HBM, run many frames through a multi-stream pipeline with the host post-process
+ * on worker threads, and look at intermediate planes (tests).  Semantics of the detector are unchanged.
+ */
+#ifndef RECTDETECT_HIP_H
+#define RECTDETECT_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#if defined(__cplusplus)
+extern "C" {
+#endif
+
+const char *rd_version(void);
+int rd_device_count(void);                  /* number of HIP devices visible to this process */
+void rd_select_device(int ordinal);         /* device used by simpleGetDevice(0) and new detectors (default 0) */
+
+/* device memory helpers for callers without a HIP binding of their own (tests, bench) */
+void *rd_device_alloc(size_t bytes);
+void rd_device_free(void *dptr);
+void rd_upload(void *dptr, const void *host, size_t bytes);
+void rd_download(void *host, const void *dptr, size_t bytes);
+
+/* ---- one detector instance = one stream of frames (state carried between frames) */
+typedef struct rd_detector rd_detector;
+
+/* nslots frames in flight (>= 1), nworkers host threads for the post-process (0 = run it on the polling thread) */
+rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nworkers);
+void rd_detector_destroy(rd_detector *d);
+
+/* Enqueue one BGR frame (row stride ws bytes).  on_device != 0: `frame` is a device pointer that must stay valid
+ * until the matching rd_detector_poll returned.  Returns the frame's sequence number. */
+long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_device);
+
+/* Result of the oldest frame not yet polled: malloc'd array of rect_t-compatible records (176 bytes each, element 0
+ * holds nItems), owned by the caller.  Blocks until that frame is done. */
+void *rd_detector_poll(rd_detector *d, double tanAOV);
+
+/* device-side work only (no host post-process): waits until every enqueued frame has left the GPU */
+void rd_detector_drain(rd_detector *d);
+
+/* copy of the line-segment list of the most recently POLLED frame: returns n (records 1..n), writes up to max records */
+int rd_detector_last_segments(rd_detector *d, void *dst, int max_records);
+
+/* Test hook: copy an internal plane of the most recently completed frame to host memory.  Returns bytes written,
+ * 0 for an unknown name.  Names: plab0 plab1 lblur vxy strength nms mask0 tidy label1 strsum edge500 smooth quant
+ * strong junction mergemask region rsize boundarysrc boundary lsid */
+size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size_t max_bytes);
+
+/* timing of the device stages of the last drained batch, microseconds per named stage (NULL-terminated names) */
+int rd_detector_stage_times(rd_detector *d, const char **names, float *usec, int max);
+
+/* ---- host post-process alone (oclrect.c:1049-1226 restated): segments + samples -> rectangles.  Used by tests to
+ * check the post-process against the reference with identical inputs.  `boundary` is the boundary-label plane,
+ * `table` the reduceLS table (iw*ih*4/5 entries of 5 ints), `segs` the linesegment_t list with header. */
+void *rd_postprocess_planes(const void *segs, const int32_t *boundary, const int32_t *table, int iw, int ih, double tanAOV);
+
+/* ---- synthetic frames (csrc/rd_synth.c) */
+int rd_synth_num_quads(int iw, int ih);
+void rd_synth_frame(uint8_t *bgr, int iw, int ih, int ws, uint64_t seed, int t, int noise);
+
+#if defined(__cplusplus)
+}
+#endif
+#endif

@@ -702,3 +702,111 @@ void rdo_rect_frame(rdo_rect_t *c, const uint8_t *bgr, int ws) {
 
   free(fa); free(fb); free(ba); free(bb); free(t0); free(t1); free(e8);
 }
+
+/* ------------------------------------------------------------------ experiments for the GPU formulation */
+
+/* Candidate closed form of the 8 rc:300-334 passes: components of the graph that has an (undirected) edge
+ * p0 - p1 whenever the kernel would let p0 adopt p1's label (4-neighbours, interior p0), label = smallest index. */
+void rdo_region_cc(int *label, const int *pix, const int *mask, const int *edge, int iw, int ih) {
+  const int N = iw * ih;
+  rdo_region_label_init(label, pix, iw, ih);
+  /* the initialisation links are unions too */
+  int *lab = (int *)malloc(sizeof(int) * N);
+  for (int p = 0; p < N; p++) lab[p] = p;
+  for (int p = 0; p < N; p++) if (label[p] != p) uf_union(lab, p, label[p]);
+  for (int y = 1; y < ih - 1; y++)
+    for (int x = 1; x < iw - 1; x++) {
+      const int p0 = y * iw + x;
+      const int any = mask[p0] != 0;
+      int p1;
+      p1 = p0 - iw; if ((pix[p0] == pix[p1] || any) && edge[p0] <= 0) uf_union(lab, p0, p1);
+      p1 = p0 - 1;  if ((pix[p0] == pix[p1] || any) && edge[p0] <= 0) uf_union(lab, p0, p1);
+      p1 = p0 + 1;  if ((pix[p0] == pix[p1] || any) && edge[p1] <= 0) uf_union(lab, p0, p1);
+      p1 = p0 + iw; if ((pix[p0] == pix[p1] || any) && edge[p1] <= 0) uf_union(lab, p0, p1);
+    }
+  for (int p = 0; p < N; p++) label[p] = uf_find(lab, p);
+  free(lab);
+}
+
+/* same per-pixel rule as rdo_region_merge_pass, but (a) any visiting order, (b) optional synchronous
+ * (double-buffered) update, (c) full root search instead of 8 jumps.  Returns number of changed pixels. */
+int rdo_region_merge_pass_x(int *label, const int *pix, const int *mask, const int *edge, int iw, int ih, int mode) {
+  const int N = iw * ih;
+  int *src = label, *snap = NULL;
+  if (mode == 2) { snap = (int *)malloc(sizeof(int) * N); memcpy(snap, label, sizeof(int) * N); src = snap; }
+  int changed = 0;
+  for (int k = 0; k < N; k++) {
+    const int p0 = mode == 1 ? N - 1 - k : k;
+    const int x = p0 % iw, y = p0 / iw;
+    if (x <= 0 || y <= 0 || x >= iw - 1 || y >= ih - 1) continue;
+    int g = src[p0];
+    const int og = g;
+    const int any = mask[p0] != 0;
+    int p1, s;
+    p1 = p0 - iw; s = src[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p0] <= 0) g = s;
+    p1 = p0 - 1;  s = src[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p0] <= 0) g = s;
+    p1 = p0 + 1;  s = src[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p1] <= 0) g = s;
+    p1 = p0 + iw; s = src[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p1] <= 0) g = s;
+    while (src[g] != g) g = src[g];
+    if (g != og) {
+      if (g < label[og]) { label[og] = g; changed++; }
+      if (g < label[p0]) { label[p0] = g; changed++; }
+    }
+  }
+  free(snap);
+  return changed;
+}
+
+/* experiment: pure min-label propagation (no hooking of the old parent), alternating sweep directions */
+int rdo_region_propagate_pass(int *label, const int *pix, const int *mask, const int *edge, int iw, int ih, int reverse) {
+  const int N = iw * ih;
+  int changed = 0;
+  for (int k = 0; k < N; k++) {
+    const int p0 = reverse ? N - 1 - k : k;
+    const int x = p0 % iw, y = p0 / iw;
+    if (x <= 0 || y <= 0 || x >= iw - 1 || y >= ih - 1) continue;
+    int g = label[p0];
+    const int any = mask[p0] != 0;
+    int p1, s;
+    p1 = p0 - iw; s = label[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p0] <= 0) g = s;
+    p1 = p0 - 1;  s = label[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p0] <= 0) g = s;
+    p1 = p0 + 1;  s = label[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p1] <= 0) g = s;
+    p1 = p0 + iw; s = label[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p1] <= 0) g = s;
+    if (g != label[p0]) { label[p0] = g; changed++; }
+  }
+  return changed;
+}
+
+/* experiment: Jacobi evaluation of rdo_despeckle2's raster-order recurrence; returns rounds until fixpoint */
+int rdo_despeckle2_jacobi(int *label, const int *size, int thre, int iw, int ih, int *nsmall) {
+  const int N = iw * ih;
+  int *old = (int *)malloc(sizeof(int) * N), *cur = (int *)malloc(sizeof(int) * N), *nxt = (int *)malloc(sizeof(int) * N);
+  memcpy(old, label, sizeof(int) * N); memcpy(cur, label, sizeof(int) * N);
+  int rounds = 0, ns = 0;
+  for (int p = 0; p < N; p++) if (size[old[p]] <= thre) ns++;
+  *nsmall = ns;
+  for (;;) {
+    int changed = 0;
+    memcpy(nxt, cur, sizeof(int) * N);
+    for (int y = 0; y < ih; y++)
+      for (int x = 0; x < iw; x++) {
+        const int p0 = y * iw + x;
+        if (size[old[p0]] > thre) continue;
+        int maxSize = 0, maxLabel = old[p0];
+        for (int yy = -1; yy <= 1; yy++)
+          for (int xx = -1; xx <= 1; xx++) {
+            if (x + xx < 0 || x + xx >= iw || y + yy < 0 || y + yy >= ih) continue;
+            const int p1 = p0 + yy * iw + xx;
+            const int l1 = (yy < 0 || (yy == 0 && xx < 0)) ? cur[p1] : old[p1];
+            if (size[l1] > maxSize) { maxSize = size[l1]; maxLabel = l1; }
+          }
+        if (nxt[p0] != maxLabel) { nxt[p0] = maxLabel; changed++; }
+      }
+    memcpy(cur, nxt, sizeof(int) * N);
+    rounds++;
+    if (!changed) break;
+  }
+  memcpy(label, cur, sizeof(int) * N);
+  free(old); free(cur); free(nxt);
+  return rounds;
+}

@@ -1,0 +1,518 @@
+// rectdetect-mi355x: the reference's public operator API (oclimgutil.h, oclpolyline.h, oclrect.h) and the rd_detector
+// extension on top of the gfx950 kernels.  C ABI, opaque handles, fatal-on-error like the reference.
+#include "rd_internal.h"
+#include "rd_kernels.h"
+#include "rectdetect_hip.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+
+extern "C" {
+#include "vec234.h"
+#include "oclimgutil.h"
+#include "oclpolyline.h"
+#include "oclrect.h"
+#include "rd_post.h"
+}
+
+using rdrt::dptr;
+using rdrt::stream;
+
+#define MAGIC_IMGUTIL 0xa640d893u
+#define MAGIC_POLYLINE 0x808f3801u
+#define MAGIC_RECT 0x808f3802u
+
+template <typename T> static T *dnew(size_t n) { void *p = NULL; RD_HIP(hipMalloc(&p, (n ? n : 1) * sizeof(T))); return (T *)p; }
+static void dfree(void *p) { if (p) RD_HIP(hipFree(p)); }
+
+// ================================================================================================ oclimgutil
+struct ImgutilImpl { int N; float *s[3]; };
+
+static void imgutil_scratch(oclimgutil_t *t, int N) {
+  ImgutilImpl *im = (ImgutilImpl *)t->impl;
+  if (im->N >= N) return;
+  for (int k = 0; k < 3; k++) { dfree(im->s[k]); im->s[k] = dnew<float>((size_t)N); }
+  im->N = N;
+}
+
+extern "C" {
+
+oclimgutil_t *init_oclimgutil(cl_device_id device, cl_context context) {
+  oclimgutil_t *t = (oclimgutil_t *)calloc(1, sizeof(*t));
+  t->magic = MAGIC_IMGUTIL; t->device = device; t->context = context;
+  t->impl = calloc(1, sizeof(ImgutilImpl));
+  if (device) RD_HIP(hipSetDevice(device->ordinal));
+  return t;
+}
+
+void dispose_oclimgutil(oclimgutil_t *t) {
+  if (!t || t->magic != MAGIC_IMGUTIL) exitf(-1, "dispose_oclimgutil: bad handle\n");
+  ImgutilImpl *im = (ImgutilImpl *)t->impl;
+  for (int k = 0; k < 3; k++) dfree(im->s[k]);
+  free(im);
+  t->magic = 0;
+  free(t);
+}
+
+#define IU_BEGIN(name)                                                                   \
+  if (!thiz || thiz->magic != MAGIC_IMGUTIL) exitf(-1, name ": bad oclimgutil handle\n"); \
+  rdrt::wait_list(queue, events);                                                        \
+  hipStream_t s = stream(queue)
+#define IU_END(name) rdrt::check_launch(name); return rdrt::finish_op(queue, events)
+
+cl_event oclimgutil_clear(oclimgutil_t *thiz, cl_mem out, int size, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_clear");
+  rdk::clear_i(s, (int *)dptr(out), (size + 3) / 4);
+  IU_END("oclimgutil_clear");
+}
+cl_event oclimgutil_copy(oclimgutil_t *thiz, cl_mem out, cl_mem in, int size, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_copy");
+  rdk::copy_i(s, (int *)dptr(out), (const int *)dptr(in), (size + 3) / 4);
+  IU_END("oclimgutil_copy");
+}
+cl_event oclimgutil_cast_i_f(oclimgutil_t *thiz, cl_mem out, cl_mem in, float scale, int size, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_cast_i_f");
+  rdk::cast_i_f(s, (int *)dptr(out), (const float *)dptr(in), scale, size);
+  IU_END("oclimgutil_cast_i_f");
+}
+cl_event oclimgutil_cast_c_i(oclimgutil_t *thiz, cl_mem out, cl_mem in, int size, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_cast_c_i");
+  rdk::cast_c_i(s, (int8_t *)dptr(out), (const int *)dptr(in), size);
+  IU_END("oclimgutil_cast_c_i");
+}
+cl_event oclimgutil_threshold_i_i(oclimgutil_t *thiz, cl_mem out, cl_mem in, int vlow, int threshold, int vhigh, int size, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_threshold_i_i");
+  rdk::threshold_i(s, (int *)dptr(out), (const int *)dptr(in), vlow, threshold, vhigh, size);
+  IU_END("oclimgutil_threshold_i_i");
+}
+cl_event oclimgutil_threshold_f_f(oclimgutil_t *thiz, cl_mem out, cl_mem in, float vlow, float threshold, float vhigh, int size, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_threshold_f_f");
+  rdk::threshold_f(s, (float *)dptr(out), (const float *)dptr(in), vlow, threshold, vhigh, size);
+  IU_END("oclimgutil_threshold_f_f");
+}
+cl_event oclimgutil_rand(oclimgutil_t *thiz, cl_mem out, int size, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_rand");
+  rdk::rand_i(s, (int *)dptr(out), 0, (size + 3) / 4);   // the reference's wrapper never sets the seed argument (oclimgutil.c:178-183)
+  IU_END("oclimgutil_rand");
+}
+cl_event oclimgutil_convert_plab_bgr(oclimgutil_t *thiz, cl_mem out, cl_mem in, int iw, int ih, int ws, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_convert_plab_bgr");
+  rdk::bgr2plab(s, (uint32_t *)dptr(out), (const uint8_t *)dptr(in), iw, ih, ws);
+  IU_END("oclimgutil_convert_plab_bgr");
+}
+cl_event oclimgutil_unpack_f_f_f_plab(oclimgutil_t *thiz, cl_mem out0, cl_mem out1, cl_mem out2, cl_mem in, int iw, int ih, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_unpack_f_f_f_plab");
+  rdk::unpack_plab(s, (float *)dptr(out0), (float *)dptr(out1), (float *)dptr(out2), (const uint32_t *)dptr(in), iw * ih);
+  IU_END("oclimgutil_unpack_f_f_f_plab");
+}
+cl_event oclimgutil_pack_plab_f_f_f(oclimgutil_t *thiz, cl_mem out, cl_mem in0, cl_mem in1, cl_mem in2, int iw, int ih, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_pack_plab_f_f_f");
+  rdk::pack_plab(s, (uint32_t *)dptr(out), (const float *)dptr(in0), (const float *)dptr(in1), (const float *)dptr(in2), iw * ih);
+  IU_END("oclimgutil_pack_plab_f_f_f");
+}
+
+// oclimgutil.c:248-273.  obuf = vertical(horizontal(ibuf)); tmp0 / tmp1 end up holding the causal / anti-causal
+// vertical sweeps like in the reference.  Only r = 2 (sigma 1) is implemented - the only radius any caller uses.
+cl_event oclimgutil_iirblur_f_f(oclimgutil_t *thiz, cl_mem obuf, cl_mem ibuf, cl_mem tmp0, cl_mem tmp1, int r, int iw, int ih, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_iirblur_f_f");
+  if (r != 2) exitf(-1, "oclimgutil_iirblur_f_f: only r = 2 (sigma = 1) is implemented in this build, got r = %d\n", r);
+  imgutil_scratch(thiz, iw * ih);
+  ImgutilImpl *im = (ImgutilImpl *)thiz->impl;
+  float *o = (float *)dptr(obuf), *t0 = (float *)dptr(tmp0), *t1 = (float *)dptr(tmp1);
+  const float *in = (const float *)dptr(ibuf);
+  float *d1[3] = { im->s[0], NULL, NULL }; const float *s1[3] = { in, NULL, NULL };
+  rdk::transpose_f(s, d1, s1, 1, iw, ih);                                   // s0 = in^T (ih wide)
+  float *f[3] = { im->s[1], NULL, NULL }, *b[3] = { im->s[2], NULL, NULL }; const float *c[3] = { im->s[0], NULL, NULL };
+  rdk::iir_columns(s, f, b, c, 1, ih, iw);                                  // sweeps along x of the original
+  float *oo[3] = { o, NULL, NULL }; const float *fc[3] = { im->s[1], NULL, NULL }, *bc[3] = { im->s[2], NULL, NULL };
+  rdk::iir_combine_transpose(s, oo, fc, bc, c, 1, ih, iw);                  // o = horizontal result, original layout
+  float *f2[3] = { t0, NULL, NULL }, *b2[3] = { t1, NULL, NULL }; const float *c2[3] = { o, NULL, NULL };
+  rdk::iir_columns(s, f2, b2, c2, 1, iw, ih);
+  const float *f2c[3] = { t0, NULL, NULL }, *b2c[3] = { t1, NULL, NULL };
+  rdk::iir_combine(s, oo, f2c, b2c, c2, 1, iw * ih);
+  IU_END("oclimgutil_iirblur_f_f");
+}
+
+cl_event oclimgutil_edgevec_f2_f(oclimgutil_t *thiz, cl_mem out, cl_mem in, int iw, int ih, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_edgevec_f2_f");
+  rdk::edgevec(s, (float *)dptr(out), (const float *)dptr(in), iw, ih);
+  IU_END("oclimgutil_edgevec_f2_f");
+}
+cl_event oclimgutil_edge_f_plab(oclimgutil_t *thiz, cl_mem out, cl_mem in, int iw, int ih, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_edge_f_plab");
+  rdk::edge_plab(s, (float *)dptr(out), (const uint32_t *)dptr(in), iw, ih);
+  IU_END("oclimgutil_edge_f_plab");
+}
+cl_event oclimgutil_thinthres_f_f_f2(oclimgutil_t *thiz, cl_mem out, cl_mem in, cl_mem vec, int iw, int ih, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_thinthres_f_f_f2");
+  rdk::thinthres(s, (float *)dptr(out), (const float *)dptr(in), (const float *)dptr(vec), iw, ih);
+  IU_END("oclimgutil_thinthres_f_f_f2");
+}
+// oclimgutil.c:227-246: converged labelling instead of 1 + 10 propagation passes; `tmp` (the reference's pass flags) is unused
+cl_event oclimgutil_label8x_int_int(oclimgutil_t *thiz, cl_mem out, cl_mem in, cl_mem tmp, int bgc, int iw, int ih, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_label8x_int_int");
+  (void)tmp;
+  rdk::label8(s, (int *)dptr(out), (const int *)dptr(in), bgc, iw, ih);
+  IU_END("oclimgutil_label8x_int_int");
+}
+cl_event oclimgutil_calcStrength(oclimgutil_t *thiz, cl_mem out, cl_mem edge, cl_mem label, int iw, int ih, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_calcStrength");
+  rdk::calc_strength(s, (int *)dptr(out), (const float *)dptr(edge), (const int *)dptr(label), iw, ih);
+  IU_END("oclimgutil_calcStrength");
+}
+cl_event oclimgutil_filterStrength(oclimgutil_t *thiz, cl_mem labelinout, cl_mem str, int thre, int iw, int ih, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_filterStrength");
+  rdk::filter_strength(s, (int *)dptr(labelinout), (const int *)dptr(str), thre, iw, ih);
+  IU_END("oclimgutil_filterStrength");
+}
+
+// Debug visualisers and operators no application calls (SURVEY.md 8a "dead for the apps", 8f rank 4): declared so that
+// programs link, but not implemented yet - they fail loudly instead of silently doing nothing.
+#define IU_TODO(name) exitf(-1, name ": not implemented in this build (debug/unused operator of the reference)\n"); return NULL
+cl_event oclimgutil_convert_bgr_luminancef(oclimgutil_t *, cl_mem, cl_mem, int, int, int, cl_command_queue, const cl_event *) { IU_TODO("oclimgutil_convert_bgr_luminancef"); }
+cl_event oclimgutil_convert_bgr_lumaf(oclimgutil_t *, cl_mem, cl_mem, float, int, int, int, cl_command_queue, const cl_event *) { IU_TODO("oclimgutil_convert_bgr_lumaf"); }
+cl_event oclimgutil_convert_bgr_labeli(oclimgutil_t *, cl_mem, cl_mem, int, int, int, int, cl_command_queue, const cl_event *) { IU_TODO("oclimgutil_convert_bgr_labeli"); }
+cl_event oclimgutil_convert_bgr_plab(oclimgutil_t *, cl_mem, cl_mem, int, int, int, cl_command_queue, const cl_event *) { IU_TODO("oclimgutil_convert_bgr_plab"); }
+cl_event oclimgutil_edge_f_f(oclimgutil_t *, cl_mem, cl_mem, int, int, cl_command_queue, const cl_event *) { IU_TODO("oclimgutil_edge_f_f"); }
+cl_event oclimgutil_edgevec_f2_plab(oclimgutil_t *, cl_mem, cl_mem, int, int, cl_command_queue, const cl_event *) { IU_TODO("oclimgutil_edgevec_f2_plab"); }
+cl_event oclimgutil_thincubic_f_f_f2(oclimgutil_t *, cl_mem, cl_mem, cl_mem, int, int, cl_command_queue, const cl_event *) { IU_TODO("oclimgutil_thincubic_f_f_f2"); }
+
+}  // extern "C"
+
+// ================================================================================================ oclpolyline
+struct PolylineImpl { int iw, ih; rdk::PolyScratch *ps; };
+
+extern "C" {
+
+oclpolyline_t *init_oclpolyline(cl_device_id device, cl_context context) {
+  oclpolyline_t *t = (oclpolyline_t *)calloc(1, sizeof(*t));
+  t->magic = MAGIC_POLYLINE; t->device = device; t->context = context;
+  t->impl = calloc(1, sizeof(PolylineImpl));
+  if (device) RD_HIP(hipSetDevice(device->ordinal));
+  return t;
+}
+
+void dispose_oclpolyline(oclpolyline_t *t) {
+  if (!t || t->magic != MAGIC_POLYLINE) exitf(-1, "dispose_oclpolyline: bad handle\n");
+  PolylineImpl *im = (PolylineImpl *)t->impl;
+  rdk::poly_scratch_destroy(im->ps);
+  free(im);
+  t->magic = 0;
+  free(t);
+}
+
+// oclpolyline.c:218-309.  The caller's scratch planes are not needed by this implementation (it keeps its own compact
+// scratch), except that the ring of tmp3 is read for the stale-ring semantics of the reference (see oclpolyline.h).
+cl_event oclpolyline_execute(oclpolyline_t *thiz, cl_mem lsList, int lsListSize, cl_mem lsIdOut, cl_mem in, cl_mem tmp0, cl_mem tmp1, cl_mem tmp2, cl_mem tmp3,
+                             cl_mem tmp4, cl_mem tmp5, cl_mem tmp6, float minerror, int sizeThre, int iw, int ih, cl_command_queue queue, const cl_event *events) {
+  if (!thiz || thiz->magic != MAGIC_POLYLINE) exitf(-1, "oclpolyline_execute: bad handle\n");
+  (void)tmp0; (void)tmp1; (void)tmp2; (void)tmp4; (void)tmp5; (void)tmp6;
+  PolylineImpl *im = (PolylineImpl *)thiz->impl;
+  if (!im->ps || im->iw != iw || im->ih != ih) {
+    rdk::poly_scratch_destroy(im->ps);
+    im->ps = rdk::poly_scratch_create(iw, ih);
+    im->iw = iw; im->ih = ih;
+  }
+  rdrt::wait_list(queue, events);
+  rdk::polyline(stream(queue), im->ps, dptr(lsList), lsListSize, (int *)dptr(lsIdOut), (const int *)dptr(in), (const int *)dptr(tmp3), 0, minerror, sizeThre, iw, ih);
+  rdrt::check_launch("oclpolyline_execute");
+  return rdrt::finish_op(queue, events);
+}
+
+}  // extern "C"
+
+// ================================================================================================ detector
+#define RD_MAXREC 2048      // records copied back per frame without a second transfer
+
+struct Slot {
+  hipStream_t st;
+  hipEvent_t ev_done, ev_strong;
+  uint8_t *bgr;
+  uint32_t *plab0, *plab1, *smooth, *quant;
+  float *tr[3], *fw[3], *bw[3], *hz[3], *bl[3], *vxy, *strength, *nms;
+  int *i0, *i1, *mask0, *tidy, *label1, *strsum, *edge500, *strong, *junction, *mergemask, *region, *rsize, *scratch2, *boundarysrc, *boundary, *lsid, *table, *claim, *probes;
+  int8_t *e8;
+  void *lslist;
+  rdk::PolyScratch *ps;
+  // host side
+  void *h_bgr;            // pinned staging for host frames
+  void *h_segs; int *h_probes;
+  long seq;
+  int ws;
+};
+
+struct rd_detector {
+  uint32_t magic;
+  int device, iw, ih, N, nslots, nworkers, maxrec_dev;
+  Slot *slots;
+  int *prev_strong;       // strong-edge mask of the previous frame (reference quirk H1)
+  hipEvent_t last_strong; int have_last_strong;
+  long next_enqueue, next_poll;
+  int last_polled_slot;
+  void *last_segs; int last_nsegs;
+};
+
+static void slot_alloc(rd_detector *d, Slot *s) {
+  const size_t N = (size_t)d->N;
+  RD_HIP(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+  RD_HIP(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+  RD_HIP(hipEventCreateWithFlags(&s->ev_strong, hipEventDisableTiming));
+  s->bgr = dnew<uint8_t>(N * 4);
+  s->plab0 = dnew<uint32_t>(N); s->plab1 = dnew<uint32_t>(N); s->smooth = dnew<uint32_t>(N); s->quant = dnew<uint32_t>(N);
+  for (int k = 0; k < 3; k++) { s->tr[k] = dnew<float>(N); s->fw[k] = dnew<float>(N); s->bw[k] = dnew<float>(N); s->hz[k] = dnew<float>(N); s->bl[k] = dnew<float>(N); }
+  s->vxy = dnew<float>(N * 2); s->strength = dnew<float>(N); s->nms = dnew<float>(N);
+  int **ip[] = { &s->i0, &s->i1, &s->mask0, &s->tidy, &s->label1, &s->strsum, &s->edge500, &s->strong, &s->junction, &s->mergemask, &s->region, &s->rsize,
+                 &s->boundarysrc, &s->boundary, &s->lsid };
+  for (size_t i = 0; i < sizeof(ip) / sizeof(ip[0]); i++) *ip[i] = dnew<int>(N);
+  s->scratch2 = dnew<int>(N * 2 + 64);
+  s->table = dnew<int>(N * 4); s->claim = dnew<int>(N);
+  s->e8 = dnew<int8_t>(N);
+  s->lslist = dnew<uint8_t>(N * 16);
+  s->probes = dnew<int>((size_t)d->maxrec_dev * 15 * 6);
+  s->ps = rdk::poly_scratch_create(d->iw, d->ih);
+  RD_HIP(hipHostMalloc(&s->h_bgr, N * 4, hipHostMallocDefault));
+  RD_HIP(hipHostMalloc(&s->h_segs, (size_t)RD_MAXREC * 56, hipHostMallocDefault));
+  RD_HIP(hipHostMalloc((void **)&s->h_probes, (size_t)RD_MAXREC * 15 * 6 * sizeof(int), hipHostMallocDefault));
+  s->seq = -1;
+}
+
+static void slot_free(Slot *s) {
+  RD_HIP(hipStreamSynchronize(s->st));
+  void *all[] = { s->bgr, s->plab0, s->plab1, s->smooth, s->quant, s->vxy, s->strength, s->nms, s->i0, s->i1, s->mask0, s->tidy, s->label1, s->strsum, s->edge500, s->strong,
+                  s->junction, s->mergemask, s->region, s->rsize, s->scratch2, s->boundarysrc, s->boundary, s->lsid, s->table, s->claim, s->probes, s->e8, s->lslist };
+  for (void *p : all) dfree(p);
+  for (int k = 0; k < 3; k++) { dfree(s->tr[k]); dfree(s->fw[k]); dfree(s->bw[k]); dfree(s->hz[k]); dfree(s->bl[k]); }
+  rdk::poly_scratch_destroy(s->ps);
+  RD_HIP(hipHostFree(s->h_bgr)); RD_HIP(hipHostFree(s->h_segs)); RD_HIP(hipHostFree(s->h_probes));
+  RD_HIP(hipEventDestroy(s->ev_done)); RD_HIP(hipEventDestroy(s->ev_strong));
+  RD_HIP(hipStreamDestroy(s->st));
+}
+
+// The device part of one frame (reference oclrect.c:235-381), enqueued on the slot's stream.
+static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
+  const int iw = d->iw, ih = d->ih, N = d->N;
+  hipStream_t st = s->st;
+
+  // colour -> sigma=1 blur of L, a, b -> packed blurred Lab (oclrect.c:245-251)
+  rdk::bgr2plab(st, s->plab0, s->bgr, iw, ih, ws);
+  rdk::transpose_unpack(st, s->tr, s->plab0, iw, ih);
+  { const float *c[3] = { s->tr[0], s->tr[1], s->tr[2] }; rdk::iir_columns(st, s->fw, s->bw, c, 3, ih, iw);
+    const float *f[3] = { s->fw[0], s->fw[1], s->fw[2] }, *b[3] = { s->bw[0], s->bw[1], s->bw[2] };
+    rdk::iir_combine_transpose(st, s->hz, f, b, c, 3, ih, iw); }
+  { const float *c[3] = { s->hz[0], s->hz[1], s->hz[2] }; rdk::iir_columns(st, s->fw, s->bw, c, 3, iw, ih);
+    const float *f[3] = { s->fw[0], s->fw[1], s->fw[2] }, *b[3] = { s->bw[0], s->bw[1], s->bw[2] };
+    rdk::iir_combine(st, s->bl, f, b, c, 3, N); }
+  rdk::pack_plab(st, s->plab1, s->bl[0], s->bl[1], s->bl[2], N);
+
+  // gradient direction, strength, non-max suppression (oclrect.c:253-258)
+  rdk::edgevec(st, s->vxy, s->bl[0], iw, ih);
+  rdk::edge_plab(st, s->strength, s->plab1, iw, ih);
+  rdk::thinthres(st, s->nms, s->strength, s->vxy, iw, ih);
+
+  // mask of positive responses and the rect-path tidy (oclrect.c:262-272)
+  rdk::threshold_f(st, (float *)s->i0, s->nms, 0.0f, 0.0f, 1.0f, N);
+  rdk::cast_i_f(st, s->mask0, (const float *)s->i0, 1.0f, N);
+  rdk::junction(st, s->i0, s->mask0, 0, iw, ih);
+  rdk::connect_rect(st, s->i1, s->i0, iw, ih);
+  rdk::stringify(st, s->i0, s->i1, 0, iw, ih);
+  rdk::stringify(st, s->tidy, s->i0, 1, iw, ih);
+
+  // components (background included), strength sums on top of last frame's strong mask (H1), filter at 500 (oclrect.c:274-284)
+  rdk::label8(st, s->label1, s->tidy, -1, iw, ih);
+  if (d->have_last_strong) RD_HIP(hipStreamWaitEvent(st, d->last_strong, 0));
+  RD_HIP(hipMemcpyAsync(s->strsum, d->prev_strong, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));
+  rdk::calc_strength(st, s->strsum, s->nms, s->label1, iw, ih);
+  rdk::filter_strength(st, s->label1, s->strsum, 500, iw, ih);
+  rdk::threshold_i(st, s->edge500, s->label1, 0, 0, 1, N);
+  rdk::cast_c_i(st, s->e8, s->edge500, N);
+
+  // edge-preserving smoothing x10, quantise, despeckle (oclrect.c:286-303)
+  { const uint32_t *src = s->plab0;
+    for (int i = 0; i < 10; i++) { rdk::blblur(st, (uint32_t *)s->i0, s->e8, src, 0, iw, ih); rdk::blblur(st, s->smooth, s->e8, (const uint32_t *)s->i0, 1, iw, ih); src = s->smooth; } }
+  rdk::quantize(st, (uint32_t *)s->i0, s->smooth, 24, 24, 24, N);
+  rdk::despeckle(st, s->quant, (const uint32_t *)s->i0, s->nms, iw, ih);
+
+  // strong edges, junction counts, merge mask (oclrect.c:307-321)
+  rdk::filter_strength(st, s->label1, s->strsum, 2500, iw, ih);
+  rdk::threshold_i(st, s->strong, s->label1, 0, 0, 1, N);
+  RD_HIP(hipMemcpyAsync(d->prev_strong, s->strong, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));
+  RD_HIP(hipEventRecord(s->ev_strong, st));
+  d->last_strong = s->ev_strong; d->have_last_strong = 1;
+  rdk::junction(st, s->junction, s->label1, 0, iw, ih);
+  rdk::merge_mask(st, s->mergemask, s->junction, iw, ih);
+
+  // regions (oclrect.c:325-336)
+  rdk::region_merge(st, s->region, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih);
+  RD_HIP(hipMemcpyAsync(s->rsize, s->junction, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));   // H2: sizes start from the junction counts
+  rdk::region_size(st, s->rsize, s->region, N);
+  rdk::despeckle2(st, s->region, s->scratch2, s->rsize, 16, iw, ih);
+
+  // region boundaries and their components (oclrect.c:340-342)
+  rdk::mark_boundary(st, s->boundarysrc, s->region, iw, ih);
+  rdk::label8(st, s->boundary, s->boundarysrc, -1, iw, ih);
+
+  // polylines of the strong edges; frame ring of the bridging step is "non-zero" on this path (oclrect.c:361, H3)
+  rdk::polyline(st, s->ps, s->lslist, N * 16, s->lsid, s->strong, NULL, 1, 4.0f, 20, iw, ih);
+
+  // segment / boundary votes (oclrect.c:365-367) and the probes the host needs (oclrect.c:1066-1098)
+  const int nentry = N * 4 / 5;
+  rdk::reduce_ls(st, s->table, s->claim, s->boundary, s->lsid, iw, ih, nentry);
+  rdk::sample_segments(st, s->probes, s->lslist, d->maxrec_dev, s->boundary, s->table, iw, ih, nentry);
+
+  RD_HIP(hipMemcpyAsync(s->h_segs, s->lslist, (size_t)RD_MAXREC * 56, hipMemcpyDeviceToHost, st));
+  RD_HIP(hipMemcpyAsync(s->h_probes, s->probes, (size_t)RD_MAXREC * 15 * 6 * sizeof(int), hipMemcpyDeviceToHost, st));
+  RD_HIP(hipEventRecord(s->ev_done, st));
+  rdrt::check_launch("rect frame");
+}
+
+extern "C" {
+
+rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nworkers) {
+  if (rd_device_count() <= 0) exitf(-1, "rd_detector_create: no HIP device available - this library has no CPU path\n");
+  if (iw < 16 || ih < 16) exitf(-1, "rd_detector_create: frame %dx%d too small\n", iw, ih);
+  if (nslots < 1) nslots = 1;
+  RD_HIP(hipSetDevice(device));
+  rd_detector *d = (rd_detector *)calloc(1, sizeof(*d));
+  d->magic = MAGIC_RECT; d->device = device; d->iw = iw; d->ih = ih; d->N = iw * ih; d->nslots = nslots; d->nworkers = nworkers;
+  d->maxrec_dev = d->N * 16 / 56;
+  if (d->maxrec_dev > 65536) d->maxrec_dev = 65536;
+  d->prev_strong = dnew<int>((size_t)d->N);
+  RD_HIP(hipMemset(d->prev_strong, 0, sizeof(int) * (size_t)d->N));
+  d->slots = (Slot *)calloc((size_t)nslots, sizeof(Slot));
+  for (int i = 0; i < nslots; i++) slot_alloc(d, &d->slots[i]);
+  d->last_polled_slot = -1;
+  RD_HIP(hipDeviceSynchronize());
+  return d;
+}
+
+void rd_detector_destroy(rd_detector *d) {
+  if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_destroy: bad handle\n");
+  RD_HIP(hipSetDevice(d->device));
+  RD_HIP(hipDeviceSynchronize());
+  for (int i = 0; i < d->nslots; i++) slot_free(&d->slots[i]);
+  free(d->slots);
+  dfree(d->prev_strong);
+  free(d->last_segs);
+  d->magic = 0;
+  free(d);
+}
+
+long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_device) {
+  if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_enqueue: bad handle\n");
+  if (d->next_enqueue - d->next_poll >= d->nslots) exitf(-1, "rd_detector_enqueue: %d frames already in flight (poll first)\n", d->nslots);
+  if ((size_t)ws * d->ih > (size_t)d->N * 4) exitf(-1, "rd_detector_enqueue: row stride %d too large for a %dx%d frame\n", ws, d->iw, d->ih);
+  RD_HIP(hipSetDevice(d->device));
+  Slot *s = &d->slots[d->next_enqueue % d->nslots];
+  s->seq = d->next_enqueue; s->ws = ws;
+  const size_t bytes = (size_t)ws * d->ih;
+  if (on_device) RD_HIP(hipMemcpyAsync(s->bgr, frame, bytes, hipMemcpyDeviceToDevice, s->st));
+  else { memcpy(s->h_bgr, frame, bytes); RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, bytes, hipMemcpyHostToDevice, s->st)); }
+  enqueue_frame(d, s, ws);
+  return d->next_enqueue++;
+}
+
+void *rd_detector_poll(rd_detector *d, double tanAOV) {
+  if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_poll: bad handle\n");
+  if (d->next_poll >= d->next_enqueue) exitf(-1, "rd_detector_poll: nothing enqueued\n");
+  RD_HIP(hipSetDevice(d->device));
+  const int si = (int)(d->next_poll % d->nslots);
+  Slot *s = &d->slots[si];
+  RD_HIP(hipEventSynchronize(s->ev_done));
+  int n = ((int *)s->h_segs)[0];
+  const void *segs = s->h_segs; const int *probes = s->h_probes;
+  void *big_segs = NULL; int *big_probes = NULL;
+  int maxrec = RD_MAXREC;
+  if (n + 1 > RD_MAXREC) {   // rare: more segments than the fixed-size transfer covers
+    if (n + 1 > d->maxrec_dev) n = d->maxrec_dev - 1;
+    big_segs = malloc((size_t)(n + 1) * 56); big_probes = (int *)malloc((size_t)(n + 1) * 15 * 6 * sizeof(int));
+    RD_HIP(hipMemcpy(big_segs, s->lslist, (size_t)(n + 1) * 56, hipMemcpyDeviceToHost));
+    RD_HIP(hipMemcpy(big_probes, s->probes, (size_t)(n + 1) * 15 * 6 * sizeof(int), hipMemcpyDeviceToHost));
+    segs = big_segs; probes = big_probes; maxrec = n + 1;
+  }
+  void *r = rd_post_run(segs, maxrec, probes, d->iw, d->ih, tanAOV);
+  free(d->last_segs);
+  d->last_nsegs = n < maxrec ? n : maxrec - 1;
+  d->last_segs = malloc((size_t)(d->last_nsegs + 1) * 56);
+  memcpy(d->last_segs, segs, (size_t)(d->last_nsegs + 1) * 56);
+  free(big_segs); free(big_probes);
+  d->last_polled_slot = si;
+  d->next_poll++;
+  return r;
+}
+
+void rd_detector_drain(rd_detector *d) {
+  if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_drain: bad handle\n");
+  RD_HIP(hipSetDevice(d->device));
+  for (int i = 0; i < d->nslots; i++) RD_HIP(hipStreamSynchronize(d->slots[i].st));
+}
+
+int rd_detector_last_segments(rd_detector *d, void *dst, int max_records) {
+  if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_last_segments: bad handle\n");
+  if (!d->last_segs) return -1;
+  int m = d->last_nsegs + 1 < max_records ? d->last_nsegs + 1 : max_records;
+  if (dst && m > 0) memcpy(dst, d->last_segs, (size_t)m * 56);
+  return d->last_nsegs;
+}
+
+size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size_t max_bytes) {
+  if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_debug_plane: bad handle\n");
+  if (d->last_polled_slot < 0) return 0;
+  RD_HIP(hipSetDevice(d->device));
+  Slot *s = &d->slots[d->last_polled_slot];
+  const size_t N = (size_t)d->N;
+  struct { const char *n; const void *p; size_t bytes; } tab[] = {
+    { "plab0", s->plab0, N * 4 }, { "plab1", s->plab1, N * 4 }, { "lblur", s->bl[0], N * 4 }, { "vxy", s->vxy, N * 8 }, { "strength", s->strength, N * 4 },
+    { "nms", s->nms, N * 4 }, { "mask0", s->mask0, N * 4 }, { "tidy", s->tidy, N * 4 }, { "label1", s->label1, N * 4 }, { "strsum", s->strsum, N * 4 },
+    { "edge500", s->edge500, N * 4 }, { "smooth", s->smooth, N * 4 }, { "quant", s->quant, N * 4 }, { "strong", s->strong, N * 4 }, { "junction", s->junction, N * 4 },
+    { "mergemask", s->mergemask, N * 4 }, { "region", s->region, N * 4 }, { "rsize", s->rsize, N * 4 }, { "boundarysrc", s->boundarysrc, N * 4 },
+    { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 },
+  };
+  for (size_t i = 0; i < sizeof(tab) / sizeof(tab[0]); i++)
+    if (!strcmp(tab[i].n, name)) {
+      const size_t b = tab[i].bytes < max_bytes ? tab[i].bytes : max_bytes;
+      RD_HIP(hipStreamSynchronize(s->st));
+      RD_HIP(hipMemcpy(dst, tab[i].p, b, hipMemcpyDeviceToHost));
+      return b;
+    }
+  return 0;
+}
+
+int rd_detector_stage_times(rd_detector *d, const char **names, float *usec, int max) { (void)d; (void)names; (void)usec; (void)max; return 0; }
+
+// ================================================================================================ oclrect (reference API)
+struct oclrect_t { uint32_t magic; rd_detector *det; int iw, ih; };
+
+struct oclrect_t *init_oclrect(struct oclimgutil_t *oclimgutil, struct oclpolyline_t *oclpolyline, cl_device_id device, cl_context context, cl_command_queue queue, int iw, int ih) {
+  (void)oclimgutil; (void)oclpolyline; (void)context; (void)queue;
+  struct oclrect_t *t = (struct oclrect_t *)calloc(1, sizeof(*t));
+  t->magic = MAGIC_RECT; t->iw = iw; t->ih = ih;
+  t->det = rd_detector_create(device ? device->ordinal : rdrt::current_device(), iw, ih, 2, 0);   // two pages like oclrect.c:54
+  return t;
+}
+
+void dispose_oclrect(struct oclrect_t *t) {
+  if (!t || t->magic != MAGIC_RECT) exitf(-1, "dispose_oclrect: bad handle\n");
+  rd_detector_destroy(t->det);
+  t->magic = 0;
+  free(t);
+}
+
+rect_t *oclrect_executeOnce(struct oclrect_t *t, uint8_t *imgData, int ws, const double tanAOV) {
+  if (!t || t->magic != MAGIC_RECT) exitf(-1, "oclrect_executeOnce: bad handle\n");
+  if (t->det->next_enqueue != t->det->next_poll) exitf(-1, "oclrect_executeOnce: a task is still pending (poll it first)\n");
+  rd_detector_enqueue(t->det, imgData, ws, 0);
+  return (rect_t *)rd_detector_poll(t->det, tanAOV);
+}
+
+void oclrect_enqueueTask(struct oclrect_t *t, uint8_t *imgData, int ws) {
+  if (!t || t->magic != MAGIC_RECT) exitf(-1, "oclrect_enqueueTask: bad handle\n");
+  rd_detector_enqueue(t->det, imgData, ws, 0);
+}
+
+rect_t *oclrect_pollTask(struct oclrect_t *t, const double tanAOV) {
+  if (!t || t->magic != MAGIC_RECT) exitf(-1, "oclrect_pollTask: bad handle\n");
+  return (rect_t *)rd_detector_poll(t->det, tanAOV);
+}
+
+}  // extern "C"

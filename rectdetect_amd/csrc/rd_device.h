@@ -1,0 +1,100 @@
+// rectdetect-mi355x: device-side inline helpers shared by all gfx950 kernels.
+//
+// Arithmetic contract: every translation unit that includes this file is
+// compiled with -ffp-contract=off; sqrtf(), sqrt() and `/` are the IEEE correctly rounded forms hipcc emits by
+// default (never -ffast-math, never the __f*_rn intrinsics, which map to native approximations on ROCm 7.2).
+// Citations: "iu" = reference oclimgutil.cl, "rc" = oclrect.cl, "pl" = oclpolyline.cl.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define RD_WAVE 64
+
+namespace rd {
+
+__device__ __forceinline__ int clampi(int x, int lo, int hi) { return x < lo ? lo : (x > hi ? hi : x); }
+__device__ __forceinline__ uint32_t clampu(uint32_t x, uint32_t lo, uint32_t hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// iu:41-49: reflect without repeating the border sample
+__device__ __forceinline__ int mirror1(int x, int n) { return clampi(x, -x, 2 * n - 2 - x); }
+__device__ __forceinline__ int mirror2(int x, int y, int iw, int ih) { return mirror1(x, iw) + mirror1(y, ih) * iw; }
+
+// OpenCL convert_uint_rtn(float): floor, saturating at both ends
+__device__ __forceinline__ uint32_t floor_u32(float f) {
+  float g = floorf(f);
+  if (!(g > 0.0f)) return 0u;
+  if (g >= 4294967296.0f) return 0xffffffffu;
+  return (uint32_t)g;
+}
+
+// iu:28-34 packed Lab: bits 0-11 L*4096, 12-21 a*1024, 22-31 b*1024
+__device__ __forceinline__ uint32_t pack_lab(float L, float a, float b) {
+  uint32_t r = clampu(floor_u32(b * 1024), 0u, 1023u);
+  r = (r << 10) | clampu(floor_u32(a * 1024), 0u, 1023u);
+  r = (r << 12) | clampu(floor_u32(L * 4096), 0u, 4095u);
+  return r;
+}
+
+// iu:36-39: integer field * 2^-k + half an LSB (a multiply and an add, not fused)
+__device__ __forceinline__ void unpack_lab(uint32_t p, float &L, float &a, float &b) {
+  L = (float)(int)(p & 4095u) * (1.0f / 4096) + 0.5f / 4096;
+  a = (float)(int)((p >> 12) & 1023u) * (1.0f / 1024) + 0.5f / 1024;
+  b = (float)(int)((p >> 22) & 1023u) * (1.0f / 1024) + 0.5f / 1024;
+}
+
+// iu:65-74 Catmull-Rom style cubic through p0..p3 at fraction x (operation order is part of the result)
+__device__ __forceinline__ float cubic1(float p0, float p1, float p2, float p3, float x) {
+  float v = p1 - p2, w = p3 - p0;
+  float u = v * 3.0f + w;
+  u = u * x + (-4.0f * v + (p0 - p1 - w));
+  u = u * x + (p2 - p0);
+  u = u * x * 0.5f + p1;
+  return u;
+}
+
+// 8-neighbour offsets in the order E, NE, N, NW, W, SW, S, SE (rc:12-13, pl:63-64); the order matters for
+// "first two same-label neighbours" in the chain tracer.
+__device__ __forceinline__ int nbr_dx(int i) { return (0x0 | ((i == 0 || i == 1 || i == 7) ? 1 : ((i == 3 || i == 4 || i == 5) ? -1 : 0))); }
+__device__ __forceinline__ int nbr_dy(int i) { return (i >= 1 && i <= 3) ? -1 : ((i >= 5 && i <= 7) ? 1 : 0); }
+
+// pl:870-889 per-pixel 64-bit mixing function used to break distance ties in the polyline split
+__device__ __forceinline__ uint64_t rotl64(uint64_t t, int n) { n &= 63; return n ? (t << n) | (t >> (64 - n)) : t; }
+__device__ __forceinline__ uint64_t mix64(uint64_t s) {
+  uint64_t t = s;
+  t = rotl64(t, (int)((s >> 24) & 63)); t ^= 0xf3dd0fb7820fde37ULL;
+  t = rotl64(t, (int)((s >> 6) & 63));  t ^= 0xe6c6ac2c59e52811ULL;
+  t = rotl64(t, (int)((s >> 18) & 63)); t ^= 0x2fc7871fff7c5b45ULL;
+  t = rotl64(t, (int)((s >> 48) & 63)); t ^= 0x47c7e1f70aa4f7c5ULL;
+  t = rotl64(t, (int)((s >> 0) & 63));  t ^= 0x094f02b7fb9ba895ULL;
+  t = rotl64(t, (int)((s >> 12) & 63)); t ^= 0x89afda817e744570ULL;
+  t = rotl64(t, (int)((s >> 36) & 63)); t ^= 0xc7277d052c7bf14bULL;
+  return t;
+}
+__device__ __forceinline__ int pixel_rand(int p, uint64_t seed) {
+  return (int)mix64(((uint64_t)(int64_t)p ^ 0xb21c2cb635b48285ULL) * 0x9b923b9cec745401ULL + (seed ^ 0x7bb93d75a79d2f15ULL) * 0x22cab58ada573a29ULL);
+}
+
+// lock-free union-find on an int label array where a root r satisfies label[r] == r and the smaller index wins
+__device__ __forceinline__ int uf_find(const int *label, int a) {
+  int l = label[a];
+  while (l != a) { a = l; l = label[a]; }
+  return a;
+}
+__device__ __forceinline__ int uf_find_volatile(volatile int *label, int a) {
+  int l = label[a];
+  while (l != a) { a = l; l = label[a]; }
+  return a;
+}
+__device__ __forceinline__ void uf_union(int *label, int a, int b) {
+  for (;;) {
+    a = uf_find_volatile(label, a);
+    b = uf_find_volatile(label, b);
+    if (a == b) return;
+    if (a < b) { int t = a; a = b; b = t; }   // a > b: hang a under b
+    int old = atomicMin(&label[a], b);
+    if (old == a) return;                      // a was still a root: linked
+    a = old;                                   // somebody re-parented a meanwhile: retry from there
+  }
+}
+
+}  // namespace rd

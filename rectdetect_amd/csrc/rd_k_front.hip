@@ -1,0 +1,357 @@
+// rectdetect-mi355x: front-end kernels for gfx950 - colour conversion, sigma=1 IIR Gaussian, gradient
+// direction, edge strength, bicubic non-max suppression and the element-wise operators.
+//
+// Reference behaviour being reproduced (file:line into the reference): oclimgutil.cl ("iu").
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (see rd_device.h for the arithmetic contract).
+#include "rd_device.h"
+#include "rd_kernels.h"
+
+#define RD_LUT_ATTR __device__
+#include "rd_luts.h"
+
+namespace {
+
+using namespace rd;
+
+struct P3 { float *p[3]; };
+struct P3c { const float *p[3]; };
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+inline dim3 grid2(int iw, int ih) { return dim3(cdiv(iw, 64), cdiv(ih, 4)); }
+const dim3 block2(64, 4);
+inline int grid1(int n) { int g = cdiv(n, 256); return g < 1 ? 1 : g; }
+
+// ------------------------------------------------------------------------------------------------ colour
+// iu:106-134.  Integer-only sRGB -> packed Lab.  Matrix entries are (int)(m*16384+0.5f) of the sRGB->XYZ matrix,
+// 34476 / 30097 = (int)(32768/xn + 0.5f), (int)(32768/zn + 0.5f); the three LUTs are staged in LDS because every
+// lane indexes them with a different colour.
+__device__ __forceinline__ int lerp_lut(const unsigned short *t, int c) { return t[c >> 8] * (256 - (c & 255)) + t[(c >> 8) + 1] * (c & 255); }
+
+__global__ __launch_bounds__(256) void k_bgr2plab(uint32_t *__restrict__ out, const uint8_t *__restrict__ bgr, int iw, int ih, int ws) {
+  __shared__ unsigned short s_s2l[RD_LUT_S2L_N], s_cf[RD_LUT_CF_N], s_cf2[RD_LUT_CF_N];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int i = tid; i < RD_LUT_S2L_N; i += 256) s_s2l[i] = rd_lut_s2l[i];
+  for (int i = tid; i < RD_LUT_CF_N; i += 256) { s_cf[i] = rd_lut_cfunc[i]; s_cf2[i] = rd_lut_cfunc2[i]; }
+  __syncthreads();
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  if (x >= iw) return;
+  // 4 rows per thread-row so that the LUT staging is amortised over 1024 pixels per block
+  for (int r = 0; r < 4; r++) {
+    const int y = (blockIdx.y * 4 + threadIdx.y) * 4 + r;
+    if (y >= ih) break;
+    const uint8_t *p = bgr + (size_t)y * ws + x * 3;
+    const int ib = s_s2l[p[0]], ig = s_s2l[p[1]], ir = s_s2l[p[2]];
+    const int cx = (((ir * 6758 + ig * 5859 + ib * 2956 + (1 << 14)) >> 15) * 34476 + (1 << 10)) >> 11;
+    const int cy = ((ir * 3484 + ig * 11717 + ib * 1182) + (1 << 10)) >> 11;
+    const int cz = (((ir * 317 + ig * 1953 + ib * 15569 + (1 << 14)) >> 15) * 30097 + (1 << 10)) >> 11;
+    const int cl = ((lerp_lut(s_cf2, cy) >> 12) + 1) >> 1;
+    const int fx = lerp_lut(s_cf, cx), fy = lerp_lut(s_cf, cy), fz = lerp_lut(s_cf, cz);
+    const int fxy = (fx - fy + (1 << 7)) >> 8, fyz = (fy - fz + (1 << 7)) >> 8;
+    const int ca = (fxy * 8031 + (134744072 + (1 << 17))) >> 18;
+    const int cb = (fyz * 3213 + (134744072 + (1 << 17))) >> 18;
+    uint32_t v = clampu((uint32_t)cb, 0u, 1023u);
+    v = (v << 10) | clampu((uint32_t)ca, 0u, 1023u);
+    v = (v << 12) | clampu((uint32_t)cl, 0u, 4095u);
+    out[y * iw + x] = v;
+  }
+}
+
+// iu:333-342 / iu:325-331
+__global__ void k_unpack_plab(float *__restrict__ L, float *__restrict__ a, float *__restrict__ b, const uint32_t *__restrict__ in, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float l, aa, bb;
+    unpack_lab(in[i], l, aa, bb);
+    L[i] = l; a[i] = aa; b[i] = bb;
+  }
+}
+
+__global__ void k_pack_plab(uint32_t *__restrict__ out, const float *__restrict__ L, const float *__restrict__ a, const float *__restrict__ b, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = pack_lab(L[i], a[i], b[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ transposes
+// 64x64 tiles through LDS (row pitch 65 floats -> conflict-free column reads); block = 64x4 threads.
+template <int MODE>  // 0: plain float planes, 1: source is packed Lab (unpack while transposing), 2: IIR combine while transposing
+__global__ __launch_bounds__(256) void k_transpose(P3 dst, P3c src, P3c fwd, P3c bwd, const uint32_t *__restrict__ plab, int np, int W, int H) {
+  __shared__ float tile[3][64][65];
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+  for (int r = threadIdx.y; r < 64; r += 4) {
+    const int x = x0 + threadIdx.x, y = y0 + r;
+    if (x < W && y < H) {
+      const size_t i = (size_t)y * W + x;
+      if (MODE == 1) {
+        float l, a, b;
+        unpack_lab(plab[i], l, a, b);
+        tile[0][r][threadIdx.x] = l; tile[1][r][threadIdx.x] = a; tile[2][r][threadIdx.x] = b;
+      } else if (MODE == 2) {
+        // iu:580-589: horizontal result = anti-causal + causal - c0 * input
+        for (int k = 0; k < np; k++) tile[k][r][threadIdx.x] = bwd.p[k][i] + fwd.p[k][i] - src.p[k][i] * 0.3989422804f;
+      } else {
+        for (int k = 0; k < np; k++) tile[k][r][threadIdx.x] = src.p[k][i];
+      }
+    }
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 64; r += 4) {
+    const int ox = y0 + threadIdx.x, oy = x0 + r;   // output plane is H wide, W tall
+    if (ox < H && oy < W)
+      for (int k = 0; k < np; k++) dst.p[k][(size_t)oy * H + ox] = tile[k][threadIdx.x][r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ IIR Gaussian
+// iu:542-627 with iircoef[2] (iu:915-921): d[x] = c0 in[x] + sum_{k=1..7} c_k in[x-k] + sum_{k=0..6} c_{8+k} d[x-1-k],
+// evaluated in exactly that association; the sweep starts 11 samples before the line with mirrored inputs and zero state.
+// One lane owns one column of a W-column plane and walks down (dir 0) or up (dir 1) its H samples; lanes of a wave
+// read/write consecutive addresses.  The recurrence is latency bound (8 dependent ops per step), so loads are
+// software-pipelined one chunk ahead.
+#define IIR_C0 0.3989422804f
+#define IIR_C1 0.1414542400f
+#define IIR_C2 -0.0030406818f
+#define IIR_C3 -0.0041116157f
+#define IIR_C4 0.0006696623f
+#define IIR_C5 0.0000498707f
+#define IIR_C6 -0.0000449761f
+#define IIR_C7 -0.0000051528f
+#define IIR_C8 0.2519574622f
+#define IIR_C9 -0.0098627835f
+#define IIR_C10 -0.0067013653f
+#define IIR_C11 0.0012572396f
+#define IIR_C12 0.0000481394f
+#define IIR_C13 -0.0000097781f
+#define IIR_C14 0.0000006462f
+#define IIR_WARM 11
+#define IIR_CH 16
+
+__global__ __launch_bounds__(64) void k_iir_columns(P3 fwd, P3 bwd, P3c src, int W, int H) {
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  const int k = blockIdx.y >> 1, dir = blockIdx.y & 1;
+  if (x >= W) return;
+  const float *__restrict__ in = src.p[k] + x;
+  float *__restrict__ out = (dir ? bwd.p[k] : fwd.p[k]) + x;
+  const int y0 = dir ? H + IIR_WARM : -IIR_WARM, step = dir ? -1 : 1;
+  const int count = H + IIR_WARM + dir;   // down: -11..H-1, up: H+11..0
+  float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
+  float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+  float cur[IIR_CH], nxt[IIR_CH];
+#pragma unroll
+  for (int j = 0; j < IIR_CH; j++) {
+    const int yy = y0 + j * step;
+    cur[j] = j < count ? in[(size_t)mirror1(yy, H) * W] : 0.0f;
+  }
+  for (int base = 0; base < count; base += IIR_CH) {
+#pragma unroll
+    for (int j = 0; j < IIR_CH; j++) {
+      const int n = base + IIR_CH + j;
+      const int yy = y0 + n * step;
+      nxt[j] = n < count ? in[(size_t)mirror1(yy, H) * W] : 0.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < IIR_CH; j++) {
+      const int n = base + j;
+      if (n < count) {
+        const int yy = y0 + n * step;
+        const float i0 = cur[j];
+        float d = i0 * IIR_C0;
+        d += IIR_C1 * i1 + IIR_C2 * i2 + IIR_C3 * i3 + IIR_C4 * i4 + IIR_C5 * i5 + IIR_C6 * i6 + IIR_C7 * i7;
+        d += IIR_C8 * t0 + IIR_C9 * t1 + IIR_C10 * t2 + IIR_C11 * t3 + IIR_C12 * t4 + IIR_C13 * t5 + IIR_C14 * t6;
+        if (yy >= 0 && yy < H) out[(size_t)yy * W] = d;
+        i7 = i6; i6 = i5; i5 = i4; i4 = i3; i3 = i2; i2 = i1; i1 = i0;
+        t6 = t5; t5 = t4; t4 = t3; t3 = t2; t2 = t1; t1 = t0; t0 = d;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < IIR_CH; j++) cur[j] = nxt[j];
+  }
+}
+
+// iu:629-637: vertical result = anti-causal + causal - c0 * (horizontal result)
+__global__ void k_iir_combine(P3 dst, P3c fwd, P3c bwd, P3c src, int np, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    for (int k = 0; k < np; k++) dst.p[k][i] = bwd.p[k][i] + fwd.p[k][i] - src.p[k][i] * IIR_C0;
+}
+
+// ------------------------------------------------------------------------------------------------ gradient direction
+// iu:346-352 (5x5 kernel; double literals narrowed to float) and iu:395-420
+__device__ __forceinline__ float v5c(int i) {
+  const float t[25] = {
+    (float)-4.667, (float)-4.083, (float)0.000, (float)4.083, (float)4.667,
+    (float)-10.024, (float)-0.963, (float)0.000, (float)0.963, (float)10.024,
+    (float)-14.120, (float)3.622, (float)0.000, (float)-3.622, (float)14.120,
+    (float)-10.024, (float)-0.963, (float)0.000, (float)0.963, (float)10.024,
+    (float)-4.667, (float)-4.083, (float)0.000, (float)4.083, (float)4.667,
+  };
+  return t[i];
+}
+
+__global__ __launch_bounds__(256) void k_edgevec(float2 *__restrict__ dst, const float *__restrict__ in, int iw, int ih) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= iw || y >= ih) return;
+  float vx = 0, vy = 0;
+#pragma unroll
+  for (int yy = -2; yy <= 2; yy++) {
+#pragma unroll
+    for (int xx = -2; xx <= 2; xx++) {
+      const float s = in[mirror2(x + xx, y + yy, iw, ih)];
+      vx += v5c((xx + 2) + (yy + 2) * 5) * s;
+      vy += v5c((yy + 2) + (xx + 2) * 5) * s;
+    }
+  }
+  float len = vx * vx + vy * vy;
+  if ((double)len > 1e-10) {
+    len = 1.0f / sqrtf(len);
+    vx *= len; vy *= len;
+  } else {
+    vx = vy = 0.70710678118f;
+  }
+  dst[y * iw + x] = make_float2(vx, vy);
+}
+
+// ------------------------------------------------------------------------------------------------ edge strength
+// iu:422-437 on the blurred packed Lab: per channel (NW-SE)(N+W-S-E) + (NE-SW)(N-W+E-S), clamped at 0, summed, sqrt
+__global__ __launch_bounds__(256) void k_edge_plab(float *__restrict__ out, const uint32_t *__restrict__ in, int iw, int ih) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= iw || y >= ih) return;
+  float n[3], s[3], w[3], e[3], nw[3], ne[3], sw[3], se[3];
+  unpack_lab(in[mirror2(x, y - 1, iw, ih)], n[0], n[1], n[2]);
+  unpack_lab(in[mirror2(x, y + 1, iw, ih)], s[0], s[1], s[2]);
+  unpack_lab(in[mirror2(x - 1, y, iw, ih)], w[0], w[1], w[2]);
+  unpack_lab(in[mirror2(x + 1, y, iw, ih)], e[0], e[1], e[2]);
+  unpack_lab(in[mirror2(x - 1, y - 1, iw, ih)], nw[0], nw[1], nw[2]);
+  unpack_lab(in[mirror2(x + 1, y - 1, iw, ih)], ne[0], ne[1], ne[2]);
+  unpack_lab(in[mirror2(x - 1, y + 1, iw, ih)], sw[0], sw[1], sw[2]);
+  unpack_lab(in[mirror2(x + 1, y + 1, iw, ih)], se[0], se[1], se[2]);
+  float sum[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) {
+    float t = n[c] + w[c] - s[c] - e[c];
+    float acc = 0;
+    acc += (nw[c] - se[c]) * t;
+    t = n[c] - w[c] + e[c] - s[c];
+    acc += (ne[c] - sw[c]) * t;
+    sum[c] = fmaxf(0.0f, acc);
+  }
+  const float tot = sum[0] + sum[1] + sum[2];
+  out[y * iw + x] = tot > 0 ? sqrtf(tot) : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------ non-max suppression
+// iu:87-94 + iu:456-471: strength sampled at +-1, +-2 along the gradient direction with a 4x4 bicubic (mirrored
+// borders); local maxima keep the 5-sample sum, everything else 0.
+__device__ __forceinline__ float bicubic(const float *__restrict__ p, float x, float y, int iw, int ih) {
+  const int ix = (int)x, iy = (int)y;
+  const float fx = x - ix, fy = y - iy;
+  const int xa = mirror1(ix - 1, iw), xb = mirror1(ix, iw), xc = mirror1(ix + 1, iw), xd = mirror1(ix + 2, iw);
+  float r[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float *row = p + (size_t)mirror1(iy - 1 + k, ih) * iw;
+    r[k] = cubic1(row[xa], row[xb], row[xc], row[xd], fx);
+  }
+  return cubic1(r[0], r[1], r[2], r[3], fy);
+}
+
+__global__ __launch_bounds__(256) void k_thinthres(float *__restrict__ out, const float *__restrict__ in, const float2 *__restrict__ vxy, int iw, int ih) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= iw || y >= ih) return;
+  const int p0 = y * iw + x;
+  const float2 v = vxy[p0];
+  const float am2 = bicubic(in, x - 2 * v.x, y - 2 * v.y, iw, ih);
+  const float am1 = bicubic(in, x - 1 * v.x, y - 1 * v.y, iw, ih);
+  const float a0 = in[p0];
+  const float ap1 = bicubic(in, x + 1 * v.x, y + 1 * v.y, iw, ih);
+  const float ap2 = bicubic(in, x + 2 * v.x, y + 2 * v.y, iw, ih);
+  out[p0] = (am1 <= a0 && a0 >= ap1) ? (am2 + am1 + a0 + ap1 + ap2) : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------ element-wise (iu:197-254)
+__global__ void k_threshold_f(float *out, const float *in, float lo, float thr, float hi, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i] > thr ? hi : lo;
+}
+__global__ void k_threshold_i(int *out, const int *in, int lo, int thr, int hi, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i] > thr ? hi : lo;
+}
+__global__ void k_cast_i_f(int *out, const float *in, float scale, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = (int)(in[i] * scale);
+}
+__global__ void k_cast_c_i(int8_t *out, const int *in, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = (int8_t)in[i];
+}
+__global__ void k_clear_i(int *out, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = 0;
+}
+__global__ void k_copy_i(int *out, const int *in, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i];
+}
+__global__ void k_rand_i(int *out, uint64_t seed, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = pixel_rand(i, seed);
+}
+
+inline int ew_grid(int n) { int g = cdiv(n, 256 * 4); return g < 1 ? 1 : (g > 4096 ? 4096 : g); }
+
+}  // namespace
+
+namespace rdk {
+
+void bgr2plab(hipStream_t s, uint32_t *out, const uint8_t *bgr, int iw, int ih, int ws) {
+  hipLaunchKernelGGL(k_bgr2plab, dim3(cdiv(iw, 64), cdiv(ih, 16)), block2, 0, s, out, bgr, iw, ih, ws);
+}
+void unpack_plab(hipStream_t s, float *L, float *a, float *b, const uint32_t *in, int n) {
+  hipLaunchKernelGGL(k_unpack_plab, dim3(ew_grid(n)), dim3(256), 0, s, L, a, b, in, n);
+}
+void pack_plab(hipStream_t s, uint32_t *out, const float *L, const float *a, const float *b, int n) {
+  hipLaunchKernelGGL(k_pack_plab, dim3(ew_grid(n)), dim3(256), 0, s, out, L, a, b, n);
+}
+
+static P3 mk3(float *const p[3], int np) { P3 r = { { nullptr, nullptr, nullptr } }; for (int k = 0; k < np; k++) r.p[k] = p[k]; return r; }
+static P3c mk3c(const float *const p[3], int np) { P3c r = { { nullptr, nullptr, nullptr } }; for (int k = 0; k < np; k++) r.p[k] = p[k]; return r; }
+
+void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], int np, int W, int H) {
+  P3c z = { { nullptr, nullptr, nullptr } };
+  hipLaunchKernelGGL(k_transpose<0>, dim3(cdiv(W, 64), cdiv(H, 64)), block2, 0, s, mk3(dst, np), mk3c(src, np), z, z, (const uint32_t *)nullptr, np, W, H);
+}
+void transpose_unpack(hipStream_t s, float *const dst[3], const uint32_t *plab, int W, int H) {
+  P3c z = { { nullptr, nullptr, nullptr } };
+  hipLaunchKernelGGL(k_transpose<1>, dim3(cdiv(W, 64), cdiv(H, 64)), block2, 0, s, mk3(dst, 3), z, z, z, plab, 3, W, H);
+}
+void iir_columns(hipStream_t s, float *const fwd[3], float *const bwd[3], const float *const src[3], int np, int W, int H) {
+  hipLaunchKernelGGL(k_iir_columns, dim3(cdiv(W, 64), np * 2), dim3(64), 0, s, mk3(fwd, np), mk3(bwd, np), mk3c(src, np), W, H);
+}
+void iir_combine_transpose(hipStream_t s, float *const dst[3], const float *const fwd[3], const float *const bwd[3], const float *const src[3], int np, int W, int H) {
+  hipLaunchKernelGGL(k_transpose<2>, dim3(cdiv(W, 64), cdiv(H, 64)), block2, 0, s, mk3(dst, np), mk3c(src, np), mk3c(fwd, np), mk3c(bwd, np), (const uint32_t *)nullptr, np, W, H);
+}
+void iir_combine(hipStream_t s, float *const dst[3], const float *const fwd[3], const float *const bwd[3], const float *const src[3], int np, int n) {
+  hipLaunchKernelGGL(k_iir_combine, dim3(ew_grid(n)), dim3(256), 0, s, mk3(dst, np), mk3c(fwd, np), mk3c(bwd, np), mk3c(src, np), np, n);
+}
+void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih) {
+  hipLaunchKernelGGL(k_edgevec, grid2(iw, ih), block2, 0, s, (float2 *)vxy, in, iw, ih);
+}
+void edge_plab(hipStream_t s, float *out, const uint32_t *in, int iw, int ih) {
+  hipLaunchKernelGGL(k_edge_plab, grid2(iw, ih), block2, 0, s, out, in, iw, ih);
+}
+void thinthres(hipStream_t s, float *out, const float *in, const float *vxy, int iw, int ih) {
+  hipLaunchKernelGGL(k_thinthres, grid2(iw, ih), block2, 0, s, out, in, (const float2 *)vxy, iw, ih);
+}
+void threshold_f(hipStream_t s, float *out, const float *in, float lo, float thr, float hi, int n) {
+  hipLaunchKernelGGL(k_threshold_f, dim3(ew_grid(n)), dim3(256), 0, s, out, in, lo, thr, hi, n);
+}
+void threshold_i(hipStream_t s, int *out, const int *in, int lo, int thr, int hi, int n) {
+  hipLaunchKernelGGL(k_threshold_i, dim3(ew_grid(n)), dim3(256), 0, s, out, in, lo, thr, hi, n);
+}
+void cast_i_f(hipStream_t s, int *out, const float *in, float scale, int n) {
+  hipLaunchKernelGGL(k_cast_i_f, dim3(ew_grid(n)), dim3(256), 0, s, out, in, scale, n);
+}
+void cast_c_i(hipStream_t s, int8_t *out, const int *in, int n) {
+  hipLaunchKernelGGL(k_cast_c_i, dim3(ew_grid(n)), dim3(256), 0, s, out, in, n);
+}
+void clear_i(hipStream_t s, int *out, int n) {
+  if (n > 0) hipLaunchKernelGGL(k_clear_i, dim3(ew_grid(n)), dim3(256), 0, s, out, n);
+}
+void copy_i(hipStream_t s, int *out, const int *in, int n) {
+  if (n > 0) hipLaunchKernelGGL(k_copy_i, dim3(ew_grid(n)), dim3(256), 0, s, out, in, n);
+}
+void rand_i(hipStream_t s, int *out, uint64_t seed, int n) {
+  if (n > 0) hipLaunchKernelGGL(k_rand_i, dim3(ew_grid(n)), dim3(256), 0, s, out, seed, n);
+}
+
+}  // namespace rdk

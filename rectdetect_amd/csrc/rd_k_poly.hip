@@ -1,0 +1,750 @@
+// rectdetect-mi355x: polyline extraction for gfx950 (the reference's oclpolyline_execute, oclpolyline.c:218-309,
+// kernels oclpolyline.cl = "pl").
+//
+// The reference runs 116 full-frame launches over dense int planes although only chain pixels (a few per cent of the
+// frame at most) take part after the tidy step.  Here the tidy step is dense, then chain pixels are compacted IN RASTER
+// ORDER (ballot + prefix scan) and every later step works on the compact arrays; raster-ordered compaction makes the
+// reference's order-dependent id hand-outs plain prefix ranks.  Pointer-jumping steps keep the
+// reference's hop counts (4 x 8 hops, 3 x 32 hops) so results agree even where those limits bite.
+#include "rd_device.h"
+#include "rd_kernels.h"
+
+namespace rdk {
+
+struct PolyScratch {
+  int cap;            // = iw*ih, capacity of every per-pixel array
+  int *planeA, *planeB, *planeC;   // dense int planes
+  int *cidx;          // dense: pixel -> compact index or -1
+  int *blk;           // per-block counts / offsets for the compaction
+  int *pos;           // compact: pixel index, ascending
+  int *nbr;           // compact: 8 neighbour compact indices (E,NE,N,NW,W,SW,S,SE), -1 = none
+  int *lab, *alive, *ends;
+  int *nx[2], *pv[2], *flag, *flag2;
+  int *num[2], *link[2];
+  int *lab2, *size, *rootid, *id, *dist;
+  int *cand;          // candidate records of one split round (8 ints each)
+  int *ctr;           // counters: [0]=cnt, [1]=nchains, [2..18]=candidates per round, [20]=refine done count ...
+  void *lsx;          // per-segment moment sums
+  int *segaux;        // per-segment: startPix, endPix
+};
+
+}  // namespace rdk
+
+namespace {
+
+using namespace rd;
+using rdk::PolyScratch;
+
+inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+const dim3 block2(64, 4);
+inline dim3 grid2(int iw, int ih) { return dim3(cdiv(iw, 64), cdiv(ih, 4)); }
+#define RD_XY const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y
+#define SPARSE_GRID 512
+#define SPARSE_LOOP(i, cnt) for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < (cnt); i += gridDim.x * blockDim.x)
+
+struct ls_rec { float x0, y0, x1, y1; int startIndex, endIndex, leftPtr, rightPtr, startCount, endCount, maxDist, polyid, npix, level; };
+struct lsx_rec { long long mx00, mx01, mx11, my0, my1; short dx, dy, vx, vy; int d2, pad; };
+
+// ------------------------------------------------------------------------------------------------ dense tidy
+// pl:66-87 junction counts (`!= 0`)
+__global__ __launch_bounds__(256) void k_junction_nz(int *__restrict__ out, const int *__restrict__ in, int iw, int ih) {
+  RD_XY;
+  if (x >= iw || y >= ih) return;
+  const int p = y * iw + x;
+  int r = 0;
+  if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && in[p] != 0) {
+    int count = 1;
+#pragma unroll
+    for (int i = 0; i < 8; i++) if (in[p + nbr_dx(i) + nbr_dy(i) * iw] != 0) count++;
+    r = count == 1 ? 0 : count;
+  }
+  out[p] = r;
+}
+
+// pl:89-110: 1-px gaps between two curve ends are bridged (8 strict patterns).  The kernel of the reference does not
+// write the 2-px frame ring of its output plane, so the ring keeps the plane's previous content: here it
+// is taken from ring_src (the caller's plane) or, when that is null, set to ring_const.
+__global__ __launch_bounds__(256) void k_connect_poly(int *__restrict__ out, const int *__restrict__ in, const int *__restrict__ ring_src, int ring_const, int iw, int ih) {
+  RD_XY;
+  if (x >= iw || y >= ih) return;
+  const int p = y * iw + x;
+  int o;
+  if (x <= 1 || y <= 1 || x >= iw - 2 || y >= ih - 2) {
+    o = ring_src ? ring_src[p] : ring_const;
+  } else if (in[p] != 0) {
+    o = 1;
+  } else {
+    o = 0;
+    const int W = iw;
+    if (in[p - 2] != 0 && in[p - 1] == 2 && in[p + 1] == 2 && in[p + 2] != 0) o = 1;
+    if (in[p - W * 2] != 0 && in[p - W] == 2 && in[p + W] == 2 && in[p + W * 2] != 0) o = 1;
+    if (in[p - W * 2 - 2] != 0 && in[p - W - 1] == 2 && in[p + W + 1] == 2 && in[p + W * 2 + 2] != 0) o = 1;
+    if (in[p - W * 2 + 2] != 0 && in[p - W + 1] == 2 && in[p + W - 1] == 2 && in[p + W * 2 - 2] != 0) o = 1;
+    if (in[p + 2] != 0 && in[p + 1] == 2 && in[p + W - 1] == 2 && in[p + W - 2] != 0) o = 1;
+    if (in[p - 2] != 0 && in[p - 1] == 2 && in[p + W + 1] == 2 && in[p + W + 2] != 0) o = 1;
+    if (in[p - W * 2 + 1] != 0 && in[p - W + 1] == 2 && in[p + W] == 2 && in[p + W * 2] != 0) o = 1;
+    if (in[p - W * 2 - 1] != 0 && in[p - W - 1] == 2 && in[p + W] == 2 && in[p + W * 2] != 0) o = 1;
+  }
+  out[p] = o;
+}
+
+// pl:112-124
+__global__ __launch_bounds__(256) void k_stringify_p(int *__restrict__ out, const int *__restrict__ in, int mod2, int iw, int ih) {
+  RD_XY;
+  if (x >= iw || y >= ih) return;
+  const int p = y * iw + x;
+  int v = in[p];
+  if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && ((x + y) & 1) == mod2) {
+    const bool up = in[p - iw] != 0, dn = in[p + iw] != 0, lf = in[p - 1] != 0, rt = in[p + 1] != 0;
+    if ((up || dn) && (lf || rt)) v = 0;
+  }
+  out[p] = v;
+}
+
+// pl:126-147: keep on-pixels with at most two on-neighbours (cuts the curves at junctions)
+__global__ __launch_bounds__(256) void k_remove_branch(int *__restrict__ out, const int *__restrict__ in, int iw, int ih) {
+  RD_XY;
+  if (x >= iw || y >= ih) return;
+  const int p = y * iw + x;
+  int r = 0;
+  if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && in[p] != 0) {
+    int count = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) if (in[p + nbr_dx(i) + nbr_dy(i) * iw] != 0) count++;
+    r = count <= 2 ? 1 : 0;
+  }
+  out[p] = r;
+}
+
+// ------------------------------------------------------------------------------------------------ raster-order compaction
+#define CP_PER_BLOCK 2048
+__global__ __launch_bounds__(256) void k_compact_count(int *__restrict__ blk, const int *__restrict__ plane, int n) {
+  __shared__ int total;
+  if (threadIdx.x == 0) total = 0;
+  __syncthreads();
+  int c = 0;
+  for (int k = 0; k < CP_PER_BLOCK / 256; k++) {
+    const int i = blockIdx.x * CP_PER_BLOCK + k * 256 + threadIdx.x;
+    c += __popcll(__ballot(i < n && plane[i] != 0));
+  }
+  if ((threadIdx.x & 63) == 0) atomicAdd(&total, c);
+  __syncthreads();
+  if (threadIdx.x == 0) blk[blockIdx.x] = total;
+}
+
+// exclusive scan of nblk block counts by one 1024-thread block; total -> *cnt
+__global__ __launch_bounds__(1024) void k_compact_scan(int *blk, int nblk, int *cnt) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int base = 0; base < nblk; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nblk ? blk[i] : 0;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int woff = 0;
+    for (int k = 0; k < w; k++) woff += wsum[k];
+    const int c0 = carry;
+    if (i < nblk) blk[i] = c0 + woff + inc - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = c0 + woff + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *cnt = carry;
+}
+
+__global__ __launch_bounds__(256) void k_compact_scatter(int *__restrict__ pos, int *__restrict__ cidx, const int *__restrict__ blk, const int *__restrict__ plane, int n) {
+  __shared__ int wcount[4];
+  __shared__ int running;
+  if (threadIdx.x == 0) running = blk[blockIdx.x];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int k = 0; k < CP_PER_BLOCK / 256; k++) {
+    const int i = blockIdx.x * CP_PER_BLOCK + k * 256 + threadIdx.x;
+    const bool on = i < n && plane[i] != 0;
+    const unsigned long long m = __ballot(on);
+    if (lane == 0) wcount[w] = __popcll(m);
+    __syncthreads();
+    int off = running;
+    for (int q = 0; q < w; q++) off += wcount[q];
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (i < n) {
+      if (on) { pos[off + rank] = i; cidx[i] = off + rank; }
+      else cidx[i] = -1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) running += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ chain graph
+__global__ void k_build_nbr(PolyScratch s, int iw) {
+  const int cnt = s.ctr[0];
+  SPARSE_LOOP(i, cnt) {
+    const int p = s.pos[i];
+    int deg = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int j = s.cidx[p + nbr_dx(k) + nbr_dy(k) * iw];   // chain pixels are interior: no bounds check needed
+      s.nbr[i * 8 + k] = j;
+      deg += j >= 0;
+    }
+    s.lab[i] = i;
+    s.alive[i] = 1;
+    s.ends[i] = 0;
+    s.flag2[i] = deg;     // degree, used for the end-point count
+  }
+}
+
+// 8-connected components of the chain mask (pl:811-854 to convergence): union with every neighbour of smaller index
+__global__ void k_chain_union(PolyScratch s) {
+  const int cnt = s.ctr[0];
+  SPARSE_LOOP(i, cnt) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int j = s.nbr[i * 8 + k];
+      if (j >= 0 && j < i) uf_union(s.lab, i, j);
+    }
+  }
+}
+
+__global__ void k_flatten(int *lab, const int *ctr) {
+  const int cnt = ctr[0];
+  SPARSE_LOOP(i, cnt) {
+    const int l = lab[i];
+    if (l >= 0) { const int r = uf_find(lab, l); if (r != l) lab[i] = r; }
+  }
+}
+
+// pl:149-155: a pixel with junction count 2 (itself + one neighbour) is a chain end; count ends per chain
+__global__ void k_count_ends(PolyScratch s) {
+  const int cnt = s.ctr[0];
+  SPARSE_LOOP(i, cnt) if (s.flag2[i] == 1) atomicAdd(&s.ends[s.lab[i]], 1);
+}
+
+// pl:157-167: a chain without ends is a closed loop: open it by deleting its root pixel
+__global__ void k_break_loops(PolyScratch s) {
+  const int cnt = s.ctr[0];
+  SPARSE_LOOP(i, cnt) if (s.lab[i] == i && s.ends[i] == 0) s.alive[i] = 0;
+}
+
+// pl:169-220: the first two living neighbours (order E,NE,N,NW,W,SW,S,SE) become next / prev; self if missing
+__global__ void k_find_ends0(PolyScratch s) {
+  const int cnt = s.ctr[0];
+  SPARSE_LOOP(i, cnt) {
+    int a = i, b = i;
+    if (s.alive[i]) {
+      int k = 0;
+      for (; k < 8; k++) { const int j = s.nbr[i * 8 + k]; if (j >= 0 && s.alive[j]) { a = j; break; } }
+      for (k++; k < 8; k++) { const int j = s.nbr[i * 8 + k]; if (j >= 0 && s.alive[j]) { b = j; break; } }
+    }
+    s.nx[0][i] = a; s.pv[0][i] = b;
+  }
+}
+
+__global__ void k_find_ends0_flags(PolyScratch s) {
+  const int cnt = s.ctr[0];
+  SPARSE_LOOP(i, cnt) {
+    int f = 0;
+    if (s.alive[i]) {
+      const int a = s.nx[0][i], b = s.pv[0][i];
+      if (a != i && s.nx[0][a] == i) f |= 1;
+      if (b != i && s.pv[0][b] == i) f |= 2;
+    }
+    s.flag[i] = f;
+  }
+}
+
+// pl:222-267: eight hops towards both chain ends with orientation-reversal tracking; page selects the flag bit pair
+__global__ void k_find_ends1(PolyScratch s, int page) {
+  const int cnt = s.ctr[0];
+  const int *ni = s.nx[page], *pi = s.pv[page];
+  int *no = s.nx[page ^ 1], *po = s.pv[page ^ 1];
+  const int *fin = page == 0 ? s.flag : s.flag2;
+  int *fout = page == 0 ? s.flag2 : s.flag;
+  SPARSE_LOOP(i, cnt) {
+    if (!s.alive[i]) { no[i] = i; po[i] = i; fout[i] = fin[i]; continue; }
+    const int f0 = fin[i];
+    bool revn = page == 0 ? (f0 & 1) != 0 : (f0 & 4) != 0;
+    bool revp = page == 0 ? (f0 & 2) != 0 : (f0 & 8) != 0;
+    int nn = ni[i], pp = pi[i];
+    for (int h = 0; h < 8; h++) {
+      const int nn2 = revn ? pi[nn] : ni[nn];
+      const int pp2 = revp ? ni[pp] : pi[pp];
+      int nf = fin[nn], pf = fin[pp];
+      if (page != 0) { nf >>= 2; pf >>= 2; }
+      revn = revn ? ((nf & 2) == 0) : ((nf & 1) != 0);
+      revp = revp ? ((pf & 1) == 0) : ((pf & 2) != 0);
+      nn = nn2; pp = pp2;
+    }
+    no[i] = nn; po[i] = pp;
+    int f = f0;
+    if (page == 0) { f &= 3; f |= revn ? 4 : 0; f |= revp ? 8 : 0; }
+    else { f &= (3 << 2); f |= revn ? 1 : 0; f |= revp ? 2 : 0; }
+    fout[i] = f;
+  }
+}
+
+// pl:269-285: link towards the end with the smaller index; the end itself gets number 0
+__global__ void k_find_ends2(PolyScratch s) {
+  const int cnt = s.ctr[0];
+  SPARSE_LOOP(i, cnt) {
+    int lk = -1, nm = 0;
+    if (s.alive[i]) {
+      int a = i, b = i, k = 0;
+      for (; k < 8; k++) { const int j = s.nbr[i * 8 + k]; if (j >= 0 && s.alive[j]) { a = j; break; } }
+      for (k++; k < 8; k++) { const int j = s.nbr[i * 8 + k]; if (j >= 0 && s.alive[j]) { b = j; break; } }
+      lk = s.nx[0][i] < s.pv[0][i] ? a : b;
+      nm = lk == i ? 0 : 1;
+    }
+    s.num[0][i] = nm; s.link[0][i] = lk;
+  }
+}
+
+// pl:287-310: 32-hop pointer-jumping prefix sum of the hop counts
+__global__ void k_number(PolyScratch s, int src) {
+  const int cnt = s.ctr[0];
+  const int *ni = s.num[src], *li = s.link[src];
+  int *no = s.num[src ^ 1], *lo_ = s.link[src ^ 1];
+  SPARSE_LOOP(i, cnt) {
+    if (li[i] == -1) { no[i] = ni[i]; lo_[i] = -1; continue; }
+    int n = ni[i], l = li[i];
+    bool ok = true;
+    for (int h = 0; h < 32; h++) {
+      if (l < 0) { ok = false; break; }
+      n += ni[l];
+      l = li[l];
+    }
+    no[i] = ok ? n : 0;
+    lo_[i] = ok ? l : -1;
+  }
+}
+
+// pl:312-355 to convergence: split chains where the numbering jumps by more than one
+__global__ void k_sub_init(PolyScratch s, const int *number) {
+  const int cnt = s.ctr[0];
+  SPARSE_LOOP(i, cnt) { s.lab2[i] = number[i] == 0 ? -1 : i; s.size[i] = 0; s.rootid[i] = 0; }
+}
+
+__global__ void k_sub_union(PolyScratch s, const int *number) {
+  const int cnt = s.ctr[0];
+  SPARSE_LOOP(i, cnt) {
+    const int a = number[i];
+    if (a == 0) continue;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int j = s.nbr[i * 8 + k];
+      if (j < 0 || j > i) continue;
+      const int b = number[j];
+      if (b == 0) continue;
+      const int d = a > b ? a - b : b - a;
+      if (d <= 1) uf_union(s.lab2, i, j);
+    }
+  }
+}
+
+// pl:357-378 sizes of the sub-chains
+__global__ void k_sub_size(PolyScratch s) {
+  const int cnt = s.ctr[0];
+  SPARSE_LOOP(i, cnt) if (s.lab2[i] >= 0) atomicAdd(&s.size[s.lab2[i]], 1);
+}
+
+// pl:380-420: surviving roots are numbered 1..K in raster order (= compact order): one block, ballot prefix scan
+__global__ __launch_bounds__(1024) void k_relabel_scan(PolyScratch s, int sizeThre) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  const int cnt = s.ctr[0];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int base = 0; base < cnt; base += 1024) {
+    const int i = base + threadIdx.x;
+    const bool root = i < cnt && s.lab2[i] == i && s.size[i] > sizeThre;
+    const unsigned long long m = __ballot(root);
+    if (lane == 0) wsum[w] = __popcll(m);
+    __syncthreads();
+    int off = carry;
+    for (int k = 0; k < w; k++) off += wsum[k];
+    if (root) s.rootid[i] = off + __popcll(m & ((1ull << lane) - 1ull)) + 1;
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < 16; k++) t += wsum[k]; carry += t; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) s.ctr[1] = carry;
+}
+
+__global__ void k_assign_ids(PolyScratch s) {
+  const int cnt = s.ctr[0];
+  SPARSE_LOOP(i, cnt) { const int l = s.lab2[i]; s.id[i] = l >= 0 ? s.rootid[l] : 0; }
+}
+
+// ------------------------------------------------------------------------------------------------ initial segments (pl:439-506)
+#define FITS(g, bytes) ((g) >= 0 && (long long)(bytes) > (long long)((g) + 1) * 56ll)
+
+__global__ void k_seg_clear(PolyScratch s, ls_rec *ls, int lsbytes) {
+  const int K = s.ctr[1];
+  const int maxrec = lsbytes / 56;
+  SPARSE_LOOP(g, K + 1) {
+    if (g >= maxrec) continue;
+    ls_rec z = {};
+    ls[g] = z;
+    s.segaux[2 * g] = -1;            // last pixel with number 1
+    s.segaux[2 * g + 1] = 0x7fffffff; // first pixel carrying the largest number
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) for (int k = 2; k < 24; k++) s.ctr[k] = 0;
+}
+
+__global__ void k_seg_pass0a(PolyScratch s, ls_rec *ls, int lsbytes, const int *number) {
+  const int cnt = s.ctr[0];
+  SPARSE_LOOP(i, cnt) {
+    const int g = s.id[i];
+    if (g == 0 || !FITS(g, lsbytes)) continue;
+    const int n = number[i];
+    if (n == 1) { atomicAdd(&ls[g].startCount, 1); atomicMax(&s.segaux[2 * g], i); }
+    atomicAdd(&ls[g].npix, 1);
+    atomicMax(&ls[g].endIndex, n);
+  }
+}
+
+__global__ void k_seg_pass0b(PolyScratch s, ls_rec *ls, int lsbytes, const int *number) {
+  const int cnt = s.ctr[0];
+  SPARSE_LOOP(i, cnt) {
+    const int g = s.id[i];
+    if (g == 0 || !FITS(g, lsbytes)) continue;
+    if (number[i] != ls[g].endIndex) continue;
+    if (ls[g].startCount == 1 && ls[g].npix >= 2) { atomicAdd(&ls[g].endCount, 1); atomicMin(&s.segaux[2 * g + 1], i); }
+  }
+}
+
+__global__ void k_seg_finish(PolyScratch s, ls_rec *ls, int lsbytes, int iw) {
+  const int K = s.ctr[1];
+  SPARSE_LOOP(g0, K) {
+    const int g = g0 + 1;
+    if (!FITS(g, lsbytes)) continue;
+    const int sp = s.segaux[2 * g], ep = s.segaux[2 * g + 1];
+    if (sp >= 0) { const int p = s.pos[sp]; ls[g].x0 = (float)(p % iw); ls[g].y0 = (float)(p / iw); }
+    if (ls[g].startCount == 1 && ls[g].npix >= 2 && ep != 0x7fffffff) {
+      const int p = s.pos[ep];
+      ls[g].x1 = (float)(p % iw); ls[g].y1 = (float)(p / iw);
+      ls[g].polyid = g;
+    } else ls[g].polyid = 0;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) { const int maxrec = lsbytes / 56; *(int *)ls = K < maxrec - 1 ? K : (maxrec >= 2 ? maxrec - 2 : 0); }
+}
+
+// ------------------------------------------------------------------------------------------------ subdivision rounds (pl:509-646)
+__device__ __forceinline__ float dist2f(float vx, float vy, float wx, float wy) { return (vx - wx) * (vx - wx) + (vy - wy) * (vy - wy); }
+
+// pass 3 of the previous round (pixels beyond the new end move right) fused with pass 1 of this round (distance to
+// the chord with integer-truncated end points, tie-breaking hash, per-segment maximum)
+__global__ void k_split_move_dist(PolyScratch s, ls_rec *ls, int lsbytes, const int *number, int iw, int do_dist) {
+  const int cnt = s.ctr[0];
+  SPARSE_LOOP(i, cnt) {
+    int g = s.id[i];
+    if (g == 0 || !FITS(g, lsbytes) || ls[g].polyid == 0) continue;
+    if (ls[g].endIndex < number[i]) { g = ls[g].rightPtr; s.id[i] = g; }
+    if (!do_dist) continue;
+    if (g == 0 || !FITS(g, lsbytes) || ls[g].polyid == 0) continue;
+    const int p = s.pos[i], x = p % iw, y = p / iw;
+    const float vx = (float)(int)ls[g].x0, vy = (float)(int)ls[g].y0, wx = (float)(int)ls[g].x1, wy = (float)(int)ls[g].y1;
+    float cx, cy;
+    const float l2 = dist2f(vx, vy, wx, wy);
+    if (l2 <= 1e-4f) { cx = vx; cy = vy; }
+    else {
+      const float t = (((float)x - vx) * (wx - vx) + ((float)y - vy) * (wy - vy)) / l2;
+      if (t < 0.0f) { cx = vx; cy = vy; }
+      else if (t > 1.0f) { cx = wx; cy = wy; }
+      else { cx = vx + t * (wx - vx); cy = vy + t * (wy - vy); }
+    }
+    const float a = cx - (float)x, b = cy - (float)y;
+    int d = (int)((float)sqrt((double)a * (double)a + (double)b * (double)b) * 65536);
+    d ^= pixel_rand(p, 0) & 0x1fff;
+    s.dist[i] = d;
+    atomicMax(&ls[g].maxDist, d);
+  }
+}
+
+// pass 2, detection: the pixel that realises its segment's maximum distance and passes the split tests becomes a
+// candidate; everything pass 2 needs from the OLD list is stored with the candidate (the reference reads a snapshot).
+// cand record: {i, g, n, maxDist, oldEndIndex, oldRight, x1 bits, y1 bits}
+__global__ void k_split_detect(PolyScratch s, const ls_rec *ls, int lsbytes, const int *number, float minerror, int iw, int round) {
+  const int cnt = s.ctr[0];
+  SPARSE_LOOP(i, cnt) {
+    const int g = s.id[i];
+    if (g == 0 || !FITS(g, lsbytes)) continue;
+    const ls_rec r = ls[g];
+    if (r.polyid == 0) continue;
+    if (r.endIndex - r.startIndex < 3) continue;
+    if (r.startCount > 1 || r.endCount > 1) continue;
+    const int md = r.maxDist;
+    if (s.dist[i] != md) continue;
+    if (md < (int)(minerror * 65536)) continue;
+    if ((float)md < (minerror * 3 * 65536) && (float)md * (float)md / dist2f(r.x0, r.y0, r.x1, r.y1) < 100000.0f) continue;
+    const int p = s.pos[i], x = p % iw, y = p / iw;
+    if (dist2f((float)x, (float)y, r.x0, r.y0) < 1) continue;
+    if (dist2f((float)x, (float)y, r.x1, r.y1) < 1) continue;
+    const int c = atomicAdd(&s.ctr[2 + round], 1);
+    int *e = s.cand + (size_t)c * 8;
+    e[0] = i; e[1] = g; e[2] = number[i]; e[3] = md; e[4] = r.endIndex; e[5] = r.rightPtr;
+    e[6] = __float_as_int(r.x1); e[7] = __float_as_int(r.y1);
+  }
+}
+
+// pass 2, application: new ids follow the raster order of the candidates (rank by pixel index); when several
+// candidates share a segment the one latest in raster order decides the shared fields, as a serial execution would.
+__global__ void k_split_apply(PolyScratch s, ls_rec *ls, int lsbytes, int iw, int round) {
+  const int C = s.ctr[2 + round];
+  const int base = *(const int *)ls;
+  SPARSE_LOOP(c, C) {
+    const int *e = s.cand + (size_t)c * 8;
+    const int i = e[0], g = e[1];
+    int rank = 0;
+    bool last = true;
+    for (int k = 0; k < C; k++) {
+      const int *f = s.cand + (size_t)k * 8;
+      if (f[0] < i) rank++;
+      if (f[1] == g && f[0] > i) last = false;
+    }
+    const int gn = base + 1 + rank;
+    if (!FITS(gn, lsbytes)) continue;
+    const int p = s.pos[i], x = p % iw, y = p / iw;
+    ls_rec nr = {};
+    nr.startIndex = e[2]; nr.endIndex = e[4];
+    nr.x0 = (float)x; nr.y0 = (float)y; nr.x1 = __int_as_float(e[6]); nr.y1 = __int_as_float(e[7]);
+    nr.leftPtr = g; nr.rightPtr = e[5];
+    nr.maxDist = 0; nr.polyid = ls[g].polyid; nr.level = e[3];
+    ls[gn] = nr;
+    if (last) {
+      ls[g].endIndex = e[2]; ls[g].x1 = (float)x; ls[g].y1 = (float)y; ls[g].rightPtr = gn; ls[g].maxDist = 0;
+      if (e[5] != 0) ls[e[5]].leftPtr = gn;
+    }
+  }
+}
+
+__global__ void k_split_commit(PolyScratch s, ls_rec *ls, int round) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *(int *)ls += s.ctr[2 + round];
+}
+
+// ------------------------------------------------------------------------------------------------ refinement (pl:680-809)
+__global__ void k_refine0(PolyScratch s, const ls_rec *ls, int maxrec) {
+  const int n = *(const int *)ls;
+  lsx_rec *sx = (lsx_rec *)s.lsx;
+  SPARSE_LOOP(g0, n) {
+    const int g = g0 + 1;
+    if (g >= maxrec) continue;
+    lsx_rec z = {};
+    if (ls[g].polyid != 0) {
+      z.dx = (short)(ls[g].x1 - ls[g].x0); z.dy = (short)(ls[g].y1 - ls[g].y0);
+      z.vx = (short)-z.dy; z.vy = z.dx;
+      z.d2 = z.dx * z.dx + z.dy * z.dy;
+    }
+    sx[g] = z;
+  }
+}
+
+__global__ void k_refine1(PolyScratch s, const ls_rec *ls, int maxrec, int iw) {
+  const int cnt = s.ctr[0];
+  const int n = *(const int *)ls;
+  lsx_rec *sx = (lsx_rec *)s.lsx;
+  SPARSE_LOOP(i, cnt) {
+    const int g = s.id[i];
+    if (g <= 0 || n < g || g >= maxrec || ls[g].polyid == 0) continue;
+    const int p = s.pos[i], x = p % iw, y = p / iw;
+    const int vx = x - (int)rintf(ls[g].x0), vy = y - (int)rintf(ls[g].y0);
+    const int ay = vx * sx[g].vx + vy * sx[g].vy;
+    const int ax0 = vx * sx[g].dx + vy * sx[g].dy;
+    const int ax1 = sx[g].d2;
+    atomicAdd((unsigned long long *)&sx[g].mx00, (unsigned long long)(long long)rintf((float)ax0 * (float)ax0));
+    atomicAdd((unsigned long long *)&sx[g].mx01, (unsigned long long)(long long)rintf((float)ax0 * (float)ax1));
+    atomicAdd((unsigned long long *)&sx[g].mx11, (unsigned long long)(long long)rintf((float)ax1 * (float)ax1));
+    atomicAdd((unsigned long long *)&sx[g].my0, (unsigned long long)(long long)rintf((float)ax0 * (float)ay));
+    atomicAdd((unsigned long long *)&sx[g].my1, (unsigned long long)(long long)rintf((float)ax1 * (float)ay));
+  }
+}
+
+__global__ void k_refine2(PolyScratch s, ls_rec *ls, int maxrec) {
+  const int n = *(const int *)ls;
+  const lsx_rec *sx = (const lsx_rec *)s.lsx;
+  SPARSE_LOOP(g0, n) {
+    const int g = g0 + 1;
+    if (g >= maxrec || ls[g].polyid == 0) continue;
+    float rdet = (float)sx[g].mx00 * (float)sx[g].mx11 - (float)sx[g].mx01 * (float)sx[g].mx01;
+    if (rdet == 0) continue;
+    rdet = (float)(1.0 / (double)rdet);
+    const float as0 = ((float)sx[g].mx11 * (float)sx[g].my0 - (float)sx[g].mx01 * (float)sx[g].my1) * rdet;
+    const float as1 = ((float)sx[g].mx00 * (float)sx[g].my1 - (float)sx[g].mx01 * (float)sx[g].my0) * rdet;
+    ls[g].x0 += (float)sx[g].vx * as1; ls[g].y0 += (float)sx[g].vy * as1;
+    ls[g].x1 += (float)sx[g].vx * (as0 + as1); ls[g].y1 += (float)sx[g].vy * (as0 + as1);
+  }
+}
+
+// pl:772-809.  Segment g joins its end point with the start point of its right neighbour h, and h's own step reads that
+// start point, so the result depends on the order of the steps; the canonical order is ascending g.
+// Steps of non-adjacent segments commute, hence the serial result is obtained by letting a segment run as soon as every
+// neighbour with a smaller id has run and keeping neighbours with larger ids waiting: one block, rounds separated by
+// barriers; `done` lives in global scratch.
+__global__ __launch_bounds__(1024) void k_refine3(PolyScratch s, ls_rec *ls, int maxrec) {
+  __shared__ int progress;
+  const int n0 = *(const int *)ls;
+  const int n = n0 < maxrec - 1 ? n0 : maxrec - 1;
+  int *done = s.dist;   // free at this point; n <= cap
+  for (int g = threadIdx.x + 1; g <= n; g += 1024) done[g] = (ls[g].polyid == 0 || ls[g].rightPtr == 0) ? 1 : 0;
+  __syncthreads();
+  for (int iter = 0; iter <= n; iter++) {
+    if (threadIdx.x == 0) progress = 0;
+    __syncthreads();
+    // decide with the flags as they are at the start of the round
+    for (int g = threadIdx.x + 1; g <= n; g += 1024) {
+      if (done[g]) continue;
+      const int h = ls[g].rightPtr, l = ls[g].leftPtr;
+      // every step that touches g's or h's coordinates and has a smaller id must be finished:
+      //   left neighbour l (writes g.start), h itself (reads/writes h.start, h.end), h's right neighbour does not touch g or h.start
+      const bool l_ok = l <= 0 || l > g || l > n || done[l] == 1;
+      const bool h_ok = h > g || h > n || done[h] == 1;
+      if (l_ok && h_ok) done[g] = 2;   // runs in this round
+    }
+    __syncthreads();
+    for (int g = threadIdx.x + 1; g <= n; g += 1024) {
+      if (done[g] != 2) continue;
+      const int h = ls[g].rightPtr;
+      const float v0 = ls[g].x0, v1 = ls[g].y0, v2 = ls[g].x1, v3 = ls[g].y1;
+      const float u0 = ls[h].x0, u1 = ls[h].y0, u2 = ls[h].x1, u3 = ls[h].y1;
+      const float d = (v2 - v0) * (u3 - u1) - (v3 - v1) * (u2 - u0);
+      float wx, wy;
+      if ((double)fabsf(d) < 1e-6) {
+        wx = (v2 + u0) * 0.5f; wy = (v3 + u1) * 0.5f;
+      } else {
+        const float nn = (v1 - u1) * (u2 - u0) - (v0 - u0) * (u3 - u1);
+        const float q = nn / d;
+        wx = v0 + q * (v2 - v0); wy = v1 + q * (v3 - v1);
+        const float e0 = sqrtf((wx - v2) * (wx - v2) + (wy - v3) * (wy - v3));
+        const float e1 = sqrtf((wx - u0) * (wx - u0) + (wy - u1) * (wy - u1));
+        if (e0 > 10 && e1 > 10) { wx = (v2 + u0) * 0.5f; wy = (v3 + u1) * 0.5f; }
+      }
+      ls[g].x1 = wx; ls[g].y1 = wy; ls[h].x0 = wx; ls[h].y0 = wy;
+      progress = 1;
+    }
+    __syncthreads();
+    for (int g = threadIdx.x + 1; g <= n; g += 1024) if (done[g] == 2) done[g] = 1;
+    __syncthreads();
+    if (!progress) break;
+    __syncthreads();
+  }
+}
+
+__global__ void k_scatter_ids(PolyScratch s, int *ids) {
+  const int cnt = s.ctr[0];
+  SPARSE_LOOP(i, cnt) ids[s.pos[i]] = s.id[i];
+}
+
+template <typename T> T *dalloc(size_t n) { void *p = nullptr; if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr; return (T *)p; }
+
+}  // namespace
+
+namespace rdk {
+
+PolyScratch *poly_scratch_create(int iw, int ih) {
+  PolyScratch *ps = new PolyScratch();
+  const size_t N = (size_t)iw * ih;
+  ps->cap = (int)N;
+  ps->planeA = dalloc<int>(N); ps->planeB = dalloc<int>(N); ps->planeC = dalloc<int>(N);
+  ps->cidx = dalloc<int>(N);
+  ps->blk = dalloc<int>(N / CP_PER_BLOCK + 2);
+  ps->pos = dalloc<int>(N); ps->nbr = dalloc<int>(N * 8);
+  ps->lab = dalloc<int>(N); ps->alive = dalloc<int>(N); ps->ends = dalloc<int>(N);
+  for (int k = 0; k < 2; k++) { ps->nx[k] = dalloc<int>(N); ps->pv[k] = dalloc<int>(N); ps->num[k] = dalloc<int>(N); ps->link[k] = dalloc<int>(N); }
+  ps->flag = dalloc<int>(N); ps->flag2 = dalloc<int>(N);
+  ps->lab2 = dalloc<int>(N); ps->size = dalloc<int>(N); ps->rootid = dalloc<int>(N); ps->id = dalloc<int>(N); ps->dist = dalloc<int>(N + 2);
+  ps->cand = dalloc<int>(N * 8 / 4 + 64);
+  ps->ctr = dalloc<int>(64);
+  ps->lsx = dalloc<lsx_rec>(N * 16 / 56 + 2);
+  ps->segaux = dalloc<int>(2 * (N * 16 / 56 + 2));
+  (void)hipMemset(ps->ctr, 0, 64 * sizeof(int));
+  return ps;
+}
+
+void poly_scratch_destroy(PolyScratch *ps) {
+  if (!ps) return;
+  void *all[] = { ps->planeA, ps->planeB, ps->planeC, ps->cidx, ps->blk, ps->pos, ps->nbr, ps->lab, ps->alive, ps->ends, ps->nx[0], ps->nx[1], ps->pv[0], ps->pv[1],
+                  ps->num[0], ps->num[1], ps->link[0], ps->link[1], ps->flag, ps->flag2, ps->lab2, ps->size, ps->rootid, ps->id, ps->dist, ps->cand, ps->ctr, ps->lsx, ps->segaux };
+  for (void *p : all) if (p) (void)hipFree(p);
+  delete ps;
+}
+
+void polyline(hipStream_t st, PolyScratch *ps, void *lslist, int lslist_bytes, int *ids, const int *in, const int *ring_src, int ring_const,
+              float minerror, int sizeThre, int iw, int ih) {
+  const int N = iw * ih;
+  PolyScratch s = *ps;
+  ls_rec *ls = (ls_rec *)lslist;
+  const int maxrec = lslist_bytes / 56;
+  const dim3 sg(SPARSE_GRID), sb(256);
+
+  // tidy (oclpolyline.c:222-235)
+  hipLaunchKernelGGL(k_junction_nz, grid2(iw, ih), block2, 0, st, s.planeA, in, iw, ih);
+  hipLaunchKernelGGL(k_connect_poly, grid2(iw, ih), block2, 0, st, s.planeB, (const int *)s.planeA, ring_src, ring_const, iw, ih);
+  hipLaunchKernelGGL(k_stringify_p, grid2(iw, ih), block2, 0, st, s.planeA, (const int *)s.planeB, 0, iw, ih);
+  hipLaunchKernelGGL(k_stringify_p, grid2(iw, ih), block2, 0, st, s.planeB, (const int *)s.planeA, 1, iw, ih);
+  hipLaunchKernelGGL(k_remove_branch, grid2(iw, ih), block2, 0, st, s.planeC, (const int *)s.planeB, iw, ih);
+
+  // compaction of the chain pixels in raster order
+  const int nblk = cdiv(N, CP_PER_BLOCK);
+  hipLaunchKernelGGL(k_compact_count, dim3(nblk), dim3(256), 0, st, s.blk, (const int *)s.planeC, N);
+  hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, s.blk, nblk, s.ctr);
+  hipLaunchKernelGGL(k_compact_scatter, dim3(nblk), dim3(256), 0, st, s.pos, s.cidx, (const int *)s.blk, (const int *)s.planeC, N);
+
+  // chains, loops, ends (oclpolyline.c:237-266)
+  hipLaunchKernelGGL(k_build_nbr, sg, sb, 0, st, s, iw);
+  hipLaunchKernelGGL(k_chain_union, sg, sb, 0, st, s);
+  hipLaunchKernelGGL(k_flatten, sg, sb, 0, st, s.lab, (const int *)s.ctr);
+  hipLaunchKernelGGL(k_count_ends, sg, sb, 0, st, s);
+  hipLaunchKernelGGL(k_break_loops, sg, sb, 0, st, s);
+  hipLaunchKernelGGL(k_find_ends0, sg, sb, 0, st, s);
+  hipLaunchKernelGGL(k_find_ends0_flags, sg, sb, 0, st, s);
+  for (int r = 0; r < 4; r++) hipLaunchKernelGGL(k_find_ends1, sg, sb, 0, st, s, r & 1);
+  hipLaunchKernelGGL(k_find_ends2, sg, sb, 0, st, s);
+  // numbering (oclpolyline.c:268-275): three rounds 0->1->0->1
+  for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k_number, sg, sb, 0, st, s, r & 1);
+  const int *number = s.num[1];
+
+  // split at numbering jumps, size filter, compact ids (oclpolyline.c:277-295)
+  hipLaunchKernelGGL(k_sub_init, sg, sb, 0, st, s, number);
+  hipLaunchKernelGGL(k_sub_union, sg, sb, 0, st, s, number);
+  hipLaunchKernelGGL(k_flatten, sg, sb, 0, st, s.lab2, (const int *)s.ctr);
+  hipLaunchKernelGGL(k_sub_size, sg, sb, 0, st, s);
+  hipLaunchKernelGGL(k_relabel_scan, dim3(1), dim3(1024), 0, st, s, sizeThre);
+  hipLaunchKernelGGL(k_assign_ids, sg, sb, 0, st, s);
+
+  // initial segments (oclpolyline.c:191-197)
+  (void)hipMemsetAsync(lslist, 0, 56, st);
+  hipLaunchKernelGGL(k_seg_clear, sg, sb, 0, st, s, ls, lslist_bytes);
+  hipLaunchKernelGGL(k_seg_pass0a, sg, sb, 0, st, s, ls, lslist_bytes, number);
+  hipLaunchKernelGGL(k_seg_pass0b, sg, sb, 0, st, s, ls, lslist_bytes, number);
+  hipLaunchKernelGGL(k_seg_finish, sg, sb, 0, st, s, ls, lslist_bytes, iw);
+
+  // 15 subdivision rounds (oclpolyline.c:202-213)
+  for (int r = 0; r < 15; r++) {
+    hipLaunchKernelGGL(k_split_move_dist, sg, sb, 0, st, s, ls, lslist_bytes, number, iw, 1);
+    hipLaunchKernelGGL(k_split_detect, sg, sb, 0, st, s, (const ls_rec *)ls, lslist_bytes, number, minerror, iw, r);
+    hipLaunchKernelGGL(k_split_apply, sg, sb, 0, st, s, ls, lslist_bytes, iw, r);
+    hipLaunchKernelGGL(k_split_commit, dim3(1), dim3(64), 0, st, s, ls, r);
+  }
+  hipLaunchKernelGGL(k_split_move_dist, sg, sb, 0, st, s, ls, lslist_bytes, number, iw, 0);
+
+  // refinement (oclpolyline.c:299-306)
+  hipLaunchKernelGGL(k_refine0, sg, sb, 0, st, s, (const ls_rec *)ls, maxrec);
+  hipLaunchKernelGGL(k_refine1, sg, sb, 0, st, s, (const ls_rec *)ls, maxrec, iw);
+  hipLaunchKernelGGL(k_refine2, sg, sb, 0, st, s, ls, maxrec);
+  hipLaunchKernelGGL(k_refine3, dim3(1), dim3(1024), 0, st, s, ls, maxrec);
+
+  // per-pixel segment ids as a dense plane (lsIdOut)
+  (void)hipMemsetAsync(ids, 0, sizeof(int) * (size_t)N, st);
+  hipLaunchKernelGGL(k_scatter_ids, sg, sb, 0, st, s, ids);
+}
+
+}  // namespace rdk

@@ -1,0 +1,63 @@
+// rectdetect-mi355x: host-callable launchers of the gfx950 kernels (implemented in rd_k_*.hip).
+// All pointers are device pointers; every launcher enqueues on `s` and returns immediately.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rdk {
+
+// ---- rd_k_front.hip: colour, blur, gradient, non-max suppression, element-wise ops
+void bgr2plab(hipStream_t s, uint32_t *out, const uint8_t *bgr, int iw, int ih, int ws);
+void unpack_plab(hipStream_t s, float *L, float *a, float *b, const uint32_t *in, int n);
+void pack_plab(hipStream_t s, uint32_t *out, const float *L, const float *a, const float *b, int n);
+// transposes of `np` float planes (src planes W x H row-major -> dst planes H x W); src may be packed Lab (np = 3)
+void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], int np, int W, int H);
+void transpose_unpack(hipStream_t s, float *const dst[3], const uint32_t *plab, int W, int H);
+// causal + anti-causal sigma=1 IIR sweeps down the columns of np planes (W columns, H rows): fwd[k], bwd[k] <- src[k]
+void iir_columns(hipStream_t s, float *const fwd[3], float *const bwd[3], const float *const src[3], int np, int W, int H);
+// dst[k] (H x W) = transpose( bwd[k] + fwd[k] - src[k] * c0 )   with fwd/bwd/src given as W x H planes
+void iir_combine_transpose(hipStream_t s, float *const dst[3], const float *const fwd[3], const float *const bwd[3], const float *const src[3], int np, int W, int H);
+// dst[k] = bwd[k] + fwd[k] - src[k] * c0   (no transpose)
+void iir_combine(hipStream_t s, float *const dst[3], const float *const fwd[3], const float *const bwd[3], const float *const src[3], int np, int n);
+void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih);
+void edge_plab(hipStream_t s, float *out, const uint32_t *in, int iw, int ih);
+void thinthres(hipStream_t s, float *out, const float *in, const float *vxy, int iw, int ih);
+void threshold_f(hipStream_t s, float *out, const float *in, float lo, float thr, float hi, int n);
+void threshold_i(hipStream_t s, int *out, const int *in, int lo, int thr, int hi, int n);
+void cast_i_f(hipStream_t s, int *out, const float *in, float scale, int n);
+void cast_c_i(hipStream_t s, int8_t *out, const int *in, int n);
+void clear_i(hipStream_t s, int *out, int n);
+void copy_i(hipStream_t s, int *out, const int *in, int n);
+void rand_i(hipStream_t s, int *out, uint64_t seed, int n);
+
+// ---- rd_k_label.hip: connected components and per-label reductions
+// 8-connected components of equal `pix` value, pixels equal to bgc -> -1, label = smallest pixel index
+void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih);
+void calc_strength(hipStream_t s, int *out, const float *edge, const int *label, int iw, int ih);
+void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih);
+
+// ---- rd_k_rect.hip: rect-path stages
+void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih);
+void connect_rect(hipStream_t s, int *out, const int *in, int iw, int ih);
+void stringify(hipStream_t s, int *out, const int *in, int mod2, int iw, int ih);
+void blblur(hipStream_t s, uint32_t *out, const int8_t *edge, const uint32_t *in, int vertical, int iw, int ih);
+void quantize(hipStream_t s, uint32_t *out, const uint32_t *in, int n0, int n1, int n2, int n);
+void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih);
+void merge_mask(hipStream_t s, int *out, const int *junction, int iw, int ih);   // clears out, sets ring, erases discs
+void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih);
+void region_size(hipStream_t s, int *out, const int *label, int n);              // accumulates into out
+void despeckle2(hipStream_t s, int *label, int *scratch, const int *size, int thre, int iw, int ih);
+void mark_boundary(hipStream_t s, int *out, const int *in, int iw, int ih);
+void reduce_ls(hipStream_t s, int *table, int *claim, const int *boundary, const int *lsid, int iw, int ih, int nentry);
+// per segment, 15 probe points: {boundary id, table slot owner, 4 box values} -> out[(seg*15 + k)*6 ..]
+void sample_segments(hipStream_t s, int *out, const void *lslist, int max_records, const int *boundary, const int *table, int iw, int ih, int nentry);
+
+// ---- rd_k_poly.hip: polyline stage on compacted chain pixels
+struct PolyScratch;   // opaque, owned by the caller (see rd_k_poly.hip)
+PolyScratch *poly_scratch_create(int iw, int ih);
+void poly_scratch_destroy(PolyScratch *ps);
+// ring_src: plane whose 2-px frame ring supplies the stale ring values (may be null -> ring_const is used)
+void polyline(hipStream_t s, PolyScratch *ps, void *lslist, int lslist_bytes, int *ids, const int *in, const int *ring_src, int ring_const,
+              float minerror, int sizeThre, int iw, int ih);
+
+}  // namespace rdk
