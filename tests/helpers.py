@@ -1,0 +1,169 @@
+"""Test infrastructure: ctypes access to the oracle (oracle/librd_oracle.so, our CPU restatement) and, where it was
+built, to the reference itself (oracle/_ref/librdref.so).  Only tests, smoke() and bench.py's cpu_baseline leg use this."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_SO = os.path.join(ROOT, "oracle", "librd_oracle.so")
+REF_SO = os.path.join(ROOT, "oracle", "_ref", "librdref.so")
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+RECT_PLANES = {  # name -> (dtype, ints per pixel)
+    "plab0": ("u4", 1), "plab1": ("u4", 1), "Lblur": ("f4", 1), "vxy": ("f4", 2), "strength": ("f4", 1), "nms": ("f4", 1),
+    "mask0": ("i4", 1), "tidy": ("i4", 1), "label1": ("i4", 1), "str_sum": ("i4", 1), "edge500": ("i4", 1), "smooth": ("u4", 1),
+    "quant": ("u4", 1), "strong": ("i4", 1), "junction": ("i4", 1), "mergemask": ("i4", 1), "region": ("i4", 1), "rsize": ("i4", 1),
+    "boundary_src": ("i4", 1), "boundary": ("i4", 1), "lsid": ("i4", 1), "lslist": ("i4", 4), "table": ("i4", 4),
+}
+
+_oracle = None
+_ref = None
+
+
+def P(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        if not os.path.exists(ORACLE_SO):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"], stdout=subprocess.DEVNULL)
+        O = ctypes.CDLL(ORACLE_SO)
+        O.rdo_rect_new.restype = ctypes.c_void_p
+        O.rdo_rect_new.argtypes = [ctypes.c_int, ctypes.c_int]
+        O.rdo_rect_free.argtypes = [ctypes.c_void_p]
+        O.rdo_rect_plane.restype = ctypes.c_void_p
+        O.rdo_rect_plane.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+        O.rdo_rect_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        O.rdo_poly_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]
+        O.rdo_polyline.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        O.rdo_lut.restype = ctypes.POINTER(ctypes.c_uint16)
+        _oracle = O
+    return _oracle
+
+
+class OracleRect:
+    """All device stages of the rect path on the CPU (oracle/rd_oracle.c), every plane inspectable."""
+
+    def __init__(self, iw, ih):
+        self.iw, self.ih, self.N = iw, ih, iw * ih
+        self.h = oracle().rdo_rect_new(iw, ih)
+
+    def frame(self, bgr):
+        a = np.ascontiguousarray(bgr)
+        oracle().rdo_rect_frame(self.h, a.ctypes.data, a.strides[0])
+
+    def plane(self, name):
+        dt, k = RECT_PLANES[name]
+        p = oracle().rdo_rect_plane(self.h, name.encode())
+        return np.frombuffer((ctypes.c_char * (self.N * 4 * k)).from_address(p), dtype=dt).copy()
+
+    def segments(self):
+        from rectdetect_amd import LS_DTYPE
+        raw = self.plane("lslist")
+        n = int(raw[0])
+        return raw[: 14 * (n + 1)].view(LS_DTYPE).copy()
+
+    def close(self):
+        oracle().rdo_rect_free(self.h)
+
+
+def oracle_poly(bgr, strength_thre=500, minerror=1.0, size_thre=20):
+    from rectdetect_amd import LS_DTYPE
+    a = np.ascontiguousarray(bgr)
+    ih, iw = a.shape[:2]
+    N = iw * ih
+    ls = np.zeros(N * 4, np.int32)
+    ids = np.zeros(N, np.int32)
+    oracle().rdo_poly_frame(P(ls), P(ids), a.ctypes.data, iw, ih, a.strides[0], strength_thre, minerror, size_thre)
+    n = int(ls[0])
+    return ls[: 14 * (n + 1)].view(LS_DTYPE).copy(), ids
+
+
+def have_ref():
+    return os.path.exists(REF_SO)
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        R = ctypes.CDLL(REF_SO)
+        R.rdref_rect_open.restype = ctypes.c_void_p
+        R.rdref_rect_open.argtypes = [ctypes.c_int, ctypes.c_int]
+        R.rdref_rect_close.argtypes = [ctypes.c_void_p]
+        R.rdref_rect_execute_once.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_int]
+        R.rdref_rect_enqueue.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        R.rdref_rect_poll.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_void_p, ctypes.c_int]
+        R.rdref_poly_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        R.rdcl_snapshot_request.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+        R.rdcl_snapshot_fetch.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
+        R.rdcl_trace_name.restype = ctypes.c_char_p
+        R.rdcl_trace_name.argtypes = [ctypes.c_int]
+        _ref = R
+    return _ref
+
+
+# where each oracle plane lives in a run of the reference: (kernel, occurrence, argument index)
+REF_SNAPSHOTS = {
+    "plab0": ("imgutil:bgr2plab", 0, 0), "Lblur": ("imgutil:iirblur_f_f_pass3", 2, 0), "plab1": ("imgutil:pack_plab", 0, 0),
+    "vxy": ("imgutil:edgevec_f", 0, 0), "strength": ("imgutil:edge_plab", 0, 0), "nms": ("imgutil:thinthres_f_f_f2", 0, 0),
+    "mask0": ("imgutil:cast_i_f", 0, 0), "tidy": ("rect:stringify", 1, 0), "str_sum": ("rect:calcStrength", 0, 0),
+    "edge500": ("imgutil:threshold_i_i", 0, 0), "smooth": ("rect:blblur1", 9, 0), "quant": ("rect:despeckle", 0, 0),
+    "strong": ("imgutil:threshold_i_i", 1, 0), "label1": ("rect:filterStrength", 1, 0), "junction": ("rect:simpleJunction", 1, 0),
+    "mergemask": ("rect:mkMergeMask1", 0, 0), "rsize": ("rect:calcSize", 0, 0), "region": ("rect:despeckle2", 0, 0),
+    "boundary_src": ("rect:markBoundary", 0, 0), "boundary": ("imgutil:label8xMain_int_int", 19, 0),
+    "lslist": ("polyline:refine_pass3", 0, 0), "lsid": ("polyline:refine_pass1", 0, 2), "table": ("rect:reduceLS", 0, 0),
+    "flags_label1": ("imgutil:label8xMain_int_int", 9, 2), "flags_boundary": ("imgutil:label8xMain_int_int", 19, 2),
+    "flags_chain": ("polyline:label8xMain_int_int", 9, 2), "flags_sub": ("polyline:labelpl_main", 10, 2),
+}
+
+
+def ref_snapshot_fetch(handle, dtype):
+    p = ctypes.c_void_p()
+    sz = ctypes.c_size_t()
+    o = ctypes.c_int()
+    if ref().rdcl_snapshot_fetch(handle, ctypes.byref(p), ctypes.byref(sz), ctypes.byref(o)) != 0:
+        raise RuntimeError("snapshot not taken")
+    return np.frombuffer((ctypes.c_char * sz.value).from_address(p.value), dtype=dtype).copy()
+
+
+class RefRect:
+    """The reference's oclrect_* API running on the serial OpenCL shim, with access to intermediate planes."""
+
+    def __init__(self, iw, ih):
+        self.iw, self.ih = iw, ih
+        self.h = ref().rdref_rect_open(iw, ih)
+
+    def execute_once(self, bgr, tan_aov, snapshots=()):
+        from rectdetect_amd import RECT_DTYPE
+        R = ref()
+        a = np.ascontiguousarray(bgr).copy()
+        R.rdcl_trace_reset()
+        R.rdcl_snapshot_clear()
+        hs = {k: R.rdcl_snapshot_request(REF_SNAPSHOTS[k][0].encode(), REF_SNAPSHOTS[k][1], REF_SNAPSHOTS[k][2]) for k in snapshots}
+        out = np.zeros(1024, RECT_DTYPE)
+        k = R.rdref_rect_execute_once(self.h, a.ctypes.data, a.strides[0], float(tan_aov), out.ctypes.data, 1024)
+        self.launches = R.rdcl_trace_count()
+        snaps = {name: ref_snapshot_fetch(h, "u4") for name, h in hs.items()}
+        return out[1:k].copy(), snaps
+
+    def close(self):
+        ref().rdref_rect_close(self.h)
+
+
+def rects_equal(a, b):
+    return len(a) == len(b) and all(a[f].tobytes() == b[f].tobytes() for f in ("c2", "c3", "value", "status"))
+
+
+def segments_equal(a, b):
+    """bit-exact comparison of the valid records of two linesegment_t lists (records with polyid == 0 carry no meaning)."""
+    if len(a) != len(b) or int(a.view("i4")[0]) != int(b.view("i4")[0]):
+        return False
+    va, vb = a[1:], b[1:]
+    if not np.array_equal(va["polyid"] != 0, vb["polyid"] != 0):
+        return False
+    m = va["polyid"] != 0
+    return va[m].tobytes() == vb[m].tobytes()
