@@ -1,0 +1,91 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads without a GPU and exports every function that
+include/*.h declares; calling into the detector without a GPU fails loudly (no CPU fallback)."""
+import ctypes
+import glob
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+import rectdetect_amd as ra
+from tests import helpers
+
+HDRS = sorted(glob.glob(os.path.join(helpers.ROOT, "include", "*.h")))
+
+
+def declared_functions(path):
+    txt = open(path).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"//[^\n]*", "", txt)
+    txt = re.sub(r"#[^\n]*", "", txt)
+    names = set()
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_]*)\s*\(([^;{}()]|\([^()]*\))*\)\s*;", txt):
+        n = m.group(1)
+        if n not in ("sizeof", "defined", "for", "if", "return", "while") and not n.startswith("RD_"):
+            names.add(n)
+    return names
+
+
+def test_headers_present():
+    base = {os.path.basename(h) for h in HDRS}
+    assert {"helper.h", "oclhelper.h", "oclimgutil.h", "oclpolyline.h", "oclrect.h", "vec234.h", "rectdetect_hip.h"} <= base
+
+
+@pytest.mark.parametrize("hdr", [h for h in HDRS if not h.endswith("vec234.h")])
+def test_every_declared_symbol_is_exported(hdr):
+    L = ctypes.CDLL(ra.LIB_PATH)
+    names = declared_functions(hdr)
+    assert len(names) >= 3, (hdr, names)
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, f"{os.path.basename(hdr)} declares symbols the library does not export: {missing}"
+
+
+def test_reference_surface_counts():
+    """24 operator wrappers + init/dispose in oclimgutil.h (reference oclimgutil.h:74-100)"""
+    names = declared_functions(os.path.join(helpers.ROOT, "include", "oclimgutil.h"))
+    assert len([n for n in names if n.startswith("oclimgutil_")]) == 24
+    assert {"init_oclimgutil", "dispose_oclimgutil"} <= names
+
+
+def test_headers_compile_as_c_and_cpp(tmp_path):
+    src = '#define CL_TARGET_OPENCL_VERSION 120\n#include <stdint.h>\n#include <CL/cl.h>\n#include "vec234.h"\n#include "helper.h"\n#include "oclhelper.h"\n' \
+          '#include "oclimgutil.h"\n#include "oclpolyline.h"\n#include "oclrect.h"\n#include "rectdetect_hip.h"\n' \
+          'int main(void){ rect_t r; linesegment_t l; (void)r; (void)l; return sizeof(rect_t) == 176 && sizeof(linesegment_t) == 56 ? 0 : 1; }\n'
+    for comp, ext in (("gcc", "c"), ("g++", "cpp")):
+        f = tmp_path / f"t.{ext}"
+        f.write_text(src)
+        exe = tmp_path / f"t_{ext}"
+        subprocess.check_call([comp, "-I", os.path.join(helpers.ROOT, "include"), str(f), "-o", str(exe)])
+        assert subprocess.call([str(exe)]) == 0
+
+
+def test_no_gpu_means_loud_failure():
+    """In a process without a HIP device the detector refuses to start instead of computing on the CPU."""
+    code = "import rectdetect_amd as ra, sys\n" \
+           "sys.exit(3) if ra.lib().rd_device_count() > 0 else None\n" \
+           "ra.Detector(64, 48)\n"
+    p = subprocess.run([sys.executable, "-c", code], cwd=helpers.ROOT, capture_output=True, text=True)
+    if p.returncode == 3:
+        pytest.skip("a GPU is visible here")
+    assert p.returncode != 0
+    assert "no CPU" in (p.stderr + p.stdout) or "no HIP device" in (p.stderr + p.stdout)
+
+
+def test_product_does_not_reference_the_oracle():
+    """nothing under rectdetect_amd/ or include/ may import, link or load anything from oracle/"""
+    bad = []
+    for root in ("rectdetect_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(helpers.ROOT, root)):
+            if "build" in dp:
+                continue
+            for fn in fns:
+                if fn.endswith((".so", ".o", ".pyc")):
+                    continue
+                txt = open(os.path.join(dp, fn), errors="ignore").read()
+                if re.search(r"rd_oracle|librd_oracle|librdref|oracle/", txt):
+                    bad.append(os.path.join(dp, fn))
+    assert not bad, bad
+    out = subprocess.check_output(["ldd", ra.LIB_PATH], text=True)
+    assert "oracle" not in out and "rdref" not in out

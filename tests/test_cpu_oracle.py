@@ -1,0 +1,134 @@
+"""CPU tests: the oracle (oracle/rd_oracle*.c, our restatement) against golden vectors that were produced by the
+reference itself (tools/make_golden.py), the host post-process, the LUT closed forms and the synthetic generator."""
+import glob
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import rectdetect_amd as ra
+from rectdetect_amd import synth
+from tests import helpers
+
+
+def crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+def golden(name):
+    return np.load(os.path.join(helpers.GOLDEN, name + ".npz"), allow_pickle=False)
+
+
+RECT_FAST = ["rect_640x480_s0", "rect_640x480_s5", "rect_333x217_s2", "rect_1280x720_s1"]
+
+
+@pytest.mark.parametrize("name", RECT_FAST)
+def test_oracle_matches_reference_golden_planes(name):
+    """Every intermediate plane of the restatement has the CRC the reference produced, frame after frame (H1 state)."""
+    g = golden(name)
+    iw, ih, N = int(g["iw"]), int(g["ih"]), int(g["iw"]) * int(g["ih"])
+    orc = helpers.OracleRect(iw, ih)
+    planes = [str(p) for p in g["planes"]]
+    sizes = {"vxy": 2 * N, "table": (N * 4 // 5) * 5}
+    for t in range(int(g["nframes"])):
+        img = synth.frame(int(g["seed"]), iw, ih, t)
+        assert crc(img) == int(g[f"f{t}_input_crc"])
+        # parity is asserted where the reference's fixed-pass labelling had converged (last flag 0): SURVEY.md H4
+        flags = g[f"f{t}_flags"]
+        assert (flags[:, 10] == 0).all() and flags[3, 11] == 0
+        orc.frame(img)
+        got = [crc(orc.plane(p).view(np.uint32)[: sizes.get(p, N)]) for p in planes]
+        bad = [p for p, a, b in zip(planes, got, g[f"f{t}_plane_crc"]) if a != int(b)]
+        assert not bad, f"frame {t}: planes differ from the reference: {bad}"
+        assert helpers.segments_equal(orc.segments(), g[f"f{t}_segments"])
+    orc.close()
+
+
+@pytest.mark.parametrize("name", RECT_FAST)
+def test_postprocess_matches_reference_rectangles(name):
+    """csrc/rd_post.c on the oracle's planes returns exactly the rect_t list the reference returned."""
+    g = golden(name)
+    iw, ih = int(g["iw"]), int(g["ih"])
+    orc = helpers.OracleRect(iw, ih)
+    for t in range(int(g["nframes"])):
+        orc.frame(synth.frame(int(g["seed"]), iw, ih, t))
+        rects = ra.postprocess_planes(orc.segments(), orc.plane("boundary"), orc.plane("table"), iw, ih, float(g["tan_aov"]))
+        assert helpers.rects_equal(rects, g[f"f{t}_rects"])
+    orc.close()
+
+
+@pytest.mark.parametrize("name", ["poly_640x480_s0", "poly_333x217_s2", "poly_1280x720_s1_vid"])
+def test_oracle_poly_path_matches_reference(name):
+    g = golden(name)
+    iw, ih = int(g["iw"]), int(g["ih"])
+    img = synth.frame(int(g["seed"]), iw, ih, 0)
+    assert crc(img) == int(g["input_crc"])
+    segs, ids = helpers.oracle_poly(img, int(g["strength_thre"]), float(g["minerror"]), int(g["size_thre"]))
+    assert helpers.segments_equal(segs, g["segments"])
+    assert crc(ids) == int(g["ids_crc"])
+    assert int(g["launches"]) == 163      # the reference's own launch count on this path
+
+
+def test_reference_launch_count_recorded():
+    assert int(golden("rect_640x480_s0")["f0_launches"]) == 220
+
+
+def test_lut_closed_forms():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_luts", os.path.join(helpers.ROOT, "tools", "gen_luts.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    O = helpers.oracle()
+    import ctypes
+    for which, tab in enumerate(m.tables()):
+        n = ctypes.c_int()
+        p = O.rdo_lut(which, ctypes.byref(n))
+        assert np.array_equal(np.ctypeslib.as_array(p, (n.value,)), np.array(tab))
+    # the generated header is up to date
+    hdr = open(os.path.join(helpers.ROOT, "rectdetect_amd", "csrc", "rd_luts.h")).read()
+    assert ",".join(str(v) for v in m.tables()[1][:16]) in hdr
+
+
+def test_synth_c_and_numpy_twins_agree():
+    L = ra.lib()
+    for iw, ih, t in [(64, 48, 0), (333, 217, 5), (640, 480, 299)]:
+        a = np.zeros((ih, iw * 3 + 5), np.uint8)
+        L.rd_synth_frame(a.ctypes.data, iw, ih, iw * 3 + 5, synth.SEED0 + 3, t, 1)
+        b = synth.frame(synth.SEED0 + 3, iw, ih, t)
+        assert np.array_equal(a[:, : iw * 3].reshape(ih, iw, 3), b)
+    assert synth.num_quads(1920, 1080) == 12 == L.rd_synth_num_quads(1920, 1080)
+    assert synth.num_quads(640, 480) == 3
+
+
+def test_oracle_edge_cases():
+    """empty (flat) frame, tiny frame, frame narrower than a wavefront"""
+    for iw, ih in [(64, 48), (40, 33), (130, 70)]:
+        flat = np.full((ih, iw, 3), 40, np.uint8)
+        orc = helpers.OracleRect(iw, ih)
+        orc.frame(flat)
+        assert int(orc.segments().view("i4")[0]) == 0
+        rects = ra.postprocess_planes(orc.segments(), orc.plane("boundary"), orc.plane("table"), iw, ih, 0.7)
+        assert len(rects) == 0
+        orc.close()
+
+
+@pytest.mark.ref
+def test_oracle_against_live_reference_new_seed():
+    """where the reference build exists: a seed that has no golden file, compared plane by plane"""
+    iw, ih = 320, 240
+    img = synth.frame(synth.SEED0 + 11, iw, ih, 3)
+    r = helpers.RefRect(iw, ih)
+    names = ["plab0", "Lblur", "plab1", "vxy", "strength", "nms", "tidy", "str_sum", "smooth", "quant", "strong", "mergemask", "region", "boundary", "lsid", "table"]
+    rects, snaps = r.execute_once(img, 0.7, snapshots=names + ["lslist"])
+    r.close()
+    orc = helpers.OracleRect(iw, ih)
+    orc.frame(img)
+    N = iw * ih
+    sizes = {"vxy": 2 * N, "table": (N * 4 // 5) * 5}
+    for p in names:
+        k = sizes.get(p, N)
+        assert np.array_equal(orc.plane(p).view(np.uint32)[:k], snaps[p][:k]), p
+    mine = ra.postprocess_planes(orc.segments(), orc.plane("boundary"), orc.plane("table"), iw, ih, 0.7)
+    assert helpers.rects_equal(mine, rects)
+    orc.close()
