@@ -360,8 +360,9 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   rdk::reduce_ls(st, s->table, s->claim, s->boundary, s->lsid, iw, ih, nentry);
   rdk::sample_segments(st, s->probes, s->lslist, d->maxrec_dev, s->boundary, s->table, iw, ih, nentry);
 
-  RD_HIP(hipMemcpyAsync(s->h_segs, s->lslist, (size_t)RD_MAXREC * 56, hipMemcpyDeviceToHost, st));
-  RD_HIP(hipMemcpyAsync(s->h_probes, s->probes, (size_t)RD_MAXREC * 15 * 6 * sizeof(int), hipMemcpyDeviceToHost, st));
+  const int ncopy = d->maxrec_dev < RD_MAXREC ? d->maxrec_dev : RD_MAXREC;
+  RD_HIP(hipMemcpyAsync(s->h_segs, s->lslist, (size_t)ncopy * 56, hipMemcpyDeviceToHost, st));
+  RD_HIP(hipMemcpyAsync(s->h_probes, s->probes, (size_t)ncopy * 15 * 6 * sizeof(int), hipMemcpyDeviceToHost, st));
   RD_HIP(hipEventRecord(s->ev_done, st));
   rdrt::check_launch("rect frame");
 }
@@ -422,8 +423,8 @@ void *rd_detector_poll(rd_detector *d, double tanAOV) {
   int n = ((int *)s->h_segs)[0];
   const void *segs = s->h_segs; const int *probes = s->h_probes;
   void *big_segs = NULL; int *big_probes = NULL;
-  int maxrec = RD_MAXREC;
-  if (n + 1 > RD_MAXREC) {   // rare: more segments than the fixed-size transfer covers
+  int maxrec = d->maxrec_dev < RD_MAXREC ? d->maxrec_dev : RD_MAXREC;
+  if (n + 1 > maxrec) {   // rare: more segments than the fixed-size transfer covers
     if (n + 1 > d->maxrec_dev) n = d->maxrec_dev - 1;
     big_segs = malloc((size_t)(n + 1) * 56); big_probes = (int *)malloc((size_t)(n + 1) * 15 * 6 * sizeof(int));
     RD_HIP(hipMemcpy(big_segs, s->lslist, (size_t)(n + 1) * 56, hipMemcpyDeviceToHost));

@@ -133,32 +133,27 @@ __global__ __launch_bounds__(64) void k_iir_columns(P3 fwd, P3 bwd, P3c src, int
   const int count = H + IIR_WARM + dir;   // down: -11..H-1, up: H+11..0
   float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
   float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+  // Loads and recurrence steps are unconditional (indices clamped into the mirrored range; steps past the end of the
+  // sweep compute garbage that is never stored), so the compiler keeps IIR_CH independent loads in flight while the
+  // previous chunk's dependent chain runs.
+  const int ylo = -IIR_WARM, yhi = H + IIR_WARM;
   float cur[IIR_CH], nxt[IIR_CH];
 #pragma unroll
-  for (int j = 0; j < IIR_CH; j++) {
-    const int yy = y0 + j * step;
-    cur[j] = j < count ? in[(size_t)mirror1(yy, H) * W] : 0.0f;
-  }
+  for (int j = 0; j < IIR_CH; j++) cur[j] = in[(size_t)mirror1(clampi(y0 + j * step, ylo, yhi), H) * W];
   for (int base = 0; base < count; base += IIR_CH) {
 #pragma unroll
-    for (int j = 0; j < IIR_CH; j++) {
-      const int n = base + IIR_CH + j;
-      const int yy = y0 + n * step;
-      nxt[j] = n < count ? in[(size_t)mirror1(yy, H) * W] : 0.0f;
-    }
+    for (int j = 0; j < IIR_CH; j++) nxt[j] = in[(size_t)mirror1(clampi(y0 + (base + IIR_CH + j) * step, ylo, yhi), H) * W];
 #pragma unroll
     for (int j = 0; j < IIR_CH; j++) {
       const int n = base + j;
-      if (n < count) {
-        const int yy = y0 + n * step;
-        const float i0 = cur[j];
-        float d = i0 * IIR_C0;
-        d += IIR_C1 * i1 + IIR_C2 * i2 + IIR_C3 * i3 + IIR_C4 * i4 + IIR_C5 * i5 + IIR_C6 * i6 + IIR_C7 * i7;
-        d += IIR_C8 * t0 + IIR_C9 * t1 + IIR_C10 * t2 + IIR_C11 * t3 + IIR_C12 * t4 + IIR_C13 * t5 + IIR_C14 * t6;
-        if (yy >= 0 && yy < H) out[(size_t)yy * W] = d;
-        i7 = i6; i6 = i5; i5 = i4; i4 = i3; i3 = i2; i2 = i1; i1 = i0;
-        t6 = t5; t5 = t4; t4 = t3; t3 = t2; t2 = t1; t1 = t0; t0 = d;
-      }
+      const int yy = y0 + n * step;
+      const float i0 = cur[j];
+      float d = i0 * IIR_C0;
+      d += IIR_C1 * i1 + IIR_C2 * i2 + IIR_C3 * i3 + IIR_C4 * i4 + IIR_C5 * i5 + IIR_C6 * i6 + IIR_C7 * i7;
+      d += IIR_C8 * t0 + IIR_C9 * t1 + IIR_C10 * t2 + IIR_C11 * t3 + IIR_C12 * t4 + IIR_C13 * t5 + IIR_C14 * t6;
+      if (n < count && yy >= 0 && yy < H) out[(size_t)yy * W] = d;
+      i7 = i6; i6 = i5; i5 = i4; i4 = i3; i3 = i2; i2 = i1; i1 = i0;
+      t6 = t5; t5 = t4; t4 = t3; t3 = t2; t2 = t1; t1 = t0; t0 = d;
     }
 #pragma unroll
     for (int j = 0; j < IIR_CH; j++) cur[j] = nxt[j];

@@ -203,22 +203,36 @@ __global__ __launch_bounds__(256) void k_region_propose(const int *__restrict__ 
                                                         const int *__restrict__ edge, int iw, int ih, const int *flags, int round) {
   if (round > 0 && flags[round - 1] == 0) return;
   RD_XY;
-  if (x <= 0 || y <= 0 || x >= iw - 1 || y >= ih - 1) return;
-  const int p0 = y * iw + x;
-  const int og = label[p0];
-  int g = og;
-  const int c = pix[p0];
-  const bool any = mask[p0] != 0;
-  const bool e0 = edge[p0] <= 0;
-  int p1, s;
-  p1 = p0 - iw; s = label[p1]; if (s < g && (c == pix[p1] || any) && e0) g = s;
-  p1 = p0 - 1;  s = label[p1]; if (s < g && (c == pix[p1] || any) && e0) g = s;
-  p1 = p0 + 1;  s = label[p1]; if (s < g && (c == pix[p1] || any) && edge[p1] <= 0) g = s;
-  p1 = p0 + iw; s = label[p1]; if (s < g && (c == pix[p1] || any) && edge[p1] <= 0) g = s;
-  g = uf_find(label, g);
-  if (g != og) {
-    atomicMin(&prop[og], g);
-    atomicMin(&prop[p0], g);
+  const bool inside = x > 0 && y > 0 && x < iw - 1 && y < ih - 1;
+  int og = 0, g = 0, p0 = 0;
+  if (inside) {
+    p0 = y * iw + x;
+    og = label[p0];
+    g = og;
+    const int c = pix[p0];
+    const bool any = mask[p0] != 0;
+    const bool e0 = edge[p0] <= 0;
+    int p1, s;
+    p1 = p0 - iw; s = label[p1]; if (s < g && (c == pix[p1] || any) && e0) g = s;
+    p1 = p0 - 1;  s = label[p1]; if (s < g && (c == pix[p1] || any) && e0) g = s;
+    p1 = p0 + 1;  s = label[p1]; if (s < g && (c == pix[p1] || any) && edge[p1] <= 0) g = s;
+    p1 = p0 + iw; s = label[p1]; if (s < g && (c == pix[p1] || any) && edge[p1] <= 0) g = s;
+    for (int j = 0; j < 8; j++) g = label[g];   // rc:328: eight pointer jumps
+  }
+  bool todo = inside && g != og;
+  if (todo && g < prop[p0]) atomicMin(&prop[p0], g);
+  // the old parent is shared by (up to) a whole region: one atomic per distinct parent per wave, and only if it can
+  // still lower the stored proposal (a stale read only costs a redundant atomic)
+  while (__any(todo)) {
+    const unsigned long long m = __ballot(todo);
+    const int leader = __ffsll((long long)m) - 1;
+    const int lo = __shfl(og, leader);
+    const bool mine = todo && og == lo;
+    int v = mine ? g : 0x7fffffff;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    if ((int)threadIdx.x == leader && v < prop[lo]) atomicMin(&prop[lo], v);
+    if (mine) todo = false;
   }
 }
 
@@ -458,7 +472,7 @@ void merge_mask(hipStream_t s, int *out, const int *junction, int iw, int ih) {
 
 // scratch: 2*N ints (proposal plane + round flags at the start of the second plane)
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih) {
-  const int n = iw * ih, ROUNDS = 24;
+  const int n = iw * ih, ROUNDS = 32;
   int *prop = scratch, *flags = scratch + n;
   (void)hipMemsetAsync(prop, 0x7f, sizeof(int) * (size_t)n, s);
   (void)hipMemsetAsync(flags, 0, sizeof(int) * (ROUNDS + 1), s);
