@@ -92,7 +92,7 @@ def main():
             a = np.zeros((IH, IW, 3), np.uint8)
             L.rd_synth_frame(a.ctypes.data, IW, IH, IW * 3, synth.SEED0 + seed_stream, t, 1)
             frames.append(a)
-        det = ra.Detector(IW, IH, device=local, nslots=args.slots)
+        det = ra.Detector(IW, IH, device=local, nslots=args.slots, nworkers=1)
         dframes = []
         for a in frames:
             p = L.rd_device_alloc(a.nbytes)

@@ -44,6 +44,10 @@ void rd_detector_drain(rd_detector *d);
 /* copy of the line-segment list of the most recently POLLED frame: returns n (records 1..n), writes up to max records */
 int rd_detector_last_segments(rd_detector *d, void *dst, int max_records);
 
+/* counters since creation: which 0 = frames whose polyline stage did not fit the single-launch kernel's on-chip tables and
+ * was repeated with the multi-launch path (same results, slower) */
+long rd_detector_counter(rd_detector *d, int which);
+
 /* Test hook: copy an internal plane of the most recently completed frame to host memory.  Returns bytes written,
  * 0 for an unknown name.  Names: plab0 plab1 lblur vxy strength nms mask0 tidy label1 strsum edge500 smooth quant
  * strong junction mergemask region rsize boundarysrc boundary lsid */

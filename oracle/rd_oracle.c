@@ -810,3 +810,92 @@ int rdo_despeckle2_jacobi(int *label, const int *size, int thre, int iw, int ih,
   free(old); free(cur); free(nxt);
   return rounds;
 }
+
+/* experiment "S": (1) union-find over the initial links and the symmetric allowed pairs, (2) synchronous rounds of
+ * root-level adoption over the asymmetric pairs (masked pixel may adopt a differently coloured neighbour's tree). */
+int rdo_region_S(int *label, const int *pix, const int *mask, const int *edge, int iw, int ih) {
+  const int N = iw * ih;
+  int *lab = (int *)malloc(sizeof(int) * N), *nxt = (int *)malloc(sizeof(int) * N);
+  rdo_region_label_init(label, pix, iw, ih);
+  for (int p = 0; p < N; p++) lab[p] = p;
+  for (int p = 0; p < N; p++) if (label[p] != p) uf_union(lab, p, label[p]);
+  for (int y = 1; y < ih - 1; y++)
+    for (int x = 1; x < iw - 1; x++) {
+      const int p0 = y * iw + x;
+      const int nb[4] = { p0 - iw, p0 - 1, p0 + 1, p0 + iw };
+      for (int k = 0; k < 4; k++) {
+        const int p1 = nb[k];
+        const int eok = k < 2 ? edge[p0] <= 0 : edge[p1] <= 0;
+        if (!eok) continue;
+        const int x1 = p1 % iw, y1 = p1 / iw;
+        const int p1_interior = x1 > 0 && y1 > 0 && x1 < iw - 1 && y1 < ih - 1;
+        if (pix[p0] == pix[p1] || (mask[p0] != 0 && mask[p1] != 0 && p1_interior)) uf_union(lab, p0, p1);
+      }
+    }
+  int rounds = 0;
+  for (;;) {
+    for (int p = 0; p < N; p++) lab[p] = uf_find(lab, p);
+    for (int p = 0; p < N; p++) nxt[p] = lab[p];
+    int changed = 0;
+    for (int y = 1; y < ih - 1; y++)
+      for (int x = 1; x < iw - 1; x++) {
+        const int p0 = y * iw + x;
+        if (mask[p0] == 0) continue;
+        const int nb[4] = { p0 - iw, p0 - 1, p0 + 1, p0 + iw };
+        for (int k = 0; k < 4; k++) {
+          const int p1 = nb[k];
+          const int eok = k < 2 ? edge[p0] <= 0 : edge[p1] <= 0;
+          if (!eok || pix[p0] == pix[p1]) continue;
+          const int ra = lab[p0], rb = lab[p1];
+          if (rb < ra && rb < nxt[ra]) { nxt[ra] = rb; changed = 1; }
+        }
+      }
+    rounds++;
+    if (!changed) break;
+    for (int p = 0; p < N; p++) if (lab[p] == p && nxt[p] < p) lab[p] = nxt[p];
+  }
+  for (int p = 0; p < N; p++) label[p] = lab[p];
+  free(lab); free(nxt);
+  return rounds;
+}
+
+/* experiment: chunked evaluation of one IIR sweep.  Chunk c covers logical steps [c*C, (c+1)*C); it starts Wm steps
+ * earlier with zero state (real inputs) and its results are accepted as-is.  Returns the number of output samples
+ * that differ (bitwise) from the full sweep; *unverified counts chunk starts whose 7 preceding outputs differ. */
+int rdo_iir_chunk_test(const float *src, int n, int st, int dir, int C, int Wm, int *unverified) {
+  float *full = (float *)malloc(sizeof(float) * (size_t)n * st + 64), *chk = (float *)malloc(sizeof(float) * (size_t)n * st + 64);
+  memset(full, 0, sizeof(float) * (size_t)n * st);
+  memset(chk, 0, sizeof(float) * (size_t)n * st);
+  iir_sweep(full, src, n, st, dir);
+  const int count = n + IIR_WARM + (dir > 0 ? 0 : 1);
+  const int x0 = dir > 0 ? -IIR_WARM : n + IIR_WARM;
+  int bad = 0, unv = 0;
+  for (int c0 = 0; c0 < count; c0 += C) {
+    const int begin = c0 == 0 ? 0 : (c0 - Wm < 0 ? 0 : c0 - Wm);
+    float iv[8] = { 0 }, tv[8] = { 0 };
+    float tail_w[7]; int ok = 1;
+    for (int s = begin; s < count && s < c0 + C; s++) {
+      const int x = x0 + s * dir;
+      iv[0] = src[mirror1(x, n) * st];
+      float d = iv[0] * IIR[0];
+      d += IIR[1] * iv[1] + IIR[2] * iv[2] + IIR[3] * iv[3] + IIR[4] * iv[4] + IIR[5] * iv[5] + IIR[6] * iv[6] + IIR[7] * iv[7];
+      d += IIR[8] * tv[0] + IIR[9] * tv[1] + IIR[10] * tv[2] + IIR[11] * tv[3] + IIR[12] * tv[4] + IIR[13] * tv[5] + IIR[14] * tv[6];
+      if (s >= c0 && x >= 0 && x < n) chk[x * st] = d;
+      if (s < c0 && s >= c0 - 7) tail_w[s - (c0 - 7)] = d;
+      for (int k = 7; k > 0; k--) { iv[k] = iv[k - 1]; tv[k] = tv[k - 1]; }
+      tv[0] = d;
+    }
+    (void)tail_w; (void)ok;
+  }
+  for (int x = 0; x < n; x++) if (memcmp(&full[x * st], &chk[x * st], 4) != 0) bad++;
+  /* a chunk start is "verified" when the 7 outputs before it agree between the warm-up run and the true sweep; here we
+   * simply count chunks containing a wrong sample */
+  for (int c0 = C; c0 < count; c0 += C) {
+    int wrong = 0;
+    for (int s = c0; s < count && s < c0 + C; s++) { const int x = x0 + s * dir; if (x >= 0 && x < n && memcmp(&full[x * st], &chk[x * st], 4) != 0) wrong = 1; }
+    unv += wrong;
+  }
+  *unverified = unv;
+  free(full); free(chk);
+  return bad;
+}

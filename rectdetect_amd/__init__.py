@@ -58,6 +58,7 @@ def _declare(L):
         "rd_detector_enqueue": (ctypes.c_long, [vp, vp, ci, ci]),
         "rd_detector_poll": (vp, [vp, cd]),
         "rd_detector_drain": (None, [vp]),
+        "rd_detector_counter": (ctypes.c_long, [vp, ci]),
         "rd_detector_last_segments": (ci, [vp, vp, ci]),
         "rd_detector_debug_plane": (cz, [vp, ctypes.c_char_p, vp, cz]),
         "rd_postprocess_planes": (vp, [vp, vp, vp, ci, ci, cd]),
@@ -256,6 +257,10 @@ class Detector:
 
     def drain(self):
         lib().rd_detector_drain(self.h)
+
+    def redone_frames(self):
+        """frames whose polyline stage overflowed the single-launch kernel and was repeated the long way"""
+        return lib().rd_detector_counter(self.h, 0)
 
     def last_segments(self):
         n = lib().rd_detector_last_segments(self.h, None, 0)

@@ -27,12 +27,15 @@ template <typename T> static T *dnew(size_t n) { void *p = NULL; RD_HIP(hipMallo
 static void dfree(void *p) { if (p) RD_HIP(hipFree(p)); }
 
 // ================================================================================================ oclimgutil
-struct ImgutilImpl { int N; float *s[3]; };
+struct ImgutilImpl { int N; float *s[3]; float *tails; int *flags; };
 
 static void imgutil_scratch(oclimgutil_t *t, int N) {
   ImgutilImpl *im = (ImgutilImpl *)t->impl;
   if (im->N >= N) return;
   for (int k = 0; k < 3; k++) { dfree(im->s[k]); im->s[k] = dnew<float>((size_t)N); }
+  dfree(im->tails); dfree(im->flags);
+  im->tails = dnew<float>((size_t)N);   // >= iir_scratch_floats(1, ., .) for any frame with both sides >= 64
+  im->flags = dnew<int>(16);
   im->N = N;
 }
 
@@ -50,6 +53,7 @@ void dispose_oclimgutil(oclimgutil_t *t) {
   if (!t || t->magic != MAGIC_IMGUTIL) exitf(-1, "dispose_oclimgutil: bad handle\n");
   ImgutilImpl *im = (ImgutilImpl *)t->impl;
   for (int k = 0; k < 3; k++) dfree(im->s[k]);
+  dfree(im->tails); dfree(im->flags);
   free(im);
   t->magic = 0;
   free(t);
@@ -124,11 +128,13 @@ cl_event oclimgutil_iirblur_f_f(oclimgutil_t *thiz, cl_mem obuf, cl_mem ibuf, cl
   float *d1[3] = { im->s[0], NULL, NULL }; const float *s1[3] = { in, NULL, NULL };
   rdk::transpose_f(s, d1, s1, 1, iw, ih);                                   // s0 = in^T (ih wide)
   float *f[3] = { im->s[1], NULL, NULL }, *b[3] = { im->s[2], NULL, NULL }; const float *c[3] = { im->s[0], NULL, NULL };
-  rdk::iir_columns(s, f, b, c, 1, ih, iw);                                  // sweeps along x of the original
+  const bool chunked = rdk::iir_scratch_floats(1, ih, iw) <= (size_t)iw * ih && rdk::iir_scratch_floats(1, iw, ih) <= (size_t)iw * ih;
+  if (chunked) RD_HIP(hipMemsetAsync(im->flags, 0, 16 * sizeof(int), s));
+  rdk::iir_columns(s, f, b, c, 1, ih, iw, chunked ? im->tails : NULL, chunked ? im->flags : NULL);   // sweeps along x of the original
   float *oo[3] = { o, NULL, NULL }; const float *fc[3] = { im->s[1], NULL, NULL }, *bc[3] = { im->s[2], NULL, NULL };
   rdk::iir_combine_transpose(s, oo, fc, bc, c, 1, ih, iw);                  // o = horizontal result, original layout
   float *f2[3] = { t0, NULL, NULL }, *b2[3] = { t1, NULL, NULL }; const float *c2[3] = { o, NULL, NULL };
-  rdk::iir_columns(s, f2, b2, c2, 1, iw, ih);
+  rdk::iir_columns(s, f2, b2, c2, 1, iw, ih, chunked ? im->tails : NULL, chunked ? im->flags + 1 : NULL);
   const float *f2c[3] = { t0, NULL, NULL }, *b2c[3] = { t1, NULL, NULL };
   rdk::iir_combine(s, oo, f2c, b2c, c2, 1, iw * ih);
   IU_END("oclimgutil_iirblur_f_f");
@@ -215,7 +221,7 @@ cl_event oclpolyline_execute(oclpolyline_t *thiz, cl_mem lsList, int lsListSize,
     im->iw = iw; im->ih = ih;
   }
   rdrt::wait_list(queue, events);
-  rdk::polyline(stream(queue), im->ps, dptr(lsList), lsListSize, (int *)dptr(lsIdOut), (const int *)dptr(in), (const int *)dptr(tmp3), 0, minerror, sizeThre, iw, ih);
+  rdk::polyline(stream(queue), im->ps, dptr(lsList), lsListSize, (int *)dptr(lsIdOut), (const int *)dptr(in), (const int *)dptr(tmp3), 0, minerror, sizeThre, iw, ih, 0);
   rdrt::check_launch("oclpolyline_execute");
   return rdrt::finish_op(queue, events);
 }
@@ -233,13 +239,23 @@ struct Slot {
   float *tr[3], *fw[3], *bw[3], *hz[3], *bl[3], *vxy, *strength, *nms;
   int *i0, *i1, *mask0, *tidy, *label1, *strsum, *edge500, *strong, *junction, *mergemask, *region, *rsize, *scratch2, *boundarysrc, *boundary, *lsid, *table, *claim, *probes;
   int8_t *e8;
+  uint16_t *ext;
+  float *tails; int *flags; int iir_chunked;
   void *lslist;
   rdk::PolyScratch *ps;
   // host side
   void *h_bgr;            // pinned staging for host frames
-  void *h_segs; int *h_probes;
+  void *h_segs; int *h_probes; int *h_ctr;
   long seq;
   int ws;
+  // captured launch sequences (three segments, see enqueue_frame) and the stride they were captured for
+  hipGraphExec_t gexec[3]; int graph_ws;
+  // post-process worker
+  pthread_t th; pthread_mutex_t mu; pthread_cond_t cv;
+  int state;              // 0 idle, 1 submitted to the GPU, 2 result ready
+  int quit;
+  void *result; double result_tan; void *res_segs; int res_nsegs;
+  struct rd_detector *owner;
 };
 
 struct rd_detector {
@@ -251,6 +267,9 @@ struct rd_detector {
   long next_enqueue, next_poll;
   int last_polled_slot;
   void *last_segs; int last_nsegs;
+  int use_graph, poly_mode, force_redo; long n_redo;
+  double tan_aov; int have_tan;    // what the workers use ahead of the poll that asks for the result
+  pthread_mutex_t tan_mu; pthread_cond_t tan_cv;
 };
 
 static void slot_alloc(rd_detector *d, Slot *s) {
@@ -265,42 +284,71 @@ static void slot_alloc(rd_detector *d, Slot *s) {
   int **ip[] = { &s->i0, &s->i1, &s->mask0, &s->tidy, &s->label1, &s->strsum, &s->edge500, &s->strong, &s->junction, &s->mergemask, &s->region, &s->rsize,
                  &s->boundarysrc, &s->boundary, &s->lsid };
   for (size_t i = 0; i < sizeof(ip) / sizeof(ip[0]); i++) *ip[i] = dnew<int>(N);
-  s->scratch2 = dnew<int>(N * 2 + 64);
+  s->scratch2 = dnew<int>(N * 3 + 64);
   s->table = dnew<int>(N * 4); s->claim = dnew<int>(N);
   s->e8 = dnew<int8_t>(N);
+  s->ext = dnew<uint16_t>(N);
+  { size_t a = rdk::iir_scratch_floats(3, d->ih, d->iw), b = rdk::iir_scratch_floats(3, d->iw, d->ih); s->tails = dnew<float>(a > b ? a : b); }
+  s->flags = dnew<int>(16);
+  s->iir_chunked = 1;
   s->lslist = dnew<uint8_t>(N * 16);
   s->probes = dnew<int>((size_t)d->maxrec_dev * 15 * 6);
   s->ps = rdk::poly_scratch_create(d->iw, d->ih);
   RD_HIP(hipHostMalloc(&s->h_bgr, N * 4, hipHostMallocDefault));
   RD_HIP(hipHostMalloc(&s->h_segs, (size_t)RD_MAXREC * 56, hipHostMallocDefault));
   RD_HIP(hipHostMalloc((void **)&s->h_probes, (size_t)RD_MAXREC * 15 * 6 * sizeof(int), hipHostMallocDefault));
+  RD_HIP(hipHostMalloc((void **)&s->h_ctr, 32 * sizeof(int), hipHostMallocDefault)); memset(s->h_ctr, 0, 32 * sizeof(int));
   s->seq = -1;
 }
 
 static void slot_free(Slot *s) {
   RD_HIP(hipStreamSynchronize(s->st));
   void *all[] = { s->bgr, s->plab0, s->plab1, s->smooth, s->quant, s->vxy, s->strength, s->nms, s->i0, s->i1, s->mask0, s->tidy, s->label1, s->strsum, s->edge500, s->strong,
-                  s->junction, s->mergemask, s->region, s->rsize, s->scratch2, s->boundarysrc, s->boundary, s->lsid, s->table, s->claim, s->probes, s->e8, s->lslist };
+                  s->junction, s->mergemask, s->region, s->rsize, s->scratch2, s->boundarysrc, s->boundary, s->lsid, s->table, s->claim, s->probes, s->e8, s->ext, s->tails, s->flags, s->lslist };
   for (void *p : all) dfree(p);
   for (int k = 0; k < 3; k++) { dfree(s->tr[k]); dfree(s->fw[k]); dfree(s->bw[k]); dfree(s->hz[k]); dfree(s->bl[k]); }
   rdk::poly_scratch_destroy(s->ps);
-  RD_HIP(hipHostFree(s->h_bgr)); RD_HIP(hipHostFree(s->h_segs)); RD_HIP(hipHostFree(s->h_probes));
+  RD_HIP(hipHostFree(s->h_bgr)); RD_HIP(hipHostFree(s->h_segs)); RD_HIP(hipHostFree(s->h_probes)); RD_HIP(hipHostFree(s->h_ctr));
   RD_HIP(hipEventDestroy(s->ev_done)); RD_HIP(hipEventDestroy(s->ev_strong));
   RD_HIP(hipStreamDestroy(s->st));
 }
 
-// The device part of one frame (reference oclrect.c:235-381), enqueued on the slot's stream.
-static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
+// The device part of one frame (reference oclrect.c:235-381), enqueued on the slot's stream in three segments so that
+// each can be captured into a hipGraph: [0] up to the first labelling, [1] up to the hand-over of the strong-edge mask
+// to the next frame (quirk H1, needs an event wait before it and an event record after it), [2] the rest.
+// last part of a frame: polylines of the strong edges, votes, probes, transfers.  mode 1 uses the single-launch polyline
+// stage, which reports frames that do not fit its on-chip tables in counter 25; slot_postprocess() then repeats this
+// part with mode 0.
+static void frame_tail(rd_detector *d, Slot *s, int mode) {
   const int iw = d->iw, ih = d->ih, N = d->N;
   hipStream_t st = s->st;
+  // frame ring of the bridging step is "non-zero" on this path (oclrect.c:361, H3)
+  rdk::polyline(st, s->ps, s->lslist, N * 16, s->lsid, s->strong, NULL, 1, 4.0f, 20, iw, ih, mode);
+
+  // segment / boundary votes (oclrect.c:365-367) and the probes the host needs (oclrect.c:1066-1098)
+  const int nentry = N * 4 / 5;
+  rdk::reduce_ls(st, s->table, s->claim, s->boundary, s->ps, iw, ih, nentry);
+  rdk::sample_segments(st, s->probes, s->lslist, d->maxrec_dev, s->boundary, s->table, iw, ih, nentry);
+
+  const int ncopy = d->maxrec_dev < RD_MAXREC ? d->maxrec_dev : RD_MAXREC;
+  RD_HIP(hipMemcpyAsync(s->h_segs, s->lslist, (size_t)ncopy * 56, hipMemcpyDeviceToHost, st));
+  RD_HIP(hipMemcpyAsync(s->h_probes, s->probes, (size_t)ncopy * 15 * 6 * sizeof(int), hipMemcpyDeviceToHost, st));
+  RD_HIP(hipMemcpyAsync(s->h_ctr, rdk::poly_scratch_counters(s->ps), 32 * sizeof(int), hipMemcpyDeviceToHost, st));
+}
+
+static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
+  const int iw = d->iw, ih = d->ih, N = d->N;
+  hipStream_t st = s->st;
+  if (seg == 0) {
 
   // colour -> sigma=1 blur of L, a, b -> packed blurred Lab (oclrect.c:245-251)
   rdk::bgr2plab(st, s->plab0, s->bgr, iw, ih, ws);
   rdk::transpose_unpack(st, s->tr, s->plab0, iw, ih);
-  { const float *c[3] = { s->tr[0], s->tr[1], s->tr[2] }; rdk::iir_columns(st, s->fw, s->bw, c, 3, ih, iw);
+  RD_HIP(hipMemsetAsync(s->flags, 0, 16 * sizeof(int), st));
+  { const float *c[3] = { s->tr[0], s->tr[1], s->tr[2] }; rdk::iir_columns(st, s->fw, s->bw, c, 3, ih, iw, s->tails, s->flags);
     const float *f[3] = { s->fw[0], s->fw[1], s->fw[2] }, *b[3] = { s->bw[0], s->bw[1], s->bw[2] };
     rdk::iir_combine_transpose(st, s->hz, f, b, c, 3, ih, iw); }
-  { const float *c[3] = { s->hz[0], s->hz[1], s->hz[2] }; rdk::iir_columns(st, s->fw, s->bw, c, 3, iw, ih);
+  { const float *c[3] = { s->hz[0], s->hz[1], s->hz[2] }; rdk::iir_columns(st, s->fw, s->bw, c, 3, iw, ih, s->tails, s->flags + 1);
     const float *f[3] = { s->fw[0], s->fw[1], s->fw[2] }, *b[3] = { s->bw[0], s->bw[1], s->bw[2] };
     rdk::iir_combine(st, s->bl, f, b, c, 3, N); }
   rdk::pack_plab(st, s->plab1, s->bl[0], s->bl[1], s->bl[2], N);
@@ -318,9 +366,12 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   rdk::stringify(st, s->i0, s->i1, 0, iw, ih);
   rdk::stringify(st, s->tidy, s->i0, 1, iw, ih);
 
-  // components (background included), strength sums on top of last frame's strong mask (H1), filter at 500 (oclrect.c:274-284)
+  // components (background included)
   rdk::label8(st, s->label1, s->tidy, -1, iw, ih);
-  if (d->have_last_strong) RD_HIP(hipStreamWaitEvent(st, d->last_strong, 0));
+  return;
+  }
+  if (seg == 1) {
+  // strength sums on top of last frame's strong mask (H1), filter at 500 (oclrect.c:274-284)
   RD_HIP(hipMemcpyAsync(s->strsum, d->prev_strong, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));
   rdk::calc_strength(st, s->strsum, s->nms, s->label1, iw, ih);
   rdk::filter_strength(st, s->label1, s->strsum, 500, iw, ih);
@@ -328,8 +379,9 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   rdk::cast_c_i(st, s->e8, s->edge500, N);
 
   // edge-preserving smoothing x10, quantise, despeckle (oclrect.c:286-303)
-  { const uint32_t *src = s->plab0;
-    for (int i = 0; i < 10; i++) { rdk::blblur(st, (uint32_t *)s->i0, s->e8, src, 0, iw, ih); rdk::blblur(st, s->smooth, s->e8, (const uint32_t *)s->i0, 1, iw, ih); src = s->smooth; } }
+  rdk::blblur_extents(st, s->ext, s->e8, iw, ih);
+  { const uint32_t *src = s->plab0;     // ping-pong between i0 and smooth; the 10th pair lands in smooth
+    for (int i = 0; i < 10; i++) { uint32_t *dst = (i & 1) ? s->smooth : (uint32_t *)s->i0; rdk::blblur_pair(st, dst, s->ext, src, iw, ih); src = dst; } }
   rdk::quantize(st, (uint32_t *)s->i0, s->smooth, 24, 24, 24, N);
   rdk::despeckle(st, s->quant, (const uint32_t *)s->i0, s->nms, iw, ih);
 
@@ -337,10 +389,10 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   rdk::filter_strength(st, s->label1, s->strsum, 2500, iw, ih);
   rdk::threshold_i(st, s->strong, s->label1, 0, 0, 1, N);
   RD_HIP(hipMemcpyAsync(d->prev_strong, s->strong, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));
-  RD_HIP(hipEventRecord(s->ev_strong, st));
-  d->last_strong = s->ev_strong; d->have_last_strong = 1;
+  return;
+  }
   rdk::junction(st, s->junction, s->label1, 0, iw, ih);
-  rdk::merge_mask(st, s->mergemask, s->junction, iw, ih);
+  rdk::merge_mask(st, s->mergemask, s->scratch2, s->junction, iw, ih);
 
   // regions (oclrect.c:325-336)
   rdk::region_merge(st, s->region, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih);
@@ -352,19 +404,88 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   rdk::mark_boundary(st, s->boundarysrc, s->region, iw, ih);
   rdk::label8(st, s->boundary, s->boundarysrc, -1, iw, ih);
 
-  // polylines of the strong edges; frame ring of the bridging step is "non-zero" on this path (oclrect.c:361, H3)
-  rdk::polyline(st, s->ps, s->lslist, N * 16, s->lsid, s->strong, NULL, 1, 4.0f, 20, iw, ih);
+  frame_tail(d, s, d->poly_mode);
+}
 
-  // segment / boundary votes (oclrect.c:365-367) and the probes the host needs (oclrect.c:1066-1098)
-  const int nentry = N * 4 / 5;
-  rdk::reduce_ls(st, s->table, s->claim, s->boundary, s->lsid, iw, ih, nentry);
-  rdk::sample_segments(st, s->probes, s->lslist, d->maxrec_dev, s->boundary, s->table, iw, ih, nentry);
+static void run_segment(rd_detector *d, Slot *s, int ws, int seg) {
+  if (!d->use_graph) { frame_segment(d, s, ws, seg); return; }
+  if (!s->gexec[seg]) {
+    hipGraph_t g = NULL;
+    RD_HIP(hipStreamBeginCapture(s->st, hipStreamCaptureModeThreadLocal));
+    frame_segment(d, s, ws, seg);
+    RD_HIP(hipStreamEndCapture(s->st, &g));
+    RD_HIP(hipGraphInstantiate(&s->gexec[seg], g, NULL, NULL, 0));
+    RD_HIP(hipGraphDestroy(g));
+  }
+  RD_HIP(hipGraphLaunch(s->gexec[seg], s->st));
+}
 
-  const int ncopy = d->maxrec_dev < RD_MAXREC ? d->maxrec_dev : RD_MAXREC;
-  RD_HIP(hipMemcpyAsync(s->h_segs, s->lslist, (size_t)ncopy * 56, hipMemcpyDeviceToHost, st));
-  RD_HIP(hipMemcpyAsync(s->h_probes, s->probes, (size_t)ncopy * 15 * 6 * sizeof(int), hipMemcpyDeviceToHost, st));
-  RD_HIP(hipEventRecord(s->ev_done, st));
+static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
+  if (d->use_graph && s->graph_ws != ws) {
+    for (int k = 0; k < 3; k++) if (s->gexec[k]) { RD_HIP(hipGraphExecDestroy(s->gexec[k])); s->gexec[k] = NULL; }
+    s->graph_ws = ws;
+  }
+  run_segment(d, s, ws, 0);
+  if (d->have_last_strong) RD_HIP(hipStreamWaitEvent(s->st, d->last_strong, 0));
+  run_segment(d, s, ws, 1);
+  RD_HIP(hipEventRecord(s->ev_strong, s->st));
+  d->last_strong = s->ev_strong; d->have_last_strong = 1;
+  run_segment(d, s, ws, 2);
+  RD_HIP(hipEventRecord(s->ev_done, s->st));
   rdrt::check_launch("rect frame");
+}
+
+// host post-process of one finished slot (on the polling thread or on the slot's worker)
+static void *slot_postprocess(rd_detector *d, Slot *s, double tanAOV, void **segs_out, int *nsegs_out) {
+  if (s->h_ctr[25] != 0 || d->force_redo) {   // the single-launch polyline stage overflowed: repeat the tail the long way
+    frame_tail(d, s, 0);
+    RD_HIP(hipStreamSynchronize(s->st));
+    __atomic_add_fetch(&d->n_redo, 1, __ATOMIC_RELAXED);
+  }
+  int n = ((int *)s->h_segs)[0];
+  const void *segs = s->h_segs; const int *probes = s->h_probes;
+  void *big_segs = NULL; int *big_probes = NULL;
+  int maxrec = d->maxrec_dev < RD_MAXREC ? d->maxrec_dev : RD_MAXREC;
+  if (n + 1 > maxrec) {   // rare: more segments than the fixed-size transfer covers
+    if (n + 1 > d->maxrec_dev) n = d->maxrec_dev - 1;
+    big_segs = malloc((size_t)(n + 1) * 56); big_probes = (int *)malloc((size_t)(n + 1) * 15 * 6 * sizeof(int));
+    RD_HIP(hipMemcpy(big_segs, s->lslist, (size_t)(n + 1) * 56, hipMemcpyDeviceToHost));
+    RD_HIP(hipMemcpy(big_probes, s->probes, (size_t)(n + 1) * 15 * 6 * sizeof(int), hipMemcpyDeviceToHost));
+    segs = big_segs; probes = big_probes; maxrec = n + 1;
+  }
+  void *r = rd_post_run(segs, maxrec, probes, d->iw, d->ih, tanAOV);
+  const int ns = n < maxrec ? n : maxrec - 1;
+  void *copy = malloc((size_t)(ns + 1) * 56);
+  memcpy(copy, segs, (size_t)(ns + 1) * 56);
+  free(big_segs); free(big_probes);
+  *segs_out = copy; *nsegs_out = ns;
+  return r;
+}
+
+static void *slot_worker(void *arg) {
+  Slot *s = (Slot *)arg;
+  rd_detector *d = s->owner;
+  RD_HIP(hipSetDevice(d->device));
+  for (;;) {
+    pthread_mutex_lock(&s->mu);
+    while (s->state != 1 && !s->quit) pthread_cond_wait(&s->cv, &s->mu);
+    if (s->quit) { pthread_mutex_unlock(&s->mu); return NULL; }
+    pthread_mutex_unlock(&s->mu);
+    // the aperture arrives with the poll (reference API); workers run ahead with the last one seen
+    pthread_mutex_lock(&d->tan_mu);
+    while (!d->have_tan && !s->quit) pthread_cond_wait(&d->tan_cv, &d->tan_mu);
+    const double tan = d->tan_aov;
+    pthread_mutex_unlock(&d->tan_mu);
+    if (s->quit) return NULL;
+    RD_HIP(hipEventSynchronize(s->ev_done));
+    void *segs = NULL; int ns = 0;
+    void *r = slot_postprocess(d, s, tan, &segs, &ns);
+    pthread_mutex_lock(&s->mu);
+    s->result = r; s->result_tan = tan; s->res_segs = segs; s->res_nsegs = ns;
+    s->state = 2;
+    pthread_cond_broadcast(&s->cv);
+    pthread_mutex_unlock(&s->mu);
+  }
 }
 
 extern "C" {
@@ -380,8 +501,18 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   if (d->maxrec_dev > 65536) d->maxrec_dev = 65536;
   d->prev_strong = dnew<int>((size_t)d->N);
   RD_HIP(hipMemset(d->prev_strong, 0, sizeof(int) * (size_t)d->N));
+  d->use_graph = getenv("RD_NO_GRAPH") ? 0 : 1;
+  d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : 1;
+  d->force_redo = getenv("RD_POLY_FORCE_REDO") ? 1 : 0;
+  pthread_mutex_init(&d->tan_mu, NULL); pthread_cond_init(&d->tan_cv, NULL);
   d->slots = (Slot *)calloc((size_t)nslots, sizeof(Slot));
-  for (int i = 0; i < nslots; i++) slot_alloc(d, &d->slots[i]);
+  for (int i = 0; i < nslots; i++) {
+    Slot *s = &d->slots[i];
+    slot_alloc(d, s);
+    s->owner = d;
+    pthread_mutex_init(&s->mu, NULL); pthread_cond_init(&s->cv, NULL);
+    if (nworkers > 0 && pthread_create(&s->th, NULL, slot_worker, s) != 0) exitf(-1, "rd_detector_create: cannot start worker thread\n");
+  }
   d->last_polled_slot = -1;
   RD_HIP(hipDeviceSynchronize());
   return d;
@@ -391,7 +522,17 @@ void rd_detector_destroy(rd_detector *d) {
   if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_destroy: bad handle\n");
   RD_HIP(hipSetDevice(d->device));
   RD_HIP(hipDeviceSynchronize());
-  for (int i = 0; i < d->nslots; i++) slot_free(&d->slots[i]);
+  for (int i = 0; i < d->nslots; i++) {
+    Slot *s = &d->slots[i];
+    if (d->nworkers > 0) {
+      pthread_mutex_lock(&s->mu); s->quit = 1; pthread_cond_broadcast(&s->cv); pthread_mutex_unlock(&s->mu);
+      pthread_mutex_lock(&d->tan_mu); pthread_cond_broadcast(&d->tan_cv); pthread_mutex_unlock(&d->tan_mu);
+      pthread_join(s->th, NULL);
+    }
+    free(s->result); free(s->res_segs);
+    for (int k = 0; k < 3; k++) if (s->gexec[k]) RD_HIP(hipGraphExecDestroy(s->gexec[k]));
+    slot_free(s);
+  }
   free(d->slots);
   dfree(d->prev_strong);
   free(d->last_segs);
@@ -410,6 +551,12 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
   if (on_device) RD_HIP(hipMemcpyAsync(s->bgr, frame, bytes, hipMemcpyDeviceToDevice, s->st));
   else { memcpy(s->h_bgr, frame, bytes); RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, bytes, hipMemcpyHostToDevice, s->st)); }
   enqueue_frame(d, s, ws);
+  if (d->nworkers > 0) {
+    pthread_mutex_lock(&s->mu);
+    s->state = 1;
+    pthread_cond_broadcast(&s->cv);
+    pthread_mutex_unlock(&s->mu);
+  }
   return d->next_enqueue++;
 }
 
@@ -419,24 +566,28 @@ void *rd_detector_poll(rd_detector *d, double tanAOV) {
   RD_HIP(hipSetDevice(d->device));
   const int si = (int)(d->next_poll % d->nslots);
   Slot *s = &d->slots[si];
-  RD_HIP(hipEventSynchronize(s->ev_done));
-  int n = ((int *)s->h_segs)[0];
-  const void *segs = s->h_segs; const int *probes = s->h_probes;
-  void *big_segs = NULL; int *big_probes = NULL;
-  int maxrec = d->maxrec_dev < RD_MAXREC ? d->maxrec_dev : RD_MAXREC;
-  if (n + 1 > maxrec) {   // rare: more segments than the fixed-size transfer covers
-    if (n + 1 > d->maxrec_dev) n = d->maxrec_dev - 1;
-    big_segs = malloc((size_t)(n + 1) * 56); big_probes = (int *)malloc((size_t)(n + 1) * 15 * 6 * sizeof(int));
-    RD_HIP(hipMemcpy(big_segs, s->lslist, (size_t)(n + 1) * 56, hipMemcpyDeviceToHost));
-    RD_HIP(hipMemcpy(big_probes, s->probes, (size_t)(n + 1) * 15 * 6 * sizeof(int), hipMemcpyDeviceToHost));
-    segs = big_segs; probes = big_probes; maxrec = n + 1;
+  void *r = NULL, *segs = NULL; int ns = 0;
+  if (d->nworkers > 0) {
+    pthread_mutex_lock(&d->tan_mu);
+    d->tan_aov = tanAOV; d->have_tan = 1;
+    pthread_cond_broadcast(&d->tan_cv);
+    pthread_mutex_unlock(&d->tan_mu);
+    pthread_mutex_lock(&s->mu);
+    while (s->state != 2) pthread_cond_wait(&s->cv, &s->mu);
+    r = s->result; segs = s->res_segs; ns = s->res_nsegs;
+    const double used = s->result_tan;
+    s->result = NULL; s->res_segs = NULL; s->state = 0;
+    pthread_mutex_unlock(&s->mu);
+    if (used != tanAOV) {      // the worker ran ahead with another aperture: redo with the requested one
+      free(r); free(segs);
+      r = slot_postprocess(d, s, tanAOV, &segs, &ns);
+    }
+  } else {
+    RD_HIP(hipEventSynchronize(s->ev_done));
+    r = slot_postprocess(d, s, tanAOV, &segs, &ns);
   }
-  void *r = rd_post_run(segs, maxrec, probes, d->iw, d->ih, tanAOV);
   free(d->last_segs);
-  d->last_nsegs = n < maxrec ? n : maxrec - 1;
-  d->last_segs = malloc((size_t)(d->last_nsegs + 1) * 56);
-  memcpy(d->last_segs, segs, (size_t)(d->last_nsegs + 1) * 56);
-  free(big_segs); free(big_probes);
+  d->last_segs = segs; d->last_nsegs = ns;
   d->last_polled_slot = si;
   d->next_poll++;
   return r;
@@ -446,6 +597,11 @@ void rd_detector_drain(rd_detector *d) {
   if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_drain: bad handle\n");
   RD_HIP(hipSetDevice(d->device));
   for (int i = 0; i < d->nslots; i++) RD_HIP(hipStreamSynchronize(d->slots[i].st));
+}
+
+long rd_detector_counter(rd_detector *d, int which) {
+  if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_counter: bad handle\n");
+  return which == 0 ? __atomic_load_n(&d->n_redo, __ATOMIC_RELAXED) : -1;
 }
 
 int rd_detector_last_segments(rd_detector *d, void *dst, int max_records) {
@@ -467,7 +623,7 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
     { "nms", s->nms, N * 4 }, { "mask0", s->mask0, N * 4 }, { "tidy", s->tidy, N * 4 }, { "label1", s->label1, N * 4 }, { "strsum", s->strsum, N * 4 },
     { "edge500", s->edge500, N * 4 }, { "smooth", s->smooth, N * 4 }, { "quant", s->quant, N * 4 }, { "strong", s->strong, N * 4 }, { "junction", s->junction, N * 4 },
     { "mergemask", s->mergemask, N * 4 }, { "region", s->region, N * 4 }, { "rsize", s->rsize, N * 4 }, { "boundarysrc", s->boundarysrc, N * 4 },
-    { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 },
+    { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 }, { "polyctr", rdk::poly_scratch_counters(s->ps), 64 * 4 }, { "iirflags", s->flags, 16 * 4 },
   };
   for (size_t i = 0; i < sizeof(tab) / sizeof(tab[0]); i++)
     if (!strcmp(tab[i].n, name)) {

@@ -74,6 +74,10 @@ __device__ __forceinline__ int pixel_rand(int p, uint64_t seed) {
   return (int)mix64(((uint64_t)(int64_t)p ^ 0xb21c2cb635b48285ULL) * 0x9b923b9cec745401ULL + (seed ^ 0x7bb93d75a79d2f15ULL) * 0x22cab58ada573a29ULL);
 }
 
+// L2-coherent (device-scope) load: used to guard hot atomics so that later waves see an earlier wave's update instead of
+// a stale L1 line and skip the atomic
+__device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // lock-free union-find on an int label array where a root r satisfies label[r] == r and the smaller index wins
 __device__ __forceinline__ int uf_find(const int *label, int a) {
   int l = label[a];

@@ -9,26 +9,7 @@
 #include "rd_device.h"
 #include "rd_kernels.h"
 
-namespace rdk {
-
-struct PolyScratch {
-  int cap;            // = iw*ih, capacity of every per-pixel array
-  int *planeA, *planeB, *planeC;   // dense int planes
-  int *cidx;          // dense: pixel -> compact index or -1
-  int *blk;           // per-block counts / offsets for the compaction
-  int *pos;           // compact: pixel index, ascending
-  int *nbr;           // compact: 8 neighbour compact indices (E,NE,N,NW,W,SW,S,SE), -1 = none
-  int *lab, *alive, *ends;
-  int *nx[2], *pv[2], *flag, *flag2;
-  int *num[2], *link[2];
-  int *lab2, *size, *rootid, *id, *dist;
-  int *cand;          // candidate records of one split round (8 ints each)
-  int *ctr;           // counters: [0]=cnt, [1]=nchains, [2..18]=candidates per round, [20]=refine done count ...
-  void *lsx;          // per-segment moment sums
-  int *segaux;        // per-segment: startPix, endPix
-};
-
-}  // namespace rdk
+#include "rd_poly_scratch.h"
 
 namespace {
 
@@ -118,15 +99,20 @@ __global__ __launch_bounds__(256) void k_remove_branch(int *__restrict__ out, co
 
 // ------------------------------------------------------------------------------------------------ raster-order compaction
 #define CP_PER_BLOCK 2048
-__global__ __launch_bounds__(256) void k_compact_count(int *__restrict__ blk, const int *__restrict__ plane, int n) {
+// Stable (index-ordered) compaction of the non-zero elements of `plane` in three launches: per-block counts, exclusive
+// scan of the counts by one block, scatter.  The element count may live on the device (nptr).  Outputs (each optional):
+// pos[rank] = index, cidx[index] = rank or -1, rank1[index] = rank + 1 for non-zero elements.
+__global__ __launch_bounds__(256) void k_compact_count(int *__restrict__ blk, const int *__restrict__ plane, int n, const int *nptr) {
   __shared__ int total;
+  if (nptr) n = *nptr;
   if (threadIdx.x == 0) total = 0;
   __syncthreads();
   int c = 0;
-  for (int k = 0; k < CP_PER_BLOCK / 256; k++) {
-    const int i = blockIdx.x * CP_PER_BLOCK + k * 256 + threadIdx.x;
-    c += __popcll(__ballot(i < n && plane[i] != 0));
-  }
+  if (blockIdx.x * CP_PER_BLOCK < n)
+    for (int k = 0; k < CP_PER_BLOCK / 256; k++) {
+      const int i = blockIdx.x * CP_PER_BLOCK + k * 256 + threadIdx.x;
+      c += __popcll(__ballot(i < n && plane[i] != 0));
+    }
   if ((threadIdx.x & 63) == 0) atomicAdd(&total, c);
   __syncthreads();
   if (threadIdx.x == 0) blk[blockIdx.x] = total;
@@ -158,9 +144,12 @@ __global__ __launch_bounds__(1024) void k_compact_scan(int *blk, int nblk, int *
   if (threadIdx.x == 0) *cnt = carry;
 }
 
-__global__ __launch_bounds__(256) void k_compact_scatter(int *__restrict__ pos, int *__restrict__ cidx, const int *__restrict__ blk, const int *__restrict__ plane, int n) {
+__global__ __launch_bounds__(256) void k_compact_scatter(int *__restrict__ pos, int *__restrict__ cidx, int *__restrict__ rank1, const int *__restrict__ blk,
+                                                         const int *__restrict__ plane, int n, const int *nptr) {
   __shared__ int wcount[4];
   __shared__ int running;
+  if (nptr) n = *nptr;
+  if (blockIdx.x * CP_PER_BLOCK >= n) return;
   if (threadIdx.x == 0) running = blk[blockIdx.x];
   __syncthreads();
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -172,10 +161,10 @@ __global__ __launch_bounds__(256) void k_compact_scatter(int *__restrict__ pos, 
     __syncthreads();
     int off = running;
     for (int q = 0; q < w; q++) off += wcount[q];
-    const int rank = __popcll(m & ((1ull << lane) - 1ull));
+    const int rank = off + __popcll(m & ((1ull << lane) - 1ull));
     if (i < n) {
-      if (on) { pos[off + rank] = i; cidx[i] = off + rank; }
-      else cidx[i] = -1;
+      if (on) { if (pos) pos[rank] = i; if (rank1) rank1[i] = rank + 1; }
+      if (cidx) cidx[i] = on ? rank : -1;
     }
     __syncthreads();
     if (threadIdx.x == 0) running += wcount[0] + wcount[1] + wcount[2] + wcount[3];
@@ -356,29 +345,13 @@ __global__ void k_sub_size(PolyScratch s) {
 }
 
 // pl:380-420: surviving roots are numbered 1..K in raster order (= compact order): one block, ballot prefix scan
-__global__ __launch_bounds__(1024) void k_relabel_scan(PolyScratch s, int sizeThre) {
-  __shared__ int wsum[16];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
+// pl:380-420: surviving roots are numbered 1..K in raster order (= compact order): flag them, rank them by compaction
+__global__ void k_root_flags(PolyScratch s, int sizeThre) {
   const int cnt = s.ctr[0];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int base = 0; base < cnt; base += 1024) {
-    const int i = base + threadIdx.x;
-    const bool root = i < cnt && s.lab2[i] == i && s.size[i] > sizeThre;
-    const unsigned long long m = __ballot(root);
-    if (lane == 0) wsum[w] = __popcll(m);
-    __syncthreads();
-    int off = carry;
-    for (int k = 0; k < w; k++) off += wsum[k];
-    if (root) s.rootid[i] = off + __popcll(m & ((1ull << lane) - 1ull)) + 1;
-    __syncthreads();
-    if (threadIdx.x == 0) { int t = 0; for (int k = 0; k < 16; k++) t += wsum[k]; carry += t; }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) s.ctr[1] = carry;
+  SPARSE_LOOP(i, cnt) s.flag2[i] = (s.lab2[i] == i && s.size[i] > sizeThre) ? 1 : 0;
 }
 
+// ids of the surviving chains for every chain pixel (0 = dropped)
 __global__ void k_assign_ids(PolyScratch s) {
   const int cnt = s.ctr[0];
   SPARSE_LOOP(i, cnt) { const int l = s.lab2[i]; s.id[i] = l >= 0 ? s.rootid[l] : 0; }
@@ -397,12 +370,13 @@ __global__ void k_seg_clear(PolyScratch s, ls_rec *ls, int lsbytes) {
     s.segaux[2 * g] = -1;            // last pixel with number 1
     s.segaux[2 * g + 1] = 0x7fffffff; // first pixel carrying the largest number
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) for (int k = 2; k < 24; k++) s.ctr[k] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { for (int k = 2; k < 24; k++) s.ctr[k] = 0; s.ctr[25] = 0; }
 }
 
 __global__ void k_seg_pass0a(PolyScratch s, ls_rec *ls, int lsbytes, const int *number) {
-  const int cnt = s.ctr[0];
-  SPARSE_LOOP(i, cnt) {
+  const int nlive = s.ctr[24];
+  SPARSE_LOOP(j, nlive) {
+    const int i = s.live[j];
     const int g = s.id[i];
     if (g == 0 || !FITS(g, lsbytes)) continue;
     const int n = number[i];
@@ -413,8 +387,9 @@ __global__ void k_seg_pass0a(PolyScratch s, ls_rec *ls, int lsbytes, const int *
 }
 
 __global__ void k_seg_pass0b(PolyScratch s, ls_rec *ls, int lsbytes, const int *number) {
-  const int cnt = s.ctr[0];
-  SPARSE_LOOP(i, cnt) {
+  const int nlive = s.ctr[24];
+  SPARSE_LOOP(j, nlive) {
+    const int i = s.live[j];
     const int g = s.id[i];
     if (g == 0 || !FITS(g, lsbytes)) continue;
     if (number[i] != ls[g].endIndex) continue;
@@ -444,8 +419,9 @@ __device__ __forceinline__ float dist2f(float vx, float vy, float wx, float wy) 
 // pass 3 of the previous round (pixels beyond the new end move right) fused with pass 1 of this round (distance to
 // the chord with integer-truncated end points, tie-breaking hash, per-segment maximum)
 __global__ void k_split_move_dist(PolyScratch s, ls_rec *ls, int lsbytes, const int *number, int iw, int do_dist) {
-  const int cnt = s.ctr[0];
-  SPARSE_LOOP(i, cnt) {
+  const int nlive = s.ctr[24];
+  SPARSE_LOOP(j, nlive) {
+    const int i = s.live[j];
     int g = s.id[i];
     if (g == 0 || !FITS(g, lsbytes) || ls[g].polyid == 0) continue;
     if (ls[g].endIndex < number[i]) { g = ls[g].rightPtr; s.id[i] = g; }
@@ -474,8 +450,9 @@ __global__ void k_split_move_dist(PolyScratch s, ls_rec *ls, int lsbytes, const 
 // candidate; everything pass 2 needs from the OLD list is stored with the candidate (the reference reads a snapshot).
 // cand record: {i, g, n, maxDist, oldEndIndex, oldRight, x1 bits, y1 bits}
 __global__ void k_split_detect(PolyScratch s, const ls_rec *ls, int lsbytes, const int *number, float minerror, int iw, int round) {
-  const int cnt = s.ctr[0];
-  SPARSE_LOOP(i, cnt) {
+  const int nlive = s.ctr[24];
+  SPARSE_LOOP(j, nlive) {
+    const int i = s.live[j];
     const int g = s.id[i];
     if (g == 0 || !FITS(g, lsbytes)) continue;
     const ls_rec r = ls[g];
@@ -549,10 +526,11 @@ __global__ void k_refine0(PolyScratch s, const ls_rec *ls, int maxrec) {
 }
 
 __global__ void k_refine1(PolyScratch s, const ls_rec *ls, int maxrec, int iw) {
-  const int cnt = s.ctr[0];
+  const int nlive = s.ctr[24];
   const int n = *(const int *)ls;
   lsx_rec *sx = (lsx_rec *)s.lsx;
-  SPARSE_LOOP(i, cnt) {
+  SPARSE_LOOP(j, nlive) {
+    const int i = s.live[j];
     const int g = s.id[i];
     if (g <= 0 || n < g || g >= maxrec || ls[g].polyid == 0) continue;
     const int p = s.pos[i], x = p % iw, y = p / iw;
@@ -638,9 +616,276 @@ __global__ __launch_bounds__(1024) void k_refine3(PolyScratch s, ls_rec *ls, int
   }
 }
 
+// ------------------------------------------------------------------------------------------------ persistent variant
+// Everything from the initial segments to the end-point joining (pl:439-809: about 85 tiny launches above) in ONE
+// single-block launch: per-pixel state lives in registers (PP_PX live pixels per thread), segment records and moment
+// sums in LDS, phases are separated by block barriers.  Same arithmetic, same tie rules as the kernels above.  If the
+// frame does not fit (too many live pixels, records or candidates) the kernel sets ctr[25] and the caller repeats the
+// stage with the multi-launch path.
+#define PP_T 1024
+#define PP_PX 16
+#define PP_MAXSEG 1024
+#define PP_MAXCAND 448
+struct pp_lds {
+  ls_rec rec[PP_MAXSEG];
+  lsx_rec sx[PP_MAXSEG];
+  int start_i[PP_MAXSEG], end_i[PP_MAXSEG];
+  int done[PP_MAXSEG];
+  int cand[PP_MAXCAND * 8];
+  int ncand, count, fail, progress;
+};
+
+__device__ __noinline__ int2 pp_move_dist(pp_lds &L, int pk, int xyv, int dreg, bool move_only, int iw) {
+  int g = pk & 0x7ff;
+  const int num = (int)((unsigned)pk >> 11);
+  if (g == 0 || L.rec[g].polyid == 0) return make_int2(pk, dreg);
+  if (L.rec[g].endIndex < num) { g = L.rec[g].rightPtr; pk = (pk & ~0x7ff) | g; }
+  if (move_only) return make_int2(pk, dreg);
+  if (g == 0 || L.rec[g].polyid == 0) return make_int2(pk, dreg);
+  const int x = xyv & 0xffff, y = xyv >> 16;
+  const float vx = (float)(int)L.rec[g].x0, vy = (float)(int)L.rec[g].y0, wx = (float)(int)L.rec[g].x1, wy = (float)(int)L.rec[g].y1;
+  float cx, cy;
+  const float l2 = dist2f(vx, vy, wx, wy);
+  if (l2 <= 1e-4f) { cx = vx; cy = vy; }
+  else {
+    const float t = (((float)x - vx) * (wx - vx) + ((float)y - vy) * (wy - vy)) / l2;
+    if (t < 0.0f) { cx = vx; cy = vy; }
+    else if (t > 1.0f) { cx = wx; cy = wy; }
+    else { cx = vx + t * (wx - vx); cy = vy + t * (wy - vy); }
+  }
+  const float a = cx - (float)x, b = cy - (float)y;
+  int d = (int)((float)sqrt((double)a * (double)a + (double)b * (double)b) * 65536);
+  d ^= pixel_rand(y * iw + x, 0) & 0x1fff;
+  dreg = d;
+  atomicMax(&L.rec[g].maxDist, d);
+  return make_int2(pk, dreg);
+}
+
+// (reads the list as it is: nothing is modified in this phase)
+__device__ __noinline__ void pp_detect(pp_lds &L, int pk, int xyv, int dreg, float minerror, const int *live, int j) {
+  const int g = pk & 0x7ff;
+  const ls_rec r = L.rec[g];
+  if (r.polyid == 0) return;
+  if (r.endIndex - r.startIndex < 3) return;
+  if (r.startCount > 1 || r.endCount > 1) return;
+  const int md = r.maxDist;
+  if (dreg != md) return;
+  if (md < (int)(minerror * 65536)) return;
+  if ((float)md < (minerror * 3 * 65536) && (float)md * (float)md / dist2f(r.x0, r.y0, r.x1, r.y1) < 100000.0f) return;
+  const int x = xyv & 0xffff, y = xyv >> 16;
+  if (dist2f((float)x, (float)y, r.x0, r.y0) < 1) return;
+  if (dist2f((float)x, (float)y, r.x1, r.y1) < 1) return;
+  const int c = atomicAdd(&L.ncand, 1);
+  if (c >= PP_MAXCAND) { L.fail = 1; return; }
+  int *e = L.cand + c * 8;
+  e[0] = live[j]; e[1] = g; e[2] = (int)((unsigned)pk >> 11); e[3] = md; e[4] = r.endIndex; e[5] = r.rightPtr;
+  e[6] = __float_as_int(r.x1); e[7] = __float_as_int(r.y1);
+}
+
+__device__ __noinline__ void pp_moments(pp_lds &L, int pk, int xyv, int n) {
+  const int g = pk & 0x7ff;
+  if (g <= 0 || n < g || L.rec[g].polyid == 0) return;
+  const int vx = (xyv & 0xffff) - (int)rintf(L.rec[g].x0), vy = (xyv >> 16) - (int)rintf(L.rec[g].y0);
+  const int ay = vx * L.sx[g].vx + vy * L.sx[g].vy;
+  const int ax0 = vx * L.sx[g].dx + vy * L.sx[g].dy;
+  const int ax1 = L.sx[g].d2;
+  atomicAdd((unsigned long long *)&L.sx[g].mx00, (unsigned long long)(long long)rintf((float)ax0 * (float)ax0));
+  atomicAdd((unsigned long long *)&L.sx[g].mx01, (unsigned long long)(long long)rintf((float)ax0 * (float)ax1));
+  atomicAdd((unsigned long long *)&L.sx[g].mx11, (unsigned long long)(long long)rintf((float)ax1 * (float)ax1));
+  atomicAdd((unsigned long long *)&L.sx[g].my0, (unsigned long long)(long long)rintf((float)ax0 * (float)ay));
+  atomicAdd((unsigned long long *)&L.sx[g].my1, (unsigned long long)(long long)rintf((float)ax1 * (float)ay));
+}
+
+__global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec *ls, int lsbytes, const int *__restrict__ number, float minerror, int iw) {
+  extern __shared__ __attribute__((aligned(16))) char pp_raw[];
+  pp_lds &L = *(pp_lds *)pp_raw;
+  const int tid = threadIdx.x;
+  const int nlive = s.ctr[24], K = s.ctr[1];
+  const int maxrec = lsbytes / 56;
+  if (nlive > PP_T * PP_PX || K >= PP_MAXSEG - 1 || K >= maxrec - 1) { if (tid == 0) s.ctr[25] = 1; return; }
+
+  // per-pixel state in registers: id (11 bits) | position along the chain << 11, x | y << 16, last distance
+  int pk[PP_PX], xy[PP_PX], dreg[PP_PX];
+#define PP_ID(k) (pk[k] & 0x7ff)
+#define PP_NUM(k) ((int)((unsigned)pk[k] >> 11))
+#define PP_CI(k) (s.live[tid + (k) * PP_T])
+#define PP_SEQ __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+  for (int k = 0; k < PP_PX; k++) {
+    const int j = tid + k * PP_T;
+    pk[k] = 0; xy[k] = 0; dreg[k] = 0;
+    if (j < nlive) {
+      const int c = s.live[j];
+      const int p = s.pos[c];
+      pk[k] = s.id[c] | (number[c] << 11);
+      xy[k] = (p % iw) | ((p / iw) << 16);
+    }
+  }
+  for (int g = tid; g <= K; g += PP_T) { ls_rec z = {}; L.rec[g] = z; L.start_i[g] = -1; L.end_i[g] = 0x7fffffff; }
+  if (tid == 0) { L.ncand = 0; L.count = K; L.fail = 0; L.progress = 0; }
+  __syncthreads();
+
+  // initial segments (pl:439-506)
+#pragma unroll
+  for (int k = 0; k < PP_PX; k++) {
+    const int g = PP_ID(k);
+    if (g != 0) {
+      if (PP_NUM(k) == 1) { atomicAdd(&L.rec[g].startCount, 1); atomicMax(&L.start_i[g], PP_CI(k)); }
+      atomicAdd(&L.rec[g].npix, 1);
+      atomicMax(&L.rec[g].endIndex, PP_NUM(k));
+    }
+    PP_SEQ;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PP_PX; k++) {
+    const int g = PP_ID(k);
+    if (g != 0 && PP_NUM(k) == L.rec[g].endIndex && L.rec[g].startCount == 1 && L.rec[g].npix >= 2) { atomicAdd(&L.rec[g].endCount, 1); atomicMin(&L.end_i[g], PP_CI(k)); }
+    PP_SEQ;
+  }
+  __syncthreads();
+  for (int g = tid + 1; g <= K; g += PP_T) {
+    const int sp = L.start_i[g], ep = L.end_i[g];
+    if (sp >= 0) { const int p = s.pos[sp]; L.rec[g].x0 = (float)(p % iw); L.rec[g].y0 = (float)(p / iw); }
+    if (L.rec[g].startCount == 1 && L.rec[g].npix >= 2 && ep != 0x7fffffff) {
+      const int p = s.pos[ep];
+      L.rec[g].x1 = (float)(p % iw); L.rec[g].y1 = (float)(p / iw);
+      L.rec[g].polyid = g;
+    } else L.rec[g].polyid = 0;
+  }
+  __syncthreads();
+
+  // subdivision rounds (pl:509-646); round 15 only moves pixels
+  for (int round = 0; round <= 15; round++) {
+#pragma unroll
+    for (int k = 0; k < PP_PX; k++) {
+      const int2 r2 = pp_move_dist(L, pk[k], xy[k], dreg[k], round == 15, iw);
+      pk[k] = r2.x; dreg[k] = r2.y;
+      PP_SEQ;
+    }
+    __syncthreads();
+    if (round == 15) break;
+    // detection (reads the list as it is: nothing is modified in this phase)
+#pragma unroll
+    for (int k = 0; k < PP_PX; k++) {
+      if (PP_ID(k) != 0) pp_detect(L, pk[k], xy[k], dreg[k], minerror, s.live, tid + k * PP_T);
+      PP_SEQ;
+    }
+    __syncthreads();
+    {
+      const int C = L.ncand < PP_MAXCAND ? L.ncand : PP_MAXCAND;
+      const int base = L.count;
+      for (int c = tid; c < C; c += PP_T) {
+        const int *e = L.cand + c * 8;
+        const int i = e[0], g = e[1];
+        int rank = 0;
+        bool last = true;
+        for (int q = 0; q < C; q++) {
+          const int *f = L.cand + q * 8;
+          if (f[0] < i) rank++;
+          if (f[1] == g && f[0] > i) last = false;
+        }
+        const int gn = base + 1 + rank;
+        if (gn >= PP_MAXSEG || gn >= maxrec - 1) { L.fail = 1; continue; }
+        const int p = s.pos[i], x = p % iw, y = p / iw;
+        ls_rec nr = {};
+        nr.startIndex = e[2]; nr.endIndex = e[4];
+        nr.x0 = (float)x; nr.y0 = (float)y; nr.x1 = __int_as_float(e[6]); nr.y1 = __int_as_float(e[7]);
+        nr.leftPtr = g; nr.rightPtr = e[5];
+        nr.maxDist = 0; nr.polyid = L.rec[g].polyid; nr.level = e[3];
+        L.rec[gn] = nr;
+        if (last) {
+          L.rec[g].endIndex = e[2]; L.rec[g].x1 = (float)x; L.rec[g].y1 = (float)y; L.rec[g].rightPtr = gn; L.rec[g].maxDist = 0;
+          if (e[5] != 0) L.rec[e[5]].leftPtr = gn;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid == 0) { const int C = L.ncand < PP_MAXCAND ? L.ncand : PP_MAXCAND; L.count = (L.count + C < PP_MAXSEG - 1) ? L.count + C : PP_MAXSEG - 1; L.ncand = 0; }
+    __syncthreads();
+  }
+
+  // refinement (pl:680-809)
+  const int n = L.count;
+  for (int g = tid + 1; g <= n; g += PP_T) {
+    lsx_rec z = {};
+    if (L.rec[g].polyid != 0) {
+      z.dx = (short)(L.rec[g].x1 - L.rec[g].x0); z.dy = (short)(L.rec[g].y1 - L.rec[g].y0);
+      z.vx = (short)-z.dy; z.vy = z.dx;
+      z.d2 = z.dx * z.dx + z.dy * z.dy;
+    }
+    L.sx[g] = z;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < PP_PX; k++) {
+    pp_moments(L, pk[k], xy[k], n);
+    PP_SEQ;
+  }
+  __syncthreads();
+  for (int g = tid + 1; g <= n; g += PP_T) {
+    if (L.rec[g].polyid == 0) continue;
+    const lsx_rec q = L.sx[g];
+    float rdet = (float)q.mx00 * (float)q.mx11 - (float)q.mx01 * (float)q.mx01;
+    if (rdet == 0) continue;
+    rdet = (float)(1.0 / (double)rdet);
+    const float as0 = ((float)q.mx11 * (float)q.my0 - (float)q.mx01 * (float)q.my1) * rdet;
+    const float as1 = ((float)q.mx00 * (float)q.my1 - (float)q.mx01 * (float)q.my0) * rdet;
+    L.rec[g].x0 += (float)q.vx * as1; L.rec[g].y0 += (float)q.vy * as1;
+    L.rec[g].x1 += (float)q.vx * (as0 + as1); L.rec[g].y1 += (float)q.vy * (as0 + as1);
+  }
+  __syncthreads();
+  // end-point joining in dependency order (see k_refine3)
+  for (int g = tid + 1; g <= n; g += PP_T) L.done[g] = (L.rec[g].polyid == 0 || L.rec[g].rightPtr == 0) ? 1 : 0;
+  __syncthreads();
+  for (int iter = 0; iter <= n; iter++) {
+    if (tid == 0) L.progress = 0;
+    __syncthreads();
+    for (int g = tid + 1; g <= n; g += PP_T) {
+      if (L.done[g]) continue;
+      const int h = L.rec[g].rightPtr, l = L.rec[g].leftPtr;
+      const bool l_ok = l <= 0 || l > g || l > n || L.done[l] == 1;
+      const bool h_ok = h > g || h > n || L.done[h] == 1;
+      if (l_ok && h_ok) L.done[g] = 2;
+    }
+    __syncthreads();
+    for (int g = tid + 1; g <= n; g += PP_T) {
+      if (L.done[g] != 2) continue;
+      const int h = L.rec[g].rightPtr;
+      const float v0 = L.rec[g].x0, v1 = L.rec[g].y0, v2 = L.rec[g].x1, v3 = L.rec[g].y1;
+      const float u0 = L.rec[h].x0, u1 = L.rec[h].y0, u2 = L.rec[h].x1, u3 = L.rec[h].y1;
+      const float d = (v2 - v0) * (u3 - u1) - (v3 - v1) * (u2 - u0);
+      float wx, wy;
+      if ((double)fabsf(d) < 1e-6) {
+        wx = (v2 + u0) * 0.5f; wy = (v3 + u1) * 0.5f;
+      } else {
+        const float nn = (v1 - u1) * (u2 - u0) - (v0 - u0) * (u3 - u1);
+        const float q = nn / d;
+        wx = v0 + q * (v2 - v0); wy = v1 + q * (v3 - v1);
+        const float e0 = sqrtf((wx - v2) * (wx - v2) + (wy - v3) * (wy - v3));
+        const float e1 = sqrtf((wx - u0) * (wx - u0) + (wy - u1) * (wy - u1));
+        if (e0 > 10 && e1 > 10) { wx = (v2 + u0) * 0.5f; wy = (v3 + u1) * 0.5f; }
+      }
+      L.rec[g].x1 = wx; L.rec[g].y1 = wy; L.rec[h].x0 = wx; L.rec[h].y0 = wy;
+      L.progress = 1;
+    }
+    __syncthreads();
+    for (int g = tid + 1; g <= n; g += PP_T) if (L.done[g] == 2) L.done[g] = 1;
+    __syncthreads();
+    if (!L.progress) break;
+    __syncthreads();
+  }
+
+  // results: record list (header = count) and the final per-pixel ids
+  if (tid == 0) { ls_rec z = {}; ls[0] = z; *(int *)ls = n; if (L.fail) s.ctr[25] = 1; }
+  for (int g = tid + 1; g <= n; g += PP_T) ls[g] = L.rec[g];
+#pragma unroll
+  for (int k = 0; k < PP_PX; k++) if (tid + k * PP_T < nlive) s.id[PP_CI(k)] = PP_ID(k);
+}
+
 __global__ void k_scatter_ids(PolyScratch s, int *ids) {
-  const int cnt = s.ctr[0];
-  SPARSE_LOOP(i, cnt) ids[s.pos[i]] = s.id[i];
+  const int nlive = s.ctr[24];
+  SPARSE_LOOP(j, nlive) { const int i = s.live[j]; ids[s.pos[i]] = s.id[i]; }
 }
 
 template <typename T> T *dalloc(size_t n) { void *p = nullptr; if (hipMalloc(&p, n * sizeof(T)) != hipSuccess) return nullptr; return (T *)p; }
@@ -665,20 +910,23 @@ PolyScratch *poly_scratch_create(int iw, int ih) {
   ps->ctr = dalloc<int>(64);
   ps->lsx = dalloc<lsx_rec>(N * 16 / 56 + 2);
   ps->segaux = dalloc<int>(2 * (N * 16 / 56 + 2));
+  ps->live = dalloc<int>(N);
   (void)hipMemset(ps->ctr, 0, 64 * sizeof(int));
   return ps;
 }
 
+const int *poly_scratch_counters(const PolyScratch *ps) { return ps->ctr; }
+
 void poly_scratch_destroy(PolyScratch *ps) {
   if (!ps) return;
   void *all[] = { ps->planeA, ps->planeB, ps->planeC, ps->cidx, ps->blk, ps->pos, ps->nbr, ps->lab, ps->alive, ps->ends, ps->nx[0], ps->nx[1], ps->pv[0], ps->pv[1],
-                  ps->num[0], ps->num[1], ps->link[0], ps->link[1], ps->flag, ps->flag2, ps->lab2, ps->size, ps->rootid, ps->id, ps->dist, ps->cand, ps->ctr, ps->lsx, ps->segaux };
+                  ps->num[0], ps->num[1], ps->link[0], ps->link[1], ps->flag, ps->flag2, ps->lab2, ps->size, ps->rootid, ps->id, ps->dist, ps->cand, ps->ctr, ps->lsx, ps->segaux, ps->live };
   for (void *p : all) if (p) (void)hipFree(p);
   delete ps;
 }
 
 void polyline(hipStream_t st, PolyScratch *ps, void *lslist, int lslist_bytes, int *ids, const int *in, const int *ring_src, int ring_const,
-              float minerror, int sizeThre, int iw, int ih) {
+              float minerror, int sizeThre, int iw, int ih, int mode) {
   const int N = iw * ih;
   PolyScratch s = *ps;
   ls_rec *ls = (ls_rec *)lslist;
@@ -694,9 +942,9 @@ void polyline(hipStream_t st, PolyScratch *ps, void *lslist, int lslist_bytes, i
 
   // compaction of the chain pixels in raster order
   const int nblk = cdiv(N, CP_PER_BLOCK);
-  hipLaunchKernelGGL(k_compact_count, dim3(nblk), dim3(256), 0, st, s.blk, (const int *)s.planeC, N);
+  hipLaunchKernelGGL(k_compact_count, dim3(nblk), dim3(256), 0, st, s.blk, (const int *)s.planeC, N, (const int *)nullptr);
   hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, s.blk, nblk, s.ctr);
-  hipLaunchKernelGGL(k_compact_scatter, dim3(nblk), dim3(256), 0, st, s.pos, s.cidx, (const int *)s.blk, (const int *)s.planeC, N);
+  hipLaunchKernelGGL(k_compact_scatter, dim3(nblk), dim3(256), 0, st, s.pos, s.cidx, (int *)nullptr, (const int *)s.blk, (const int *)s.planeC, N, (const int *)nullptr);
 
   // chains, loops, ends (oclpolyline.c:237-266)
   hipLaunchKernelGGL(k_build_nbr, sg, sb, 0, st, s, iw);
@@ -717,8 +965,26 @@ void polyline(hipStream_t st, PolyScratch *ps, void *lslist, int lslist_bytes, i
   hipLaunchKernelGGL(k_sub_union, sg, sb, 0, st, s, number);
   hipLaunchKernelGGL(k_flatten, sg, sb, 0, st, s.lab2, (const int *)s.ctr);
   hipLaunchKernelGGL(k_sub_size, sg, sb, 0, st, s);
-  hipLaunchKernelGGL(k_relabel_scan, dim3(1), dim3(1024), 0, st, s, sizeThre);
+  // (the chain-pixel count lives on the device: launch for the worst case, blocks beyond it exit at once)
+  hipLaunchKernelGGL(k_root_flags, sg, sb, 0, st, s, sizeThre);
+  hipLaunchKernelGGL(k_compact_count, dim3(nblk), dim3(256), 0, st, s.blk, (const int *)s.flag2, N, (const int *)s.ctr);
+  hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, s.blk, nblk, s.ctr + 1);
+  hipLaunchKernelGGL(k_compact_scatter, dim3(nblk), dim3(256), 0, st, (int *)nullptr, (int *)nullptr, s.rootid, (const int *)s.blk, (const int *)s.flag2, N, (const int *)s.ctr);
   hipLaunchKernelGGL(k_assign_ids, sg, sb, 0, st, s);
+  hipLaunchKernelGGL(k_compact_count, dim3(nblk), dim3(256), 0, st, s.blk, (const int *)s.id, N, (const int *)s.ctr);
+  hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, s.blk, nblk, s.ctr + 24);
+  hipLaunchKernelGGL(k_compact_scatter, dim3(nblk), dim3(256), 0, st, s.live, (int *)nullptr, (int *)nullptr, (const int *)s.blk, (const int *)s.id, N, (const int *)s.ctr);
+
+  if (mode == 1) {
+    // fast path: initial segments, 15 subdivision rounds and the refinement in one persistent launch (overflow -> ctr[25])
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_poly_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pp_lds)); attr_set = true; }
+    hipLaunchKernelGGL(k_seg_clear, dim3(1), dim3(64), 0, st, s, ls, 56);     // resets the counters (ctr[2..23], ctr[25])
+    hipLaunchKernelGGL(k_poly_persistent, dim3(1), dim3(PP_T), sizeof(pp_lds), st, s, ls, lslist_bytes, number, minerror, iw);
+    (void)hipMemsetAsync(ids, 0, sizeof(int) * (size_t)N, st);
+    hipLaunchKernelGGL(k_scatter_ids, sg, sb, 0, st, s, ids);
+    return;
+  }
 
   // initial segments (oclpolyline.c:191-197)
   (void)hipMemsetAsync(lslist, 0, 56, st);

@@ -4,6 +4,7 @@
 // Reference behaviour being reproduced: oclrect.cl ("rc"), oclrect.c ("rh").  See rd_device.h for arithmetic rules.
 #include "rd_device.h"
 #include "rd_kernels.h"
+#include "rd_poly_scratch.h"
 
 namespace {
 
@@ -80,50 +81,121 @@ __global__ __launch_bounds__(256) void k_stringify(int *__restrict__ out, const 
 
 // ------------------------------------------------------------------------------------------------ edge-stopped box blur
 // rc:155-205: mean of the packed-Lab integer fields over up to 4 pixels on either side along one axis (centre counted
-// twice), each side stopping at transitions of the int8 edge mask.  VERT selects the axis.
-template <int VERT>
-__global__ __launch_bounds__(256) void k_blblur(uint32_t *__restrict__ out, const int8_t *__restrict__ edge, const uint32_t *__restrict__ in, int iw, int ih) {
+// twice), each side stopping at transitions of the int8 edge mask.  The stopping positions depend on the mask only and
+// the mask is the same for all 20 passes (rh:286-296), so they are computed once per frame (k_blblur_extents: number of
+// samples taken towards smaller / larger coordinates, 0..5 each, for both axes) and every pass is a branch-free gather.
+__global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ ext, const int8_t *__restrict__ edge, int iw, int ih) {
   RD_XY;
   if (x >= iw || y >= ih) return;
   const int p = y * iw + x;
-  const int c0 = VERT ? y : x, n = VERT ? ih : iw, st = VERT ? iw : 1;
-  const int base = VERT ? x : y * iw;
-  const bool has_side = VERT ? (x < iw - 1) : (y < ih - 1);
-  const int side = VERT ? 1 : iw;
-  int wsum = 0, s0 = 0, s1 = 0, s2 = 0;
   const bool oe = edge[p] != 0;
-  for (int d = 0; d >= -4; d--) {
-    const int c = c0 + d;
-    if (c < 0) break;
-    const int q = base + c * st;
-    const int ec = edge[q];
-    if (c > 0) {
-      const int em = edge[q - st];
-      if (ec != 0 && em == 0) break;
-      if (has_side && ec == 0 && em != 0 && edge[q + side] != 0) break;
+  unsigned e = 0;
+#pragma unroll
+  for (int vert = 0; vert < 2; vert++) {
+    const int c0 = vert ? y : x, n = vert ? ih : iw, st = vert ? iw : 1;
+    const int base = vert ? x : y * iw;
+    const bool has_side = vert ? (x < iw - 1) : (y < ih - 1);
+    const int side = vert ? 1 : iw;
+    int nl = 0, nr = 0;
+    for (int d = 0; d >= -4; d--) {
+      const int c = c0 + d;
+      if (c < 0) break;
+      const int q = base + c * st;
+      const int ec = edge[q];
+      if (c > 0) {
+        const int em = edge[q - st];
+        if (ec != 0 && em == 0) break;
+        if (has_side && ec == 0 && em != 0 && edge[q + side] != 0) break;
+      }
+      nl++;
     }
-    wsum++;
-    const uint32_t v = in[q];
-    s0 += v & 4095; s1 += (v >> 12) & 1023; s2 += (v >> 22) & 1023;
+    for (int d = 0; d <= 4; d++) {
+      const int c = c0 + d;
+      if (c > n - 1) break;
+      const int q = base + c * st;
+      const int ec = edge[q];
+      if (c < n - 1 && ec == 0 && edge[q + st] != 0) break;
+      if (oe && ec == 0) break;
+      nr++;
+    }
+    e |= (unsigned)(nl | (nr << 3)) << (vert * 6);
   }
-  for (int d = 0; d <= 4; d++) {
-    const int c = c0 + d;
-    if (c > n - 1) break;
-    const int q = base + c * st;
-    const int ec = edge[q];
-    if (c < n - 1 && ec == 0 && edge[q + st] != 0) break;
-    if (oe && ec == 0) break;
-    wsum++;
-    const uint32_t v = in[q];
-    s0 += v & 4095; s1 += (v >> 12) & 1023; s2 += (v >> 22) & 1023;
-  }
-  uint32_t r = in[p];
-  if (wsum != 0) {
-    r = (uint32_t)clampi(s2 / wsum, 0, 1023);
-    r = (r << 10) | (uint32_t)clampi(s1 / wsum, 0, 1023);
-    r = (r << 12) | (uint32_t)clampi(s0 / wsum, 0, 4095);
-  }
+  ext[p] = (uint16_t)e;
+}
+
+// floor(s / w) for s <= 40950, 2 <= w <= 10 as a multiply-high with ceil(2^32 / w) (exact in that range; checked offline)
+__device__ __forceinline__ unsigned div_small(unsigned s, int w) {
+  const unsigned R[11] = { 0u, 0u, 2147483648u, 1431655766u, 1073741824u, 858993460u, 715827883u, 613566757u, 536870912u, 477218589u, 429496730u };
+  return w == 1 ? s : __umulhi(s, R[w]);
+}
+
+template <int VERT>
+__global__ __launch_bounds__(256) void k_blblur(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih) {
+  RD_XY;
+  if (x >= iw || y >= ih) return;
+  const int p = y * iw + x;
+  const unsigned e = ext[p] >> (VERT ? 6 : 0);
+  const int nl = e & 7, nr = (e >> 3) & 7;
+  const int st = VERT ? iw : 1;
+  unsigned s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+  for (int d = 0; d < 5; d++)
+    if (d < nl) { const uint32_t v = in[p - d * st]; s0 += v & 4095; s1 += (v >> 12) & 1023; s2 += (v >> 22) & 1023; }
+#pragma unroll
+  for (int d = 0; d < 5; d++)
+    if (d < nr) { const uint32_t v = in[p + d * st]; s0 += v & 4095; s1 += (v >> 12) & 1023; s2 += (v >> 22) & 1023; }
+  const int w = nl + nr;
+  uint32_t r;
+  if (w == 0) r = in[p];
+  else r = (div_small(s2, w) << 22) | (div_small(s1, w) << 12) | div_small(s0, w);   // fields cannot exceed their range: no clamp needed
   out[p] = r;
+}
+
+// One (horizontal, vertical) pair of passes (rh:286-296) in a single launch: the block computes the horizontal pass for
+// a 64 x (BP_ROWS + 8) strip into LDS (4 extra rows above and below) and the vertical pass reads it from there, so the
+// intermediate plane never travels through HBM.
+#define BP_ROWS 32
+__global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih) {
+  __shared__ uint32_t hz[BP_ROWS + 8][64];
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  const int y0 = blockIdx.y * BP_ROWS;
+  for (int r = threadIdx.y; r < BP_ROWS + 8; r += 16) {
+    const int y = y0 - 4 + r;
+    uint32_t v = 0;
+    if (x < iw && y >= 0 && y < ih) {
+      const int p = y * iw + x;
+      const unsigned e = ext[p];
+      const int nl = e & 7, nr = (e >> 3) & 7;
+      unsigned s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+      for (int d = 0; d < 5; d++)
+        if (d < nl) { const uint32_t q = in[p - d]; s0 += q & 4095; s1 += (q >> 12) & 1023; s2 += (q >> 22) & 1023; }
+#pragma unroll
+      for (int d = 0; d < 5; d++)
+        if (d < nr) { const uint32_t q = in[p + d]; s0 += q & 4095; s1 += (q >> 12) & 1023; s2 += (q >> 22) & 1023; }
+      const int w = nl + nr;
+      v = w == 0 ? in[p] : ((div_small(s2, w) << 22) | (div_small(s1, w) << 12) | div_small(s0, w));
+    }
+    hz[r][threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (x >= iw) return;
+  for (int r = threadIdx.y; r < BP_ROWS; r += 16) {
+    const int y = y0 + r;
+    if (y >= ih) break;
+    const int p = y * iw + x;
+    const unsigned e = ext[p] >> 6;
+    const int nl = e & 7, nr = (e >> 3) & 7;
+    unsigned s0 = 0, s1 = 0, s2 = 0;
+#pragma unroll
+    for (int d = 0; d < 5; d++)
+      if (d < nl) { const uint32_t q = hz[r + 4 - d][threadIdx.x]; s0 += q & 4095; s1 += (q >> 12) & 1023; s2 += (q >> 22) & 1023; }
+#pragma unroll
+    for (int d = 0; d < 5; d++)
+      if (d < nr) { const uint32_t q = hz[r + 4 + d][threadIdx.x]; s0 += q & 4095; s1 += (q >> 12) & 1023; s2 += (q >> 22) & 1023; }
+    const int w = nl + nr;
+    out[p] = w == 0 ? hz[r + 4][threadIdx.x] : ((div_small(s2, w) << 22) | (div_small(s1, w) << 12) | div_small(s0, w));
+  }
 }
 
 // rc:207-216
@@ -161,30 +233,68 @@ __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, c
 }
 
 // ------------------------------------------------------------------------------------------------ merge mask
-// rc:246-287.  pass 0: every pixel with a non-zero junction count sets the ring 16 <= d^2 < 36 around itself;
-// pass 1: curve ends (count 2) erase the disc d^2 < 64, all other counted pixels the disc d^2 < 16.  The writes of one
-// pass all store the same value, so their order is irrelevant; the two passes are separate launches.
-__global__ __launch_bounds__(256) void k_merge_mask(int *out, const int *__restrict__ junction, int pass, int iw, int ih) {
+// rc:246-287.  The reference scatters: every pixel with a non-zero junction count sets the ring 16 <= d^2 < 36 around
+// itself, then curve ends (count 2) erase the disc d^2 < 64 and all other counted pixels the disc d^2 < 16.  Equivalent
+// gather: mask(p) = A & ~B & ~C with A = "a counted pixel lies on the ring around p", B = "a curve end within d^2 < 64",
+// C = "another counted pixel within d^2 < 16".  The three pixel classes are turned into bit rows (one 64-bit word per
+// wave-row, by ballot) and each output pixel tests, per row offset dy, a 17-bit window against a precomputed dx mask.
+__global__ __launch_bounds__(256) void k_mm_bits(unsigned long long *__restrict__ bits, const int *__restrict__ junction, int iw, int ih, int wpr) {
   RD_XY;
-  if (x >= iw || y >= ih) return;
-  const int j = junction[y * iw + x];
-  if (j == 0) return;
-  const int r = pass == 0 ? 6 : (j == 2 ? 8 : 4);
-  const int lim = j == 2 ? 64 : 16;
-  for (int yy = y - r; yy <= y + r; yy++) {
-    if (yy < 0 || yy >= ih) continue;
-    for (int xx = x - r; xx <= x + r; xx++) {
-      if (xx < 0 || xx >= iw) continue;
-      const int d2 = (yy - y) * (yy - y) + (xx - x) * (xx - x);
-      if (pass == 0) { if (16 <= d2 && d2 < 36) out[yy * iw + xx] = 1; }
-      else if (d2 < lim) out[yy * iw + xx] = 0;
-    }
+  if (y >= ih) return;
+  const int j = x < iw ? junction[y * iw + x] : 0;
+  const unsigned long long any = __ballot(j != 0), end = __ballot(j == 2);
+  if (threadIdx.x == 0) {
+    unsigned long long *o = bits + ((size_t)y * wpr + blockIdx.x) * 2;
+    o[0] = any; o[1] = end;
   }
 }
 
+// bit dx+8 of the result is set when dx^2 + dy^2 lies in [lo, hi)
+__device__ __forceinline__ unsigned dxmask(int dy, int lo, int hi) {
+  unsigned m = 0;
+#pragma unroll
+  for (int dx = -8; dx <= 8; dx++) { const int d2 = dx * dx + dy * dy; if (d2 >= lo && d2 < hi) m |= 1u << (dx + 8); }
+  return m;
+}
+
+__global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const unsigned long long *__restrict__ bits, int iw, int ih, int wpr) {
+  RD_XY;
+  if (y >= ih) return;
+  unsigned A = 0, B = 0, C = 0;
+  const int k = blockIdx.x;                 // word holding this wave's own 64 columns
+  const int sh = threadIdx.x + 64 - 8;      // bit position of column x-8 inside the 192-bit window (words k-1, k, k+1)
+#pragma unroll
+  for (int dy = -8; dy <= 8; dy++) {
+    const int yy = y + dy;
+    if (yy < 0 || yy >= ih) continue;       // wave-uniform
+    const unsigned long long *row = bits + (size_t)yy * wpr * 2;
+    unsigned long long a0 = k > 0 ? row[(k - 1) * 2] : 0ull, a1 = row[k * 2], a2 = k + 1 < wpr ? row[(k + 1) * 2] : 0ull;
+    unsigned long long e0 = k > 0 ? row[(k - 1) * 2 + 1] : 0ull, e1 = row[k * 2 + 1], e2 = k + 1 < wpr ? row[(k + 1) * 2 + 1] : 0ull;
+    // 17 bits starting at window bit sh (64-8 <= sh <= 127-8+... < 128+64): take from (w0,w1) or (w1,w2)
+    unsigned wa, we;
+    if (sh < 64) {
+      wa = (unsigned)((a0 >> sh) | (sh ? (a1 << (64 - sh)) : 0ull));
+      we = (unsigned)((e0 >> sh) | (sh ? (e1 << (64 - sh)) : 0ull));
+    } else {
+      const int s2 = sh - 64;
+      wa = (unsigned)((a1 >> s2) | (s2 ? (a2 << (64 - s2)) : 0ull));
+      we = (unsigned)((e1 >> s2) | (s2 ? (e2 << (64 - s2)) : 0ull));
+    }
+    wa &= 0x1ffffu; we &= 0x1ffffu;
+    const int ady = dy < 0 ? -dy : dy;
+    A |= wa & dxmask(ady, 16, 36);
+    B |= we & dxmask(ady, 0, 64);
+    C |= (wa & ~we) & dxmask(ady, 0, 16);
+  }
+  if (x < iw) out[y * iw + x] = (A != 0 && B == 0 && C == 0) ? 1 : 0;
+}
+
 // ------------------------------------------------------------------------------------------------ regions
-// rc:289-298 initial links (up if same colour, else left if same colour, else self)
-__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, const int *__restrict__ pix, int iw, int ih) {
+// rc:289-298 initial links (up if same colour, else left if same colour, else self), plus - because colours, merge mask
+// and edges do not change between the rounds - one byte per pixel telling from which of its 4 neighbours the pixel may
+// adopt a label (rc:308-326): bit0 up, bit1 left, bit2 right, bit3 down; 0 for frame-border pixels (never processed).
+__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, const int *__restrict__ pix, const int *__restrict__ mask,
+                                                     const int *__restrict__ edge, int iw, int ih) {
   RD_XY;
   if (x >= iw || y >= ih) return;
   const int p = y * iw + x;
@@ -193,58 +303,94 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, co
   if (y > 0 && v == pix[p - iw]) l = p - iw;
   else if (x > 0 && v == pix[p - 1]) l = p - 1;
   label[p] = l;
+  unsigned a = 0;
+  if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1) {
+    const bool any = mask[p] != 0;
+    const bool e0 = edge[p] <= 0;
+    if ((v == pix[p - iw] || any) && e0) a |= 1;
+    if ((v == pix[p - 1] || any) && e0) a |= 2;
+    if ((v == pix[p + 1] || any) && edge[p + 1] <= 0) a |= 4;
+    if ((v == pix[p + iw] || any) && edge[p + iw] <= 0) a |= 8;
+    a |= 16;   // interior
+  }
+  allow[p] = (uint8_t)a;
 }
 
-// rc:300-334 per-pixel rule, evaluated in SYNCHRONOUS rounds: every pixel reads the labels of the previous round,
+// rc:300-334 per-pixel rule, evaluated in SYNCHRONOUS rounds on the flattened initial forest: every pixel reads the labels of the previous round,
 // proposes `min` updates for itself and for its old parent, and the proposals are applied between rounds.  The
 // reference applies the same rule in place for 8 launches, which makes its result depend on the work-item order
 // (SURVEY.md H5); synchronous rounds to convergence are the order-free reading of the same rule.
-__global__ __launch_bounds__(256) void k_region_propose(const int *__restrict__ label, int *prop, const int *__restrict__ pix, const int *__restrict__ mask,
-                                                        const int *__restrict__ edge, int iw, int ih, const int *flags, int round) {
+__global__ __launch_bounds__(256) void k_region_propose(const int *__restrict__ label, int *prop, int *__restrict__ selfp, const uint8_t *__restrict__ allow, int iw, int ih, const int *flags, int round) {
   if (round > 0 && flags[round - 1] == 0) return;
+  __shared__ int hk[512], hv[512];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int t = tid; t < 512; t += 256) { hk[t] = -1; hv[t] = 0x7fffffff; }
+  __syncthreads();
   RD_XY;
-  const bool inside = x > 0 && y > 0 && x < iw - 1 && y < ih - 1;
   int og = 0, g = 0, p0 = 0;
-  if (inside) {
+  bool todo = false;
+  if (x < iw && y < ih) {
     p0 = y * iw + x;
-    og = label[p0];
-    g = og;
-    const int c = pix[p0];
-    const bool any = mask[p0] != 0;
-    const bool e0 = edge[p0] <= 0;
-    int p1, s;
-    p1 = p0 - iw; s = label[p1]; if (s < g && (c == pix[p1] || any) && e0) g = s;
-    p1 = p0 - 1;  s = label[p1]; if (s < g && (c == pix[p1] || any) && e0) g = s;
-    p1 = p0 + 1;  s = label[p1]; if (s < g && (c == pix[p1] || any) && edge[p1] <= 0) g = s;
-    p1 = p0 + iw; s = label[p1]; if (s < g && (c == pix[p1] || any) && edge[p1] <= 0) g = s;
-    for (int j = 0; j < 8; j++) g = label[g];   // rc:328: eight pointer jumps
+    const unsigned a = allow[p0];
+    if (a & 16) {
+      og = label[p0];
+      g = og;
+      int s;
+      if (a & 1) { s = label[p0 - iw]; if (s < g) g = s; }
+      if (a & 2) { s = label[p0 - 1]; if (s < g) g = s; }
+      if (a & 4) { s = label[p0 + 1]; if (s < g) g = s; }
+      if (a & 8) { s = label[p0 + iw]; if (s < g) g = s; }
+      for (int j = 0; j < 8; j++) { const int n = label[g]; if (n == g) break; g = n; }   // rc:328: eight pointer jumps (a root maps to itself)
+      todo = g != og;
+    }
   }
-  bool todo = inside && g != og;
-  if (todo && g < prop[p0]) atomicMin(&prop[p0], g);
-  // the old parent is shared by (up to) a whole region: one atomic per distinct parent per wave, and only if it can
-  // still lower the stored proposal (a stale read only costs a redundant atomic)
-  while (__any(todo)) {
-    const unsigned long long m = __ballot(todo);
-    const int leader = __ffsll((long long)m) - 1;
-    const int lo = __shfl(og, leader);
-    const bool mine = todo && og == lo;
-    int v = mine ? g : 0x7fffffff;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-    if ((int)threadIdx.x == leader && v < prop[lo]) atomicMin(&prop[lo], v);
-    if (mine) todo = false;
+  if (x < iw && y < ih) selfp[p0] = todo ? g : 0x7f7f7f7f;   // own update: nobody else writes this word
+  // Hooking the old parent: after flattening, all pixels of a tree share one parent, so the block first reduces its
+  // (parent -> smallest proposal) pairs in a small LDS hash and then issues one guarded atomic per distinct parent.
+  if (todo) {
+    unsigned h = ((unsigned)og * 2654435761u) >> 23;
+    int probes = 0;
+    for (;;) {
+      const int kprev = atomicCAS(&hk[h], -1, og);
+      if (kprev == -1 || kprev == og) { atomicMin(&hv[h], g); break; }
+      h = (h + 1) & 511;
+      if (++probes == 16) { if (g < ld_agent(&prop[og])) atomicMin(&prop[og], g); break; }
+    }
+  }
+  __syncthreads();
+  for (int t = tid; t < 512; t += 256) {
+    const int key = hk[t];
+    if (key != -1) { const int v = hv[t]; if (v < ld_agent(&prop[key])) atomicMin(&prop[key], v); }
   }
 }
 
-__global__ void k_region_apply(int *label, int *prop, int n, int *flags, int round) {
+// In-place pointer jumping on the forest of initial links (parent index < child index): each launch replaces a
+// pixel's parent by its great-great-grandparent; any interleaving only ever stores ancestors, so the iteration ends
+// with every pixel pointing at the root of its initial tree.
+__global__ void k_region_flatten(int *label, int n, int *flags, int round) {
   if (round > 0 && flags[round - 1] == 0) return;
   bool changed = false;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int m = prop[i];
-    if (m != 0x7f7f7f7f) {
-      prop[i] = 0x7f7f7f7f;
-      if (m < label[i]) { label[i] = m; changed = true; }
+    const int l = label[i];
+    int a = label[l];
+    if (a != l) {
+      a = label[a]; a = label[a];
+      label[i] = a;
+      changed = true;
     }
+  }
+  if (__any(changed) && (threadIdx.x & 63) == 0) flags[round] = 1;
+}
+
+__global__ void k_region_apply(int *label, int *prop, const int *__restrict__ selfp, int n, int *flags, int round) {
+  if (round > 0 && flags[round - 1] == 0) return;
+  bool changed = false;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int m = prop[i];
+    if (m != 0x7f7f7f7f) prop[i] = 0x7f7f7f7f;
+    const int sp = selfp[i];
+    if (sp < m) m = sp;
+    if (m < label[i]) { label[i] = m; changed = true; }
   }
   if (__any(changed) && (threadIdx.x & 63) == 0) flags[round] = 1;
 }
@@ -252,32 +398,39 @@ __global__ void k_region_apply(int *label, int *prop, int n, int *flags, int rou
 // rc:336-346: out[label]++ for every pixel.  Most pixels belong to a handful of huge regions, so counts are
 // aggregated per wave (ballot of equal labels), then per block in an LDS hash, before touching global atomics.
 #define RS_T 1024
+#define RS_PER_THREAD 32
+__device__ __forceinline__ void rs_accum(int *keys, int *vals, int *out, int label, int cnt) {
+  unsigned h = ((unsigned)label * 2654435761u) >> 22;
+  int probes = 0;
+  for (;;) {
+    const int kprev = atomicCAS(&keys[h], -1, label);
+    if (kprev == -1 || kprev == label) { atomicAdd(&vals[h], cnt); return; }
+    h = (h + 1) & (RS_T - 1);
+    if (++probes == 32) { atomicAdd(&out[label], cnt); return; }
+  }
+}
+
 __global__ __launch_bounds__(256) void k_region_size(int *out, const int *__restrict__ label, int n) {
   __shared__ int keys[RS_T], vals[RS_T];
   for (int i = threadIdx.x; i < RS_T; i += 256) { keys[i] = -1; vals[i] = 0; }
   __syncthreads();
-  const int per_block = 256 * 32;
-  const int begin = blockIdx.x * per_block;
-  for (int k = 0; k < 32; k++) {
+  const int begin = blockIdx.x * 256 * RS_PER_THREAD;
+  for (int k = 0; k < RS_PER_THREAD; k++) {
     const int i = begin + k * 256 + threadIdx.x;
-    int l = i < n ? label[i] : -1;
-    bool todo = l != -1;
+    const int lk = i < n ? label[i] : -1;
+    const int l0 = __shfl(lk, 0);
+    if (__all(lk == l0)) {          // the usual case: the whole wave lies inside one region
+      if ((threadIdx.x & 63) == 0 && l0 != -1) rs_accum(keys, vals, out, l0, 64);
+      continue;
+    }
+    bool todo = lk != -1;
     while (__any(todo)) {
       const unsigned long long m = __ballot(todo);
       const int leader = __ffsll((long long)m) - 1;
-      const int ll = __shfl(l, leader);
-      const bool mine = todo && l == ll;
+      const int ll = __shfl(lk, leader);
+      const bool mine = todo && lk == ll;
       const int cnt = __popcll(__ballot(mine));
-      if ((int)(threadIdx.x & 63) == leader) {
-        unsigned h = ((unsigned)ll * 2654435761u) >> 22;
-        int probes = 0;
-        for (;;) {
-          const int kprev = atomicCAS(&keys[h], -1, ll);
-          if (kprev == -1 || kprev == ll) { atomicAdd(&vals[h], cnt); break; }
-          h = (h + 1) & (RS_T - 1);
-          if (++probes == 32) { atomicAdd(&out[ll], cnt); break; }
-        }
-      }
+      if ((int)(threadIdx.x & 63) == leader) rs_accum(keys, vals, out, ll, cnt);
       if (mine) todo = false;
     }
   }
@@ -335,72 +488,93 @@ __global__ __launch_bounds__(256) void k_mark_boundary(int *__restrict__ out, co
 // box (atomicMax), both over the pixels that carry a segment id.
 __device__ __forceinline__ unsigned ls_slot(int id, int bid, int nentry) { return (((unsigned)id * (unsigned)bid) & 0x7fffffffu) % (unsigned)nentry; }
 
-__global__ __launch_bounds__(256) void k_reduce_claim(int *claim, const int *__restrict__ boundary, const int *__restrict__ lsid, int iw, int ih, int nentry) {
-  RD_XY;
-  if (x <= 0 || y <= 0 || x >= iw - 1 || y >= ih - 1) return;
-  const int p0 = y * iw + x, id = lsid[p0];
-  if (id <= 0) return;
-  for (int yy = -3; yy <= 3; yy++) {
-    if (y + yy < 0 || y + yy >= ih) continue;
-    for (int xx = -3; xx <= 3; xx++) {
-      if (x + xx < 0 || x + xx >= iw) continue;
-      const int b = boundary[(y + yy) * iw + x + xx];
-      if (b <= 0) continue;
-      atomicMin(&claim[ls_slot(id, b, nentry)], p0);
+// sparse: one thread per chain pixel left by the polyline stage (raster-ordered compact list, so the compact index orders
+// pixels like the pixel index does)
+__global__ void k_reduce_claim(int *claim, const int *__restrict__ boundary, rdk::PolyScratch s, int iw, int ih, int nentry) {
+  const int nlive = s.ctr[24];
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nlive; j += gridDim.x * blockDim.x) {
+    const int i = s.live[j];
+    const int id = s.id[i];
+    if (id <= 0) continue;
+    const int p0 = s.pos[i], x = p0 % iw, y = p0 / iw;
+    int win[49];
+#pragma unroll
+    for (int k = 0; k < 49; k++) {
+      const int xx = x + k % 7 - 3, yy = y + k / 7 - 3;
+      win[k] = (xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? boundary[yy * iw + xx] : 0;
+    }
+    int lastb = 0;
+    {
+#pragma unroll
+      for (int k = 0; k < 49; k++) {
+        const int b = win[k];
+        if (b <= 0 || b == lastb) continue;      // the slot depends on (id, b) only
+        lastb = b;
+        const unsigned slot = ls_slot(id, b, nentry);
+        if (i < ld_agent(&claim[slot])) atomicMin(&claim[slot], i);
+      }
     }
   }
 }
 
-__global__ __launch_bounds__(256) void k_reduce_box(int *table, const int *__restrict__ claim, const int *__restrict__ boundary, const int *__restrict__ lsid, int iw, int ih, int nentry) {
-  RD_XY;
-  if (x <= 0 || y <= 0 || x >= iw - 1 || y >= ih - 1) return;
-  const int p0 = y * iw + x, id = lsid[p0];
-  if (id <= 0) return;
-  // slots this pixel touches, in scan order; a slot can be touched several times (same or different boundary ids)
-  unsigned first_claimed = 0xffffffffu;   // slot whose claiming touch (by this pixel) has been consumed
-  bool have_first = false;
-  for (int yy = -3; yy <= 3; yy++) {
-    if (y + yy < 0 || y + yy >= ih) continue;
-    for (int xx = -3; xx <= 3; xx++) {
-      if (x + xx < 0 || x + xx >= iw) continue;
-      const int b = boundary[(y + yy) * iw + x + xx];
+__global__ void k_reduce_box(int *table, const int *__restrict__ claim, const int *__restrict__ boundary, rdk::PolyScratch s, int iw, int ih, int nentry) {
+  const int nlive = s.ctr[24];
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nlive; j += gridDim.x * blockDim.x) {
+    const int i = s.live[j];
+    const int id = s.id[i];
+    if (id <= 0) continue;
+    const int p0 = s.pos[i], x = p0 % iw, y = p0 / iw;
+    int win[49];
+#pragma unroll
+    for (int k = 0; k < 49; k++) {
+      const int xx = x + k % 7 - 3, yy = y + k / 7 - 3;
+      win[k] = (xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? boundary[yy * iw + xx] : 0;
+    }
+    // state for the boundary id of the previous touch: the slot, whether its owner carries our segment id, whether we
+    // are the claiming pixel and still owe the "first touch only claims" skip (rc:449-456), whether we already widened it
+    int lastb = 0;
+    unsigned slot = 0;
+    bool ok = false, skip_first = false, done = false;
+#pragma unroll
+    for (int k = 0; k < 49; k++) {
+      const int b = win[k];
       if (b <= 0) continue;
-      const unsigned slot = ls_slot(id, b, nentry);
-      const int owner_pixel = claim[slot];
-      const int owner_id = lsid[owner_pixel];
-      if (owner_id != id) continue;
-      if (owner_pixel == p0) {
-        // this pixel claimed the slot: its first touch of the slot only claims (a pixel can own several slots)
-        bool seen = false;
-        if (have_first && first_claimed == slot) seen = true;
-        if (!seen) {
-          // was an earlier touch of this same slot already consumed?  keep a tiny set: re-scan the window prefix
+      if (b != lastb) {
+        lastb = b;
+        slot = ls_slot(id, b, nentry);
+        const int owner = claim[slot];
+        ok = s.id[owner] == id;
+        done = false;
+        skip_first = false;
+        if (ok && owner == i) {
+          // claiming pixel (rare): was there an earlier touch of this slot, through any boundary id, in this window?
           bool earlier = false;
-          for (int y2 = -3; y2 <= yy && !earlier; y2++) {
-            if (y + y2 < 0 || y + y2 >= ih) continue;
-            for (int x2 = -3; x2 <= 3; x2++) {
-              if (y2 == yy && x2 >= xx) break;
-              if (x + x2 < 0 || x + x2 >= iw) continue;
-              const int b2 = boundary[(y + y2) * iw + x + x2];
-              if (b2 > 0 && ls_slot(id, b2, nentry) == slot) { earlier = true; break; }
-            }
+          for (int k2 = 0; k2 < k && !earlier; k2++) {
+            const int xx = x + k2 % 7 - 3, yy = y + k2 / 7 - 3;
+            if (xx < 0 || xx >= iw || yy < 0 || yy >= ih) continue;
+            const int b2 = boundary[yy * iw + xx];
+            if (b2 > 0 && ls_slot(id, b2, nentry) == slot) earlier = true;
           }
-          if (!earlier) { first_claimed = slot; have_first = true; continue; }
+          skip_first = !earlier;
         }
       }
+      if (!ok) continue;
+      if (skip_first) { skip_first = false; continue; }
+      if (done) continue;               // max is idempotent: one widening per run of touches is enough
+      done = true;
       int *e = table + (size_t)slot * 5;
-      atomicMax(&e[1], iw - x);
-      atomicMax(&e[2], x);
-      atomicMax(&e[3], ih - y);
-      atomicMax(&e[4], y);
+      if (iw - x > ld_agent(&e[1])) atomicMax(&e[1], iw - x);
+      if (x > ld_agent(&e[2])) atomicMax(&e[2], x);
+      if (ih - y > ld_agent(&e[3])) atomicMax(&e[3], ih - y);
+      if (y > ld_agent(&e[4])) atomicMax(&e[4], y);
     }
   }
 }
 
-__global__ void k_reduce_owner(int *table, const int *__restrict__ claim, const int *__restrict__ lsid, int nentry) {
+__global__ void k_reduce_owner(int *table, const int *__restrict__ claim, rdk::PolyScratch s, int nentry) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nentry; i += gridDim.x * blockDim.x) {
     const int c = claim[i];
-    if (c != 0x7f7f7f7f) table[(size_t)i * 5] = lsid[c];
+    if (c != 0x7f7f7f7f) table[(size_t)i * 5] = s.id[c];
   }
 }
 
@@ -454,9 +628,15 @@ void connect_rect(hipStream_t s, int *out, const int *in, int iw, int ih) {
 void stringify(hipStream_t s, int *out, const int *in, int mod2, int iw, int ih) {
   hipLaunchKernelGGL(k_stringify, grid2(iw, ih), block2, 0, s, out, in, mod2, iw, ih);
 }
-void blblur(hipStream_t s, uint32_t *out, const int8_t *edge, const uint32_t *in, int vertical, int iw, int ih) {
-  if (vertical) hipLaunchKernelGGL(k_blblur<1>, grid2(iw, ih), block2, 0, s, out, edge, in, iw, ih);
-  else hipLaunchKernelGGL(k_blblur<0>, grid2(iw, ih), block2, 0, s, out, edge, in, iw, ih);
+void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih) {
+  hipLaunchKernelGGL(k_blblur_extents, grid2(iw, ih), block2, 0, s, ext, edge, iw, ih);
+}
+void blblur(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int vertical, int iw, int ih) {
+  if (vertical) hipLaunchKernelGGL(k_blblur<1>, grid2(iw, ih), block2, 0, s, out, ext, in, iw, ih);
+  else hipLaunchKernelGGL(k_blblur<0>, grid2(iw, ih), block2, 0, s, out, ext, in, iw, ih);
+}
+void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih) {
+  hipLaunchKernelGGL(k_blblur_pair, dim3(cdiv(iw, 64), cdiv(ih, BP_ROWS)), dim3(64, 16), 0, s, out, ext, in, iw, ih);
 }
 void quantize(hipStream_t s, uint32_t *out, const uint32_t *in, int n0, int n1, int n2, int n) {
   hipLaunchKernelGGL(k_quantize, dim3(ew_grid(n)), dim3(256), 0, s, out, in, n0, n1, n2, n);
@@ -464,27 +644,32 @@ void quantize(hipStream_t s, uint32_t *out, const uint32_t *in, int n0, int n1, 
 void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih) {
   hipLaunchKernelGGL(k_despeckle, grid2(iw, ih), block2, 0, s, out, in, edge, iw, ih);
 }
-void merge_mask(hipStream_t s, int *out, const int *junction, int iw, int ih) {
-  (void)hipMemsetAsync(out, 0, sizeof(int) * (size_t)iw * ih, s);
-  hipLaunchKernelGGL(k_merge_mask, grid2(iw, ih), block2, 0, s, out, junction, 0, iw, ih);
-  hipLaunchKernelGGL(k_merge_mask, grid2(iw, ih), block2, 0, s, out, junction, 1, iw, ih);
+// scratch: ih * ceil(iw/64) * 2 64-bit words
+void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih) {
+  const int wpr = cdiv(iw, 64);
+  hipLaunchKernelGGL(k_mm_bits, grid2(iw, ih), block2, 0, s, (unsigned long long *)scratch, junction, iw, ih, wpr);
+  hipLaunchKernelGGL(k_mm_gather, grid2(iw, ih), block2, 0, s, out, (const unsigned long long *)scratch, iw, ih, wpr);
 }
 
-// scratch: 2*N ints (proposal plane + round flags at the start of the second plane)
+// scratch: 3*N ints (hook proposals; round flags + allowed-direction bytes; self proposals)
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih) {
-  const int n = iw * ih, ROUNDS = 32;
-  int *prop = scratch, *flags = scratch + n;
+  const int n = iw * ih, ROUNDS = 20, FLAT = 8;
+  int *prop = scratch, *flags = scratch + n, *fflags = flags + 32;
   (void)hipMemsetAsync(prop, 0x7f, sizeof(int) * (size_t)n, s);
-  (void)hipMemsetAsync(flags, 0, sizeof(int) * (ROUNDS + 1), s);
-  hipLaunchKernelGGL(k_region_init, grid2(iw, ih), block2, 0, s, label, pix, iw, ih);
+  (void)hipMemsetAsync(flags, 0, sizeof(int) * 64, s);
+  uint8_t *allow = (uint8_t *)(flags + 64);
+  int *selfp = scratch + 2 * (size_t)n;
+  hipLaunchKernelGGL(k_region_init, grid2(iw, ih), block2, 0, s, label, allow, pix, mask, edge, iw, ih);
+  // the initial links are flattened first (4^8 hops of reach); the synchronous rounds then start from trees of depth 1
+  for (int r = 0; r < FLAT; r++) hipLaunchKernelGGL(k_region_flatten, dim3(ew_grid(n)), dim3(256), 0, s, label, n, fflags, r);
   for (int r = 0; r < ROUNDS; r++) {
-    hipLaunchKernelGGL(k_region_propose, grid2(iw, ih), block2, 0, s, (const int *)label, prop, pix, mask, edge, iw, ih, (const int *)flags, r);
-    hipLaunchKernelGGL(k_region_apply, dim3(ew_grid(n)), dim3(256), 0, s, label, prop, n, flags, r);
+    hipLaunchKernelGGL(k_region_propose, grid2(iw, ih), block2, 0, s, (const int *)label, prop, selfp, (const uint8_t *)allow, iw, ih, (const int *)flags, r);
+    hipLaunchKernelGGL(k_region_apply, dim3(ew_grid(n)), dim3(256), 0, s, label, prop, (const int *)selfp, n, flags, r);
   }
 }
 
 void region_size(hipStream_t s, int *out, const int *label, int n) {
-  hipLaunchKernelGGL(k_region_size, dim3(cdiv(n, 256 * 32)), dim3(256), 0, s, out, label, n);
+  hipLaunchKernelGGL(k_region_size, dim3(cdiv(n, 256 * RS_PER_THREAD)), dim3(256), 0, s, out, label, n);
 }
 
 // scratch: 2*N ints.  On return `label` holds the result.
@@ -505,12 +690,12 @@ void mark_boundary(hipStream_t s, int *out, const int *in, int iw, int ih) {
 }
 
 // table: nentry*5 ints (cleared here); claim: nentry ints of scratch
-void reduce_ls(hipStream_t s, int *table, int *claim, const int *boundary, const int *lsid, int iw, int ih, int nentry) {
+void reduce_ls(hipStream_t s, int *table, int *claim, const int *boundary, const PolyScratch *ps, int iw, int ih, int nentry) {
   (void)hipMemsetAsync(table, 0, sizeof(int) * 5 * (size_t)nentry, s);
   (void)hipMemsetAsync(claim, 0x7f, sizeof(int) * (size_t)nentry, s);
-  hipLaunchKernelGGL(k_reduce_claim, grid2(iw, ih), block2, 0, s, claim, boundary, lsid, iw, ih, nentry);
-  hipLaunchKernelGGL(k_reduce_owner, dim3(ew_grid(nentry)), dim3(256), 0, s, table, (const int *)claim, lsid, nentry);
-  hipLaunchKernelGGL(k_reduce_box, grid2(iw, ih), block2, 0, s, table, (const int *)claim, boundary, lsid, iw, ih, nentry);
+  hipLaunchKernelGGL(k_reduce_claim, dim3(512), dim3(256), 0, s, claim, boundary, *ps, iw, ih, nentry);
+  hipLaunchKernelGGL(k_reduce_owner, dim3(ew_grid(nentry)), dim3(256), 0, s, table, (const int *)claim, *ps, nentry);
+  hipLaunchKernelGGL(k_reduce_box, dim3(512), dim3(256), 0, s, table, (const int *)claim, boundary, *ps, iw, ih, nentry);
 }
 
 void sample_segments(hipStream_t s, int *out, const void *lslist, int max_records, const int *boundary, const int *table, int iw, int ih, int nentry) {

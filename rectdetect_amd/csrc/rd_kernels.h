@@ -14,7 +14,10 @@ void pack_plab(hipStream_t s, uint32_t *out, const float *L, const float *a, con
 void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], int np, int W, int H);
 void transpose_unpack(hipStream_t s, float *const dst[3], const uint32_t *plab, int W, int H);
 // causal + anti-causal sigma=1 IIR sweeps down the columns of np planes (W columns, H rows): fwd[k], bwd[k] <- src[k]
-void iir_columns(hipStream_t s, float *const fwd[3], float *const bwd[3], const float *const src[3], int np, int W, int H);
+// tails/bad: scratch for the chunked evaluation (iir_scratch_floats() floats, one int that must be 0 on entry and stays 0
+// unless a chunk failed its verification); pass nullptr for plain full-length sweeps
+size_t iir_scratch_floats(int np, int W, int H);
+void iir_columns(hipStream_t s, float *const fwd[3], float *const bwd[3], const float *const src[3], int np, int W, int H, float *tails, int *bad);
 // dst[k] (H x W) = transpose( bwd[k] + fwd[k] - src[k] * c0 )   with fwd/bwd/src given as W x H planes
 void iir_combine_transpose(hipStream_t s, float *const dst[3], const float *const fwd[3], const float *const bwd[3], const float *const src[3], int np, int W, int H);
 // dst[k] = bwd[k] + fwd[k] - src[k] * c0   (no transpose)
@@ -40,24 +43,30 @@ void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw
 void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih);
 void connect_rect(hipStream_t s, int *out, const int *in, int iw, int ih);
 void stringify(hipStream_t s, int *out, const int *in, int mod2, int iw, int ih);
-void blblur(hipStream_t s, uint32_t *out, const int8_t *edge, const uint32_t *in, int vertical, int iw, int ih);
+// run extents of the edge-stopped blur (depend on the edge mask only): ext[p] = nl_h | nr_h<<3 | nl_v<<6 | nr_v<<9
+void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih);
+void blblur(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int vertical, int iw, int ih);
+// one horizontal + vertical pass pair; out must not alias in
+void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih);
 void quantize(hipStream_t s, uint32_t *out, const uint32_t *in, int n0, int n1, int n2, int n);
 void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih);
-void merge_mask(hipStream_t s, int *out, const int *junction, int iw, int ih);   // clears out, sets ring, erases discs
+void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih);   // scratch: >= ih*ceil(iw/64)*4 ints
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih);
 void region_size(hipStream_t s, int *out, const int *label, int n);              // accumulates into out
 void despeckle2(hipStream_t s, int *label, int *scratch, const int *size, int thre, int iw, int ih);
 void mark_boundary(hipStream_t s, int *out, const int *in, int iw, int ih);
-void reduce_ls(hipStream_t s, int *table, int *claim, const int *boundary, const int *lsid, int iw, int ih, int nentry);
+struct PolyScratch;
+// votes of the chain pixels left in `ps` by the last polyline() call on this stream (their final segment ids)
+void reduce_ls(hipStream_t s, int *table, int *claim, const int *boundary, const PolyScratch *ps, int iw, int ih, int nentry);
 // per segment, 15 probe points: {boundary id, table slot owner, 4 box values} -> out[(seg*15 + k)*6 ..]
 void sample_segments(hipStream_t s, int *out, const void *lslist, int max_records, const int *boundary, const int *table, int iw, int ih, int nentry);
 
 // ---- rd_k_poly.hip: polyline stage on compacted chain pixels
-struct PolyScratch;   // opaque, owned by the caller (see rd_k_poly.hip)
 PolyScratch *poly_scratch_create(int iw, int ih);
 void poly_scratch_destroy(PolyScratch *ps);
+const int *poly_scratch_counters(const PolyScratch *ps);   // device pointer: [0] chain pixels, [1] chains, [2+r] split candidates of round r
 // ring_src: plane whose 2-px frame ring supplies the stale ring values (may be null -> ring_const is used)
 void polyline(hipStream_t s, PolyScratch *ps, void *lslist, int lslist_bytes, int *ids, const int *in, const int *ring_src, int ring_const,
-              float minerror, int sizeThre, int iw, int ih);
+              float minerror, int sizeThre, int iw, int ih, int mode);   // mode 0: always complete; 1: single persistent launch for the split/refine part, may set counter 25 (overflow: repeat with mode 0)
 
 }  // namespace rdk

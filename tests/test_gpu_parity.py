@@ -227,3 +227,98 @@ def test_full_size_properties_1080p():
         cr = d[:, 0] * np.roll(d, -1, 0)[:, 1] - d[:, 1] * np.roll(d, -1, 0)[:, 0]
         assert (cr > 0).all() or (cr < 0).all()
         assert (c > -0.5 * iw).all() and (c < 1.5 * iw).all()
+
+
+def test_chunked_blur_verifies_and_counters():
+    """the chunked IIR evaluation must pass its own on-device verification (no fallback taken) on real frames"""
+    iw, ih = 1920, 1080
+    det = ra.Detector(iw, ih, nslots=1)
+    det.enqueue(synth.frame(synth.SEED0 + 1, iw, ih, 3))
+    det.poll(TAN36)
+    flags = det.plane("iirflags", np.int32, 16)
+    assert flags[0] == 0 and flags[1] == 0
+    ctr = det.plane("polyctr", np.int32, 64)
+    assert 0 < ctr[0] < iw * ih and 0 < ctr[1] <= ctr[0]
+    print("chain pixels", int(ctr[0]), "chains", int(ctr[1]), "live pixels", int(ctr[24]), "split candidates per round", ctr[2:17].tolist())
+    det.close()
+
+
+def test_pipelined_workers_equal_sequential():
+    """several frames in flight + post-process on worker threads + captured graphs == one frame at a time, inline"""
+    iw, ih = 640, 480
+    frames = [synth.frame(synth.SEED0 + 8, iw, ih, t) for t in range(7)]
+    seq = ra.Detector(iw, ih, nslots=1, nworkers=0)
+    want = []
+    for f in frames:
+        seq.enqueue(f)
+        want.append((seq.poll(TAN36), seq.last_segments()))
+    seq.close()
+    par = ra.Detector(iw, ih, nslots=3, nworkers=1)
+    got, inflight = [], 0
+    for f in frames:
+        if inflight == 3:
+            got.append((par.poll(TAN36), par.last_segments()))
+            inflight -= 1
+        par.enqueue(f)
+        inflight += 1
+    while inflight:
+        got.append((par.poll(TAN36), par.last_segments()))
+        inflight -= 1
+    par.close()
+    assert len(got) == len(want)
+    for (r1, s1), (r2, s2) in zip(want, got):
+        assert helpers.rects_equal(r1, r2) and helpers.segments_equal(s1, s2)
+
+
+def _run_with_env(env, iw, ih, frames):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        det = ra.Detector(iw, ih, nslots=1)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    out = []
+    for f in frames:
+        det.enqueue(f)
+        out.append((det.poll(TAN36), det.last_segments()))
+    redone = det.redone_frames()
+    det.close()
+    return out, redone
+
+
+@pytest.mark.parametrize("iw,ih,seed", [(640, 480, 5), (1920, 1080, 0)])
+def test_polyline_single_launch_equals_multilaunch(iw, ih, seed):
+    """the persistent single-launch split/refine kernel, the ~85-launch form of the same stage, and the overflow
+    fallback (tail repeated the long way) must give identical segment lists and rectangles"""
+    frames = [synth.frame(synth.SEED0 + seed, iw, ih, t) for t in range(2)]
+    fast, n0 = _run_with_env({}, iw, ih, frames)
+    slow, n1 = _run_with_env({"RD_POLY_MULTILAUNCH": "1"}, iw, ih, frames)
+    redo, n2 = _run_with_env({"RD_POLY_FORCE_REDO": "1"}, iw, ih, frames)
+    assert n0 == 0 and n1 == 0 and n2 == len(frames)
+    for (r0, s0), (r1, s1), (r2, s2) in zip(fast, slow, redo):
+        assert helpers.segments_equal(s0, s1) and helpers.segments_equal(s0, s2)
+        assert helpers.rects_equal(r0, r1) and helpers.rects_equal(r0, r2)
+
+
+def test_polyline_overflow_takes_fallback_and_matches_oracle():
+    """a frame with far more chains than the single-launch kernel's on-chip tables hold: the overflow flag must come
+    back, the stage is repeated with the multi-launch path, and the segments still equal the oracle's"""
+    iw, ih = 1280, 720
+    rng = np.random.default_rng(77)
+    tiles = rng.integers(0, 256, (ih // 16, iw // 16, 3), dtype=np.uint8)
+    img = np.ascontiguousarray(np.repeat(np.repeat(tiles, 16, 0), 16, 1))
+    det = ra.Detector(iw, ih, nslots=1)
+    orc = helpers.OracleRect(iw, ih)
+    det.enqueue(img)
+    det.poll(TAN36)
+    orc.frame(img)
+    ctr = det.plane("polyctr", np.int32, 64)
+    print("overflow frame: live pixels", int(ctr[24]), "chains", int(ctr[1]), "segments", int(det.last_segments()[0]["x0"].view(np.int32)) if False else "", "redone", det.redone_frames())
+    assert det.redone_frames() == 1
+    assert helpers.segments_equal(det.last_segments(), orc.segments())
+    det.close()
+    orc.close()
