@@ -15,43 +15,144 @@ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 const dim3 block2(64, 4);
 inline dim3 grid2(int iw, int ih) { return dim3(cdiv(iw, 64), cdiv(ih, 4)); }
 
-// Phase 1: every pixel points at the first pixel of its horizontal run inside the wave's 64-pixel row segment
-// (ballot of run starts + count-leading-zeros); runs are the unit the merge phase works on.
-__global__ __launch_bounds__(256) void k_label_init(int *__restrict__ label, const int *__restrict__ pix, int bgc, int iw, int ih) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-  if (y >= ih) return;                       // whole wave leaves together (one wave = one row segment)
-  const bool valid = x < iw;
-  const int p = y * iw + x;
-  const int v = valid ? pix[p] : 0;
-  const int vl = __shfl_up(v, 1);
-  const bool vlvalid = threadIdx.x > 0;      // lane 0 always starts a run; its left neighbour is handled by the merge phase
-  const bool same = valid && vlvalid && vl == v;
-  const unsigned long long starts = __ballot(!same);
-  const unsigned long long upto = starts & ((2ull << threadIdx.x) - 1ull);
-  const int start = 63 - __clzll((long long)upto);
-  if (valid) label[p] = v == bgc ? -1 : y * iw + blockIdx.x * 64 + start;
+// Phase 1 (one block per 64x32 tile, everything in LDS): runs inside each 64-pixel row segment (ballot of run starts +
+// count-leading-zeros), unions between the rows of the tile, path compression; the tile's pixels leave pointing at the
+// GLOBAL index of their tile-local root, which is the smallest index of the component's part inside the tile.
+#define LT_W 64
+#define LT_H 32
+__device__ __forceinline__ int lt_find(const volatile int *lab, int a) {
+  int l = lab[a];
+  while (l != a) { a = l; l = lab[a]; }
+  return a;
+}
+__device__ __forceinline__ void lt_union(int *lab, int a, int b) {
+  for (;;) {
+    a = lt_find(lab, a);
+    b = lt_find(lab, b);
+    if (a == b) return;
+    if (a < b) { const int t = a; a = b; b = t; }
+    const int old = atomicMin(&lab[a], b);
+    if (old == a) return;
+    a = old;
+  }
 }
 
-// Phase 2: unions across rows and across 64-pixel segment borders.  A pixel only issues a union when no pixel of
-// its run to the left/right is guaranteed to issue an equivalent one (see the case analysis in DESIGN.md).
-__global__ __launch_bounds__(256) void k_label_merge(int *label, const int *__restrict__ pix, int bgc, int iw, int ih) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-  if (x >= iw || y >= ih) return;
-  const int p = y * iw + x;
-  const int v = pix[p];
-  if (v == bgc) return;
-  const bool wSame = x > 0 && pix[p - 1] == v;
-  if (wSame && threadIdx.x == 0) uf_union(label, p, p - 1);
-  if (y == 0) return;
-  const bool nSame = pix[p - iw] == v;
-  const bool nwSame = x > 0 && pix[p - iw - 1] == v;
-  if (nSame) {
-    if (!(wSame && nwSame)) uf_union(label, p, p - iw);
+__global__ __launch_bounds__(256) void k_label_tile(int *__restrict__ label, const int *__restrict__ pix, int bgc, int iw, int ih) {
+  __shared__ int lab[LT_W * LT_H];
+  __shared__ int pv[LT_W * LT_H];
+  const int tx = threadIdx.x, x = blockIdx.x * LT_W + tx, y0 = blockIdx.y * LT_H;
+  const bool xin = x < iw;
+#pragma unroll
+  for (int r = threadIdx.y; r < LT_H; r += 4) {
+    const int y = y0 + r;
+    const bool valid = xin && y < ih;
+    const int v = valid ? pix[y * iw + x] : 0;
+    const int vl = __shfl_up(v, 1);
+    const bool lvalid = __shfl_up((int)valid, 1) != 0;
+    const bool same = valid && tx > 0 && lvalid && vl == v;
+    const unsigned long long starts = __ballot(!same);
+    const unsigned long long upto = starts & ((2ull << tx) - 1ull);
+    const int start = 63 - __clzll((long long)upto);
+    pv[r * LT_W + tx] = v;
+    lab[r * LT_W + tx] = (!valid || v == bgc) ? -1 : r * LT_W + start;
+  }
+  __syncthreads();
+  // unions with the row above, inside the tile; a pixel only issues one when no pixel of its run is guaranteed to issue
+  // an equivalent one (same case analysis as k_label_border below)
+#pragma unroll
+  for (int r = threadIdx.y; r < LT_H; r += 4) {
+    if (r == 0) continue;
+    const int q = r * LT_W + tx;
+    if (lab[q] < 0) continue;
+    const int v = pv[q];
+    const bool wSame = tx > 0 && lab[q - 1] >= 0 && pv[q - 1] == v;
+    const bool nSame = lab[q - LT_W] >= 0 && pv[q - LT_W] == v;
+    const bool nwSame = tx > 0 && lab[q - LT_W - 1] >= 0 && pv[q - LT_W - 1] == v;
+    if (nSame) {
+      if (!(wSame && nwSame)) lt_union(lab, q, q - LT_W);
+    } else {
+      const bool neSame = tx < LT_W - 1 && lab[q - LT_W + 1] >= 0 && pv[q - LT_W + 1] == v;
+      const bool eSame = tx < LT_W - 1 && lab[q + 1] >= 0 && pv[q + 1] == v;
+      if (nwSame && !wSame) lt_union(lab, q, q - LT_W - 1);
+      if (neSame && !eSame) lt_union(lab, q, q - LT_W + 1);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = threadIdx.y; r < LT_H; r += 4) {
+    const int y = y0 + r;
+    if (!xin || y >= ih) continue;
+    const int q = r * LT_W + tx;
+    int l = lab[q];
+    if (l >= 0) { l = lt_find(lab, l); l = (y0 + l / LT_W) * iw + blockIdx.x * LT_W + l % LT_W; }
+    label[y * iw + x] = l;
+  }
+}
+
+// Phase 2: unions across tile borders, on the global array (roots: label[r] == r).  `horizontal` = 1: the pixels of rows
+// y = 32k (k >= 1) against the row above; 0: the pixels of columns x = 64k (k >= 1) against column x-1 and the pixels of
+// columns x = 64k-1 against their NE neighbour; lanes are consecutive pixels ALONG the border so that a lane whose
+// (label, neighbour label) pair equals its predecessor's can leave the union to that lane.
+__device__ __forceinline__ void border_union(int *label, int p, int q, bool want) {
+  const int la = want ? label[p] : -1, lb = want ? label[q] : -2;   // the tile roots (constant during this kernel unless roots themselves)
+  const int pa = __shfl_up(la, 1), pb = __shfl_up(lb, 1);
+  if (want && !(__lane_id() > 0 && pa == la && pb == lb)) {
+    int a = la, b = lb;
+    for (;;) {
+      a = uf_find_volatile(label, a);
+      b = uf_find_volatile(label, b);
+      if (a == b) break;
+      if (a < b) { const int t = a; a = b; b = t; }
+      const int old = atomicMin(&label[a], b);
+      if (old == a) break;
+      a = old;
+    }
+    // shortcut: both tile roots now point (at least) as far as the common root found - later walks through them are short
+    const int r = a < b ? a : b;
+    if (r < la) atomicMin(&label[la], r);
+    if (r < lb) atomicMin(&label[lb], r);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_label_border(int *label, const int *__restrict__ pix, int bgc, int iw, int ih, int horizontal) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (horizontal) {
+    const int nb = (ih - 1) / LT_H;              // border rows
+    const int x = t % iw, k = t / iw;
+    const bool in = k < nb;
+    const int y = (k + 1) * LT_H;
+    const int p = y * iw + x;
+    const int v = in ? pix[p] : bgc;
+    const bool act = in && v != bgc;
+    const bool wSame = act && x > 0 && pix[p - 1] == v;
+    const bool nSame = act && pix[p - iw] == v;
+    const bool nwSame = act && x > 0 && pix[p - iw - 1] == v;
+    const bool neSame = act && x < iw - 1 && pix[p - iw + 1] == v;
+    const bool eSame = act && x < iw - 1 && pix[p + 1] == v;
+    border_union(label, p, p - iw, nSame && !(wSame && nwSame));
+    border_union(label, p, p - iw - 1, !nSame && nwSame && !wSame);
+    border_union(label, p, p - iw + 1, !nSame && neSame && !eSame);
   } else {
-    const bool neSame = x < iw - 1 && pix[p - iw + 1] == v;
-    const bool eSame = x < iw - 1 && pix[p + 1] == v;
-    if (nwSame && !wSame) uf_union(label, p, p - iw - 1);
-    if (neSame && !eSame) uf_union(label, p, p - iw + 1);
+    const int nb = (iw - 1) / LT_W;              // border columns
+    const int y = t % ih, k = t / ih;
+    const bool in = k < nb;
+    const int x = (k + 1) * LT_W;
+    const int p = y * iw + x;
+    const int v = in ? pix[p] : bgc;
+    const bool act = in && v != bgc;
+    const bool wSame = act && pix[p - 1] == v;
+    const bool nSame = act && y > 0 && pix[p - iw] == v;
+    const bool nwSame = act && y > 0 && pix[p - iw - 1] == v;
+    border_union(label, p, p - 1, wSame);
+    border_union(label, p, p - iw - 1, nwSame && !nSame && !wSame);
+    // the pixel left of the border and its NE neighbour (x, y-1)
+    const int pl = p - 1;
+    const int vl = in ? pix[pl] : bgc;
+    const bool actl = in && vl != bgc && y > 0;
+    const bool lne = actl && pix[pl - iw + 1] == vl;
+    const bool ln = actl && pix[pl - iw] == vl;
+    const bool le = actl && pix[pl + 1] == vl;
+    border_union(label, pl, pl - iw + 1, lne && !ln && !le);
   }
 }
 
@@ -105,8 +206,10 @@ __global__ __launch_bounds__(256) void k_filter_strength(int *label, const int *
 namespace rdk {
 
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih) {
-  hipLaunchKernelGGL(k_label_init, grid2(iw, ih), block2, 0, s, label, pix, bgc, iw, ih);
-  hipLaunchKernelGGL(k_label_merge, grid2(iw, ih), block2, 0, s, label, pix, bgc, iw, ih);
+  hipLaunchKernelGGL(k_label_tile, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, 4), 0, s, label, pix, bgc, iw, ih);
+  const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
+  if (nh > 0) hipLaunchKernelGGL(k_label_border, dim3(cdiv(nh, 256)), dim3(256), 0, s, label, pix, bgc, iw, ih, 1);
+  if (nv > 0) hipLaunchKernelGGL(k_label_border, dim3(cdiv(nv, 256)), dim3(256), 0, s, label, pix, bgc, iw, ih, 0);
   const int n = iw * ih;
   int g = cdiv(n, 256 * 4);
   hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n);

@@ -635,8 +635,10 @@ struct pp_lds {
   int ncand, count, fail, progress;
 };
 
-__device__ __noinline__ int2 pp_move_dist(pp_lds &L, int pk, int xyv, int dreg, bool move_only, int iw) {
+__device__ __noinline__ int2 pp_move_dist(pp_lds &L, int pk, int xyv, int dreg, bool move_only, int iw, int round) {
   int g = pk & 0x7ff;
+  // a segment untouched by the previous round keeps its end index, its maximum and its pixels' distances: nothing to redo
+  if (L.done[g] != round) return make_int2(pk, dreg);
   const int num = (int)((unsigned)pk >> 11);
   if (g == 0 || L.rec[g].polyid == 0) return make_int2(pk, dreg);
   if (L.rec[g].endIndex < num) { g = L.rec[g].rightPtr; pk = (pk & ~0x7ff) | g; }
@@ -702,6 +704,7 @@ __global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec 
   const int tid = threadIdx.x;
   const int nlive = s.ctr[24], K = s.ctr[1];
   const int maxrec = lsbytes / 56;
+  if (tid == 0) s.ctr[39] = (int)wall_clock64();   // ctr[39..45]: 100 MHz time stamps of the phases (diagnostics)
   if (nlive > PP_T * PP_PX || K >= PP_MAXSEG - 1 || K >= maxrec - 1) { if (tid == 0) s.ctr[25] = 1; return; }
 
   // per-pixel state in registers: id (11 bits) | position along the chain << 11, x | y << 16, last distance
@@ -721,10 +724,12 @@ __global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec 
       xy[k] = (p % iw) | ((p / iw) << 16);
     }
   }
+  for (int g = tid; g < PP_MAXSEG; g += PP_T) L.done[g] = 0;   // during the rounds: round in which the segment has to be looked at again
   for (int g = tid; g <= K; g += PP_T) { ls_rec z = {}; L.rec[g] = z; L.start_i[g] = -1; L.end_i[g] = 0x7fffffff; }
   if (tid == 0) { L.ncand = 0; L.count = K; L.fail = 0; L.progress = 0; }
   __syncthreads();
 
+  if (tid == 0) s.ctr[40] = (int)wall_clock64();
   // initial segments (pl:439-506)
 #pragma unroll
   for (int k = 0; k < PP_PX; k++) {
@@ -755,11 +760,12 @@ __global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec 
   }
   __syncthreads();
 
+  if (tid == 0) s.ctr[41] = (int)wall_clock64();
   // subdivision rounds (pl:509-646); round 15 only moves pixels
   for (int round = 0; round <= 15; round++) {
 #pragma unroll
     for (int k = 0; k < PP_PX; k++) {
-      const int2 r2 = pp_move_dist(L, pk[k], xy[k], dreg[k], round == 15, iw);
+      const int2 r2 = pp_move_dist(L, pk[k], xy[k], dreg[k], round == 15, iw, round);
       pk[k] = r2.x; dreg[k] = r2.y;
       PP_SEQ;
     }
@@ -768,7 +774,7 @@ __global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec 
     // detection (reads the list as it is: nothing is modified in this phase)
 #pragma unroll
     for (int k = 0; k < PP_PX; k++) {
-      if (PP_ID(k) != 0) pp_detect(L, pk[k], xy[k], dreg[k], minerror, s.live, tid + k * PP_T);
+      if (PP_ID(k) != 0 && L.done[PP_ID(k)] == round) pp_detect(L, pk[k], xy[k], dreg[k], minerror, s.live, tid + k * PP_T);   // others: same verdict as last round (none)
       PP_SEQ;
     }
     __syncthreads();
@@ -794,7 +800,9 @@ __global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec 
         nr.leftPtr = g; nr.rightPtr = e[5];
         nr.maxDist = 0; nr.polyid = L.rec[g].polyid; nr.level = e[3];
         L.rec[gn] = nr;
+        L.done[gn] = round + 1;
         if (last) {
+          L.done[g] = round + 1;
           L.rec[g].endIndex = e[2]; L.rec[g].x1 = (float)x; L.rec[g].y1 = (float)y; L.rec[g].rightPtr = gn; L.rec[g].maxDist = 0;
           if (e[5] != 0) L.rec[e[5]].leftPtr = gn;
         }
@@ -805,6 +813,7 @@ __global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec 
     __syncthreads();
   }
 
+  if (tid == 0) s.ctr[42] = (int)wall_clock64();
   // refinement (pl:680-809)
   const int n = L.count;
   for (int g = tid + 1; g <= n; g += PP_T) {
@@ -835,6 +844,7 @@ __global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec 
     L.rec[g].x1 += (float)q.vx * (as0 + as1); L.rec[g].y1 += (float)q.vy * (as0 + as1);
   }
   __syncthreads();
+  if (tid == 0) s.ctr[43] = (int)wall_clock64();
   // end-point joining in dependency order (see k_refine3)
   for (int g = tid + 1; g <= n; g += PP_T) L.done[g] = (L.rec[g].polyid == 0 || L.rec[g].rightPtr == 0) ? 1 : 0;
   __syncthreads();
@@ -876,11 +886,13 @@ __global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec 
     __syncthreads();
   }
 
+  if (tid == 0) s.ctr[44] = (int)wall_clock64();
   // results: record list (header = count) and the final per-pixel ids
   if (tid == 0) { ls_rec z = {}; ls[0] = z; *(int *)ls = n; if (L.fail) s.ctr[25] = 1; }
   for (int g = tid + 1; g <= n; g += PP_T) ls[g] = L.rec[g];
 #pragma unroll
   for (int k = 0; k < PP_PX; k++) if (tid + k * PP_T < nlive) s.id[PP_CI(k)] = PP_ID(k);
+  if (tid == 0) s.ctr[45] = (int)wall_clock64();
 }
 
 __global__ void k_scatter_ids(PolyScratch s, int *ids) {

@@ -442,25 +442,64 @@ __global__ __launch_bounds__(256) void k_region_size(int *out, const int *__rest
 // rc:348-371.  The reference updates labels in place in raster order: a small-region pixel sees the NEW labels of
 // its NW, N, NE, W neighbours.  One Jacobi round of that recurrence: `cur` holds the previous round's
 // values for small-region pixels; the rounds are iterated by the launcher.
-__global__ __launch_bounds__(256) void k_despeckle2_round(int *__restrict__ nxt, const int *__restrict__ cur, const int *__restrict__ old, const int *__restrict__ size,
-                                                           int thre, int iw, int ih) {
-  RD_XY;
-  if (x >= iw || y >= ih) return;
+__device__ __forceinline__ int despeckle2_pick(const int *__restrict__ cur, const int *__restrict__ old, const int *__restrict__ size, int l0, int x, int y, int iw, int ih) {
   const int p0 = y * iw + x;
-  const int l0 = old[p0];
-  int res = l0;
-  if (size[l0] <= thre) {
-    int maxSize = 0;
-    for (int yy = -1; yy <= 1; yy++)
-      for (int xx = -1; xx <= 1; xx++) {
-        if (x + xx < 0 || x + xx >= iw || y + yy < 0 || y + yy >= ih) continue;
-        const int p1 = p0 + yy * iw + xx;
-        const int l1 = (yy < 0 || (yy == 0 && xx < 0)) ? cur[p1] : old[p1];
-        const int sz = size[l1];
-        if (sz > maxSize) { maxSize = sz; res = l1; }
-      }
+  int res = l0, maxSize = 0;
+  for (int yy = -1; yy <= 1; yy++)
+    for (int xx = -1; xx <= 1; xx++) {
+      if (x + xx < 0 || x + xx >= iw || y + yy < 0 || y + yy >= ih) continue;
+      const int p1 = p0 + yy * iw + xx;
+      const int l1 = (yy < 0 || (yy == 0 && xx < 0)) ? cur[p1] : old[p1];
+      const int sz = size[l1];
+      if (sz > maxSize) { maxSize = sz; res = l1; }
+    }
+  return res;
+}
+
+// first round over the whole plane (cur == old); the pixels of small regions - the only ones later rounds can change -
+// are appended to `list` (any order), *count = their number.  One block per 64x32 tile collects its pixels in LDS and
+// reserves its share of the list with a single atomic (same-address atomics cost ~8 ns each: one per wave was 250 us).
+#define D2_ROWS 32
+__global__ __launch_bounds__(256) void k_despeckle2_first(int *__restrict__ nxt, int *__restrict__ list, int *count, const int *__restrict__ old, const int *__restrict__ size,
+                                                           int thre, int iw, int ih) {
+  __shared__ int loc[64 * D2_ROWS];
+  __shared__ int nloc, base;
+  if (threadIdx.x == 0 && threadIdx.y == 0) nloc = 0;
+  __syncthreads();
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  for (int r = threadIdx.y; r < D2_ROWS; r += 4) {
+    const int y = blockIdx.y * D2_ROWS + r;
+    const bool inside = x < iw && y < ih;
+    const int p0 = y * iw + x;
+    bool small = false;
+    if (inside) {
+      const int l0 = old[p0];
+      small = size[l0] <= thre;
+      nxt[p0] = small ? despeckle2_pick(old, old, size, l0, x, y, iw, ih) : l0;
+    }
+    const unsigned long long m = __ballot(small);
+    if (m) {
+      const int lane = threadIdx.x, leader = __ffsll((long long)m) - 1;
+      int b = 0;
+      if (lane == leader) b = atomicAdd(&nloc, __popcll(m));
+      b = __shfl(b, leader);
+      if (small) loc[b + __popcll(m & ((1ull << lane) - 1))] = p0;
+    }
   }
-  nxt[p0] = res;
+  __syncthreads();
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  if (tid == 0 && nloc > 0) base = atomicAdd(count, nloc);
+  __syncthreads();
+  for (int i = tid; i < nloc; i += 256) list[base + i] = loc[i];
+}
+
+__global__ __launch_bounds__(256) void k_despeckle2_sparse(int *__restrict__ nxt, const int *__restrict__ cur, const int *__restrict__ list, const int *__restrict__ count,
+                                                            const int *__restrict__ old, const int *__restrict__ size, int iw, int ih) {
+  const int n = *count;
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int p0 = list[j];
+    nxt[p0] = despeckle2_pick(cur, old, size, old[p0], p0 % iw, p0 / iw, iw, ih);
+  }
 }
 
 // rc:373-390
@@ -490,6 +529,32 @@ __device__ __forceinline__ unsigned ls_slot(int id, int bid, int nentry) { retur
 
 // sparse: one thread per chain pixel left by the polyline stage (raster-ordered compact list, so the compact index orders
 // pixels like the pixel index does)
+// the distinct boundary ids (> 0) inside a 7x7 window and how often each occurs, in registers; a window with more than
+// RB_MAX of them (rare) reports overflow and is processed touch by touch instead
+#define RB_MAX 6
+__device__ __forceinline__ bool rb_collect(const int (&win)[49], int (&bs)[RB_MAX], int (&cnt)[RB_MAX], int &n) {
+  bool overflow = false;
+  n = 0;
+#pragma unroll
+  for (int q = 0; q < RB_MAX; q++) { bs[q] = 0; cnt[q] = 0; }
+#pragma unroll
+  for (int k = 0; k < 49; k++) {
+    const int b = win[k];
+    if (b <= 0) continue;
+    bool found = false;
+#pragma unroll
+    for (int q = 0; q < RB_MAX; q++) if (bs[q] == b) { cnt[q]++; found = true; }
+    if (!found) {
+      if (n < RB_MAX) {
+#pragma unroll
+        for (int q = 0; q < RB_MAX; q++) if (q == n) { bs[q] = b; cnt[q] = 1; }
+        n++;
+      } else overflow = true;
+    }
+  }
+  return overflow;
+}
+
 __global__ void k_reduce_claim(int *claim, const int *__restrict__ boundary, rdk::PolyScratch s, int iw, int ih, int nentry) {
   const int nlive = s.ctr[24];
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nlive; j += gridDim.x * blockDim.x) {
@@ -503,8 +568,16 @@ __global__ void k_reduce_claim(int *claim, const int *__restrict__ boundary, rdk
       const int xx = x + k % 7 - 3, yy = y + k / 7 - 3;
       win[k] = (xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? boundary[yy * iw + xx] : 0;
     }
-    int lastb = 0;
-    {
+    int bs[RB_MAX], cnt[RB_MAX], nb;
+    if (!rb_collect(win, bs, cnt, nb)) {
+      unsigned slot[RB_MAX];
+      int cur[RB_MAX];
+#pragma unroll
+      for (int q = 0; q < RB_MAX; q++) { slot[q] = ls_slot(id, bs[q], nentry); cur[q] = ld_agent(&claim[slot[q]]); }   // independent loads
+#pragma unroll
+      for (int q = 0; q < RB_MAX; q++) if (q < nb && i < cur[q]) atomicMin(&claim[slot[q]], i);
+    } else {
+      int lastb = 0;
 #pragma unroll
       for (int k = 0; k < 49; k++) {
         const int b = win[k];
@@ -530,11 +603,40 @@ __global__ void k_reduce_box(int *table, const int *__restrict__ claim, const in
       const int xx = x + k % 7 - 3, yy = y + k / 7 - 3;
       win[k] = (xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? boundary[yy * iw + xx] : 0;
     }
+    int bs[RB_MAX], cnt[RB_MAX], nb;
+    if (!rb_collect(win, bs, cnt, nb)) {
+      // per distinct slot: the claiming pixel's first touch only claims (rc:449-456), every other touch widens the box;
+      // max is idempotent, so "widen once if the slot's owner carries our id and we touched it often enough" is the same
+      unsigned slot[RB_MAX];
+      int owner[RB_MAX], oid[RB_MAX];
+#pragma unroll
+      for (int q = 0; q < RB_MAX; q++) { slot[q] = ls_slot(id, bs[q], nentry); owner[q] = claim[slot[q]]; }
+#pragma unroll
+      for (int q = 0; q < RB_MAX; q++) oid[q] = (q < nb) ? s.id[owner[q]] : -1;
+#pragma unroll
+      for (int q = 0; q < RB_MAX; q++) {
+        if (q >= nb || oid[q] != id) continue;
+        if (owner[q] == i) {
+          int touches = 0;
+#pragma unroll
+          for (int q2 = 0; q2 < RB_MAX; q2++) if (q2 < nb && slot[q2] == slot[q]) touches += cnt[q2];
+          if (touches < 2) continue;
+        }
+        int *e = table + (size_t)slot[q] * 5;
+        if (iw - x > ld_agent(&e[1])) atomicMax(&e[1], iw - x);
+        if (x > ld_agent(&e[2])) atomicMax(&e[2], x);
+        if (ih - y > ld_agent(&e[3])) atomicMax(&e[3], ih - y);
+        if (y > ld_agent(&e[4])) atomicMax(&e[4], y);
+      }
+      continue;
+    }
     // state for the boundary id of the previous touch: the slot, whether its owner carries our segment id, whether we
     // are the claiming pixel and still owe the "first touch only claims" skip (rc:449-456), whether we already widened it
     int lastb = 0;
     unsigned slot = 0;
     bool ok = false, skip_first = false, done = false;
+    unsigned cons[4] = {0, 0, 0, 0};
+    int ncons = 0;
 #pragma unroll
     for (int k = 0; k < 49; k++) {
       const int b = win[k];
@@ -548,12 +650,24 @@ __global__ void k_reduce_box(int *table, const int *__restrict__ claim, const in
         skip_first = false;
         if (ok && owner == i) {
           // claiming pixel (rare): was there an earlier touch of this slot, through any boundary id, in this window?
+          // Every such touch came through here, so a short register list of the slots already met answers it; a 7x7
+          // window holding more than 4 slots claimed by its own centre falls back to rescanning the window.
           bool earlier = false;
-          for (int k2 = 0; k2 < k && !earlier; k2++) {
-            const int xx = x + k2 % 7 - 3, yy = y + k2 / 7 - 3;
-            if (xx < 0 || xx >= iw || yy < 0 || yy >= ih) continue;
-            const int b2 = boundary[yy * iw + xx];
-            if (b2 > 0 && ls_slot(id, b2, nentry) == slot) earlier = true;
+#pragma unroll
+          for (int q = 0; q < 4; q++) earlier |= (q < ncons && cons[q] == slot);
+          if (!earlier) {
+            if (ncons < 4) {
+#pragma unroll
+              for (int q = 0; q < 4; q++) if (q == ncons) cons[q] = slot;
+              ncons++;
+            } else {
+              for (int k2 = 0; k2 < k && !earlier; k2++) {
+                const int xx = x + k2 % 7 - 3, yy = y + k2 / 7 - 3;
+                if (xx < 0 || xx >= iw || yy < 0 || yy >= ih) continue;
+                const int b2 = boundary[yy * iw + xx];
+                if (b2 > 0 && ls_slot(id, b2, nentry) == slot) earlier = true;
+              }
+            }
           }
           skip_first = !earlier;
         }
@@ -672,15 +786,18 @@ void region_size(hipStream_t s, int *out, const int *label, int n) {
   hipLaunchKernelGGL(k_region_size, dim3(cdiv(n, 256 * RS_PER_THREAD)), dim3(256), 0, s, out, label, n);
 }
 
-// scratch: 2*N ints.  On return `label` holds the result.
+// scratch: 3*N + 1 ints.  On return `label` holds the result.  Eight Jacobi rounds of the reference's in-place sweep
+// (see DESIGN.md, H6); only pixels of small regions can change, so rounds 2..8 run over their list.
 void despeckle2(hipStream_t s, int *label, int *scratch, const int *size, int thre, int iw, int ih) {
   const int n = iw * ih, ROUNDS = 8;   // even: the last round writes back into `label`
-  int *old = scratch, *tmp = scratch + n;
+  int *old = scratch, *tmp = scratch + n, *count = scratch + 2 * (size_t)n, *list = count + 1;
   (void)hipMemcpyAsync(old, label, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, s);
-  const int *cur = old;
-  for (int r = 0; r < ROUNDS; r++) {
-    int *nxt = (r & 1) ? label : tmp;
-    hipLaunchKernelGGL(k_despeckle2_round, grid2(iw, ih), block2, 0, s, nxt, cur, (const int *)old, size, thre, iw, ih);
+  (void)hipMemsetAsync(count, 0, sizeof(int), s);
+  hipLaunchKernelGGL(k_despeckle2_first, dim3(cdiv(iw, 64), cdiv(ih, D2_ROWS)), dim3(64, 4), 0, s, tmp, list, count, (const int *)old, size, thre, iw, ih);
+  const int *cur = tmp;
+  for (int r = 1; r < ROUNDS; r++) {
+    int *nxt = (r & 1) ? label : tmp;   // both planes already agree on every pixel that is not in the list
+    hipLaunchKernelGGL(k_despeckle2_sparse, dim3(512), dim3(256), 0, s, nxt, cur, (const int *)list, (const int *)count, (const int *)old, size, iw, ih);
     cur = nxt;
   }
 }

@@ -239,7 +239,9 @@ def test_chunked_blur_verifies_and_counters():
     assert flags[0] == 0 and flags[1] == 0
     ctr = det.plane("polyctr", np.int32, 64)
     assert 0 < ctr[0] < iw * ih and 0 < ctr[1] <= ctr[0]
-    print("chain pixels", int(ctr[0]), "chains", int(ctr[1]), "live pixels", int(ctr[24]), "split candidates per round", ctr[2:17].tolist())
+    print("chain pixels", int(ctr[0]), "chains", int(ctr[1]), "live pixels", int(ctr[24]))
+    t = ctr[39:46].astype(np.int64)
+    print("single-launch polyline stage, phase durations in us (load, init, rounds, moments+fit, join, store):", (((t[1:] - t[:-1]) & 0xffffffff) / 100.0).tolist())
     det.close()
 
 
