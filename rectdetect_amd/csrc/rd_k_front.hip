@@ -313,17 +313,49 @@ __device__ __forceinline__ float bicubic(const float *__restrict__ p, float x, f
   return cubic1(r[0], r[1], r[2], r[3], fy);
 }
 
+// The four sample positions lie within 2 px of the pixel and the 4x4 footprints within [-3, +4]: the block stages a
+// (64+8) x (TT_ROWS+7) tile of the strength plane in LDS with the mirrored border already applied, so a bicubic is one
+// address computation and 16 ds_reads at constant offsets instead of 8 mirror clamps and 16 global gathers.  The outer
+// two samples are only evaluated for local maxima (they do not influence the comparison).
+#define TT_ROWS 16
+#define TT_PITCH 72
+__device__ __forceinline__ float bicubic_lds(const float *t, float x, float y, int x0, int y0) {
+  const int ix = (int)x, iy = (int)y;
+  const float fx = x - ix, fy = y - iy;
+  const float *q = t + (iy - 1 - (y0 - 3)) * TT_PITCH + (ix - 1 - (x0 - 3));
+  float r[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) r[k] = cubic1(q[k * TT_PITCH], q[k * TT_PITCH + 1], q[k * TT_PITCH + 2], q[k * TT_PITCH + 3], fx);
+  return cubic1(r[0], r[1], r[2], r[3], fy);
+}
+
 __global__ __launch_bounds__(256) void k_thinthres(float *__restrict__ out, const float *__restrict__ in, const float2 *__restrict__ vxy, int iw, int ih) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-  if (x >= iw || y >= ih) return;
-  const int p0 = y * iw + x;
-  const float2 v = vxy[p0];
-  const float am2 = bicubic(in, x - 2 * v.x, y - 2 * v.y, iw, ih);
-  const float am1 = bicubic(in, x - 1 * v.x, y - 1 * v.y, iw, ih);
-  const float a0 = in[p0];
-  const float ap1 = bicubic(in, x + 1 * v.x, y + 1 * v.y, iw, ih);
-  const float ap2 = bicubic(in, x + 2 * v.x, y + 2 * v.y, iw, ih);
-  out[p0] = (am1 <= a0 && a0 >= ap1) ? (am2 + am1 + a0 + ap1 + ap2) : 0.0f;
+  __shared__ float tile[(TT_ROWS + 7) * TT_PITCH];
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * TT_ROWS;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int t = tid; t < (TT_ROWS + 7) * TT_PITCH; t += 256) {
+    const int r = t / TT_PITCH, c = t % TT_PITCH;
+    tile[t] = in[(size_t)mirror1(y0 - 3 + r, ih) * iw + mirror1(x0 - 3 + c, iw)];
+  }
+  __syncthreads();
+  const int x = x0 + threadIdx.x;
+  if (x >= iw) return;
+  for (int r = threadIdx.y; r < TT_ROWS; r += 4) {
+    const int y = y0 + r;
+    if (y >= ih) break;
+    const int p0 = y * iw + x;
+    const float2 v = vxy[p0];
+    const float a0 = tile[(r + 3) * TT_PITCH + threadIdx.x + 3];
+    const float am1 = bicubic_lds(tile, x - 1 * v.x, y - 1 * v.y, x0, y0);
+    const float ap1 = bicubic_lds(tile, x + 1 * v.x, y + 1 * v.y, x0, y0);
+    float o = 0.0f;
+    if (am1 <= a0 && a0 >= ap1) {
+      const float am2 = bicubic_lds(tile, x - 2 * v.x, y - 2 * v.y, x0, y0);
+      const float ap2 = bicubic_lds(tile, x + 2 * v.x, y + 2 * v.y, x0, y0);
+      o = am2 + am1 + a0 + ap1 + ap2;
+    }
+    out[p0] = o;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ element-wise (iu:197-254)
@@ -402,7 +434,7 @@ void edge_plab(hipStream_t s, float *out, const uint32_t *in, int iw, int ih) {
   hipLaunchKernelGGL(k_edge_plab, grid2(iw, ih), block2, 0, s, out, in, iw, ih);
 }
 void thinthres(hipStream_t s, float *out, const float *in, const float *vxy, int iw, int ih) {
-  hipLaunchKernelGGL(k_thinthres, grid2(iw, ih), block2, 0, s, out, in, (const float2 *)vxy, iw, ih);
+  hipLaunchKernelGGL(k_thinthres, dim3(cdiv(iw, 64), cdiv(ih, TT_ROWS)), dim3(64, 4), 0, s, out, in, (const float2 *)vxy, iw, ih);
 }
 void threshold_f(hipStream_t s, float *out, const float *in, float lo, float thr, float hi, int n) {
   hipLaunchKernelGGL(k_threshold_f, dim3(ew_grid(n)), dim3(256), 0, s, out, in, lo, thr, hi, n);

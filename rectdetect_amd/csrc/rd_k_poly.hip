@@ -763,6 +763,7 @@ __global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec 
   if (tid == 0) s.ctr[41] = (int)wall_clock64();
   // subdivision rounds (pl:509-646); round 15 only moves pixels
   for (int round = 0; round <= 15; round++) {
+    // (pixels in segments that the previous round did not change return at once: see pp_move_dist)
 #pragma unroll
     for (int k = 0; k < PP_PX; k++) {
       const int2 r2 = pp_move_dist(L, pk[k], xy[k], dreg[k], round == 15, iw, round);
@@ -777,6 +778,8 @@ __global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec 
       if (PP_ID(k) != 0 && L.done[PP_ID(k)] == round) pp_detect(L, pk[k], xy[k], dreg[k], minerror, s.live, tid + k * PP_T);   // others: same verdict as last round (none)
       PP_SEQ;
     }
+    __syncthreads();
+    if (L.ncand == 0) break;     // no split this round: the remaining rounds would find the same (block-uniform)
     __syncthreads();
     {
       const int C = L.ncand < PP_MAXCAND ? L.ncand : PP_MAXCAND;

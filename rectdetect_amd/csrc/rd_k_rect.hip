@@ -151,50 +151,74 @@ __global__ __launch_bounds__(256) void k_blblur(uint32_t *__restrict__ out, cons
   out[p] = r;
 }
 
-// One (horizontal, vertical) pair of passes (rh:286-296) in a single launch: the block computes the horizontal pass for
-// a 64 x (BP_ROWS + 8) strip into LDS (4 extra rows above and below) and the vertical pass reads it from there, so the
-// intermediate plane never travels through HBM.
+// One (horizontal, vertical) pair of passes (rh:286-296) in a single launch.  The block stages a (64+8) x (BP_ROWS+8)
+// tile of the input in LDS in EXPANDED form (uint2: L | a << 16, b - 16-bit fields, so that a sum of 10 samples is two
+// plain adds without carries between fields), runs the horizontal pass for the 64 x (BP_ROWS+8) strip into a second LDS
+// tile (4 extra rows above and below) and the vertical pass from there: the intermediate plane never travels through
+// HBM, every sample is one unconditional ds_read_b64 (samples beyond the run read a zero slot), and all reads of a pixel
+// are in flight together.
 #define BP_ROWS 32
+#define BP_SW 73              // row pitch of the staged input (72 used)
+// floor(s / w) for 0 <= s <= 40950, 1 <= w <= 10 (exhaustively checked: tools/check_div_small.py)
+__device__ __forceinline__ unsigned div_small_f(unsigned s, float rw) { return (unsigned)(((float)s + 0.5f) * rw); }
+
 __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih) {
-  __shared__ uint32_t hz[BP_ROWS + 8][64];
-  const int x = blockIdx.x * 64 + threadIdx.x;
-  const int y0 = blockIdx.y * BP_ROWS;
-  for (int r = threadIdx.y; r < BP_ROWS + 8; r += 16) {
+  __shared__ uint2 src[(BP_ROWS + 8) * BP_SW + 1];
+  __shared__ uint2 hz[(BP_ROWS + 8) * 64 + 1];
+  const int ZS = (BP_ROWS + 8) * BP_SW, ZH = (BP_ROWS + 8) * 64;   // zero slots
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BP_ROWS;
+  const int x = x0 + tx;
+  if (tid == 0) { src[ZS] = make_uint2(0, 0); hz[ZH] = make_uint2(0, 0); }
+  for (int t = tid; t < (BP_ROWS + 8) * 72; t += 1024) {
+    const int r = t / 72, c = t % 72;
+    const int xx = x0 - 4 + c, yy = y0 - 4 + r;
+    uint32_t q = 0;
+    if (xx >= 0 && xx < iw && yy >= 0 && yy < ih) q = in[yy * iw + xx];
+    src[r * BP_SW + c] = make_uint2((q & 4095u) | ((q << 4) & 0x3ff0000u), q >> 22);
+  }
+  __syncthreads();
+  for (int r = ty; r < BP_ROWS + 8; r += 16) {
     const int y = y0 - 4 + r;
-    uint32_t v = 0;
-    if (x < iw && y >= 0 && y < ih) {
-      const int p = y * iw + x;
-      const unsigned e = ext[p];
-      const int nl = e & 7, nr = (e >> 3) & 7;
-      unsigned s0 = 0, s1 = 0, s2 = 0;
+    unsigned e = 0;
+    if (x < iw && y >= 0 && y < ih) e = ext[y * iw + x];
+    const int nl = e & 7, nr = (e >> 3) & 7;
+    const int c = r * BP_SW + tx + 4;
+    uint2 v[10];
 #pragma unroll
-      for (int d = 0; d < 5; d++)
-        if (d < nl) { const uint32_t q = in[p - d]; s0 += q & 4095; s1 += (q >> 12) & 1023; s2 += (q >> 22) & 1023; }
+    for (int d = 0; d < 5; d++) { v[d] = src[d < nl ? c - d : ZS]; v[5 + d] = src[d < nr ? c + d : ZS]; }
+    unsigned lo = 0, hi = 0;
 #pragma unroll
-      for (int d = 0; d < 5; d++)
-        if (d < nr) { const uint32_t q = in[p + d]; s0 += q & 4095; s1 += (q >> 12) & 1023; s2 += (q >> 22) & 1023; }
-      const int w = nl + nr;
-      v = w == 0 ? in[p] : ((div_small(s2, w) << 22) | (div_small(s1, w) << 12) | div_small(s0, w));
+    for (int d = 0; d < 10; d++) { lo += v[d].x; hi += v[d].y; }
+    const int w = nl + nr;
+    uint2 o = src[c];
+    if (w > 0) {
+      const float rw = 1.0f / (float)w;
+      o = make_uint2(div_small_f(lo & 0xffffu, rw) | (div_small_f(lo >> 16, rw) << 16), div_small_f(hi, rw));   // fields cannot exceed their range: no clamp needed
     }
-    hz[r][threadIdx.x] = v;
+    hz[r * 64 + tx] = o;
   }
   __syncthreads();
   if (x >= iw) return;
-  for (int r = threadIdx.y; r < BP_ROWS; r += 16) {
+  for (int r = ty; r < BP_ROWS; r += 16) {
     const int y = y0 + r;
     if (y >= ih) break;
-    const int p = y * iw + x;
-    const unsigned e = ext[p] >> 6;
+    const unsigned e = ext[y * iw + x] >> 6;
     const int nl = e & 7, nr = (e >> 3) & 7;
-    unsigned s0 = 0, s1 = 0, s2 = 0;
+    const int c = (r + 4) * 64 + tx;
+    uint2 v[10];
 #pragma unroll
-    for (int d = 0; d < 5; d++)
-      if (d < nl) { const uint32_t q = hz[r + 4 - d][threadIdx.x]; s0 += q & 4095; s1 += (q >> 12) & 1023; s2 += (q >> 22) & 1023; }
+    for (int d = 0; d < 5; d++) { v[d] = hz[d < nl ? c - d * 64 : ZH]; v[5 + d] = hz[d < nr ? c + d * 64 : ZH]; }
+    unsigned lo = 0, hi = 0;
 #pragma unroll
-    for (int d = 0; d < 5; d++)
-      if (d < nr) { const uint32_t q = hz[r + 4 + d][threadIdx.x]; s0 += q & 4095; s1 += (q >> 12) & 1023; s2 += (q >> 22) & 1023; }
+    for (int d = 0; d < 10; d++) { lo += v[d].x; hi += v[d].y; }
     const int w = nl + nr;
-    out[p] = w == 0 ? hz[r + 4][threadIdx.x] : ((div_small(s2, w) << 22) | (div_small(s1, w) << 12) | div_small(s0, w));
+    uint2 o = hz[c];
+    if (w > 0) {
+      const float rw = 1.0f / (float)w;
+      o = make_uint2(div_small_f(lo & 0xffffu, rw) | (div_small_f(lo >> 16, rw) << 16), div_small_f(hi, rw));
+    }
+    out[y * iw + x] = (o.x & 0xffffu) | ((o.x >> 16) << 12) | (o.y << 22);
   }
 }
 
@@ -257,36 +281,52 @@ __device__ __forceinline__ unsigned dxmask(int dy, int lo, int hi) {
   return m;
 }
 
+// block: 64 columns x MM_ROWS rows; the (MM_ROWS + 16) x 3 words x 2 classes of bit rows it needs are staged in LDS with one
+// load per thread (the row loop was a chain of dependent global loads before: latency-bound)
+#define MM_ROWS 16
 __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const unsigned long long *__restrict__ bits, int iw, int ih, int wpr) {
-  RD_XY;
-  if (y >= ih) return;
-  unsigned A = 0, B = 0, C = 0;
-  const int k = blockIdx.x;                 // word holding this wave's own 64 columns
-  const int sh = threadIdx.x + 64 - 8;      // bit position of column x-8 inside the 192-bit window (words k-1, k, k+1)
-#pragma unroll
-  for (int dy = -8; dy <= 8; dy++) {
-    const int yy = y + dy;
-    if (yy < 0 || yy >= ih) continue;       // wave-uniform
-    const unsigned long long *row = bits + (size_t)yy * wpr * 2;
-    unsigned long long a0 = k > 0 ? row[(k - 1) * 2] : 0ull, a1 = row[k * 2], a2 = k + 1 < wpr ? row[(k + 1) * 2] : 0ull;
-    unsigned long long e0 = k > 0 ? row[(k - 1) * 2 + 1] : 0ull, e1 = row[k * 2 + 1], e2 = k + 1 < wpr ? row[(k + 1) * 2 + 1] : 0ull;
-    // 17 bits starting at window bit sh (64-8 <= sh <= 127-8+... < 128+64): take from (w0,w1) or (w1,w2)
-    unsigned wa, we;
-    if (sh < 64) {
-      wa = (unsigned)((a0 >> sh) | (sh ? (a1 << (64 - sh)) : 0ull));
-      we = (unsigned)((e0 >> sh) | (sh ? (e1 << (64 - sh)) : 0ull));
-    } else {
-      const int s2 = sh - 64;
-      wa = (unsigned)((a1 >> s2) | (s2 ? (a2 << (64 - s2)) : 0ull));
-      we = (unsigned)((e1 >> s2) | (s2 ? (e2 << (64 - s2)) : 0ull));
-    }
-    wa &= 0x1ffffu; we &= 0x1ffffu;
-    const int ady = dy < 0 ? -dy : dy;
-    A |= wa & dxmask(ady, 16, 36);
-    B |= we & dxmask(ady, 0, 64);
-    C |= (wa & ~we) & dxmask(ady, 0, 16);
+  __shared__ unsigned long long sb[(MM_ROWS + 16) * 6];
+  const int k = blockIdx.x;                 // word holding this block's own 64 columns
+  const int y0 = blockIdx.y * MM_ROWS;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  if (tid < (MM_ROWS + 16) * 6) {
+    const int r = tid / 6, j = tid % 6;     // j: word k-1, k, k+1 of class any (0..2) / end (3..5)
+    const int yy = y0 - 8 + r, kk = k - 1 + j % 3;
+    unsigned long long v = 0ull;
+    if (yy >= 0 && yy < ih && kk >= 0 && kk < wpr) v = bits[((size_t)yy * wpr + kk) * 2 + j / 3];
+    sb[tid] = v;
   }
-  if (x < iw) out[y * iw + x] = (A != 0 && B == 0 && C == 0) ? 1 : 0;
+  __syncthreads();
+  const int x = k * 64 + threadIdx.x;
+  const int sh = threadIdx.x + 64 - 8;      // bit position of column x-8 inside the 192-bit window (words k-1, k, k+1)
+  for (int r = threadIdx.y; r < MM_ROWS; r += 4) {
+    const int y = y0 + r;
+    if (y >= ih) break;
+    unsigned A = 0, B = 0, C = 0;
+#pragma unroll
+    for (int dy = -8; dy <= 8; dy++) {
+      const unsigned long long *row = sb + (r + 8 + dy) * 6;   // rows outside the frame hold zeros
+      const unsigned long long a0 = row[0], a1 = row[1], a2 = row[2];
+      if ((a0 | a1 | a2) == 0ull) continue;   // wave-uniform: no counted pixel in this row of the window (ends are counted pixels too)
+      const unsigned long long e0 = row[3], e1 = row[4], e2 = row[5];
+      // 17 bits starting at window bit sh: take from (w0,w1) or (w1,w2)
+      unsigned wa, we;
+      if (sh < 64) {
+        wa = (unsigned)((a0 >> sh) | (sh ? (a1 << (64 - sh)) : 0ull));
+        we = (unsigned)((e0 >> sh) | (sh ? (e1 << (64 - sh)) : 0ull));
+      } else {
+        const int s2 = sh - 64;
+        wa = (unsigned)((a1 >> s2) | (s2 ? (a2 << (64 - s2)) : 0ull));
+        we = (unsigned)((e1 >> s2) | (s2 ? (e2 << (64 - s2)) : 0ull));
+      }
+      wa &= 0x1ffffu; we &= 0x1ffffu;
+      const int ady = dy < 0 ? -dy : dy;
+      A |= wa & dxmask(ady, 16, 36);
+      B |= we & dxmask(ady, 0, 64);
+      C |= (wa & ~we) & dxmask(ady, 0, 16);
+    }
+    if (x < iw) out[y * iw + x] = (A != 0 && B == 0 && C == 0) ? 1 : 0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ regions
@@ -762,7 +802,7 @@ void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *ed
 void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih) {
   const int wpr = cdiv(iw, 64);
   hipLaunchKernelGGL(k_mm_bits, grid2(iw, ih), block2, 0, s, (unsigned long long *)scratch, junction, iw, ih, wpr);
-  hipLaunchKernelGGL(k_mm_gather, grid2(iw, ih), block2, 0, s, out, (const unsigned long long *)scratch, iw, ih, wpr);
+  hipLaunchKernelGGL(k_mm_gather, dim3(wpr, cdiv(ih, MM_ROWS)), dim3(64, 4), 0, s, out, (const unsigned long long *)scratch, iw, ih, wpr);
 }
 
 // scratch: 3*N ints (hook proposals; round flags + allowed-direction bytes; self proposals)
