@@ -237,7 +237,7 @@ struct Slot {
   uint8_t *bgr;
   uint32_t *plab0, *plab1, *smooth, *quant;
   float *tr[3], *fw[3], *bw[3], *hz[3], *bl[3], *vxy, *strength, *nms;
-  int *i0, *i1, *mask0, *tidy, *label1, *strsum, *edge500, *strong, *junction, *mergemask, *region, *rsize, *scratch2, *boundarysrc, *boundary, *lsid, *table, *claim, *probes;
+  int *i0, *i1, *mask0, *tidy, *label1, *strsum, *edge500, *strong, *junction, *mergemask, *region, *rsize, *scratch2, *boundarysrc, *boundary, *lsid, *table, *claim, *probes, *region0, *tlist;
   int8_t *e8;
   uint16_t *ext;
   float *tails; int *flags; int iir_chunked;
@@ -282,10 +282,11 @@ static void slot_alloc(rd_detector *d, Slot *s) {
   for (int k = 0; k < 3; k++) { s->tr[k] = dnew<float>(N); s->fw[k] = dnew<float>(N); s->bw[k] = dnew<float>(N); s->hz[k] = dnew<float>(N); s->bl[k] = dnew<float>(N); }
   s->vxy = dnew<float>(N * 2); s->strength = dnew<float>(N); s->nms = dnew<float>(N);
   int **ip[] = { &s->i0, &s->i1, &s->mask0, &s->tidy, &s->label1, &s->strsum, &s->edge500, &s->strong, &s->junction, &s->mergemask, &s->region, &s->rsize,
-                 &s->boundarysrc, &s->boundary, &s->lsid };
+                 &s->boundarysrc, &s->boundary, &s->lsid, &s->region0 };
   for (size_t i = 0; i < sizeof(ip) / sizeof(ip[0]); i++) *ip[i] = dnew<int>(N);
   s->scratch2 = dnew<int>(N * 3 + 64);
-  s->table = dnew<int>(N * 4); s->claim = dnew<int>(N);
+  s->table = dnew<int>(N * 4); s->claim = dnew<int>(N); s->tlist = dnew<int>(N);
+  rdk::reduce_ls_init(s->st, s->table, s->claim, s->tlist, (int)(N * 4 / 5));
   s->e8 = dnew<int8_t>(N);
   s->ext = dnew<uint16_t>(N);
   { size_t a = rdk::iir_scratch_floats(3, d->ih, d->iw), b = rdk::iir_scratch_floats(3, d->iw, d->ih); s->tails = dnew<float>(a > b ? a : b); }
@@ -304,7 +305,7 @@ static void slot_alloc(rd_detector *d, Slot *s) {
 static void slot_free(Slot *s) {
   RD_HIP(hipStreamSynchronize(s->st));
   void *all[] = { s->bgr, s->plab0, s->plab1, s->smooth, s->quant, s->vxy, s->strength, s->nms, s->i0, s->i1, s->mask0, s->tidy, s->label1, s->strsum, s->edge500, s->strong,
-                  s->junction, s->mergemask, s->region, s->rsize, s->scratch2, s->boundarysrc, s->boundary, s->lsid, s->table, s->claim, s->probes, s->e8, s->ext, s->tails, s->flags, s->lslist };
+                  s->junction, s->mergemask, s->region, s->rsize, s->scratch2, s->boundarysrc, s->boundary, s->lsid, s->table, s->claim, s->tlist, s->region0, s->probes, s->e8, s->ext, s->tails, s->flags, s->lslist };
   for (void *p : all) dfree(p);
   for (int k = 0; k < 3; k++) { dfree(s->tr[k]); dfree(s->fw[k]); dfree(s->bw[k]); dfree(s->hz[k]); dfree(s->bl[k]); }
   rdk::poly_scratch_destroy(s->ps);
@@ -323,11 +324,11 @@ static void frame_tail(rd_detector *d, Slot *s, int mode) {
   const int iw = d->iw, ih = d->ih, N = d->N;
   hipStream_t st = s->st;
   // frame ring of the bridging step is "non-zero" on this path (oclrect.c:361, H3)
-  rdk::polyline(st, s->ps, s->lslist, N * 16, s->lsid, s->strong, NULL, 1, 4.0f, 20, iw, ih, mode);
+  rdk::polyline(st, s->ps, s->lslist, N * 16, NULL, s->strong, NULL, 1, 4.0f, 20, iw, ih, mode);   // the dense id plane is only produced on request (debug plane)
 
   // segment / boundary votes (oclrect.c:365-367) and the probes the host needs (oclrect.c:1066-1098)
   const int nentry = N * 4 / 5;
-  rdk::reduce_ls(st, s->table, s->claim, s->boundary, s->ps, iw, ih, nentry);
+  rdk::reduce_ls(st, s->table, s->claim, s->tlist, s->boundary, s->ps, iw, ih, nentry);
   rdk::sample_segments(st, s->probes, s->lslist, d->maxrec_dev, s->boundary, s->table, iw, ih, nentry);
 
   const int ncopy = d->maxrec_dev < RD_MAXREC ? d->maxrec_dev : RD_MAXREC;
@@ -387,18 +388,17 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
 
   // strong edges, junction counts, merge mask (oclrect.c:307-321)
   rdk::filter_strength(st, s->label1, s->strsum, 2500, iw, ih);
-  rdk::threshold_i(st, s->strong, s->label1, 0, 0, 1, N);
-  RD_HIP(hipMemcpyAsync(d->prev_strong, s->strong, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));
+  rdk::threshold_i2(st, s->strong, d->prev_strong, s->label1, 0, 0, 1, N);   // H1: the next frame's strength sums start from this mask
   return;
   }
   rdk::junction(st, s->junction, s->label1, 0, iw, ih);
   rdk::merge_mask(st, s->mergemask, s->scratch2, s->junction, iw, ih);
 
   // regions (oclrect.c:325-336)
-  rdk::region_merge(st, s->region, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih);
+  rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih);
   RD_HIP(hipMemcpyAsync(s->rsize, s->junction, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));   // H2: sizes start from the junction counts
-  rdk::region_size(st, s->rsize, s->region, N);
-  rdk::despeckle2(st, s->region, s->scratch2, s->rsize, 16, iw, ih);
+  rdk::region_size(st, s->rsize, s->region0, N);
+  rdk::despeckle2(st, s->region, s->region0, s->scratch2, s->rsize, 16, iw, ih);
 
   // region boundaries and their components (oclrect.c:340-342)
   rdk::mark_boundary(st, s->boundarysrc, s->region, iw, ih);
@@ -628,6 +628,7 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
   for (size_t i = 0; i < sizeof(tab) / sizeof(tab[0]); i++)
     if (!strcmp(tab[i].n, name)) {
       const size_t b = tab[i].bytes < max_bytes ? tab[i].bytes : max_bytes;
+      if (!strcmp(name, "lsid")) rdk::polyline_ids(s->st, s->ps, s->lsid, (int)N);   // not part of the frame path: built from the compact state
       RD_HIP(hipStreamSynchronize(s->st));
       RD_HIP(hipMemcpy(dst, tab[i].p, b, hipMemcpyDeviceToHost));
       return b;

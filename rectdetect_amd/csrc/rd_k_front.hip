@@ -365,6 +365,9 @@ __global__ void k_threshold_f(float *out, const float *in, float lo, float thr, 
 __global__ void k_threshold_i(int *out, const int *in, int lo, int thr, int hi, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i] > thr ? hi : lo;
 }
+__global__ void k_threshold_i2(int *out, int *out2, const int *in, int lo, int thr, int hi, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const int v = in[i] > thr ? hi : lo; out[i] = v; out2[i] = v; }
+}
 __global__ void k_cast_i_f(int *out, const float *in, float scale, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = (int)(in[i] * scale);
 }
@@ -438,6 +441,9 @@ void thinthres(hipStream_t s, float *out, const float *in, const float *vxy, int
 }
 void threshold_f(hipStream_t s, float *out, const float *in, float lo, float thr, float hi, int n) {
   hipLaunchKernelGGL(k_threshold_f, dim3(ew_grid(n)), dim3(256), 0, s, out, in, lo, thr, hi, n);
+}
+void threshold_i2(hipStream_t s, int *out, int *out2, const int *in, int lo, int thr, int hi, int n) {
+  hipLaunchKernelGGL(k_threshold_i2, dim3(ew_grid(n)), dim3(256), 0, s, out, out2, in, lo, thr, hi, n);
 }
 void threshold_i(hipStream_t s, int *out, const int *in, int lo, int thr, int hi, int n) {
   hipLaunchKernelGGL(k_threshold_i, dim3(ew_grid(n)), dim3(256), 0, s, out, in, lo, thr, hi, n);

@@ -996,8 +996,7 @@ void polyline(hipStream_t st, PolyScratch *ps, void *lslist, int lslist_bytes, i
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_poly_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pp_lds)); attr_set = true; }
     hipLaunchKernelGGL(k_seg_clear, dim3(1), dim3(64), 0, st, s, ls, 56);     // resets the counters (ctr[2..23], ctr[25])
     hipLaunchKernelGGL(k_poly_persistent, dim3(1), dim3(PP_T), sizeof(pp_lds), st, s, ls, lslist_bytes, number, minerror, iw);
-    (void)hipMemsetAsync(ids, 0, sizeof(int) * (size_t)N, st);
-    hipLaunchKernelGGL(k_scatter_ids, sg, sb, 0, st, s, ids);
+    if (ids) polyline_ids(st, ps, ids, N);
     return;
   }
 
@@ -1024,8 +1023,12 @@ void polyline(hipStream_t st, PolyScratch *ps, void *lslist, int lslist_bytes, i
   hipLaunchKernelGGL(k_refine3, dim3(1), dim3(1024), 0, st, s, ls, maxrec);
 
   // per-pixel segment ids as a dense plane (lsIdOut)
-  (void)hipMemsetAsync(ids, 0, sizeof(int) * (size_t)N, st);
-  hipLaunchKernelGGL(k_scatter_ids, sg, sb, 0, st, s, ids);
+  if (ids) polyline_ids(st, ps, ids, N);
+}
+
+void polyline_ids(hipStream_t st, PolyScratch *ps, int *ids, int n) {
+  (void)hipMemsetAsync(ids, 0, sizeof(int) * (size_t)n, st);
+  hipLaunchKernelGGL(k_scatter_ids, dim3(SPARSE_GRID), dim3(256), 0, st, *ps, ids);
 }
 
 }  // namespace rdk

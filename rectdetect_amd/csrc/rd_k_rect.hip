@@ -84,43 +84,60 @@ __global__ __launch_bounds__(256) void k_stringify(int *__restrict__ out, const 
 // twice), each side stopping at transitions of the int8 edge mask.  The stopping positions depend on the mask only and
 // the mask is the same for all 20 passes (rh:286-296), so they are computed once per frame (k_blblur_extents: number of
 // samples taken towards smaller / larger coordinates, 0..5 each, for both axes) and every pass is a branch-free gather.
+#define BE_ROWS 16
+#define BE_PITCH 76
 __global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ ext, const int8_t *__restrict__ edge, int iw, int ih) {
-  RD_XY;
-  if (x >= iw || y >= ih) return;
-  const int p = y * iw + x;
-  const bool oe = edge[p] != 0;
-  unsigned e = 0;
-#pragma unroll
-  for (int vert = 0; vert < 2; vert++) {
-    const int c0 = vert ? y : x, n = vert ? ih : iw, st = vert ? iw : 1;
-    const int base = vert ? x : y * iw;
-    const bool has_side = vert ? (x < iw - 1) : (y < ih - 1);
-    const int side = vert ? 1 : iw;
-    int nl = 0, nr = 0;
-    for (int d = 0; d >= -4; d--) {
-      const int c = c0 + d;
-      if (c < 0) break;
-      const int q = base + c * st;
-      const int ec = edge[q];
-      if (c > 0) {
-        const int em = edge[q - st];
-        if (ec != 0 && em == 0) break;
-        if (has_side && ec == 0 && em != 0 && edge[q + side] != 0) break;
-      }
-      nl++;
-    }
-    for (int d = 0; d <= 4; d++) {
-      const int c = c0 + d;
-      if (c > n - 1) break;
-      const int q = base + c * st;
-      const int ec = edge[q];
-      if (c < n - 1 && ec == 0 && edge[q + st] != 0) break;
-      if (oe && ec == 0) break;
-      nr++;
-    }
-    e |= (unsigned)(nl | (nr << 3)) << (vert * 6);
+  // the scans below look at most 5 cells away along their axis and 1 cell sideways: stage (64+10) x (BE_ROWS+10) mask bytes
+  __shared__ int8_t te[(BE_ROWS + 10) * BE_PITCH];
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BE_ROWS;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int t = tid; t < (BE_ROWS + 10) * 74; t += 256) {
+    const int r = t / 74, c = t % 74;
+    const int xx = x0 - 5 + c, yy = y0 - 5 + r;
+    te[r * BE_PITCH + c] = (xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? edge[yy * iw + xx] : (int8_t)0;
   }
-  ext[p] = (uint16_t)e;
+  __syncthreads();
+  const int x = x0 + threadIdx.x;
+  if (x >= iw) return;
+  for (int r = threadIdx.y; r < BE_ROWS; r += 4) {
+    const int y = y0 + r;
+    if (y >= ih) break;
+    const int8_t *ctr = te + (r + 5) * BE_PITCH + threadIdx.x + 5;
+    const bool oe = ctr[0] != 0;
+    unsigned e = 0;
+#pragma unroll
+    for (int vert = 0; vert < 2; vert++) {
+      const int c0 = vert ? y : x, n = vert ? ih : iw, st = vert ? BE_PITCH : 1;
+      const bool has_side = vert ? (x < iw - 1) : (y < ih - 1);
+      const int side = vert ? 1 : BE_PITCH;
+      int nl = 0, nr = 0;
+#pragma unroll
+      for (int d = 0; d >= -4; d--) {
+        const int c = c0 + d;
+        if (c < 0) break;
+        const int8_t *q = ctr + d * st;
+        const int ec = q[0];
+        if (c > 0) {
+          const int em = q[-st];
+          if (ec != 0 && em == 0) break;
+          if (has_side && ec == 0 && em != 0 && q[side] != 0) break;
+        }
+        nl++;
+      }
+#pragma unroll
+      for (int d = 0; d <= 4; d++) {
+        const int c = c0 + d;
+        if (c > n - 1) break;
+        const int8_t *q = ctr + d * st;
+        const int ec = q[0];
+        if (c < n - 1 && ec == 0 && q[st] != 0) break;
+        if (oe && ec == 0) break;
+        nr++;
+      }
+      e |= (unsigned)(nl | (nr << 3)) << (vert * 6);
+    }
+    ext[y * iw + x] = (uint16_t)e;
+  }
 }
 
 // floor(s / w) for s <= 40950, 2 <= w <= 10 as a multiply-high with ceil(2^32 / w) (exact in that range; checked offline)
@@ -333,27 +350,54 @@ __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const 
 // rc:289-298 initial links (up if same colour, else left if same colour, else self), plus - because colours, merge mask
 // and edges do not change between the rounds - one byte per pixel telling from which of its 4 neighbours the pixel may
 // adopt a label (rc:308-326): bit0 up, bit1 left, bit2 right, bit3 down; 0 for frame-border pixels (never processed).
-__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, const int *__restrict__ pix, const int *__restrict__ mask,
+// One block per 64 x RI_ROWS tile: the links that stay inside the tile are followed to their end in LDS (pointer doubling),
+// so every pixel leaves pointing either at the root of its initial tree (if that root lies in the tile) or at the first
+// pixel outside the tile on its way up/left; the few remaining tile-to-tile hops are left to k_region_flatten.
+#define RI_ROWS 32
+__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, int *__restrict__ prop, const int *__restrict__ pix, const int *__restrict__ mask,
                                                      const int *__restrict__ edge, int iw, int ih) {
-  RD_XY;
-  if (x >= iw || y >= ih) return;
-  const int p = y * iw + x;
-  const int v = pix[p];
-  int l = p;
-  if (y > 0 && v == pix[p - iw]) l = p - iw;
-  else if (x > 0 && v == pix[p - 1]) l = p - 1;
-  label[p] = l;
-  unsigned a = 0;
-  if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1) {
-    const bool any = mask[p] != 0;
-    const bool e0 = edge[p] <= 0;
-    if ((v == pix[p - iw] || any) && e0) a |= 1;
-    if ((v == pix[p - 1] || any) && e0) a |= 2;
-    if ((v == pix[p + 1] || any) && edge[p + 1] <= 0) a |= 4;
-    if ((v == pix[p + iw] || any) && edge[p + iw] <= 0) a |= 8;
-    a |= 16;   // interior
+  __shared__ int par[64 * RI_ROWS];     // >= 0: tile-local index of the parent; < 0: -(global index) - 1 of a parent outside the tile
+  const int tx = threadIdx.x, x = blockIdx.x * 64 + tx, y0 = blockIdx.y * RI_ROWS;
+  for (int r = threadIdx.y; r < RI_ROWS; r += 4) {
+    const int y = y0 + r;
+    int l = r * 64 + tx;
+    if (x < iw && y < ih) {
+      const int p = y * iw + x;
+      const int v = pix[p];
+      if (y > 0 && v == pix[p - iw]) l = r > 0 ? l - 64 : -(p - iw) - 1;
+      else if (x > 0 && v == pix[p - 1]) l = tx > 0 ? l - 1 : -(p - 1) - 1;
+      unsigned a = 0;
+      if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1) {
+        const bool any = mask[p] != 0;
+        const bool e0 = edge[p] <= 0;
+        if ((v == pix[p - iw] || any) && e0) a |= 1;
+        if ((v == pix[p - 1] || any) && e0) a |= 2;
+        if ((v == pix[p + 1] || any) && edge[p + 1] <= 0) a |= 4;
+        if ((v == pix[p + iw] || any) && edge[p + iw] <= 0) a |= 8;
+        a |= 16;   // interior
+      }
+      allow[p] = (uint8_t)a;
+      prop[p] = 0x7f7f7f7f;      // no proposal
+    }
+    par[r * 64 + tx] = l;
   }
-  allow[p] = (uint8_t)a;
+  __syncthreads();
+  // a chain inside the tile is at most RI_ROWS + 64 links long: 7 doublings (any interleaving only ever stores ancestors)
+  for (int it = 0; it < 7; it++) {
+    for (int r = threadIdx.y; r < RI_ROWS; r += 4) {
+      const int i = r * 64 + tx;
+      const int a = par[i];
+      if (a >= 0 && a != i) par[i] = par[a];
+    }
+    __syncthreads();
+  }
+  if (x >= iw) return;
+  for (int r = threadIdx.y; r < RI_ROWS; r += 4) {
+    const int y = y0 + r;
+    if (y >= ih) break;
+    const int a = par[r * 64 + tx];
+    label[y * iw + x] = a >= 0 ? (y0 + a / 64) * iw + blockIdx.x * 64 + a % 64 : -a - 1;
+  }
 }
 
 // rc:300-334 per-pixel rule, evaluated in SYNCHRONOUS rounds on the flattened initial forest: every pixel reads the labels of the previous round,
@@ -500,7 +544,7 @@ __device__ __forceinline__ int despeckle2_pick(const int *__restrict__ cur, cons
 // are appended to `list` (any order), *count = their number.  One block per 64x32 tile collects its pixels in LDS and
 // reserves its share of the list with a single atomic (same-address atomics cost ~8 ns each: one per wave was 250 us).
 #define D2_ROWS 32
-__global__ __launch_bounds__(256) void k_despeckle2_first(int *__restrict__ nxt, int *__restrict__ list, int *count, const int *__restrict__ old, const int *__restrict__ size,
+__global__ __launch_bounds__(256) void k_despeckle2_first(int *__restrict__ nxt, int *__restrict__ other, int *__restrict__ list, int *count, const int *__restrict__ old, const int *__restrict__ size,
                                                            int thre, int iw, int ih) {
   __shared__ int loc[64 * D2_ROWS];
   __shared__ int nloc, base;
@@ -516,6 +560,7 @@ __global__ __launch_bounds__(256) void k_despeckle2_first(int *__restrict__ nxt,
       const int l0 = old[p0];
       small = size[l0] <= thre;
       nxt[p0] = small ? despeckle2_pick(old, old, size, l0, x, y, iw, ih) : l0;
+      other[p0] = l0;
     }
     const unsigned long long m = __ballot(small);
     if (m) {
@@ -595,18 +640,45 @@ __device__ __forceinline__ bool rb_collect(const int (&win)[49], int (&bs)[RB_MA
   return overflow;
 }
 
-__global__ void k_reduce_claim(int *claim, const int *__restrict__ boundary, rdk::PolyScratch s, int iw, int ih, int nentry) {
+// slots that receive their first claim are appended to `tlist` (tlist[0] = count) so that the next frame can undo exactly
+// these instead of clearing the whole 20-bytes-per-entry table
+__device__ __forceinline__ void tlist_append(int *tlist, bool first, unsigned slot) {
+  const unsigned long long m = __ballot(first);
+  if (m) {
+    const int lane = __lane_id(), leader = __ffsll((long long)m) - 1;
+    int base = 0;
+    if (lane == leader) base = atomicAdd(&tlist[0], __popcll(m));
+    base = __shfl(base, leader);
+    if (first) tlist[1 + base + __popcll(m & ((1ull << lane) - 1))] = (int)slot;
+  }
+}
+
+__global__ __launch_bounds__(1024) void k_reduce_clean(int *table, int *claim, int *tlist) {
+  const int n = tlist[0];
+  for (int j = threadIdx.x; j < n; j += blockDim.x) {
+    const int slot = tlist[1 + j];
+    int *e = table + (size_t)slot * 5;
+    e[0] = 0; e[1] = 0; e[2] = 0; e[3] = 0; e[4] = 0;
+    claim[slot] = 0x7f7f7f7f;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) tlist[0] = 0;
+}
+
+__global__ void k_reduce_claim(int *claim, int *tlist, const int *__restrict__ boundary, rdk::PolyScratch s, int iw, int ih, int nentry) {
   const int nlive = s.ctr[24];
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nlive; j += gridDim.x * blockDim.x) {
-    const int i = s.live[j];
-    const int id = s.id[i];
-    if (id <= 0) continue;
-    const int p0 = s.pos[i], x = p0 % iw, y = p0 / iw;
+  const int stride = gridDim.x * blockDim.x;
+  for (int j0 = blockIdx.x * blockDim.x; j0 < nlive; j0 += stride) {    // whole waves iterate together (ballots inside)
+    const int j = j0 + threadIdx.x;
+    const int i = j < nlive ? s.live[j] : 0;
+    const int id = j < nlive ? s.id[i] : 0;
+    const bool act = id > 0;
+    const int p0 = act ? s.pos[i] : 0, x = p0 % iw, y = p0 / iw;
     int win[49];
 #pragma unroll
     for (int k = 0; k < 49; k++) {
       const int xx = x + k % 7 - 3, yy = y + k / 7 - 3;
-      win[k] = (xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? boundary[yy * iw + xx] : 0;
+      win[k] = (act && xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? boundary[yy * iw + xx] : 0;
     }
     int bs[RB_MAX], cnt[RB_MAX], nb;
     if (!rb_collect(win, bs, cnt, nb)) {
@@ -615,7 +687,11 @@ __global__ void k_reduce_claim(int *claim, const int *__restrict__ boundary, rdk
 #pragma unroll
       for (int q = 0; q < RB_MAX; q++) { slot[q] = ls_slot(id, bs[q], nentry); cur[q] = ld_agent(&claim[slot[q]]); }   // independent loads
 #pragma unroll
-      for (int q = 0; q < RB_MAX; q++) if (q < nb && i < cur[q]) atomicMin(&claim[slot[q]], i);
+      for (int q = 0; q < RB_MAX; q++) {
+        bool first = false;
+        if (q < nb && i < cur[q]) first = atomicMin(&claim[slot[q]], i) == 0x7f7f7f7f;
+        tlist_append(tlist, first, slot[q]);
+      }
     } else {
       int lastb = 0;
 #pragma unroll
@@ -624,7 +700,7 @@ __global__ void k_reduce_claim(int *claim, const int *__restrict__ boundary, rdk
         if (b <= 0 || b == lastb) continue;      // the slot depends on (id, b) only
         lastb = b;
         const unsigned slot = ls_slot(id, b, nentry);
-        if (i < ld_agent(&claim[slot])) atomicMin(&claim[slot], i);
+        if (i < ld_agent(&claim[slot]) && atomicMin(&claim[slot], i) == 0x7f7f7f7f) tlist[1 + atomicAdd(&tlist[0], 1)] = (int)slot;
       }
     }
   }
@@ -725,10 +801,11 @@ __global__ void k_reduce_box(int *table, const int *__restrict__ claim, const in
   }
 }
 
-__global__ void k_reduce_owner(int *table, const int *__restrict__ claim, rdk::PolyScratch s, int nentry) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nentry; i += gridDim.x * blockDim.x) {
-    const int c = claim[i];
-    if (c != 0x7f7f7f7f) table[(size_t)i * 5] = s.id[c];
+__global__ void k_reduce_owner(int *table, const int *__restrict__ claim, const int *__restrict__ tlist, rdk::PolyScratch s) {
+  const int n = tlist[0];
+  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
+    const int slot = tlist[1 + j];
+    table[(size_t)slot * 5] = s.id[claim[slot]];
   }
 }
 
@@ -783,7 +860,7 @@ void stringify(hipStream_t s, int *out, const int *in, int mod2, int iw, int ih)
   hipLaunchKernelGGL(k_stringify, grid2(iw, ih), block2, 0, s, out, in, mod2, iw, ih);
 }
 void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih) {
-  hipLaunchKernelGGL(k_blblur_extents, grid2(iw, ih), block2, 0, s, ext, edge, iw, ih);
+  hipLaunchKernelGGL(k_blblur_extents, dim3(cdiv(iw, 64), cdiv(ih, BE_ROWS)), dim3(64, 4), 0, s, ext, edge, iw, ih);
 }
 void blblur(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int vertical, int iw, int ih) {
   if (vertical) hipLaunchKernelGGL(k_blblur<1>, grid2(iw, ih), block2, 0, s, out, ext, in, iw, ih);
@@ -807,14 +884,16 @@ void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int 
 
 // scratch: 3*N ints (hook proposals; round flags + allowed-direction bytes; self proposals)
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih) {
-  const int n = iw * ih, ROUNDS = 20, FLAT = 8;
+  const int n = iw * ih, ROUNDS = 20;
+  // tile-to-tile hops left after k_region_init: at most ih/RI_ROWS + iw/64 + 2; each launch divides the depth by 4
+  int FLAT = 1;
+  for (long reach = 4; reach < ih / RI_ROWS + iw / 64 + 2; reach *= 4) FLAT++;
   int *prop = scratch, *flags = scratch + n, *fflags = flags + 32;
-  (void)hipMemsetAsync(prop, 0x7f, sizeof(int) * (size_t)n, s);
   (void)hipMemsetAsync(flags, 0, sizeof(int) * 64, s);
   uint8_t *allow = (uint8_t *)(flags + 64);
   int *selfp = scratch + 2 * (size_t)n;
-  hipLaunchKernelGGL(k_region_init, grid2(iw, ih), block2, 0, s, label, allow, pix, mask, edge, iw, ih);
-  // the initial links are flattened first (4^8 hops of reach); the synchronous rounds then start from trees of depth 1
+  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, label, allow, prop, pix, mask, edge, iw, ih);
+  // the initial links are flattened first; the synchronous rounds then start from trees of depth 1
   for (int r = 0; r < FLAT; r++) hipLaunchKernelGGL(k_region_flatten, dim3(ew_grid(n)), dim3(256), 0, s, label, n, fflags, r);
   for (int r = 0; r < ROUNDS; r++) {
     hipLaunchKernelGGL(k_region_propose, grid2(iw, ih), block2, 0, s, (const int *)label, prop, selfp, (const uint8_t *)allow, iw, ih, (const int *)flags, r);
@@ -826,18 +905,18 @@ void region_size(hipStream_t s, int *out, const int *label, int n) {
   hipLaunchKernelGGL(k_region_size, dim3(cdiv(n, 256 * RS_PER_THREAD)), dim3(256), 0, s, out, label, n);
 }
 
-// scratch: 3*N + 1 ints.  On return `label` holds the result.  Eight Jacobi rounds of the reference's in-place sweep
-// (see DESIGN.md, H6); only pixels of small regions can change, so rounds 2..8 run over their list.
-void despeckle2(hipStream_t s, int *label, int *scratch, const int *size, int thre, int iw, int ih) {
-  const int n = iw * ih, ROUNDS = 8;   // even: the last round writes back into `label`
-  int *old = scratch, *tmp = scratch + n, *count = scratch + 2 * (size_t)n, *list = count + 1;
-  (void)hipMemcpyAsync(old, label, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, s);
+// scratch: 2*N + 1 ints; out must not alias in.  Eight Jacobi rounds of the reference's in-place sweep (see DESIGN.md,
+// H6); only pixels of small regions can change, so rounds 2..8 run over their list.
+void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih) {
+  const int n = iw * ih, ROUNDS = 8;   // even: the last round writes into `out`
+  int *tmp = scratch, *count = scratch + (size_t)n, *list = count + 1;
   (void)hipMemsetAsync(count, 0, sizeof(int), s);
-  hipLaunchKernelGGL(k_despeckle2_first, dim3(cdiv(iw, 64), cdiv(ih, D2_ROWS)), dim3(64, 4), 0, s, tmp, list, count, (const int *)old, size, thre, iw, ih);
+  // first round: tmp <- result, out <- input (both planes then agree on every pixel that is not in the list)
+  hipLaunchKernelGGL(k_despeckle2_first, dim3(cdiv(iw, 64), cdiv(ih, D2_ROWS)), dim3(64, 4), 0, s, tmp, out, list, count, in, size, thre, iw, ih);
   const int *cur = tmp;
   for (int r = 1; r < ROUNDS; r++) {
-    int *nxt = (r & 1) ? label : tmp;   // both planes already agree on every pixel that is not in the list
-    hipLaunchKernelGGL(k_despeckle2_sparse, dim3(512), dim3(256), 0, s, nxt, cur, (const int *)list, (const int *)count, (const int *)old, size, iw, ih);
+    int *nxt = (r & 1) ? out : tmp;
+    hipLaunchKernelGGL(k_despeckle2_sparse, dim3(512), dim3(256), 0, s, nxt, cur, (const int *)list, (const int *)count, in, size, iw, ih);
     cur = nxt;
   }
 }
@@ -846,12 +925,18 @@ void mark_boundary(hipStream_t s, int *out, const int *in, int iw, int ih) {
   hipLaunchKernelGGL(k_mark_boundary, grid2(iw, ih), block2, 0, s, out, in, iw, ih);
 }
 
-// table: nentry*5 ints (cleared here); claim: nentry ints of scratch
-void reduce_ls(hipStream_t s, int *table, int *claim, const int *boundary, const PolyScratch *ps, int iw, int ih, int nentry) {
+// table: nentry*5 ints, claim: nentry ints, tlist: nentry+1 ints; all three are set up once by reduce_ls_init and kept
+// clean between frames by undoing exactly the touched slots
+void reduce_ls_init(hipStream_t s, int *table, int *claim, int *tlist, int nentry) {
   (void)hipMemsetAsync(table, 0, sizeof(int) * 5 * (size_t)nentry, s);
   (void)hipMemsetAsync(claim, 0x7f, sizeof(int) * (size_t)nentry, s);
-  hipLaunchKernelGGL(k_reduce_claim, dim3(512), dim3(256), 0, s, claim, boundary, *ps, iw, ih, nentry);
-  hipLaunchKernelGGL(k_reduce_owner, dim3(ew_grid(nentry)), dim3(256), 0, s, table, (const int *)claim, *ps, nentry);
+  (void)hipMemsetAsync(tlist, 0, sizeof(int), s);
+}
+
+void reduce_ls(hipStream_t s, int *table, int *claim, int *tlist, const int *boundary, const PolyScratch *ps, int iw, int ih, int nentry) {
+  hipLaunchKernelGGL(k_reduce_clean, dim3(1), dim3(1024), 0, s, table, claim, tlist);       // undo the previous use
+  hipLaunchKernelGGL(k_reduce_claim, dim3(512), dim3(256), 0, s, claim, tlist, boundary, *ps, iw, ih, nentry);
+  hipLaunchKernelGGL(k_reduce_owner, dim3(64), dim3(256), 0, s, table, (const int *)claim, (const int *)tlist, *ps);
   hipLaunchKernelGGL(k_reduce_box, dim3(512), dim3(256), 0, s, table, (const int *)claim, boundary, *ps, iw, ih, nentry);
 }
 

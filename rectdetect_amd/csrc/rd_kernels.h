@@ -53,11 +53,12 @@ void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *ed
 void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih);   // scratch: >= ih*ceil(iw/64)*4 ints
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih);
 void region_size(hipStream_t s, int *out, const int *label, int n);              // accumulates into out
-void despeckle2(hipStream_t s, int *label, int *scratch, const int *size, int thre, int iw, int ih);
+void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih);   // out != in; scratch: 2N+1 ints
 void mark_boundary(hipStream_t s, int *out, const int *in, int iw, int ih);
 struct PolyScratch;
 // votes of the chain pixels left in `ps` by the last polyline() call on this stream (their final segment ids)
-void reduce_ls(hipStream_t s, int *table, int *claim, const int *boundary, const PolyScratch *ps, int iw, int ih, int nentry);
+void reduce_ls_init(hipStream_t s, int *table, int *claim, int *tlist, int nentry);   // once per allocation
+void reduce_ls(hipStream_t s, int *table, int *claim, int *tlist, const int *boundary, const PolyScratch *ps, int iw, int ih, int nentry);
 // per segment, 15 probe points: {boundary id, table slot owner, 4 box values} -> out[(seg*15 + k)*6 ..]
 void sample_segments(hipStream_t s, int *out, const void *lslist, int max_records, const int *boundary, const int *table, int iw, int ih, int nentry);
 
@@ -67,6 +68,9 @@ void poly_scratch_destroy(PolyScratch *ps);
 const int *poly_scratch_counters(const PolyScratch *ps);   // device pointer: [0] chain pixels, [1] chains, [2+r] split candidates of round r
 // ring_src: plane whose 2-px frame ring supplies the stale ring values (may be null -> ring_const is used)
 void polyline(hipStream_t s, PolyScratch *ps, void *lslist, int lslist_bytes, int *ids, const int *in, const int *ring_src, int ring_const,
-              float minerror, int sizeThre, int iw, int ih, int mode);   // mode 0: always complete; 1: single persistent launch for the split/refine part, may set counter 25 (overflow: repeat with mode 0)
+              float minerror, int sizeThre, int iw, int ih, int mode);
+// ids may be null (the dense id plane is then not produced); polyline_ids() materialises it later from the compact state
+void polyline_ids(hipStream_t s, PolyScratch *ps, int *ids, int n);
+void threshold_i2(hipStream_t s, int *out, int *out2, const int *in, int lo, int thr, int hi, int n);   // mode 0: always complete; 1: single persistent launch for the split/refine part, may set counter 25 (overflow: repeat with mode 0)
 
 }  // namespace rdk
