@@ -262,6 +262,10 @@ class Detector:
         """frames whose polyline stage overflowed the single-launch kernel and was repeated the long way"""
         return lib().rd_detector_counter(self.h, 0)
 
+    def device_time(self):
+        """(summed device microseconds of the polled frames measured with HIP events, number of frames)"""
+        return lib().rd_detector_counter(self.h, 1), lib().rd_detector_counter(self.h, 2)
+
     def last_segments(self):
         n = lib().rd_detector_last_segments(self.h, None, 0)
         if n < 0:

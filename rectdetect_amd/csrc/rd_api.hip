@@ -233,7 +233,7 @@ cl_event oclpolyline_execute(oclpolyline_t *thiz, cl_mem lsList, int lsListSize,
 
 struct Slot {
   hipStream_t st;
-  hipEvent_t ev_done, ev_strong;
+  hipEvent_t ev_begin, ev_done, ev_strong;   // ev_begin/ev_done carry timestamps: device time of the frame (rd_detector_counter)
   uint8_t *bgr;
   uint32_t *plab0, *plab1, *smooth, *quant;
   float *tr[3], *fw[3], *bw[3], *hz[3], *bl[3], *vxy, *strength, *nms;
@@ -268,6 +268,7 @@ struct rd_detector {
   int last_polled_slot;
   void *last_segs; int last_nsegs;
   int use_graph, poly_mode, force_redo; long n_redo;
+  long dev_us, dev_frames;   // sum over polled frames of (last kernel end - first kernel start) on the frame's stream, HIP events
   double tan_aov; int have_tan;    // what the workers use ahead of the poll that asks for the result
   pthread_mutex_t tan_mu; pthread_cond_t tan_cv;
 };
@@ -275,7 +276,8 @@ struct rd_detector {
 static void slot_alloc(rd_detector *d, Slot *s) {
   const size_t N = (size_t)d->N;
   RD_HIP(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
-  RD_HIP(hipEventCreateWithFlags(&s->ev_done, hipEventDisableTiming));
+  RD_HIP(hipEventCreate(&s->ev_begin));
+  RD_HIP(hipEventCreate(&s->ev_done));
   RD_HIP(hipEventCreateWithFlags(&s->ev_strong, hipEventDisableTiming));
   s->bgr = dnew<uint8_t>(N * 4);
   s->plab0 = dnew<uint32_t>(N); s->plab1 = dnew<uint32_t>(N); s->smooth = dnew<uint32_t>(N); s->quant = dnew<uint32_t>(N);
@@ -310,7 +312,7 @@ static void slot_free(Slot *s) {
   for (int k = 0; k < 3; k++) { dfree(s->tr[k]); dfree(s->fw[k]); dfree(s->bw[k]); dfree(s->hz[k]); dfree(s->bl[k]); }
   rdk::poly_scratch_destroy(s->ps);
   RD_HIP(hipHostFree(s->h_bgr)); RD_HIP(hipHostFree(s->h_segs)); RD_HIP(hipHostFree(s->h_probes)); RD_HIP(hipHostFree(s->h_ctr));
-  RD_HIP(hipEventDestroy(s->ev_done)); RD_HIP(hipEventDestroy(s->ev_strong));
+  RD_HIP(hipEventDestroy(s->ev_begin)); RD_HIP(hipEventDestroy(s->ev_done)); RD_HIP(hipEventDestroy(s->ev_strong));
   RD_HIP(hipStreamDestroy(s->st));
 }
 
@@ -343,16 +345,14 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   if (seg == 0) {
 
   // colour -> sigma=1 blur of L, a, b -> packed blurred Lab (oclrect.c:245-251)
-  rdk::bgr2plab(st, s->plab0, s->bgr, iw, ih, ws);
-  rdk::transpose_unpack(st, s->tr, s->plab0, iw, ih);
+  rdk::bgr2plab_transposed(st, s->plab0, s->tr, s->bgr, iw, ih, ws);
   RD_HIP(hipMemsetAsync(s->flags, 0, 16 * sizeof(int), st));
   { const float *c[3] = { s->tr[0], s->tr[1], s->tr[2] }; rdk::iir_columns(st, s->fw, s->bw, c, 3, ih, iw, s->tails, s->flags);
     const float *f[3] = { s->fw[0], s->fw[1], s->fw[2] }, *b[3] = { s->bw[0], s->bw[1], s->bw[2] };
     rdk::iir_combine_transpose(st, s->hz, f, b, c, 3, ih, iw); }
   { const float *c[3] = { s->hz[0], s->hz[1], s->hz[2] }; rdk::iir_columns(st, s->fw, s->bw, c, 3, iw, ih, s->tails, s->flags + 1);
     const float *f[3] = { s->fw[0], s->fw[1], s->fw[2] }, *b[3] = { s->bw[0], s->bw[1], s->bw[2] };
-    rdk::iir_combine(st, s->bl, f, b, c, 3, N); }
-  rdk::pack_plab(st, s->plab1, s->bl[0], s->bl[1], s->bl[2], N);
+    rdk::iir_combine_pack(st, s->plab1, s->bl[0], f, b, c, N); }
 
   // gradient direction, strength, non-max suppression (oclrect.c:253-258)
   rdk::edgevec(st, s->vxy, s->bl[0], iw, ih);
@@ -360,12 +360,7 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   rdk::thinthres(st, s->nms, s->strength, s->vxy, iw, ih);
 
   // mask of positive responses and the rect-path tidy (oclrect.c:262-272)
-  rdk::threshold_f(st, (float *)s->i0, s->nms, 0.0f, 0.0f, 1.0f, N);
-  rdk::cast_i_f(st, s->mask0, (const float *)s->i0, 1.0f, N);
-  rdk::junction(st, s->i0, s->mask0, 0, iw, ih);
-  rdk::connect_rect(st, s->i1, s->i0, iw, ih);
-  rdk::stringify(st, s->i0, s->i1, 0, iw, ih);
-  rdk::stringify(st, s->tidy, s->i0, 1, iw, ih);
+  rdk::rect_tidy(st, s->mask0, s->tidy, s->nms, iw, ih);
 
   // components (background included)
   rdk::label8(st, s->label1, s->tidy, -1, iw, ih);
@@ -425,6 +420,7 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
     for (int k = 0; k < 3; k++) if (s->gexec[k]) { RD_HIP(hipGraphExecDestroy(s->gexec[k])); s->gexec[k] = NULL; }
     s->graph_ws = ws;
   }
+  RD_HIP(hipEventRecord(s->ev_begin, s->st));
   run_segment(d, s, ws, 0);
   if (d->have_last_strong) RD_HIP(hipStreamWaitEvent(s->st, d->last_strong, 0));
   run_segment(d, s, ws, 1);
@@ -586,6 +582,7 @@ void *rd_detector_poll(rd_detector *d, double tanAOV) {
     RD_HIP(hipEventSynchronize(s->ev_done));
     r = slot_postprocess(d, s, tanAOV, &segs, &ns);
   }
+  { float ms = 0.0f; if (hipEventElapsedTime(&ms, s->ev_begin, s->ev_done) == hipSuccess) { d->dev_us += (long)(ms * 1000.0f); d->dev_frames++; } }
   free(d->last_segs);
   d->last_segs = segs; d->last_nsegs = ns;
   d->last_polled_slot = si;
@@ -601,6 +598,8 @@ void rd_detector_drain(rd_detector *d) {
 
 long rd_detector_counter(rd_detector *d, int which) {
   if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_counter: bad handle\n");
+  if (which == 1) return d->dev_us;
+  if (which == 2) return d->dev_frames;
   return which == 0 ? __atomic_load_n(&d->n_redo, __ATOMIC_RELAXED) : -1;
 }
 

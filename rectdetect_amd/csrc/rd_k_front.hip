@@ -56,6 +56,46 @@ __global__ __launch_bounds__(256) void k_bgr2plab(uint32_t *__restrict__ out, co
   }
 }
 
+// the same conversion for one 64x64 tile, which also leaves the unpacked L, a, b planes TRANSPOSED (input of the first
+// blur sweep) - saves re-reading the packed plane and one launch per frame
+__global__ __launch_bounds__(256) void k_bgr2plab_t(uint32_t *__restrict__ out, P3 dst, const uint8_t *__restrict__ bgr, int iw, int ih, int ws) {
+  __shared__ unsigned short s_s2l[RD_LUT_S2L_N], s_cf[RD_LUT_CF_N], s_cf2[RD_LUT_CF_N];
+  __shared__ float tile[3][64][65];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int i = tid; i < RD_LUT_S2L_N; i += 256) s_s2l[i] = rd_lut_s2l[i];
+  for (int i = tid; i < RD_LUT_CF_N; i += 256) { s_cf[i] = rd_lut_cfunc[i]; s_cf2[i] = rd_lut_cfunc2[i]; }
+  __syncthreads();
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+  const int x = x0 + threadIdx.x;
+  for (int r = threadIdx.y; r < 64; r += 4) {
+    const int y = y0 + r;
+    if (x >= iw || y >= ih) continue;
+    const uint8_t *p = bgr + (size_t)y * ws + x * 3;
+    const int ib = s_s2l[p[0]], ig = s_s2l[p[1]], ir = s_s2l[p[2]];
+    const int cx = (((ir * 6758 + ig * 5859 + ib * 2956 + (1 << 14)) >> 15) * 34476 + (1 << 10)) >> 11;
+    const int cy = ((ir * 3484 + ig * 11717 + ib * 1182) + (1 << 10)) >> 11;
+    const int cz = (((ir * 317 + ig * 1953 + ib * 15569 + (1 << 14)) >> 15) * 30097 + (1 << 10)) >> 11;
+    const int cl = ((lerp_lut(s_cf2, cy) >> 12) + 1) >> 1;
+    const int fx = lerp_lut(s_cf, cx), fy = lerp_lut(s_cf, cy), fz = lerp_lut(s_cf, cz);
+    const int fxy = (fx - fy + (1 << 7)) >> 8, fyz = (fy - fz + (1 << 7)) >> 8;
+    const int ca = (fxy * 8031 + (134744072 + (1 << 17))) >> 18;
+    const int cb = (fyz * 3213 + (134744072 + (1 << 17))) >> 18;
+    uint32_t v = clampu((uint32_t)cb, 0u, 1023u);
+    v = (v << 10) | clampu((uint32_t)ca, 0u, 1023u);
+    v = (v << 12) | clampu((uint32_t)cl, 0u, 4095u);
+    out[y * iw + x] = v;
+    float l, aa, bb;
+    unpack_lab(v, l, aa, bb);
+    tile[0][r][threadIdx.x] = l; tile[1][r][threadIdx.x] = aa; tile[2][r][threadIdx.x] = bb;
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < 64; r += 4) {
+    const int ox = y0 + threadIdx.x, oy = x0 + r;   // output planes are ih wide, iw tall
+    if (ox < ih && oy < iw)
+      for (int k = 0; k < 3; k++) dst.p[k][(size_t)oy * ih + ox] = tile[k][threadIdx.x][r];
+  }
+}
+
 // iu:333-342 / iu:325-331
 __global__ void k_unpack_plab(float *__restrict__ L, float *__restrict__ a, float *__restrict__ b, const uint32_t *__restrict__ in, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -228,6 +268,16 @@ __global__ __launch_bounds__(64) void k_iir_verify(P3c fwd, P3c bwd, const float
 }
 
 // iu:629-637: vertical result = anti-causal + causal - c0 * (horizontal result)
+// vertical result of the three planes, re-packed at once (iu:580-589 + iu:325-331); the blurred L plane is also kept as floats
+__global__ void k_iir_combine_pack(uint32_t *__restrict__ plab, float *__restrict__ Lout, P3c fwd, P3c bwd, P3c src, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float v[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) v[k] = bwd.p[k][i] + fwd.p[k][i] - src.p[k][i] * IIR_C0;
+    Lout[i] = v[0];
+    plab[i] = pack_lab(v[0], v[1], v[2]);
+  }
+}
 __global__ void k_iir_combine(P3 dst, P3c fwd, P3c bwd, P3c src, int np, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     for (int k = 0; k < np; k++) dst.p[k][i] = bwd.p[k][i] + fwd.p[k][i] - src.p[k][i] * IIR_C0;
@@ -393,6 +443,10 @@ namespace rdk {
 void bgr2plab(hipStream_t s, uint32_t *out, const uint8_t *bgr, int iw, int ih, int ws) {
   hipLaunchKernelGGL(k_bgr2plab, dim3(cdiv(iw, 64), cdiv(ih, 16)), block2, 0, s, out, bgr, iw, ih, ws);
 }
+void bgr2plab_transposed(hipStream_t s, uint32_t *out, float *const dst[3], const uint8_t *bgr, int iw, int ih, int ws) {
+  P3 d = { { dst[0], dst[1], dst[2] } };
+  hipLaunchKernelGGL(k_bgr2plab_t, dim3(cdiv(iw, 64), cdiv(ih, 64)), block2, 0, s, out, d, bgr, iw, ih, ws);
+}
 void unpack_plab(hipStream_t s, float *L, float *a, float *b, const uint32_t *in, int n) {
   hipLaunchKernelGGL(k_unpack_plab, dim3(ew_grid(n)), dim3(256), 0, s, L, a, b, in, n);
 }
@@ -429,6 +483,9 @@ void iir_combine_transpose(hipStream_t s, float *const dst[3], const float *cons
 }
 void iir_combine(hipStream_t s, float *const dst[3], const float *const fwd[3], const float *const bwd[3], const float *const src[3], int np, int n) {
   hipLaunchKernelGGL(k_iir_combine, dim3(ew_grid(n)), dim3(256), 0, s, mk3(dst, np), mk3c(fwd, np), mk3c(bwd, np), mk3c(src, np), np, n);
+}
+void iir_combine_pack(hipStream_t s, uint32_t *plab, float *Lout, const float *const fwd[3], const float *const bwd[3], const float *const src[3], int n) {
+  hipLaunchKernelGGL(k_iir_combine_pack, dim3(ew_grid(n)), dim3(256), 0, s, plab, Lout, mk3c(fwd, 3), mk3c(bwd, 3), mk3c(src, 3), n);
 }
 void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih) {
   hipLaunchKernelGGL(k_edgevec, grid2(iw, ih), block2, 0, s, (float2 *)vxy, in, iw, ih);

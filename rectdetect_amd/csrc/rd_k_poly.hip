@@ -97,6 +97,89 @@ __global__ __launch_bounds__(256) void k_remove_branch(int *__restrict__ out, co
   out[p] = r;
 }
 
+// the five tidy stencils above for one 64 x PT_ROWS tile in LDS (6 cells of halo in total; after the bridging step only
+// "zero / non-zero" matters, so every intermediate is a byte)
+#define PT_ROWS 16
+#define PT_M 6
+#define PT_P (64 + 2 * PT_M)
+__global__ __launch_bounds__(256) void k_poly_tidy(int *__restrict__ out, const int *__restrict__ in, const int *__restrict__ ring_src, int ring_const, int iw, int ih) {
+  __shared__ uint8_t A[(PT_ROWS + 2 * PT_M) * PT_P], B[(PT_ROWS + 2 * PT_M) * PT_P];
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * PT_ROWS;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+#define PT_FOR(m) for (int t = tid; t < (PT_ROWS + 2 * (m)) * (64 + 2 * (m)); t += 256)
+#define PT_CELL(m) const int r = t / (64 + 2 * (m)) - (m), c = t % (64 + 2 * (m)) - (m); const int x = x0 + c, y = y0 + r; const int i = (r + PT_M) * PT_P + c + PT_M; const bool in_img = x >= 0 && x < iw && y >= 0 && y < ih
+  PT_FOR(6) {
+    PT_CELL(6);
+    A[i] = (in_img && in[y * iw + x] != 0) ? 1 : 0;
+  }
+  __syncthreads();
+  PT_FOR(5) {   // pl:66-87
+    PT_CELL(5);
+    uint8_t v = 0;
+    if (in_img && x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && A[i] != 0) {
+      int count = 1;
+#pragma unroll
+      for (int k = 0; k < 8; k++) count += A[i + nbr_dx(k) + nbr_dy(k) * PT_P] != 0;
+      v = count == 1 ? 0 : count;
+    }
+    B[i] = v;
+  }
+  __syncthreads();
+  PT_FOR(3) {   // pl:89-110 (ring: see k_connect_poly)
+    PT_CELL(3);
+    uint8_t o = 0;
+    if (in_img) {
+      if (x <= 1 || y <= 1 || x >= iw - 2 || y >= ih - 2) o = (ring_src ? ring_src[y * iw + x] : ring_const) != 0;
+      else if (B[i] != 0) o = 1;
+      else {
+        const int W = PT_P;
+        if (B[i - 2] != 0 && B[i - 1] == 2 && B[i + 1] == 2 && B[i + 2] != 0) o = 1;
+        if (B[i - W * 2] != 0 && B[i - W] == 2 && B[i + W] == 2 && B[i + W * 2] != 0) o = 1;
+        if (B[i - W * 2 - 2] != 0 && B[i - W - 1] == 2 && B[i + W + 1] == 2 && B[i + W * 2 + 2] != 0) o = 1;
+        if (B[i - W * 2 + 2] != 0 && B[i - W + 1] == 2 && B[i + W - 1] == 2 && B[i + W * 2 - 2] != 0) o = 1;
+        if (B[i + 2] != 0 && B[i + 1] == 2 && B[i + W - 1] == 2 && B[i + W - 2] != 0) o = 1;
+        if (B[i - 2] != 0 && B[i - 1] == 2 && B[i + W + 1] == 2 && B[i + W + 2] != 0) o = 1;
+        if (B[i - W * 2 + 1] != 0 && B[i - W + 1] == 2 && B[i + W] == 2 && B[i + W * 2] != 0) o = 1;
+        if (B[i - W * 2 - 1] != 0 && B[i - W - 1] == 2 && B[i + W] == 2 && B[i + W * 2] != 0) o = 1;
+      }
+    }
+    A[i] = o;
+  }
+  __syncthreads();
+  PT_FOR(2) {   // pl:112-124, parity 0
+    PT_CELL(2);
+    uint8_t v = in_img ? A[i] : 0;
+    if (in_img && x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && ((x + y) & 1) == 0) {
+      if ((A[i - PT_P] != 0 || A[i + PT_P] != 0) && (A[i - 1] != 0 || A[i + 1] != 0)) v = 0;
+    }
+    B[i] = v;
+  }
+  __syncthreads();
+  PT_FOR(1) {   // parity 1
+    PT_CELL(1);
+    uint8_t v = in_img ? B[i] : 0;
+    if (in_img && x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && ((x + y) & 1) == 1) {
+      if ((B[i - PT_P] != 0 || B[i + PT_P] != 0) && (B[i - 1] != 0 || B[i + 1] != 0)) v = 0;
+    }
+    A[i] = v;
+  }
+  __syncthreads();
+  PT_FOR(0) {   // pl:126-147
+    PT_CELL(0);
+    if (!in_img) continue;
+    int v = 0;
+    if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && A[i] != 0) {
+      int count = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) count += A[i + nbr_dx(k) + nbr_dy(k) * PT_P] != 0;
+      v = count <= 2 ? 1 : 0;
+    }
+    out[y * iw + x] = v;
+  }
+#undef PT_FOR
+#undef PT_CELL
+}
+
 // ------------------------------------------------------------------------------------------------ raster-order compaction
 #define CP_PER_BLOCK 2048
 // Stable (index-ordered) compaction of the non-zero elements of `plane` in three launches: per-block counts, exclusive
@@ -949,11 +1032,7 @@ void polyline(hipStream_t st, PolyScratch *ps, void *lslist, int lslist_bytes, i
   const dim3 sg(SPARSE_GRID), sb(256);
 
   // tidy (oclpolyline.c:222-235)
-  hipLaunchKernelGGL(k_junction_nz, grid2(iw, ih), block2, 0, st, s.planeA, in, iw, ih);
-  hipLaunchKernelGGL(k_connect_poly, grid2(iw, ih), block2, 0, st, s.planeB, (const int *)s.planeA, ring_src, ring_const, iw, ih);
-  hipLaunchKernelGGL(k_stringify_p, grid2(iw, ih), block2, 0, st, s.planeA, (const int *)s.planeB, 0, iw, ih);
-  hipLaunchKernelGGL(k_stringify_p, grid2(iw, ih), block2, 0, st, s.planeB, (const int *)s.planeA, 1, iw, ih);
-  hipLaunchKernelGGL(k_remove_branch, grid2(iw, ih), block2, 0, st, s.planeC, (const int *)s.planeB, iw, ih);
+  hipLaunchKernelGGL(k_poly_tidy, dim3(cdiv(iw, 64), cdiv(ih, PT_ROWS)), dim3(64, 4), 0, st, s.planeC, in, ring_src, ring_const, iw, ih);
 
   // compaction of the chain pixels in raster order
   const int nblk = cdiv(N, CP_PER_BLOCK);

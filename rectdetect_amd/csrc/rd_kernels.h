@@ -8,6 +8,10 @@ namespace rdk {
 
 // ---- rd_k_front.hip: colour, blur, gradient, non-max suppression, element-wise ops
 void bgr2plab(hipStream_t s, uint32_t *out, const uint8_t *bgr, int iw, int ih, int ws);
+// colour conversion that also leaves the unpacked L, a, b planes transposed (ih wide, iw tall) for the first blur sweep
+void bgr2plab_transposed(hipStream_t s, uint32_t *out, float *const dst[3], const uint8_t *bgr, int iw, int ih, int ws);
+// plab = pack(bwd + fwd - src * c0) over the three planes, Lout = the L plane of that
+void iir_combine_pack(hipStream_t s, uint32_t *plab, float *Lout, const float *const fwd[3], const float *const bwd[3], const float *const src[3], int n);
 void unpack_plab(hipStream_t s, float *L, float *a, float *b, const uint32_t *in, int n);
 void pack_plab(hipStream_t s, uint32_t *out, const float *L, const float *a, const float *b, int n);
 // transposes of `np` float planes (src planes W x H row-major -> dst planes H x W); src may be packed Lab (np = 3)
@@ -42,6 +46,8 @@ void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw
 // ---- rd_k_rect.hip: rect-path stages
 void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih);
 void connect_rect(hipStream_t s, int *out, const int *in, int iw, int ih);
+// mask0 = (nms > 0), tidy = stringify(stringify(connect_rect(junction(mask0)), 0), 1) in one launch
+void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, int ih);
 void stringify(hipStream_t s, int *out, const int *in, int mod2, int iw, int ih);
 // run extents of the edge-stopped blur (depend on the edge mask only): ext[p] = nl_h | nr_h<<3 | nl_v<<6 | nr_v<<9
 void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih);
