@@ -291,7 +291,7 @@ static void slot_alloc(rd_detector *d, Slot *s) {
   rdk::reduce_ls_init(s->st, s->table, s->claim, s->tlist, (int)(N * 4 / 5));
   s->e8 = dnew<int8_t>(N);
   s->ext = dnew<uint16_t>(N);
-  { size_t a = rdk::iir_scratch_floats(3, d->ih, d->iw), b = rdk::iir_scratch_floats(3, d->iw, d->ih); s->tails = dnew<float>(a > b ? a : b); }
+  { size_t a = rdk::iir_pass_scratch_floats(3, d->ih, d->iw), b = rdk::iir_pass_scratch_floats(3, d->iw, d->ih); s->tails = dnew<float>(a > b ? a : b); }
   s->flags = dnew<int>(16);
   s->iir_chunked = 1;
   s->lslist = dnew<uint8_t>(N * 16);
@@ -347,12 +347,9 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   // colour -> sigma=1 blur of L, a, b -> packed blurred Lab (oclrect.c:245-251)
   rdk::bgr2plab_transposed(st, s->plab0, s->tr, s->bgr, iw, ih, ws);
   RD_HIP(hipMemsetAsync(s->flags, 0, 16 * sizeof(int), st));
-  { const float *c[3] = { s->tr[0], s->tr[1], s->tr[2] }; rdk::iir_columns(st, s->fw, s->bw, c, 3, ih, iw, s->tails, s->flags);
-    const float *f[3] = { s->fw[0], s->fw[1], s->fw[2] }, *b[3] = { s->bw[0], s->bw[1], s->bw[2] };
-    rdk::iir_combine_transpose(st, s->hz, f, b, c, 3, ih, iw); }
-  { const float *c[3] = { s->hz[0], s->hz[1], s->hz[2] }; rdk::iir_columns(st, s->fw, s->bw, c, 3, iw, ih, s->tails, s->flags + 1);
-    const float *f[3] = { s->fw[0], s->fw[1], s->fw[2] }, *b[3] = { s->bw[0], s->bw[1], s->bw[2] };
-    rdk::iir_combine_pack(st, s->plab1, s->bl[0], f, b, c, N); }
+  { const float *c[3] = { s->tr[0], s->tr[1], s->tr[2] }; rdk::iir_blur_pass(st, s->hz, c, s->fw, s->bw, 3, ih, iw, 1, s->tails, s->flags); }       // along x
+  { const float *c[3] = { s->hz[0], s->hz[1], s->hz[2] }; rdk::iir_blur_pass(st, s->bl, c, s->fw, s->bw, 3, iw, ih, 0, s->tails, s->flags + 1); }   // along y
+  rdk::pack_plab(st, s->plab1, s->bl[0], s->bl[1], s->bl[2], N);
 
   // gradient direction, strength, non-max suppression (oclrect.c:253-258)
   rdk::edgevec(st, s->vxy, s->bl[0], iw, ih);

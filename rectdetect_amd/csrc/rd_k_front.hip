@@ -112,7 +112,8 @@ __global__ void k_pack_plab(uint32_t *__restrict__ out, const float *__restrict_
 // ------------------------------------------------------------------------------------------------ transposes
 // 64x64 tiles through LDS (row pitch 65 floats -> conflict-free column reads); block = 64x4 threads.
 template <int MODE>  // 0: plain float planes, 1: source is packed Lab (unpack while transposing), 2: IIR combine while transposing
-__global__ __launch_bounds__(256) void k_transpose(P3 dst, P3c src, P3c fwd, P3c bwd, const uint32_t *__restrict__ plab, int np, int W, int H) {
+__global__ __launch_bounds__(256) void k_transpose(P3 dst, P3c src, P3c fwd, P3c bwd, const uint32_t *__restrict__ plab, int np, int W, int H, const int *only_if) {
+  if (only_if && *only_if == 0) return;
   __shared__ float tile[3][64][65];
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
   for (int r = threadIdx.y; r < 64; r += 4) {
@@ -267,6 +268,127 @@ __global__ __launch_bounds__(64) void k_iir_verify(P3c fwd, P3c bwd, const float
   if (__any(differ) && threadIdx.x == 0) atomicOr(bad, 1);
 }
 
+// Both sweeps and the combination (iu:580-589 / iu:629-637: anti-causal + causal - c0 * input) for one 64-column x IF_ROWS
+// block of one plane in ONE wave: the causal outputs of the block wait in LDS while the anti-causal sweep runs over the same
+// rows and finishes each pixel, so neither sweep's result travels through HBM.  Both sweeps start IIR_WU rows outside the
+// block from a zero state (or at the true beginning of the sweep when that is nearer); whether that reproduces the full
+// sweep BIT FOR BIT is checked on the device: each block records the 7 outputs it computed just before entering its rows
+// ("warm") and its own last 7 outputs ("true"), k_iir_fused_verify compares neighbours, and on any difference the
+// full-length sweeps run instead (rdk::iir_blur_pass).  TOUT = 1 writes the result transposed (through the LDS tile).
+#define IF_ROWS 64
+#define IF_LROWS 72           // a short remainder (< 8 rows) is merged into the last block
+#define IF_WU 32              // warm-up rows (24 sufficed on every plane tried on the CPU; the on-device check is what guarantees the result)
+#define IF_PITCH 65
+__host__ __device__ inline int if_nchunks(int H) {
+  int n = (H + IF_ROWS - 1) / IF_ROWS;
+  if (n > 1 && H % IF_ROWS != 0 && H % IF_ROWS < 8) n--;
+  return n;
+}
+
+#define IIR_STEP(i0v)                                                                                                  \
+  float d = (i0v) * IIR_C0;                                                                                            \
+  d += IIR_C1 * i1 + IIR_C2 * i2 + IIR_C3 * i3 + IIR_C4 * i4 + IIR_C5 * i5 + IIR_C6 * i6 + IIR_C7 * i7;               \
+  d += IIR_C8 * t0 + IIR_C9 * t1 + IIR_C10 * t2 + IIR_C11 * t3 + IIR_C12 * t4 + IIR_C13 * t5 + IIR_C14 * t6;
+#define IIR_SHIFT(i0v)                                                                                                 \
+  i7 = i6; i6 = i5; i5 = i4; i4 = i3; i3 = i2; i2 = i1; i1 = (i0v);                                                    \
+  t6 = t5; t5 = t4; t4 = t3; t3 = t2; t2 = t1; t1 = t0; t0 = d;
+
+template <int TOUT>
+__global__ __launch_bounds__(64) void k_iir_fused(P3 dst, P3c src, float *__restrict__ tails, int W, int H, int nchunks) {
+  __shared__ float fwt[IF_LROWS * IF_PITCH];
+  const int lane = threadIdx.x;
+  const int x = blockIdx.x * 64 + lane;
+  const int k = blockIdx.y, c = blockIdx.z;
+  const bool xin = x < W;
+  const float *__restrict__ in = src.p[k] + (xin ? x : W - 1);
+  const int s0 = c * IF_ROWS, s1 = (c == nchunks - 1) ? H : s0 + IF_ROWS;
+  // tails: [plane][chunk][set: 0 fwd warm, 1 fwd true, 2 bwd warm, 3 bwd true][7][W]
+  float *__restrict__ tl = tails + ((size_t)(k * nchunks + c) * 4 * 7) * W + (xin ? x : W - 1);
+  const int ylo = -IIR_WARM, yhi = H + IIR_WARM;
+  float cur[IIR_CH], nxt[IIR_CH];
+  {   // ---------------- causal sweep: rows fb .. s1-1
+    const int fb = (s0 - IF_WU <= ylo) ? ylo : s0 - IF_WU;
+    const int total = s1 - fb;
+    float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
+    float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+#pragma unroll
+    for (int j = 0; j < IIR_CH; j++) cur[j] = in[(size_t)mirror1(clampi(fb + j, ylo, yhi), H) * W];
+    for (int base = 0; base < total; base += IIR_CH) {
+#pragma unroll
+      for (int j = 0; j < IIR_CH; j++) nxt[j] = in[(size_t)mirror1(clampi(fb + base + IIR_CH + j, ylo, yhi), H) * W];
+#pragma unroll
+      for (int j = 0; j < IIR_CH; j++) {
+        const int yy = fb + base + j;
+        IIR_STEP(cur[j]);
+        if (yy >= s0 && yy < s1) fwt[(yy - s0) * IF_PITCH + lane] = d;
+        if (xin && yy >= s0 - 7 && yy < s0) tl[(size_t)(0 * 7 + yy - (s0 - 7)) * W] = d;
+        if (xin && yy >= s1 - 7 && yy < s1) tl[(size_t)(1 * 7 + yy - (s1 - 7)) * W] = d;
+        IIR_SHIFT(cur[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < IIR_CH; j++) cur[j] = nxt[j];
+    }
+  }
+  {   // ---------------- anti-causal sweep: rows bb .. s0 (descending), finishing the block's pixels
+    const int bb = (s1 - 1 + IF_WU >= yhi) ? yhi : s1 - 1 + IF_WU;
+    const int total = bb - s0 + 1;
+    float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
+    float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+#pragma unroll
+    for (int j = 0; j < IIR_CH; j++) cur[j] = in[(size_t)mirror1(clampi(bb - j, ylo, yhi), H) * W];
+    for (int base = 0; base < total; base += IIR_CH) {
+#pragma unroll
+      for (int j = 0; j < IIR_CH; j++) nxt[j] = in[(size_t)mirror1(clampi(bb - (base + IIR_CH + j), ylo, yhi), H) * W];
+#pragma unroll
+      for (int j = 0; j < IIR_CH; j++) {
+        const int yy = bb - (base + j);
+        IIR_STEP(cur[j]);
+        if (yy >= s0 && yy < s1) {
+          const float o = d + fwt[(yy - s0) * IF_PITCH + lane] - cur[j] * IIR_C0;
+          if (TOUT) fwt[(yy - s0) * IF_PITCH + lane] = o;
+          else if (xin) dst.p[k][(size_t)yy * W + x] = o;
+        }
+        if (xin && yy >= s1 && yy < s1 + 7) tl[(size_t)(2 * 7 + yy - s1) * W] = d;
+        if (xin && yy >= s0 && yy < s0 + 7) tl[(size_t)(3 * 7 + yy - s0) * W] = d;
+        IIR_SHIFT(cur[j]);
+      }
+#pragma unroll
+      for (int j = 0; j < IIR_CH; j++) cur[j] = nxt[j];
+    }
+  }
+  if (TOUT) {
+    __syncthreads();
+    const int rows = s1 - s0;
+    for (int col = 0; col < 64; col++) {
+      const int xx = blockIdx.x * 64 + col;
+      if (xx >= W) break;
+      float *__restrict__ o = dst.p[k] + (size_t)xx * H + s0;
+      for (int r = lane; r < rows; r += 64) o[r] = fwt[r * IF_PITCH + col];
+    }
+  }
+}
+
+// the state a block reached after its warm-up must equal, bit for bit, what its neighbour computed for the same rows
+__global__ __launch_bounds__(64) void k_iir_fused_verify(const float *__restrict__ tails, int *bad, int W, int H, int nchunks) {
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  const int k = blockIdx.y, c = blockIdx.z;
+  if (x >= W) return;
+  const int s0 = c * IF_ROWS, s1 = (c == nchunks - 1) ? H : s0 + IF_ROWS;
+  const float *me = tails + ((size_t)(k * nchunks + c) * 4 * 7) * W + x;
+  bool differ = false;
+  if (c > 0 && s0 - IF_WU > -IIR_WARM) {                 // causal: my warm rows s0-7..s0-1 against the previous block's last rows
+    const float *pv = tails + ((size_t)(k * nchunks + c - 1) * 4 * 7) * W + x;
+#pragma unroll
+    for (int j = 0; j < 7; j++) differ = differ || (__float_as_uint(me[(size_t)(0 * 7 + j) * W]) != __float_as_uint(pv[(size_t)(1 * 7 + j) * W]));
+  }
+  if (c < nchunks - 1 && s1 - 1 + IF_WU < H + IIR_WARM) {   // anti-causal: my warm rows s1..s1+6 against the next block's first rows
+    const float *nx = tails + ((size_t)(k * nchunks + c + 1) * 4 * 7) * W + x;
+#pragma unroll
+    for (int j = 0; j < 7; j++) differ = differ || (__float_as_uint(me[(size_t)(2 * 7 + j) * W]) != __float_as_uint(nx[(size_t)(3 * 7 + j) * W]));
+  }
+  if (__any(differ) && threadIdx.x == 0) atomicOr(bad, 1);
+}
+
 // iu:629-637: vertical result = anti-causal + causal - c0 * (horizontal result)
 // vertical result of the three planes, re-packed at once (iu:580-589 + iu:325-331); the blurred L plane is also kept as floats
 __global__ void k_iir_combine_pack(uint32_t *__restrict__ plab, float *__restrict__ Lout, P3c fwd, P3c bwd, P3c src, int n) {
@@ -278,7 +400,8 @@ __global__ void k_iir_combine_pack(uint32_t *__restrict__ plab, float *__restric
     plab[i] = pack_lab(v[0], v[1], v[2]);
   }
 }
-__global__ void k_iir_combine(P3 dst, P3c fwd, P3c bwd, P3c src, int np, int n) {
+__global__ void k_iir_combine(P3 dst, P3c fwd, P3c bwd, P3c src, int np, int n, const int *only_if) {
+  if (only_if && *only_if == 0) return;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
     for (int k = 0; k < np; k++) dst.p[k][i] = bwd.p[k][i] + fwd.p[k][i] - src.p[k][i] * IIR_C0;
 }
@@ -459,11 +582,11 @@ static P3c mk3c(const float *const p[3], int np) { P3c r = { { nullptr, nullptr,
 
 void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], int np, int W, int H) {
   P3c z = { { nullptr, nullptr, nullptr } };
-  hipLaunchKernelGGL(k_transpose<0>, dim3(cdiv(W, 64), cdiv(H, 64)), block2, 0, s, mk3(dst, np), mk3c(src, np), z, z, (const uint32_t *)nullptr, np, W, H);
+  hipLaunchKernelGGL(k_transpose<0>, dim3(cdiv(W, 64), cdiv(H, 64)), block2, 0, s, mk3(dst, np), mk3c(src, np), z, z, (const uint32_t *)nullptr, np, W, H, (const int *)nullptr);
 }
 void transpose_unpack(hipStream_t s, float *const dst[3], const uint32_t *plab, int W, int H) {
   P3c z = { { nullptr, nullptr, nullptr } };
-  hipLaunchKernelGGL(k_transpose<1>, dim3(cdiv(W, 64), cdiv(H, 64)), block2, 0, s, mk3(dst, 3), z, z, z, plab, 3, W, H);
+  hipLaunchKernelGGL(k_transpose<1>, dim3(cdiv(W, 64), cdiv(H, 64)), block2, 0, s, mk3(dst, 3), z, z, z, plab, 3, W, H, (const int *)nullptr);
 }
 size_t iir_scratch_floats(int np, int W, int H) { return (size_t)np * 2 * cdiv(H + IIR_WARM + 1, IIR_CHUNK) * 7 * W; }
 
@@ -479,14 +602,35 @@ void iir_columns(hipStream_t s, float *const fwd[3], float *const bwd[3], const 
   hipLaunchKernelGGL(k_iir_columns, dim3(cdiv(W, 64), np * 2), dim3(64), 0, s, mk3(fwd, np), mk3(bwd, np), mk3c(src, np), W, H, (const int *)bad);
 }
 void iir_combine_transpose(hipStream_t s, float *const dst[3], const float *const fwd[3], const float *const bwd[3], const float *const src[3], int np, int W, int H) {
-  hipLaunchKernelGGL(k_transpose<2>, dim3(cdiv(W, 64), cdiv(H, 64)), block2, 0, s, mk3(dst, np), mk3c(src, np), mk3c(fwd, np), mk3c(bwd, np), (const uint32_t *)nullptr, np, W, H);
+  hipLaunchKernelGGL(k_transpose<2>, dim3(cdiv(W, 64), cdiv(H, 64)), block2, 0, s, mk3(dst, np), mk3c(src, np), mk3c(fwd, np), mk3c(bwd, np), (const uint32_t *)nullptr, np, W, H, (const int *)nullptr);
 }
 void iir_combine(hipStream_t s, float *const dst[3], const float *const fwd[3], const float *const bwd[3], const float *const src[3], int np, int n) {
-  hipLaunchKernelGGL(k_iir_combine, dim3(ew_grid(n)), dim3(256), 0, s, mk3(dst, np), mk3c(fwd, np), mk3c(bwd, np), mk3c(src, np), np, n);
+  hipLaunchKernelGGL(k_iir_combine, dim3(ew_grid(n)), dim3(256), 0, s, mk3(dst, np), mk3c(fwd, np), mk3c(bwd, np), mk3c(src, np), np, n, (const int *)nullptr);
 }
 void iir_combine_pack(hipStream_t s, uint32_t *plab, float *Lout, const float *const fwd[3], const float *const bwd[3], const float *const src[3], int n) {
   hipLaunchKernelGGL(k_iir_combine_pack, dim3(ew_grid(n)), dim3(256), 0, s, plab, Lout, mk3c(fwd, 3), mk3c(bwd, 3), mk3c(src, 3), n);
 }
+size_t iir_pass_scratch_floats(int np, int W, int H) { return (size_t)np * if_nchunks(H) * 4 * 7 * W; }
+
+// one blur pass (both sweeps + combination) down the columns of np planes (W columns, H rows); transpose_out: dst planes
+// are H wide, W tall.  fwd/bwd: scratch planes, only touched when the on-device check of the blocked evaluation fails
+// (*bad != 0) and the full-length sweeps have to run; tails: iir_pass_scratch_floats() floats; *bad must be 0 on entry.
+void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3], float *const fwd[3], float *const bwd[3], int np, int W, int H,
+                   int transpose_out, float *tails, int *bad) {
+  const int nchunks = if_nchunks(H);
+  const dim3 grid(cdiv(W, 64), np, nchunks);
+  if (transpose_out) hipLaunchKernelGGL(k_iir_fused<1>, grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks);
+  else hipLaunchKernelGGL(k_iir_fused<0>, grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks);
+  if (nchunks > 1) {
+    hipLaunchKernelGGL(k_iir_fused_verify, grid, dim3(64), 0, s, (const float *)tails, bad, W, H, nchunks);
+    // fallback (skipped on the device unless the check failed)
+    const float *f[3] = { fwd[0], np > 1 ? fwd[1] : nullptr, np > 2 ? fwd[2] : nullptr }, *b[3] = { bwd[0], np > 1 ? bwd[1] : nullptr, np > 2 ? bwd[2] : nullptr };
+    hipLaunchKernelGGL(k_iir_columns, dim3(cdiv(W, 64), np * 2), dim3(64), 0, s, mk3(fwd, np), mk3(bwd, np), mk3c(src, np), W, H, (const int *)bad);
+    if (transpose_out) hipLaunchKernelGGL(k_transpose<2>, dim3(cdiv(W, 64), cdiv(H, 64)), block2, 0, s, mk3(dst, np), mk3c(src, np), mk3c(f, np), mk3c(b, np), (const uint32_t *)nullptr, np, W, H, (const int *)bad);
+    else hipLaunchKernelGGL(k_iir_combine, dim3(ew_grid(W * H)), dim3(256), 0, s, mk3(dst, np), mk3c(f, np), mk3c(b, np), mk3c(src, np), np, W * H, (const int *)bad);
+  }
+}
+
 void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih) {
   hipLaunchKernelGGL(k_edgevec, grid2(iw, ih), block2, 0, s, (float2 *)vxy, in, iw, ih);
 }

@@ -26,6 +26,10 @@ void iir_columns(hipStream_t s, float *const fwd[3], float *const bwd[3], const 
 void iir_combine_transpose(hipStream_t s, float *const dst[3], const float *const fwd[3], const float *const bwd[3], const float *const src[3], int np, int W, int H);
 // dst[k] = bwd[k] + fwd[k] - src[k] * c0   (no transpose)
 void iir_combine(hipStream_t s, float *const dst[3], const float *const fwd[3], const float *const bwd[3], const float *const src[3], int np, int n);
+// one complete blur pass (causal + anti-causal sweep + combination) in a single launch, see rd_k_front.hip
+size_t iir_pass_scratch_floats(int np, int W, int H);
+void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3], float *const fwd[3], float *const bwd[3], int np, int W, int H,
+                   int transpose_out, float *tails, int *bad);
 void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih);
 void edge_plab(hipStream_t s, float *out, const uint32_t *in, int iw, int ih);
 void thinthres(hipStream_t s, float *out, const float *in, const float *vxy, int iw, int ih);

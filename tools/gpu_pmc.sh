@@ -1,0 +1,14 @@
+#!/bin/bash
+# hardware-counter passes (own runs, kernel trace only): usage on the box: bash tools/gpu_pmc.sh <tag>
+tag=${1:-x}
+export TMPDIR=/tmp RD_NO_GRAPH=1
+R=$PWD
+mkdir -p $R/gpurun_out
+cd /tmp
+CMD="python $R/bench.py --steps 1 --warmup 1 --slots 1 --frames-per-step 4 --no-cpu-baseline"
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace -d $R/gpurun_out/pmc${tag}_sq -o sq -- $CMD > $R/gpurun_out/pmc${tag}_sq.log 2>&1
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc${tag}_rd -o rd -- $CMD > $R/gpurun_out/pmc${tag}_rd.log 2>&1
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc${tag}_wr -o wr -- $CMD > $R/gpurun_out/pmc${tag}_wr.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc${tag}_calrd -o calrd -- python $R/tools/pmc_calibrate.py > $R/gpurun_out/pmc${tag}_calrd.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc${tag}_calwr -o calwr -- python $R/tools/pmc_calibrate.py > $R/gpurun_out/pmc${tag}_calwr.log 2>&1
+cd $R; find gpurun_out/pmc${tag}_* -name "*.db" | head; tail -3 gpurun_out/pmc${tag}_sq.log
