@@ -253,11 +253,29 @@ __device__ __forceinline__ unsigned div_small_f(unsigned s, float rw) { return (
 __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih) {
   __shared__ uint2 src[(BP_ROWS + 8) * BP_SW + 1];
   __shared__ uint2 hz[(BP_ROWS + 8) * 64 + 1];
+  __shared__ float rwt[16];                                      // 1 / w, correctly rounded (compile-time constants)
   const int ZS = (BP_ROWS + 8) * BP_SW, ZH = (BP_ROWS + 8) * 64;   // zero slots
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BP_ROWS;
   const int x = x0 + tx;
   if (tid == 0) { src[ZS] = make_uint2(0, 0); hz[ZH] = make_uint2(0, 0); }
+  if (tid < 16) {
+    const float t[16] = { 0.0f, 1.0f, 1.0f / 2.0f, 1.0f / 3.0f, 1.0f / 4.0f, 1.0f / 5.0f, 1.0f / 6.0f, 1.0f / 7.0f, 1.0f / 8.0f, 1.0f / 9.0f, 1.0f / 10.0f, 0, 0, 0, 0, 0 };
+    rwt[tid] = t[tid];
+  }
+  // the run extents of this thread's pixels (3 rows of the horizontal strip, 2 rows of the output tile): requested first so
+  // that their latency overlaps the staging of the tile
+  unsigned eh[3], ev[2];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int y = y0 - 4 + ty + 16 * k;
+    eh[k] = (ty + 16 * k < BP_ROWS + 8 && x < iw && y >= 0 && y < ih) ? ext[y * iw + x] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int y = y0 + ty + 16 * k;
+    ev[k] = (x < iw && y < ih) ? (unsigned)ext[y * iw + x] >> 6 : 0u;
+  }
   for (int t = tid; t < (BP_ROWS + 8) * 72; t += 1024) {
     const int r = t / 72, c = t % 72;
     const int xx = x0 - 4 + c, yy = y0 - 4 + r;
@@ -266,10 +284,11 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
     src[r * BP_SW + c] = make_uint2((q & 4095u) | ((q << 4) & 0x3ff0000u), q >> 22);
   }
   __syncthreads();
-  for (int r = ty; r < BP_ROWS + 8; r += 16) {
-    const int y = y0 - 4 + r;
-    unsigned e = 0;
-    if (x < iw && y >= 0 && y < ih) e = ext[y * iw + x];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int r = ty + 16 * k;
+    if (r >= BP_ROWS + 8) break;
+    const unsigned e = eh[k];
     const int nl = e & 7, nr = (e >> 3) & 7;
     const int c = r * BP_SW + tx + 4;
     uint2 v[10];
@@ -281,17 +300,19 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
     const int w = nl + nr;
     uint2 o = src[c];
     if (w > 0) {
-      const float rw = 1.0f / (float)w;
+      const float rw = rwt[w];
       o = make_uint2(div_small_f(lo & 0xffffu, rw) | (div_small_f(lo >> 16, rw) << 16), div_small_f(hi, rw));   // fields cannot exceed their range: no clamp needed
     }
     hz[r * 64 + tx] = o;
   }
   __syncthreads();
   if (x >= iw) return;
-  for (int r = ty; r < BP_ROWS; r += 16) {
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int r = ty + 16 * k;
     const int y = y0 + r;
     if (y >= ih) break;
-    const unsigned e = ext[y * iw + x] >> 6;
+    const unsigned e = ev[k];
     const int nl = e & 7, nr = (e >> 3) & 7;
     const int c = (r + 4) * 64 + tx;
     uint2 v[10];
@@ -303,7 +324,7 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
     const int w = nl + nr;
     uint2 o = hz[c];
     if (w > 0) {
-      const float rw = 1.0f / (float)w;
+      const float rw = rwt[w];
       o = make_uint2(div_small_f(lo & 0xffffu, rw) | (div_small_f(lo >> 16, rw) << 16), div_small_f(hi, rw));
     }
     out[y * iw + x] = (o.x & 0xffffu) | ((o.x >> 16) << 12) | (o.y << 22);
@@ -475,41 +496,67 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
 // proposes `min` updates for itself and for its old parent, and the proposals are applied between rounds.  The
 // reference applies the same rule in place for 8 launches, which makes its result depend on the work-item order
 // (SURVEY.md H5); synchronous rounds to convergence are the order-free reading of the same rule.
+// Memory-latency bound: every thread handles 4 pixels (64 columns apart, so each load instruction stays coalesced) and
+// issues all of their label / neighbour loads before using any, then the 4 first pointer jumps together.
+#define RP_PX 4
 __global__ __launch_bounds__(256) void k_region_propose(const int *__restrict__ label, int *prop, int *__restrict__ selfp, const uint8_t *__restrict__ allow, int iw, int ih, const int *flags, int round) {
   if (round > 0 && flags[round - 1] == 0) return;
   __shared__ int hk[512], hv[512];
   const int tid = threadIdx.y * 64 + threadIdx.x;
   for (int t = tid; t < 512; t += 256) { hk[t] = -1; hv[t] = 0x7fffffff; }
   __syncthreads();
-  RD_XY;
-  int og = 0, g = 0, p0 = 0;
-  bool todo = false;
-  if (x < iw && y < ih) {
-    p0 = y * iw + x;
-    const unsigned a = allow[p0];
-    if (a & 16) {
-      og = label[p0];
-      g = og;
-      int s;
-      if (a & 1) { s = label[p0 - iw]; if (s < g) g = s; }
-      if (a & 2) { s = label[p0 - 1]; if (s < g) g = s; }
-      if (a & 4) { s = label[p0 + 1]; if (s < g) g = s; }
-      if (a & 8) { s = label[p0 + iw]; if (s < g) g = s; }
-      for (int j = 0; j < 8; j++) { const int n = label[g]; if (n == g) break; g = n; }   // rc:328: eight pointer jumps (a root maps to itself)
-      todo = g != og;
-    }
+  const int y = blockIdx.y * 4 + threadIdx.y;
+  const int xb = blockIdx.x * (64 * RP_PX) + threadIdx.x;
+  int p0[RP_PX], og[RP_PX], g[RP_PX], nx[RP_PX];
+  unsigned a[RP_PX];
+  int lu[RP_PX], ll[RP_PX], lr[RP_PX], ld[RP_PX];
+  bool valid[RP_PX], todo[RP_PX];
+#pragma unroll
+  for (int k = 0; k < RP_PX; k++) {
+    const int x = xb + k * 64;
+    valid[k] = x < iw && y < ih;
+    p0[k] = valid[k] ? y * iw + x : 0;
+    a[k] = valid[k] ? allow[p0[k]] : 0u;
+    // neighbour addresses clamped into the plane: the loads are unconditional, their use depends on the allow bits
+    og[k] = label[p0[k]];
+    lu[k] = label[(valid[k] && y > 0) ? p0[k] - iw : p0[k]];
+    ll[k] = label[(valid[k] && x > 0) ? p0[k] - 1 : p0[k]];
+    lr[k] = label[(valid[k] && x < iw - 1) ? p0[k] + 1 : p0[k]];
+    ld[k] = label[(valid[k] && y < ih - 1) ? p0[k] + iw : p0[k]];
   }
-  if (x < iw && y < ih) selfp[p0] = todo ? g : 0x7f7f7f7f;   // own update: nobody else writes this word
+#pragma unroll
+  for (int k = 0; k < RP_PX; k++) {
+    int m = og[k];
+    if ((a[k] & 1) && lu[k] < m) m = lu[k];
+    if ((a[k] & 2) && ll[k] < m) m = ll[k];
+    if ((a[k] & 4) && lr[k] < m) m = lr[k];
+    if ((a[k] & 8) && ld[k] < m) m = ld[k];
+    g[k] = (a[k] & 16) ? m : og[k];
+  }
+#pragma unroll
+  for (int k = 0; k < RP_PX; k++) nx[k] = label[g[k]];     // rc:328: first of the eight pointer jumps (a root maps to itself)
+#pragma unroll
+  for (int k = 0; k < RP_PX; k++) {
+    if (a[k] & 16) {
+      int n = nx[k];
+      for (int j = 1; j < 8 && n != g[k]; j++) { g[k] = n; n = label[n]; }
+      if (n != g[k]) g[k] = n;          // (the eighth jump)
+    }
+    todo[k] = (a[k] & 16) && g[k] != og[k];
+    if (valid[k]) selfp[p0[k]] = todo[k] ? g[k] : 0x7f7f7f7f;   // own update: nobody else writes this word
+  }
   // Hooking the old parent: after flattening, all pixels of a tree share one parent, so the block first reduces its
   // (parent -> smallest proposal) pairs in a small LDS hash and then issues one guarded atomic per distinct parent.
-  if (todo) {
-    unsigned h = ((unsigned)og * 2654435761u) >> 23;
+#pragma unroll
+  for (int k = 0; k < RP_PX; k++) {
+    if (!todo[k]) continue;
+    unsigned h = ((unsigned)og[k] * 2654435761u) >> 23;
     int probes = 0;
     for (;;) {
-      const int kprev = atomicCAS(&hk[h], -1, og);
-      if (kprev == -1 || kprev == og) { atomicMin(&hv[h], g); break; }
+      const int kprev = atomicCAS(&hk[h], -1, og[k]);
+      if (kprev == -1 || kprev == og[k]) { atomicMin(&hv[h], g[k]); break; }
       h = (h + 1) & 511;
-      if (++probes == 16) { if (g < ld_agent(&prop[og])) atomicMin(&prop[og], g); break; }
+      if (++probes == 16) { if (g[k] < ld_agent(&prop[og[k]])) atomicMin(&prop[og[k]], g[k]); break; }
     }
   }
   __syncthreads();
@@ -540,12 +587,23 @@ __global__ void k_region_flatten(int *label, int n, int *flags, int round) {
 __global__ void k_region_apply(int *label, int *prop, const int *__restrict__ selfp, int n, int *flags, int round) {
   if (round > 0 && flags[round - 1] == 0) return;
   bool changed = false;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    int m = prop[i];
-    if (m != 0x7f7f7f7f) prop[i] = 0x7f7f7f7f;
-    const int sp = selfp[i];
-    if (sp < m) m = sp;
-    if (m < label[i]) { label[i] = m; changed = true; }
+  const int stride = gridDim.x * blockDim.x;
+  for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * 4) {
+    int m[4], sp[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = i0 + k * stride;
+      const bool in = i < n;
+      m[k] = in ? prop[i] : 0x7f7f7f7f; sp[k] = in ? selfp[i] : 0x7f7f7f7f; l[k] = in ? label[i] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = i0 + k * stride;
+      if (i >= n) continue;
+      if (m[k] != 0x7f7f7f7f) prop[i] = 0x7f7f7f7f;
+      const int v = sp[k] < m[k] ? sp[k] : m[k];
+      if (v < l[k]) { label[i] = v; changed = true; }
+    }
   }
   if (__any(changed) && (threadIdx.x & 63) == 0) flags[round] = 1;
 }
@@ -970,7 +1028,7 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
   // the initial links are flattened first; the synchronous rounds then start from trees of depth 1
   for (int r = 0; r < FLAT; r++) hipLaunchKernelGGL(k_region_flatten, dim3(ew_grid(n)), dim3(256), 0, s, label, n, fflags, r);
   for (int r = 0; r < ROUNDS; r++) {
-    hipLaunchKernelGGL(k_region_propose, grid2(iw, ih), block2, 0, s, (const int *)label, prop, selfp, (const uint8_t *)allow, iw, ih, (const int *)flags, r);
+    hipLaunchKernelGGL(k_region_propose, dim3(cdiv(iw, 64 * RP_PX), cdiv(ih, 4)), block2, 0, s, (const int *)label, prop, selfp, (const uint8_t *)allow, iw, ih, (const int *)flags, r);
     hipLaunchKernelGGL(k_region_apply, dim3(ew_grid(n)), dim3(256), 0, s, label, prop, (const int *)selfp, n, flags, r);
   }
 }
