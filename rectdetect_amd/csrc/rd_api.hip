@@ -267,7 +267,7 @@ struct rd_detector {
   long next_enqueue, next_poll;
   int last_polled_slot;
   void *last_segs; int last_nsegs;
-  int use_graph, poly_mode, force_redo; long n_redo;
+  int use_graph, poly_mode, force_redo, diag_no_post; long n_redo;
   long dev_us, dev_frames;   // sum over polled frames of (last kernel end - first kernel start) on the frame's stream, HIP events
   double tan_aov; int have_tan;    // what the workers use ahead of the poll that asks for the result
   pthread_mutex_t tan_mu; pthread_cond_t tan_cv;
@@ -446,7 +446,8 @@ static void *slot_postprocess(rd_detector *d, Slot *s, double tanAOV, void **seg
     RD_HIP(hipMemcpy(big_probes, s->probes, (size_t)(n + 1) * 15 * 6 * sizeof(int), hipMemcpyDeviceToHost));
     segs = big_segs; probes = big_probes; maxrec = n + 1;
   }
-  void *r = rd_post_run(segs, maxrec, probes, d->iw, d->ih, tanAOV);
+  // RD_DIAG_NO_POST (diagnostics only): an empty rectangle list instead of the host post-process, to see whether a run is host-bound
+  void *r = d->diag_no_post ? calloc(1, 176) : rd_post_run(segs, maxrec, probes, d->iw, d->ih, tanAOV);
   const int ns = n < maxrec ? n : maxrec - 1;
   void *copy = malloc((size_t)(ns + 1) * 56);
   memcpy(copy, segs, (size_t)(ns + 1) * 56);
@@ -497,6 +498,7 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->use_graph = getenv("RD_NO_GRAPH") ? 0 : 1;
   d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : 1;
   d->force_redo = getenv("RD_POLY_FORCE_REDO") ? 1 : 0;
+  d->diag_no_post = getenv("RD_DIAG_NO_POST") ? 1 : 0;
   pthread_mutex_init(&d->tan_mu, NULL); pthread_cond_init(&d->tan_cv, NULL);
   d->slots = (Slot *)calloc((size_t)nslots, sizeof(Slot));
   for (int i = 0; i < nslots; i++) {

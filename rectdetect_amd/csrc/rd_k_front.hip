@@ -96,6 +96,18 @@ __global__ __launch_bounds__(256) void k_bgr2plab_t(uint32_t *__restrict__ out, 
   }
 }
 
+// four independent elements per thread and iteration: these kernels are pure memory streams, and one 4-byte load in
+// flight per lane leaves most of the HBM pipeline idle
+template <typename LD, typename ST> __device__ __forceinline__ void ew4(int n, LD ld, ST st) {
+  const int stride = gridDim.x * blockDim.x;
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const auto v0 = ld(i), v1 = ld(i + stride), v2 = ld(i + 2 * stride), v3 = ld(i + 3 * stride);
+    st(i, v0); st(i + stride, v1); st(i + 2 * stride, v2); st(i + 3 * stride, v3);
+  }
+  for (; i < n; i += stride) st(i, ld(i));
+}
+
 // iu:333-342 / iu:325-331
 __global__ void k_unpack_plab(float *__restrict__ L, float *__restrict__ a, float *__restrict__ b, const uint32_t *__restrict__ in, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -106,7 +118,7 @@ __global__ void k_unpack_plab(float *__restrict__ L, float *__restrict__ a, floa
 }
 
 __global__ void k_pack_plab(uint32_t *__restrict__ out, const float *__restrict__ L, const float *__restrict__ a, const float *__restrict__ b, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = pack_lab(L[i], a[i], b[i]);
+  ew4(n, [=](int i) { return make_float3(L[i], a[i], b[i]); }, [=](int i, float3 v) { out[i] = pack_lab(v.x, v.y, v.z); });
 }
 
 // ------------------------------------------------------------------------------------------------ transposes
@@ -532,25 +544,25 @@ __global__ __launch_bounds__(256) void k_thinthres(float *__restrict__ out, cons
 }
 
 // ------------------------------------------------------------------------------------------------ element-wise (iu:197-254)
-__global__ void k_threshold_f(float *out, const float *in, float lo, float thr, float hi, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i] > thr ? hi : lo;
+__global__ void k_threshold_f(float *__restrict__ out, const float *__restrict__ in, float lo, float thr, float hi, int n) {
+  ew4(n, [=](int i) { return in[i]; }, [=](int i, float v) { out[i] = v > thr ? hi : lo; });
 }
-__global__ void k_threshold_i(int *out, const int *in, int lo, int thr, int hi, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i] > thr ? hi : lo;
+__global__ void k_threshold_i(int *__restrict__ out, const int *__restrict__ in, int lo, int thr, int hi, int n) {
+  ew4(n, [=](int i) { return in[i]; }, [=](int i, int v) { out[i] = v > thr ? hi : lo; });
 }
-__global__ void k_threshold_i2(int *out, int *out2, const int *in, int lo, int thr, int hi, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) { const int v = in[i] > thr ? hi : lo; out[i] = v; out2[i] = v; }
+__global__ void k_threshold_i2(int *__restrict__ out, int *__restrict__ out2, const int *__restrict__ in, int lo, int thr, int hi, int n) {
+  ew4(n, [=](int i) { return in[i]; }, [=](int i, int v) { const int r = v > thr ? hi : lo; out[i] = r; out2[i] = r; });
 }
-__global__ void k_cast_i_f(int *out, const float *in, float scale, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = (int)(in[i] * scale);
+__global__ void k_cast_i_f(int *__restrict__ out, const float *__restrict__ in, float scale, int n) {
+  ew4(n, [=](int i) { return in[i]; }, [=](int i, float v) { out[i] = (int)(v * scale); });
 }
-__global__ void k_cast_c_i(int8_t *out, const int *in, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = (int8_t)in[i];
+__global__ void k_cast_c_i(int8_t *__restrict__ out, const int *__restrict__ in, int n) {
+  ew4(n, [=](int i) { return in[i]; }, [=](int i, int v) { out[i] = (int8_t)v; });
 }
 __global__ void k_clear_i(int *out, int n) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = 0;
 }
-__global__ void k_copy_i(int *out, const int *in, int n) {
+__global__ void k_copy_i(int *out, const int *in, int n) {     // (in-place aliasing allowed: no restrict, plain loop)
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) out[i] = in[i];
 }
 __global__ void k_rand_i(int *out, uint64_t seed, int n) {

@@ -37,16 +37,20 @@ __device__ __forceinline__ void lt_union(int *lab, int a, int b) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_label_tile(int *__restrict__ label, const int *__restrict__ pix, int bgc, int iw, int ih) {
+#define LT_TY 16      // thread rows per block: 1024 threads keep the CU's wave slots full (256 left half of them idle)
+__global__ __launch_bounds__(1024) void k_label_tile(int *__restrict__ label, const int *__restrict__ pix, int bgc, int iw, int ih) {
   __shared__ int lab[LT_W * LT_H];
   __shared__ int pv[LT_W * LT_H];
   const int tx = threadIdx.x, x = blockIdx.x * LT_W + tx, y0 = blockIdx.y * LT_H;
   const bool xin = x < iw;
+  const int v00 = pix[(size_t)y0 * iw + blockIdx.x * LT_W];   // the tile's first pixel is always inside the frame
+  bool uniform = true;
 #pragma unroll
-  for (int r = threadIdx.y; r < LT_H; r += 4) {
+  for (int r = threadIdx.y; r < LT_H; r += LT_TY) {
     const int y = y0 + r;
     const bool valid = xin && y < ih;
     const int v = valid ? pix[y * iw + x] : 0;
+    uniform = uniform && (!valid || v == v00);
     const int vl = __shfl_up(v, 1);
     const bool lvalid = __shfl_up((int)valid, 1) != 0;
     const bool same = valid && tx > 0 && lvalid && vl == v;
@@ -56,11 +60,22 @@ __global__ __launch_bounds__(256) void k_label_tile(int *__restrict__ label, con
     pv[r * LT_W + tx] = v;
     lab[r * LT_W + tx] = (!valid || v == bgc) ? -1 : r * LT_W + start;
   }
-  __syncthreads();
+  // fast path: the whole tile holds one value (background, the inside of a large component): one component, no unions
+  {
+    if (__syncthreads_and(uniform)) {
+      const int l = v00 == bgc ? -1 : y0 * iw + blockIdx.x * LT_W;
+#pragma unroll
+      for (int r = threadIdx.y; r < LT_H; r += LT_TY) {
+        const int y = y0 + r;
+        if (xin && y < ih) label[y * iw + x] = l;
+      }
+      return;
+    }
+  }
   // unions with the row above, inside the tile; a pixel only issues one when no pixel of its run is guaranteed to issue
   // an equivalent one (same case analysis as k_label_border below)
 #pragma unroll
-  for (int r = threadIdx.y; r < LT_H; r += 4) {
+  for (int r = threadIdx.y; r < LT_H; r += LT_TY) {
     if (r == 0) continue;
     const int q = r * LT_W + tx;
     if (lab[q] < 0) continue;
@@ -79,7 +94,7 @@ __global__ __launch_bounds__(256) void k_label_tile(int *__restrict__ label, con
   }
   __syncthreads();
 #pragma unroll
-  for (int r = threadIdx.y; r < LT_H; r += 4) {
+  for (int r = threadIdx.y; r < LT_H; r += LT_TY) {
     const int y = y0 + r;
     if (!xin || y >= ih) continue;
     const int q = r * LT_W + tx;
@@ -206,7 +221,7 @@ __global__ __launch_bounds__(256) void k_filter_strength(int *label, const int *
 namespace rdk {
 
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih) {
-  hipLaunchKernelGGL(k_label_tile, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, 4), 0, s, label, pix, bgc, iw, ih);
+  hipLaunchKernelGGL(k_label_tile, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, pix, bgc, iw, ih);
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   if (nh > 0) hipLaunchKernelGGL(k_label_border, dim3(cdiv(nh, 256)), dim3(256), 0, s, label, pix, bgc, iw, ih, 1);
   if (nv > 0) hipLaunchKernelGGL(k_label_border, dim3(cdiv(nv, 256)), dim3(256), 0, s, label, pix, bgc, iw, ih, 0);
