@@ -134,12 +134,14 @@ def main():
     if dist is not None:
         dist.barrier()
     dev0 = det.device_time() if det is not None else (0, 0)
+    enq0 = ra.lib().rd_detector_counter(det.h, 3) if det is not None else 0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     elapsed = time.perf_counter() - t0
     dev1 = det.device_time() if det is not None else (0, 0)
+    enq1 = ra.lib().rd_detector_counter(det.h, 3) if det is not None else 0
     if dist is not None:
         import torch
         t = torch.tensor([elapsed], dtype=torch.float64)
@@ -165,7 +167,8 @@ def main():
                          "algorithmic_bytes_per_frame": B_ALG_PER_PIXEL * N, "traffic": None,
                          # HIP events on each frame's own stream over the timed region (rank 0): first kernel start -> last copy end.
                          # With several frames in flight these intervals overlap, which is why `achieved` is taken from the aggregate rate.
-                         "frame_device_us_avg": round((dev1[0] - dev0[0]) / max(1, dev1[1] - dev0[1]), 1), "frames_in_flight": args.slots},
+                         "frame_device_us_avg": round((dev1[0] - dev0[0]) / max(1, dev1[1] - dev0[1]), 1), "frames_in_flight": args.slots,
+                         "host_enqueue_us_avg": round((enq1 - enq0) / max(1, dev1[1] - dev0[1]), 1)},
         }
         if not args.dry_run and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames)

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <pthread.h>
+#include <time.h>
 
 extern "C" {
 #include "vec234.h"
@@ -268,6 +269,7 @@ struct rd_detector {
   int last_polled_slot;
   void *last_segs; int last_nsegs;
   int use_graph, poly_mode, force_redo, diag_no_post; long n_redo;
+  long host_enqueue_ns;      // wall time the caller spent inside rd_detector_enqueue
   long dev_us, dev_frames;   // sum over polled frames of (last kernel end - first kernel start) on the frame's stream, HIP events
   double tan_aov; int have_tan;    // what the workers use ahead of the poll that asks for the result
   pthread_mutex_t tan_mu; pthread_cond_t tan_cv;
@@ -364,9 +366,15 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   return;
   }
   if (seg == 1) {
-  // strength sums on top of last frame's strong mask (H1), filter at 500 (oclrect.c:274-284)
+  // strength sums on top of last frame's strong mask (H1, oclrect.c:274-275) and - at once - this frame's strong mask
+  // (what oclrect.c:307-313 derives from the sums later): nothing else of a frame is needed by the next one, so this
+  // short segment is the whole frame-to-frame dependency chain
   RD_HIP(hipMemcpyAsync(s->strsum, d->prev_strong, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));
   rdk::calc_strength(st, s->strsum, s->nms, s->label1, iw, ih);
+  rdk::strong_mask(st, s->strong, d->prev_strong, s->label1, s->strsum, 2500, iw, ih);
+  return;
+  }
+  // filter at 500 (oclrect.c:277-284)
   rdk::filter_strength(st, s->label1, s->strsum, 500, iw, ih);
   rdk::threshold_i(st, s->edge500, s->label1, 0, 0, 1, N);
   rdk::cast_c_i(st, s->e8, s->edge500, N);
@@ -378,11 +386,8 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   rdk::quantize(st, (uint32_t *)s->i0, s->smooth, 24, 24, 24, N);
   rdk::despeckle(st, s->quant, (const uint32_t *)s->i0, s->nms, iw, ih);
 
-  // strong edges, junction counts, merge mask (oclrect.c:307-321)
+  // labels of the strong edges, junction counts, merge mask (oclrect.c:307-321)
   rdk::filter_strength(st, s->label1, s->strsum, 2500, iw, ih);
-  rdk::threshold_i2(st, s->strong, d->prev_strong, s->label1, 0, 0, 1, N);   // H1: the next frame's strength sums start from this mask
-  return;
-  }
   rdk::junction(st, s->junction, s->label1, 0, iw, ih);
   rdk::merge_mask(st, s->mergemask, s->scratch2, s->junction, iw, ih);
 
@@ -540,6 +545,7 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
   if (d->next_enqueue - d->next_poll >= d->nslots) exitf(-1, "rd_detector_enqueue: %d frames already in flight (poll first)\n", d->nslots);
   if ((size_t)ws * d->ih > (size_t)d->N * 4) exitf(-1, "rd_detector_enqueue: row stride %d too large for a %dx%d frame\n", ws, d->iw, d->ih);
   RD_HIP(hipSetDevice(d->device));
+  struct timespec ts0; clock_gettime(CLOCK_MONOTONIC, &ts0);
   Slot *s = &d->slots[d->next_enqueue % d->nslots];
   s->seq = d->next_enqueue; s->ws = ws;
   const size_t bytes = (size_t)ws * d->ih;
@@ -552,6 +558,7 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
     pthread_cond_broadcast(&s->cv);
     pthread_mutex_unlock(&s->mu);
   }
+  { struct timespec ts1; clock_gettime(CLOCK_MONOTONIC, &ts1); d->host_enqueue_ns += (ts1.tv_sec - ts0.tv_sec) * 1000000000L + (ts1.tv_nsec - ts0.tv_nsec); }
   return d->next_enqueue++;
 }
 
@@ -597,6 +604,7 @@ void rd_detector_drain(rd_detector *d) {
 
 long rd_detector_counter(rd_detector *d, int which) {
   if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_counter: bad handle\n");
+  if (which == 3) return d->host_enqueue_ns / 1000;
   if (which == 1) return d->dev_us;
   if (which == 2) return d->dev_frames;
   return which == 0 ? __atomic_load_n(&d->n_redo, __ATOMIC_RELAXED) : -1;

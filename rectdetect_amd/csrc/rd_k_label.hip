@@ -216,6 +216,20 @@ __global__ __launch_bounds__(256) void k_filter_strength(int *label, const int *
   if (l <= 0 || str[l] < thre) label[p] = -1;
 }
 
+// The strong-edge mask that two k_filter_strength passes (thresholds t1 <= t2) followed by `label > 0` would produce,
+// computed directly from the unfiltered labels: interior pixels keep a label > 0 exactly when their sum reaches t2, the
+// frame ring is never filtered.  This mask is all the next frame needs from this one, so producing it
+// first takes everything else off the frame-to-frame dependency chain.
+__global__ __launch_bounds__(256) void k_strong_mask(int *__restrict__ out, int *__restrict__ out2, const int *__restrict__ label, const int *__restrict__ str, int thre, int iw, int ih) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= iw || y >= ih) return;
+  const int p = y * iw + x;
+  const int l = label[p];
+  int v = l > 0 ? 1 : 0;
+  if (v && x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && str[l] < thre) v = 0;
+  out[p] = v; out2[p] = v;
+}
+
 }  // namespace
 
 namespace rdk {
@@ -232,6 +246,10 @@ void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih) 
 
 void calc_strength(hipStream_t s, int *out, const float *edge, const int *label, int iw, int ih) {
   hipLaunchKernelGGL(k_calc_strength, grid2(iw, ih), block2, 0, s, out, edge, label, iw, ih);
+}
+
+void strong_mask(hipStream_t s, int *out, int *out2, const int *label, const int *str, int thre, int iw, int ih) {
+  hipLaunchKernelGGL(k_strong_mask, grid2(iw, ih), block2, 0, s, out, out2, label, str, thre, iw, ih);
 }
 
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih) {

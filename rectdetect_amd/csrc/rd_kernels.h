@@ -46,6 +46,8 @@ void rand_i(hipStream_t s, int *out, uint64_t seed, int n);
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih);
 void calc_strength(hipStream_t s, int *out, const float *edge, const int *label, int iw, int ih);
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih);
+// out = out2 = (label > 0 after filter_strength at thresholds <= thre ... thre), from the UNFILTERED labels
+void strong_mask(hipStream_t s, int *out, int *out2, const int *label, const int *str, int thre, int iw, int ih);
 
 // ---- rd_k_rect.hip: rect-path stages
 void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih);
