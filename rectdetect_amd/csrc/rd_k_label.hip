@@ -37,8 +37,8 @@ __device__ __forceinline__ void lt_union(int *lab, int a, int b) {
   }
 }
 
-#define LT_TY 16      // thread rows per block: 1024 threads keep the CU's wave slots full (256 left half of them idle)
-__global__ __launch_bounds__(1024) void k_label_tile(int *__restrict__ label, const int *__restrict__ pix, int bgc, int iw, int ih) {
+#define LT_TY 4       // thread rows per block (16 is ~20% faster run alone, but costs 50% more wave-cycles: worse with frames in flight)
+__global__ __launch_bounds__(256) void k_label_tile(int *__restrict__ label, const int *__restrict__ pix, int bgc, int iw, int ih) {
   __shared__ int lab[LT_W * LT_H];
   __shared__ int pv[LT_W * LT_H];
   const int tx = threadIdx.x, x = blockIdx.x * LT_W + tx, y0 = blockIdx.y * LT_H;

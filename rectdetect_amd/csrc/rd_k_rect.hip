@@ -459,11 +459,11 @@ __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const 
 // so every pixel leaves pointing either at the root of its initial tree (if that root lies in the tile) or at the first
 // pixel outside the tile on its way up/left; the few remaining tile-to-tile hops are left to k_region_flatten.
 #define RI_ROWS 32
-__global__ __launch_bounds__(1024) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, int *__restrict__ prop, const int *__restrict__ pix, const int *__restrict__ mask,
+__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, int *__restrict__ prop, int *__restrict__ selfp, const int *__restrict__ pix, const int *__restrict__ mask,
                                                      const int *__restrict__ edge, int iw, int ih) {
   __shared__ int par[64 * RI_ROWS];     // >= 0: tile-local index of the parent; < 0: -(global index) - 1 of a parent outside the tile
   const int tx = threadIdx.x, x = blockIdx.x * 64 + tx, y0 = blockIdx.y * RI_ROWS;
-  for (int r = threadIdx.y; r < RI_ROWS; r += 16) {
+  for (int r = threadIdx.y; r < RI_ROWS; r += 4) {
     const int y = y0 + r;
     int l = r * 64 + tx;
     if (x < iw && y < ih) {
@@ -483,13 +483,14 @@ __global__ __launch_bounds__(1024) void k_region_init(int *__restrict__ label, u
       }
       allow[p] = (uint8_t)a;
       prop[p] = 0x7f7f7f7f;      // no proposal
+      selfp[p] = 0x7f7f7f7f;
     }
     par[r * 64 + tx] = l;
   }
   __syncthreads();
   // a chain inside the tile is at most RI_ROWS + 64 links long: 7 doublings (any interleaving only ever stores ancestors)
   for (int it = 0; it < 7; it++) {
-    for (int r = threadIdx.y; r < RI_ROWS; r += 16) {
+    for (int r = threadIdx.y; r < RI_ROWS; r += 4) {
       const int i = r * 64 + tx;
       const int a = par[i];
       if (a >= 0 && a != i) par[i] = par[a];
@@ -497,7 +498,7 @@ __global__ __launch_bounds__(1024) void k_region_init(int *__restrict__ label, u
     __syncthreads();
   }
   if (x >= iw) return;
-  for (int r = threadIdx.y; r < RI_ROWS; r += 16) {
+  for (int r = threadIdx.y; r < RI_ROWS; r += 4) {
     const int y = y0 + r;
     if (y >= ih) break;
     const int a = par[r * 64 + tx];
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(256) void k_region_propose(const int *__restrict__ 
       if (n != g[k]) g[k] = n;          // (the eighth jump)
     }
     todo[k] = (a[k] & 16) && g[k] != og[k];
-    if (valid[k]) selfp[p0[k]] = todo[k] ? g[k] : 0x7f7f7f7f;   // own update: nobody else writes this word
+    if (todo[k]) selfp[p0[k]] = g[k];   // own update: nobody else writes this word; k_region_apply resets it after use
   }
   // Hooking the old parent: after flattening, all pixels of a tree share one parent, so the block first reduces its
   // (parent -> smallest proposal) pairs in a small LDS hash and then issues one guarded atomic per distinct parent.
@@ -597,25 +598,26 @@ __global__ void k_region_flatten(int *label, int n, int *flags, int round) {
   if (__any(changed) && (threadIdx.x & 63) == 0) flags[round] = 1;
 }
 
-__global__ void k_region_apply(int *label, int *prop, const int *__restrict__ selfp, int n, int *flags, int round) {
+__global__ void k_region_apply(int *label, int *prop, int *selfp, int n, int *flags, int round) {
   if (round > 0 && flags[round - 1] == 0) return;
   bool changed = false;
   const int stride = gridDim.x * blockDim.x;
   for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * 4) {
-    int m[4], sp[4], l[4];
+    int m[4], sp[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int i = i0 + k * stride;
       const bool in = i < n;
-      m[k] = in ? prop[i] : 0x7f7f7f7f; sp[k] = in ? selfp[i] : 0x7f7f7f7f; l[k] = in ? label[i] : 0;
+      m[k] = in ? prop[i] : 0x7f7f7f7f; sp[k] = in ? selfp[i] : 0x7f7f7f7f;
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int i = i0 + k * stride;
-      if (i >= n) continue;
-      if (m[k] != 0x7f7f7f7f) prop[i] = 0x7f7f7f7f;
       const int v = sp[k] < m[k] ? sp[k] : m[k];
-      if (v < l[k]) { label[i] = v; changed = true; }
+      if (v == 0x7f7f7f7f) continue;               // nothing proposed for this pixel: its label is not even read
+      if (m[k] != 0x7f7f7f7f) prop[i] = 0x7f7f7f7f;
+      if (sp[k] != 0x7f7f7f7f) selfp[i] = 0x7f7f7f7f;
+      if (v < label[i]) { label[i] = v; changed = true; }
     }
   }
   if (__any(changed) && (threadIdx.x & 63) == 0) flags[round] = 1;
@@ -686,14 +688,14 @@ __device__ __forceinline__ int despeckle2_pick(const int *__restrict__ cur, cons
 // are appended to `list` (any order), *count = their number.  One block per 64x32 tile collects its pixels in LDS and
 // reserves its share of the list with a single atomic (same-address atomics cost ~8 ns each: one per wave was 250 us).
 #define D2_ROWS 32
-__global__ __launch_bounds__(1024) void k_despeckle2_first(int *__restrict__ nxt, int *__restrict__ other, int *__restrict__ list, int *count, const int *__restrict__ old, const int *__restrict__ size,
+__global__ __launch_bounds__(256) void k_despeckle2_first(int *__restrict__ nxt, int *__restrict__ other, int *__restrict__ list, int *count, const int *__restrict__ old, const int *__restrict__ size,
                                                            int thre, int iw, int ih) {
   __shared__ int loc[64 * D2_ROWS];
   __shared__ int nloc, base;
   if (threadIdx.x == 0 && threadIdx.y == 0) nloc = 0;
   __syncthreads();
   const int x = blockIdx.x * 64 + threadIdx.x;
-  for (int r = threadIdx.y; r < D2_ROWS; r += 16) {
+  for (int r = threadIdx.y; r < D2_ROWS; r += 4) {
     const int y = blockIdx.y * D2_ROWS + r;
     const bool inside = x < iw && y < ih;
     const int p0 = y * iw + x;
@@ -717,7 +719,7 @@ __global__ __launch_bounds__(1024) void k_despeckle2_first(int *__restrict__ nxt
   const int tid = threadIdx.y * 64 + threadIdx.x;
   if (tid == 0 && nloc > 0) base = atomicAdd(count, nloc);
   __syncthreads();
-  for (int i = tid; i < nloc; i += 1024) list[base + i] = loc[i];
+  for (int i = tid; i < nloc; i += 256) list[base + i] = loc[i];
 }
 
 __global__ __launch_bounds__(256) void k_despeckle2_sparse(int *__restrict__ nxt, const int *__restrict__ cur, const int *__restrict__ list, const int *__restrict__ count,
@@ -1037,12 +1039,12 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
   (void)hipMemsetAsync(flags, 0, sizeof(int) * 64, s);
   uint8_t *allow = (uint8_t *)(flags + 64);
   int *selfp = scratch + 2 * (size_t)n;
-  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 16), 0, s, label, allow, prop, pix, mask, edge, iw, ih);
+  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, label, allow, prop, selfp, pix, mask, edge, iw, ih);
   // the initial links are flattened first; the synchronous rounds then start from trees of depth 1
   for (int r = 0; r < FLAT; r++) hipLaunchKernelGGL(k_region_flatten, dim3(ew_grid(n)), dim3(256), 0, s, label, n, fflags, r);
   for (int r = 0; r < ROUNDS; r++) {
     hipLaunchKernelGGL(k_region_propose, dim3(cdiv(iw, 64 * RP_PX), cdiv(ih, 4)), block2, 0, s, (const int *)label, prop, selfp, (const uint8_t *)allow, iw, ih, (const int *)flags, r);
-    hipLaunchKernelGGL(k_region_apply, dim3(ew_grid(n)), dim3(256), 0, s, label, prop, (const int *)selfp, n, flags, r);
+    hipLaunchKernelGGL(k_region_apply, dim3(ew_grid(n)), dim3(256), 0, s, label, prop, selfp, n, flags, r);
   }
 }
 
@@ -1057,7 +1059,7 @@ void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int 
   int *tmp = scratch, *count = scratch + (size_t)n, *list = count + 1;
   (void)hipMemsetAsync(count, 0, sizeof(int), s);
   // first round: tmp <- result, out <- input (both planes then agree on every pixel that is not in the list)
-  hipLaunchKernelGGL(k_despeckle2_first, dim3(cdiv(iw, 64), cdiv(ih, D2_ROWS)), dim3(64, 16), 0, s, tmp, out, list, count, in, size, thre, iw, ih);
+  hipLaunchKernelGGL(k_despeckle2_first, dim3(cdiv(iw, 64), cdiv(ih, D2_ROWS)), dim3(64, 4), 0, s, tmp, out, list, count, in, size, thre, iw, ih);
   const int *cur = tmp;
   for (int r = 1; r < ROUNDS; r++) {
     int *nxt = (r & 1) ? out : tmp;
