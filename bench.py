@@ -50,13 +50,23 @@ def cpu_baseline(frames):
             "sample": "%d consecutive 1920x1080 frames of the bench stream, single thread, %.1f s" % (len(sample), dt)}
 
 
+def traffic_per_frame():
+    """HBM-side bytes per frame from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE cannot be
+    collected in the same pass, nor from inside this process); null when that file is absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            return int(json.load(f)["hbm_bytes_per_frame"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-step", type=int, default=64)
-    ap.add_argument("--slots", type=int, default=8, help="frames in flight per GPU")
+    ap.add_argument("--slots", type=int, default=16, help="frames in flight per GPU")
     ap.add_argument("--host-frames", action="store_true", help="hand over host buffers (PCIe upload inside the timed region); not the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercises sharding/aggregation only (CPU tests)")
@@ -164,7 +174,7 @@ def main():
                        "frames_per_step": F, "frames_in_flight": args.slots, "input": "BGR u8 host buffers (PCIe upload timed)" if args.host_frames else "BGR u8 frames resident in HBM", "parallelism": "independent streams, one per GPU, no collective"},
             "roofline": {"bound": "hbm", "kernel": "whole per-frame device pipeline (all stages, one stream per frame slot)",
                          "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
-                         "algorithmic_bytes_per_frame": B_ALG_PER_PIXEL * N, "traffic": None,
+                         "algorithmic_bytes_per_frame": B_ALG_PER_PIXEL * N, "traffic": traffic_per_frame(), "traffic_unit": "bytes/frame",
                          # HIP events on each frame's own stream over the timed region (rank 0): first kernel start -> last copy end.
                          # With several frames in flight these intervals overlap, which is why `achieved` is taken from the aggregate rate.
                          "frame_device_us_avg": round((dev1[0] - dev0[0]) / max(1, dev1[1] - dev0[1]), 1), "frames_in_flight": args.slots,

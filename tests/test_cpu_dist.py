@@ -20,7 +20,7 @@ def free_port():
 def test_two_rank_gloo_dry_run():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry-run", "--backend", "gloo"]
+           os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--frames-per-step", "32", "--dry-run", "--backend", "gloo"]
     p = subprocess.run(cmd, cwd=helpers.ROOT, env=env, capture_output=True, text=True, timeout=240)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
