@@ -234,6 +234,8 @@ cl_event oclpolyline_execute(oclpolyline_t *thiz, cl_mem lsList, int lsListSize,
 
 struct Slot {
   hipStream_t st;
+  hipStream_t st2;                        // second stream of the slot: polyline stage, parallel to the region stages
+  hipEvent_t ev_fork, ev_join;
   hipEvent_t ev_begin, ev_done, ev_strong;   // ev_begin/ev_done carry timestamps: device time of the frame (rd_detector_counter)
   uint8_t *bgr;
   uint32_t *plab0, *plab1, *smooth, *quant;
@@ -268,7 +270,7 @@ struct rd_detector {
   long next_enqueue, next_poll;
   int last_polled_slot;
   void *last_segs; int last_nsegs;
-  int use_graph, poly_mode, force_redo, diag_no_post; long n_redo;
+  int use_graph, poly_mode, force_redo, diag_no_post, diag_skip, fork_poly; long n_redo;
   long host_enqueue_ns;      // wall time the caller spent inside rd_detector_enqueue
   long dev_us, dev_frames;   // sum over polled frames of (last kernel end - first kernel start) on the frame's stream, HIP events
   double tan_aov; int have_tan;    // what the workers use ahead of the poll that asks for the result
@@ -278,6 +280,9 @@ struct rd_detector {
 static void slot_alloc(rd_detector *d, Slot *s) {
   const size_t N = (size_t)d->N;
   RD_HIP(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+  RD_HIP(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
+  RD_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
+  RD_HIP(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
   RD_HIP(hipEventCreate(&s->ev_begin));
   RD_HIP(hipEventCreate(&s->ev_done));
   RD_HIP(hipEventCreateWithFlags(&s->ev_strong, hipEventDisableTiming));
@@ -315,6 +320,8 @@ static void slot_free(Slot *s) {
   rdk::poly_scratch_destroy(s->ps);
   RD_HIP(hipHostFree(s->h_bgr)); RD_HIP(hipHostFree(s->h_segs)); RD_HIP(hipHostFree(s->h_probes)); RD_HIP(hipHostFree(s->h_ctr));
   RD_HIP(hipEventDestroy(s->ev_begin)); RD_HIP(hipEventDestroy(s->ev_done)); RD_HIP(hipEventDestroy(s->ev_strong));
+  RD_HIP(hipEventDestroy(s->ev_fork)); RD_HIP(hipEventDestroy(s->ev_join));
+  RD_HIP(hipStreamDestroy(s->st2));
   RD_HIP(hipStreamDestroy(s->st));
 }
 
@@ -324,12 +331,14 @@ static void slot_free(Slot *s) {
 // last part of a frame: polylines of the strong edges, votes, probes, transfers.  mode 1 uses the single-launch polyline
 // stage, which reports frames that do not fit its on-chip tables in counter 25; slot_postprocess() then repeats this
 // part with mode 0.
-static void frame_tail(rd_detector *d, Slot *s, int mode) {
+static void frame_polyline(rd_detector *d, Slot *s, hipStream_t st, int mode) {
+  // frame ring of the bridging step is "non-zero" on this path (oclrect.c:361, H3)
+  rdk::polyline(st, s->ps, s->lslist, d->N * 16, NULL, s->strong, NULL, 1, 4.0f, 20, d->iw, d->ih, mode);   // the dense id plane is only produced on request (debug plane)
+}
+
+static void frame_votes(rd_detector *d, Slot *s) {
   const int iw = d->iw, ih = d->ih, N = d->N;
   hipStream_t st = s->st;
-  // frame ring of the bridging step is "non-zero" on this path (oclrect.c:361, H3)
-  rdk::polyline(st, s->ps, s->lslist, N * 16, NULL, s->strong, NULL, 1, 4.0f, 20, iw, ih, mode);   // the dense id plane is only produced on request (debug plane)
-
   // segment / boundary votes (oclrect.c:365-367) and the probes the host needs (oclrect.c:1066-1098)
   const int nentry = N * 4 / 5;
   rdk::reduce_ls(st, s->table, s->claim, s->tlist, s->boundary, s->ps, iw, ih, nentry);
@@ -339,6 +348,11 @@ static void frame_tail(rd_detector *d, Slot *s, int mode) {
   RD_HIP(hipMemcpyAsync(s->h_segs, s->lslist, (size_t)ncopy * 56, hipMemcpyDeviceToHost, st));
   RD_HIP(hipMemcpyAsync(s->h_probes, s->probes, (size_t)ncopy * 15 * 6 * sizeof(int), hipMemcpyDeviceToHost, st));
   RD_HIP(hipMemcpyAsync(s->h_ctr, rdk::poly_scratch_counters(s->ps), 32 * sizeof(int), hipMemcpyDeviceToHost, st));
+}
+
+static void frame_tail(rd_detector *d, Slot *s, int mode) {   // both, in order, on the slot's main stream (overflow redo)
+  frame_polyline(d, s, s->st, mode);
+  frame_votes(d, s);
 }
 
 static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
@@ -374,6 +388,15 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   rdk::strong_mask(st, s->strong, d->prev_strong, s->label1, s->strsum, 2500, iw, ih);
   return;
   }
+  // the polyline stage needs nothing but the strong mask: it runs on the slot's second stream, beside the blur / region
+  // stages, and joins before the votes (inside a captured graph this becomes a parallel branch)
+  if (d->fork_poly) {
+    RD_HIP(hipEventRecord(s->ev_fork, st));
+    RD_HIP(hipStreamWaitEvent(s->st2, s->ev_fork, 0));
+    if (!(d->diag_skip & 4)) frame_polyline(d, s, s->st2, d->poly_mode);
+    RD_HIP(hipEventRecord(s->ev_join, s->st2));
+  }
+
   // filter at 500 (oclrect.c:277-284)
   rdk::filter_strength(st, s->label1, s->strsum, 500, iw, ih);
   rdk::threshold_i(st, s->edge500, s->label1, 0, 0, 1, N);
@@ -382,7 +405,7 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   // edge-preserving smoothing x10, quantise, despeckle (oclrect.c:286-303)
   rdk::blblur_extents(st, s->ext, s->e8, iw, ih);
   { const uint32_t *src = s->plab0;     // ping-pong between i0 and smooth; the 10th pair lands in smooth
-    for (int i = 0; i < 10; i++) { uint32_t *dst = (i & 1) ? s->smooth : (uint32_t *)s->i0; rdk::blblur_pair(st, dst, s->ext, src, iw, ih); src = dst; } }
+    for (int i = 0; i < ((d->diag_skip & 1) ? 2 : 10); i++) { uint32_t *dst = (i & 1) ? s->smooth : (uint32_t *)s->i0; rdk::blblur_pair(st, dst, s->ext, src, iw, ih); src = dst; } }
   rdk::quantize(st, (uint32_t *)s->i0, s->smooth, 24, 24, 24, N);
   rdk::despeckle(st, s->quant, (const uint32_t *)s->i0, s->nms, iw, ih);
 
@@ -392,7 +415,7 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   rdk::merge_mask(st, s->mergemask, s->scratch2, s->junction, iw, ih);
 
   // regions (oclrect.c:325-336)
-  rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih);
+  rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih, (d->diag_skip & 2) ? 0 : 20);
   RD_HIP(hipMemcpyAsync(s->rsize, s->junction, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));   // H2: sizes start from the junction counts
   rdk::region_size(st, s->rsize, s->region0, N);
   rdk::despeckle2(st, s->region, s->region0, s->scratch2, s->rsize, 16, iw, ih);
@@ -401,7 +424,10 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   rdk::mark_boundary(st, s->boundarysrc, s->region, iw, ih);
   rdk::label8(st, s->boundary, s->boundarysrc, -1, iw, ih);
 
-  frame_tail(d, s, d->poly_mode);
+  if (d->diag_skip & 64) for (int i = 0; i < 100; i++) rdk::clear_i(st, s->i1, 64);   // diagnostics: what does a launch cost?
+  if (d->fork_poly) RD_HIP(hipStreamWaitEvent(st, s->ev_join, 0));
+  else if (!(d->diag_skip & 4)) frame_polyline(d, s, st, d->poly_mode);
+  frame_votes(d, s);
 }
 
 static void run_segment(rd_detector *d, Slot *s, int ws, int seg) {
@@ -504,6 +530,8 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : 1;
   d->force_redo = getenv("RD_POLY_FORCE_REDO") ? 1 : 0;
   d->diag_no_post = getenv("RD_DIAG_NO_POST") ? 1 : 0;
+  d->fork_poly = getenv("RD_NO_FORK") ? 0 : 1;
+  d->diag_skip = getenv("RD_DIAG_SKIP") ? atoi(getenv("RD_DIAG_SKIP")) : 0;   // timing diagnostics only: leaves stages out (wrong results)
   pthread_mutex_init(&d->tan_mu, NULL); pthread_cond_init(&d->tan_cv, NULL);
   d->slots = (Slot *)calloc((size_t)nslots, sizeof(Slot));
   for (int i = 0; i < nslots; i++) {

@@ -512,7 +512,7 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
 // (SURVEY.md H5); synchronous rounds to convergence are the order-free reading of the same rule.
 // Memory-latency bound: every thread handles 4 pixels (64 columns apart, so each load instruction stays coalesced) and
 // issues all of their label / neighbour loads before using any, then the 4 first pointer jumps together.
-#define RP_PX 4
+#define RP_PX 8
 __global__ __launch_bounds__(256) void k_region_propose(const int *__restrict__ label, int *prop, int *__restrict__ selfp, const uint8_t *__restrict__ allow, int iw, int ih, const int *flags, int round) {
   if (round > 0 && flags[round - 1] == 0) return;
   __shared__ int hk[512], hv[512];
@@ -1030,8 +1030,8 @@ void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int 
 }
 
 // scratch: 3*N ints (hook proposals; round flags + allowed-direction bytes; self proposals)
-void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih) {
-  const int n = iw * ih, ROUNDS = 20;
+void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS) {
+  const int n = iw * ih;
   // tile-to-tile hops left after k_region_init: at most ih/RI_ROWS + iw/64 + 2; each launch divides the depth by 4
   int FLAT = 1;
   for (long reach = 4; reach < ih / RI_ROWS + iw / 64 + 2; reach *= 4) FLAT++;

@@ -5,7 +5,7 @@ tag=${1:-x}
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests -m gpu -x -q -s 2>&1 | tail -15 > gpurun_out/pytest_gpu.log
 tail -4 gpurun_out/pytest_gpu.log
-for s in 1 8 16; do
+for s in 1 4 8; do
   timeout 300 python bench.py --steps 3 --warmup 1 --slots $s --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_s$s.log | cut -c1-100
 done
 export TMPDIR=/tmp
