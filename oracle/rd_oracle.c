@@ -56,7 +56,7 @@ static inline void unpack_lab(uint32_t p, float *L, float *a, float *b) {
  *   s2l[i]   = floor(32768 * srgb_to_linear(i/255)),                    i = 0..260
  *   cfunc[i] = rint(65536 * f(i/1024) - 9039),  f = CIE Lab f(t),        i = 0..1030
  *   cfunc2[i]= rint(65536/127.5 * (116 f(i/1024) - 16))                                  */
-static uint16_t lut_s2l[261], lut_cf[1031], lut_cf2[1031];
+static uint16_t lut_s2l[261], lut_cf[1031], lut_cf2[1031], lut_l2s[1024];   /* l2s (iu:697-762) = clamp(floor(256 * linear_to_srgb(i/1023) + 0.5), 0, 255) */
 static int luts_ready = 0;
 
 static void init_luts(void) {
@@ -72,6 +72,12 @@ static void init_luts(void) {
     lut_cf[i] = (uint16_t)rint(65536 * f - 9039);
     lut_cf2[i] = (uint16_t)rint(65536 / 127.5 * (116 * f - 16));
   }
+  for (int i = 0; i < 1024; i++) {
+    double c = i / 1023.0;
+    double v = c <= 0.0031308 ? 12.92 * c : 1.055 * pow(c, 1 / 2.4) - 0.055;
+    int q = (int)floor(256 * v + 0.5);
+    lut_l2s[i] = (uint16_t)(q < 0 ? 0 : q > 255 ? 255 : q);
+  }
   luts_ready = 1;
 }
 
@@ -79,6 +85,7 @@ const uint16_t *rdo_lut(int which, int *n) {
   init_luts();
   if (which == 0) { *n = 261; return lut_s2l; }
   if (which == 1) { *n = 1031; return lut_cf; }
+  if (which == 3) { *n = 1024; return lut_l2s; }
   *n = 1031; return lut_cf2;
 }
 
@@ -898,4 +905,117 @@ int rdo_iir_chunk_test(const float *src, int n, int st, int dir, int C, int Wm, 
   *unverified = unv;
   free(full); free(chk);
   return bad;
+}
+
+
+/* ================================================================================================ visualisers and the
+ * operators no application of the reference calls (oclimgutil.h:84-98).  Restated for completeness of the oclimgutil.h
+ * surface; pinned against the reference's own kernels by tests/golden/ops_*.npz (tools/make_golden_ops.py). */
+
+/* iu:283-289 */
+void rdo_convert_bgr_lumaf(uint8_t *out, const float *in, float f, int iw, int ih, int ws) {
+  for (int y = 0; y < ih; y++)
+    for (int x = 0; x < iw; x++) {
+      const int v = clampi((int)floorf(in[y * iw + x] * f * 255), 0, 255);
+      uint8_t *o = out + (size_t)y * ws + x * 3;
+      o[0] = o[1] = o[2] = (uint8_t)v;
+    }
+}
+
+/* iu:291-321 */
+void rdo_convert_bgr_labeli(uint8_t *out, const int *in, int bgc, int iw, int ih, int ws) {
+  for (int y = 0; y < ih; y++)
+    for (int x = 0; x < iw; x++) {
+      const int c = in[y * iw + x];
+      uint8_t *o = out + (size_t)y * ws + x * 3;
+      if (c == bgc) { o[0] = o[1] = o[2] = 0; continue; }
+      const int g = (int)((unsigned)c * 1103515245u + 12345u);
+      o[2] = (uint8_t)((((g & (7 << 0)) << 5) | 31) & 255);
+      o[1] = (uint8_t)((((g & (7 << 3)) << 2) | 31) & 255);
+      o[0] = (uint8_t)((((g & (7 << 6)) >> 1) | 31) & 255);
+    }
+}
+
+/* iu:136-182: packed Lab -> sRGB bytes */
+static inline float icfunc(float ft) { return ft > 0.20689270648f ? ft * ft * ft : (ft - 16.0f / 116) * (1.0f / 7.787f); }
+
+void rdo_plab2bgr(uint8_t *out, const uint32_t *in, int iw, int ih, int ws) {
+  init_luts();
+  const float xn = 0.950456f, zn = 1.088754f;
+  for (int y = 0; y < ih; y++)
+    for (int x = 0; x < iw; x++) {
+      float L, a, b;
+      unpack_lab(in[y * iw + x], &L, &a, &b);
+      L *= 256; a *= 256; b *= 256;
+      float cy;
+      if (L > 0.20689270648f) { cy = (L + 16) * (1.0f / 116.0f); cy = cy * cy * cy; }
+      else cy = L * (1.0f / 903.3f);
+      const float fy = (float)(lut_cf[clampi((int)floorf(cy * 1024), 0, 1023)] + 9039) * (1.0f / 65536.0f);
+      const float fz = fy - (b - 128) * (1.0f / 200.0f);
+      const float fx = fy + (a - 128) * (1.0f / 500.0f);
+      const float cx = icfunc(fx) * xn, cz = icfunc(fz) * zn;
+      const float r = cx * 3.240479f + cy * -1.537150f + cz * -0.498535f;
+      const float g = cx * -0.969256f + cy * 1.875991f + cz * 0.041556f;
+      const float bb = cx * 0.055648f + cy * -0.204043f + cz * 1.057311f;
+      uint8_t *o = out + (size_t)y * ws + x * 3;
+      o[2] = (uint8_t)lut_l2s[clampi((int)floorf(r * 1024), 0, 1023)];
+      o[1] = (uint8_t)lut_l2s[clampi((int)floorf(g * 1024), 0, 1023)];
+      o[0] = (uint8_t)lut_l2s[clampi((int)floorf(bb * 1024), 0, 1023)];
+    }
+}
+
+/* iu:439-453 */
+void rdo_edge_f_f(float *out, const float *in, int iw, int ih) {
+  for (int y = 0; y < ih; y++)
+    for (int x = 0; x < iw; x++) {
+      float sum = 0, t;
+      t = in[mirror2(x, y - 1, iw, ih)] + in[mirror2(x - 1, y, iw, ih)] - in[mirror2(x, y + 1, iw, ih)] - in[mirror2(x + 1, y, iw, ih)];
+      sum += (in[mirror2(x - 1, y - 1, iw, ih)] - in[mirror2(x + 1, y + 1, iw, ih)]) * t;
+      t = in[mirror2(x, y - 1, iw, ih)] - in[mirror2(x - 1, y, iw, ih)] + in[mirror2(x + 1, y, iw, ih)] - in[mirror2(x, y + 1, iw, ih)];
+      sum += (in[mirror2(x + 1, y - 1, iw, ih)] - in[mirror2(x - 1, y + 1, iw, ih)]) * t;
+      out[y * iw + x] = sqrtf(fmaxf(0.0f, sum));
+    }
+}
+
+/* iu:354-393: gradient direction of the channel with the largest response, sign taken from the L channel */
+void rdo_edgevec_plab(float *vxy, const uint32_t *in, int iw, int ih) {
+  for (int y = 0; y < ih; y++)
+    for (int x = 0; x < iw; x++) {
+      float vx3[3] = { 0, 0, 0 }, vy3[3] = { 0, 0, 0 };
+      for (int yy = -2; yy <= 2; yy++)
+        for (int xx = -2; xx <= 2; xx++) {
+          float s[3];
+          unpack_lab(in[mirror2(x + xx, y + yy, iw, ih)], &s[0], &s[1], &s[2]);
+          for (int c = 0; c < 3; c++) {
+            vx3[c] += V5C[(xx + 2) + (yy + 2) * 5] * s[c];
+            vy3[c] += V5C[(yy + 2) + (xx + 2) * 5] * s[c];
+          }
+        }
+      float l3[3];
+      for (int c = 0; c < 3; c++) l3[c] = vx3[c] * vx3[c] + vy3[c] * vy3[c];
+      float ivlen, vx, vy;
+      if (l3[0] >= l3[1] && l3[0] >= l3[2]) { ivlen = l3[0]; vx = vx3[0]; vy = vy3[0]; }
+      else if (l3[1] >= l3[2]) { ivlen = l3[1]; vx = vx3[1]; vy = vy3[1]; }
+      else { ivlen = l3[2]; vx = vx3[2]; vy = vy3[2]; }
+      if ((double)l3[0] >= 1e-6 && (vx3[0] * vx + vy3[0] * vy < 0)) { vx = -vx; vy = -vy; }
+      if ((double)ivlen > 1e-10) { ivlen = 1.0f / sqrtf(ivlen); vx *= ivlen; vy *= ivlen; }
+      else vx = vy = 0.70710678118f;
+      vxy[(y * iw + x) * 2] = vx; vxy[(y * iw + x) * 2 + 1] = vy;
+    }
+}
+
+/* iu:473-491: like thinthres, with a 1 % tolerance and all four samples in the comparison */
+void rdo_thincubic(float *out, const float *in, const float *vxy, int iw, int ih) {
+  for (int y = 0; y < ih; y++)
+    for (int x = 0; x < iw; x++) {
+      const int p0 = y * iw + x;
+      const float vx = vxy[p0 * 2], vy = vxy[p0 * 2 + 1];
+      const float am2 = bicubic(in, x - 2 * vx, y - 2 * vy, iw, ih);
+      const float am1 = bicubic(in, x - 1 * vx, y - 1 * vy, iw, ih);
+      const float a0 = in[p0];
+      const float ap1 = bicubic(in, x + 1 * vx, y + 1 * vy, iw, ih);
+      const float ap2 = bicubic(in, x + 2 * vx, y + 2 * vy, iw, ih);
+      const float C = 0.99f;
+      out[p0] = (am2 * C <= a0 && am1 * C <= a0 && a0 >= ap1 * C && a0 >= ap2 * C) ? (am2 + am1 + a0 + ap1 + ap2) : 0;
+    }
 }

@@ -29,6 +29,13 @@ void rdo_edgevec(float *vxy, const float *in, int iw, int ih);
 void rdo_edge_plab(float *out, const uint32_t *in, int iw, int ih);
 void rdo_thinthres(float *out, const float *in, const float *vxy, int iw, int ih);
 void rdo_positive_mask(int *out, const float *in, int n);
+/* visualisers and operators no application calls (oclimgutil.h:84-98) */
+void rdo_convert_bgr_lumaf(uint8_t *out, const float *in, float f, int iw, int ih, int ws);
+void rdo_convert_bgr_labeli(uint8_t *out, const int *in, int bgc, int iw, int ih, int ws);
+void rdo_plab2bgr(uint8_t *out, const uint32_t *in, int iw, int ih, int ws);
+void rdo_edge_f_f(float *out, const float *in, int iw, int ih);
+void rdo_edgevec_plab(float *vxy, const uint32_t *in, int iw, int ih);
+void rdo_thincubic(float *out, const float *in, const float *vxy, int iw, int ih);
 void rdo_label8(int *label, const int *pix, int bgc, int iw, int ih);
 void rdo_calc_strength(int *out, const float *edge, const int *label, int iw, int ih);
 void rdo_filter_strength(int *label, const int *str, int thre, int iw, int ih);

@@ -94,6 +94,12 @@ def _declare(L):
         "oclimgutil_thinthres_f_f_f2": (vp, [vp, vp, vp, vp, ci, ci, vp, vp]),
         "oclimgutil_label8x_int_int": (vp, [vp, vp, vp, vp, ci, ci, ci, vp, vp]),
         "oclimgutil_calcStrength": (vp, [vp, vp, vp, vp, ci, ci, vp, vp]),
+        "oclimgutil_convert_bgr_lumaf": (vp, [vp, vp, vp, cf, ci, ci, ci, vp, vp]),
+        "oclimgutil_convert_bgr_labeli": (vp, [vp, vp, vp, ci, ci, ci, ci, vp, vp]),
+        "oclimgutil_convert_bgr_plab": (vp, [vp, vp, vp, ci, ci, ci, vp, vp]),
+        "oclimgutil_edge_f_f": (vp, [vp, vp, vp, ci, ci, vp, vp]),
+        "oclimgutil_edgevec_f2_plab": (vp, [vp, vp, vp, ci, ci, vp, vp]),
+        "oclimgutil_thincubic_f_f_f2": (vp, [vp, vp, vp, vp, ci, ci, vp, vp]),
         "oclimgutil_filterStrength": (vp, [vp, vp, vp, ci, ci, ci, vp, vp]),
         # oclpolyline.h
         "init_oclpolyline": (vp, [vp, vp]),

@@ -174,16 +174,44 @@ cl_event oclimgutil_filterStrength(oclimgutil_t *thiz, cl_mem labelinout, cl_mem
   IU_END("oclimgutil_filterStrength");
 }
 
-// Debug visualisers and operators no application calls (SURVEY.md 8a "dead for the apps", 8f rank 4): declared so that
-// programs link, but not implemented yet - they fail loudly instead of silently doing nothing.
-#define IU_TODO(name) exitf(-1, name ": not implemented in this build (debug/unused operator of the reference)\n"); return NULL
-cl_event oclimgutil_convert_bgr_luminancef(oclimgutil_t *, cl_mem, cl_mem, int, int, int, cl_command_queue, const cl_event *) { IU_TODO("oclimgutil_convert_bgr_luminancef"); }
-cl_event oclimgutil_convert_bgr_lumaf(oclimgutil_t *, cl_mem, cl_mem, float, int, int, int, cl_command_queue, const cl_event *) { IU_TODO("oclimgutil_convert_bgr_lumaf"); }
-cl_event oclimgutil_convert_bgr_labeli(oclimgutil_t *, cl_mem, cl_mem, int, int, int, int, cl_command_queue, const cl_event *) { IU_TODO("oclimgutil_convert_bgr_labeli"); }
-cl_event oclimgutil_convert_bgr_plab(oclimgutil_t *, cl_mem, cl_mem, int, int, int, cl_command_queue, const cl_event *) { IU_TODO("oclimgutil_convert_bgr_plab"); }
-cl_event oclimgutil_edge_f_f(oclimgutil_t *, cl_mem, cl_mem, int, int, cl_command_queue, const cl_event *) { IU_TODO("oclimgutil_edge_f_f"); }
-cl_event oclimgutil_edgevec_f2_plab(oclimgutil_t *, cl_mem, cl_mem, int, int, cl_command_queue, const cl_event *) { IU_TODO("oclimgutil_edgevec_f2_plab"); }
-cl_event oclimgutil_thincubic_f_f_f2(oclimgutil_t *, cl_mem, cl_mem, cl_mem, int, int, cl_command_queue, const cl_event *) { IU_TODO("oclimgutil_thincubic_f_f_f2"); }
+// Debug visualisers and operators no application calls (SURVEY.md 8a "dead for the apps", 8f rank 4).
+cl_event oclimgutil_convert_bgr_lumaf(oclimgutil_t *thiz, cl_mem out, cl_mem in, float f, int iw, int ih, int ws, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_convert_bgr_lumaf");
+  rdk::convert_bgr_lumaf(s, (uint8_t *)dptr(out), (const float *)dptr(in), f, iw, ih, ws);
+  IU_END("oclimgutil_convert_bgr_lumaf");
+}
+cl_event oclimgutil_convert_bgr_labeli(oclimgutil_t *thiz, cl_mem out, cl_mem in, int bgc, int iw, int ih, int ws, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_convert_bgr_labeli");
+  rdk::convert_bgr_labeli(s, (uint8_t *)dptr(out), (const int *)dptr(in), bgc, iw, ih, ws);
+  IU_END("oclimgutil_convert_bgr_labeli");
+}
+cl_event oclimgutil_convert_bgr_plab(oclimgutil_t *thiz, cl_mem out, cl_mem in, int iw, int ih, int ws, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_convert_bgr_plab");
+  rdk::plab2bgr(s, (uint8_t *)dptr(out), (const uint32_t *)dptr(in), iw, ih, ws);
+  IU_END("oclimgutil_convert_bgr_plab");
+}
+cl_event oclimgutil_edge_f_f(oclimgutil_t *thiz, cl_mem out, cl_mem in, int iw, int ih, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_edge_f_f");
+  rdk::edge_f(s, (float *)dptr(out), (const float *)dptr(in), iw, ih);
+  IU_END("oclimgutil_edge_f_f");
+}
+cl_event oclimgutil_edgevec_f2_plab(oclimgutil_t *thiz, cl_mem out, cl_mem in, int iw, int ih, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_edgevec_f2_plab");
+  rdk::edgevec_plab(s, (float *)dptr(out), (const uint32_t *)dptr(in), iw, ih);
+  IU_END("oclimgutil_edgevec_f2_plab");
+}
+cl_event oclimgutil_thincubic_f_f_f2(oclimgutil_t *thiz, cl_mem out, cl_mem in, cl_mem vec, int iw, int ih, cl_command_queue queue, const cl_event *events) {
+  IU_BEGIN("oclimgutil_thincubic_f_f_f2");
+  rdk::thincubic(s, (float *)dptr(out), (const float *)dptr(in), (const float *)dptr(vec), iw, ih);
+  IU_END("oclimgutil_thincubic_f_f_f2");
+}
+// The reference sets 5 of the 6 arguments of its convert_bgr_luminancef kernel (oclimgutil.c:187 "MMiii" against
+// iu:275: out, in, f, iw, ih, ws), so the call cannot succeed on a conforming OpenCL runtime (CL_INVALID_KERNEL_ARGS ->
+// exitf); it fails here in the same way, with the reason spelled out.
+cl_event oclimgutil_convert_bgr_luminancef(oclimgutil_t *, cl_mem, cl_mem, int, int, int, cl_command_queue, const cl_event *) {
+  exitf(-1, "oclimgutil_convert_bgr_luminancef: the reference passes 5 of this kernel's 6 arguments (oclimgutil.c:187); the call is an error there and here\n");
+  return NULL;
+}
 
 }  // extern "C"
 

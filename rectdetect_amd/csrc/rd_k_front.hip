@@ -571,6 +571,117 @@ __global__ void k_rand_i(int *out, uint64_t seed, int n) {
 
 inline int ew_grid(int n) { int g = cdiv(n, 256 * 4); return g < 1 ? 1 : (g > 4096 ? 4096 : g); }
 
+// ------------------------------------------------------------------------------------------------ visualisers and operators
+// no application of the reference calls (oclimgutil.h:84-98): plain one-pixel-per-thread kernels, same operation order
+// as the reference's (iu = oclimgutil.cl), pinned by tests/golden/ops_*.npz
+
+// iu:283-289
+__global__ __launch_bounds__(256) void k_convert_bgr_lumaf(uint8_t *__restrict__ out, const float *__restrict__ in, float f, int iw, int ih, int ws) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= iw || y >= ih) return;
+  const uint8_t v = (uint8_t)clampi((int)floorf(in[y * iw + x] * f * 255), 0, 255);
+  uint8_t *o = out + (size_t)y * ws + x * 3;
+  o[0] = v; o[1] = v; o[2] = v;
+}
+
+// iu:291-321
+__global__ __launch_bounds__(256) void k_convert_bgr_labeli(uint8_t *__restrict__ out, const int *__restrict__ in, int bgc, int iw, int ih, int ws) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= iw || y >= ih) return;
+  const int c = in[y * iw + x];
+  uint8_t *o = out + (size_t)y * ws + x * 3;
+  if (c == bgc) { o[0] = 0; o[1] = 0; o[2] = 0; return; }
+  const int g = (int)((unsigned)c * 1103515245u + 12345u);
+  o[2] = (uint8_t)((((g & (7 << 0)) << 5) | 31) & 255);
+  o[1] = (uint8_t)((((g & (7 << 3)) << 2) | 31) & 255);
+  o[0] = (uint8_t)((((g & (7 << 6)) >> 1) | 31) & 255);
+}
+
+// iu:136-182, iu:264-273: packed Lab -> sRGB bytes
+__device__ __forceinline__ float icfunc(float ft) { return ft > 0.20689270648f ? ft * ft * ft : (ft - 16.0f / 116) * (1.0f / 7.787f); }
+
+__global__ __launch_bounds__(256) void k_plab2bgr(uint8_t *__restrict__ out, const uint32_t *__restrict__ in, int iw, int ih, int ws) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= iw || y >= ih) return;
+  const float xn = 0.950456f, zn = 1.088754f;
+  float L, a, b;
+  unpack_lab(in[y * iw + x], L, a, b);
+  L *= 256; a *= 256; b *= 256;
+  float cy;
+  if (L > 0.20689270648f) { cy = (L + 16) * (1.0f / 116.0f); cy = cy * cy * cy; }
+  else cy = L * (1.0f / 903.3f);
+  const float fy = (float)(rd_lut_cfunc[clampi((int)floorf(cy * 1024), 0, 1023)] + 9039) * (1.0f / 65536.0f);
+  const float fz = fy - (b - 128) * (1.0f / 200.0f);
+  const float fx = fy + (a - 128) * (1.0f / 500.0f);
+  const float cx = icfunc(fx) * xn, cz = icfunc(fz) * zn;
+  const float r = cx * 3.240479f + cy * -1.537150f + cz * -0.498535f;
+  const float g = cx * -0.969256f + cy * 1.875991f + cz * 0.041556f;
+  const float bb = cx * 0.055648f + cy * -0.204043f + cz * 1.057311f;
+  uint8_t *o = out + (size_t)y * ws + x * 3;
+  o[2] = rd_lut_l2s[clampi((int)floorf(r * 1024), 0, 1023)];
+  o[1] = rd_lut_l2s[clampi((int)floorf(g * 1024), 0, 1023)];
+  o[0] = rd_lut_l2s[clampi((int)floorf(bb * 1024), 0, 1023)];
+}
+
+// iu:439-453
+__global__ __launch_bounds__(256) void k_edge_f(float *__restrict__ out, const float *__restrict__ in, int iw, int ih) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= iw || y >= ih) return;
+  const float n = in[mirror2(x, y - 1, iw, ih)], s = in[mirror2(x, y + 1, iw, ih)], w = in[mirror2(x - 1, y, iw, ih)], e = in[mirror2(x + 1, y, iw, ih)];
+  float sum = 0, t;
+  t = n + w - s - e;
+  sum += (in[mirror2(x - 1, y - 1, iw, ih)] - in[mirror2(x + 1, y + 1, iw, ih)]) * t;
+  t = n - w + e - s;
+  sum += (in[mirror2(x + 1, y - 1, iw, ih)] - in[mirror2(x - 1, y + 1, iw, ih)]) * t;
+  out[y * iw + x] = sqrtf(fmaxf(0.0f, sum));
+}
+
+// iu:354-393: gradient direction of the channel with the largest response, sign taken from the L channel
+__global__ __launch_bounds__(256) void k_edgevec_plab(float2 *__restrict__ dst, const uint32_t *__restrict__ in, int iw, int ih) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= iw || y >= ih) return;
+  float vx3[3] = { 0, 0, 0 }, vy3[3] = { 0, 0, 0 };
+#pragma unroll
+  for (int yy = -2; yy <= 2; yy++) {
+#pragma unroll
+    for (int xx = -2; xx <= 2; xx++) {
+      float s[3];
+      unpack_lab(in[mirror2(x + xx, y + yy, iw, ih)], s[0], s[1], s[2]);
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        vx3[c] += v5c((xx + 2) + (yy + 2) * 5) * s[c];
+        vy3[c] += v5c((yy + 2) + (xx + 2) * 5) * s[c];
+      }
+    }
+  }
+  float l3[3];
+#pragma unroll
+  for (int c = 0; c < 3; c++) l3[c] = vx3[c] * vx3[c] + vy3[c] * vy3[c];
+  float ivlen, vx, vy;
+  if (l3[0] >= l3[1] && l3[0] >= l3[2]) { ivlen = l3[0]; vx = vx3[0]; vy = vy3[0]; }
+  else if (l3[1] >= l3[2]) { ivlen = l3[1]; vx = vx3[1]; vy = vy3[1]; }
+  else { ivlen = l3[2]; vx = vx3[2]; vy = vy3[2]; }
+  if ((double)l3[0] >= 1e-6 && (vx3[0] * vx + vy3[0] * vy < 0)) { vx = -vx; vy = -vy; }
+  if ((double)ivlen > 1e-10) { ivlen = 1.0f / sqrtf(ivlen); vx *= ivlen; vy *= ivlen; }
+  else vx = vy = 0.70710678118f;
+  dst[y * iw + x] = make_float2(vx, vy);
+}
+
+// iu:473-491: like k_thinthres, with a 1 % tolerance and all four samples in the comparison
+__global__ __launch_bounds__(256) void k_thincubic(float *__restrict__ out, const float *__restrict__ in, const float2 *__restrict__ vxy, int iw, int ih) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= iw || y >= ih) return;
+  const int p0 = y * iw + x;
+  const float2 v = vxy[p0];
+  const float am2 = bicubic(in, x - 2 * v.x, y - 2 * v.y, iw, ih);
+  const float am1 = bicubic(in, x - 1 * v.x, y - 1 * v.y, iw, ih);
+  const float a0 = in[p0];
+  const float ap1 = bicubic(in, x + 1 * v.x, y + 1 * v.y, iw, ih);
+  const float ap2 = bicubic(in, x + 2 * v.x, y + 2 * v.y, iw, ih);
+  const float C = 0.99f;
+  out[p0] = (am2 * C <= a0 && am1 * C <= a0 && a0 >= ap1 * C && a0 >= ap2 * C) ? (am2 + am1 + a0 + ap1 + ap2) : 0.0f;
+}
+
 }  // namespace
 
 namespace rdk {
@@ -643,6 +754,24 @@ void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3]
   }
 }
 
+void convert_bgr_lumaf(hipStream_t s, uint8_t *out, const float *in, float f, int iw, int ih, int ws) {
+  hipLaunchKernelGGL(k_convert_bgr_lumaf, grid2(iw, ih), block2, 0, s, out, in, f, iw, ih, ws);
+}
+void convert_bgr_labeli(hipStream_t s, uint8_t *out, const int *in, int bgc, int iw, int ih, int ws) {
+  hipLaunchKernelGGL(k_convert_bgr_labeli, grid2(iw, ih), block2, 0, s, out, in, bgc, iw, ih, ws);
+}
+void plab2bgr(hipStream_t s, uint8_t *out, const uint32_t *in, int iw, int ih, int ws) {
+  hipLaunchKernelGGL(k_plab2bgr, grid2(iw, ih), block2, 0, s, out, in, iw, ih, ws);
+}
+void edge_f(hipStream_t s, float *out, const float *in, int iw, int ih) {
+  hipLaunchKernelGGL(k_edge_f, grid2(iw, ih), block2, 0, s, out, in, iw, ih);
+}
+void edgevec_plab(hipStream_t s, float *vxy, const uint32_t *in, int iw, int ih) {
+  hipLaunchKernelGGL(k_edgevec_plab, grid2(iw, ih), block2, 0, s, (float2 *)vxy, in, iw, ih);
+}
+void thincubic(hipStream_t s, float *out, const float *in, const float *vxy, int iw, int ih) {
+  hipLaunchKernelGGL(k_thincubic, grid2(iw, ih), block2, 0, s, out, in, (const float2 *)vxy, iw, ih);
+}
 void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih) {
   hipLaunchKernelGGL(k_edgevec, grid2(iw, ih), block2, 0, s, (float2 *)vxy, in, iw, ih);
 }

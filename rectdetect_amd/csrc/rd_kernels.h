@@ -31,6 +31,13 @@ size_t iir_pass_scratch_floats(int np, int W, int H);
 void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3], float *const fwd[3], float *const bwd[3], int np, int W, int H,
                    int transpose_out, float *tails, int *bad);
 void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih);
+// visualisers / operators no application calls (oclimgutil.h:84-98)
+void convert_bgr_lumaf(hipStream_t s, uint8_t *out, const float *in, float f, int iw, int ih, int ws);
+void convert_bgr_labeli(hipStream_t s, uint8_t *out, const int *in, int bgc, int iw, int ih, int ws);
+void plab2bgr(hipStream_t s, uint8_t *out, const uint32_t *in, int iw, int ih, int ws);
+void edge_f(hipStream_t s, float *out, const float *in, int iw, int ih);
+void edgevec_plab(hipStream_t s, float *vxy, const uint32_t *in, int iw, int ih);
+void thincubic(hipStream_t s, float *out, const float *in, const float *vxy, int iw, int ih);
 void edge_plab(hipStream_t s, float *out, const uint32_t *in, int iw, int ih);
 void thinthres(hipStream_t s, float *out, const float *in, const float *vxy, int iw, int ih);
 void threshold_f(hipStream_t s, float *out, const float *in, float lo, float thr, float hi, int n);

@@ -132,3 +132,59 @@ def test_oracle_against_live_reference_new_seed():
     mine = ra.postprocess_planes(orc.segments(), orc.plane("boundary"), orc.plane("table"), iw, ih, 0.7)
     assert helpers.rects_equal(mine, rects)
     orc.close()
+
+
+@pytest.mark.parametrize("name", ["ops_97x61", "ops_160x131"])
+def test_oracle_operators_against_reference_golden(name):
+    """every oclimgutil.h operator the oracle restates, on the inputs stored with the reference's outputs
+    (tools/make_golden_ops.py ran the reference's own kernels): bit-exact, floats included"""
+    g = golden(name)
+    iw, ih = int(g["iw"]), int(g["ih"])
+    N, ws = iw * ih, iw * 3 + 1
+    O = helpers.oracle()
+    P = helpers.P
+    f, plab, lab = (np.ascontiguousarray(g[k]) for k in ("in_f", "in_plab", "in_lab"))
+    bits = lambda a: np.ascontiguousarray(a).view(np.uint32) if a.dtype == np.float32 else a
+
+    def bgr_out(fn, *args):
+        out = np.zeros((ih, ws), np.uint8)
+        fn(P(out), *args, iw, ih, ws)
+        return out[:, : iw * 3]
+
+    import ctypes
+    O.rdo_convert_bgr_lumaf.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    assert np.array_equal(bgr_out(O.rdo_convert_bgr_lumaf, P(f), 0.9), g["convert_bgr_lumaf"])
+    assert np.array_equal(bgr_out(O.rdo_convert_bgr_labeli, P(lab), -1), g["convert_bgr_labeli"])
+    assert np.array_equal(bgr_out(O.rdo_plab2bgr, P(plab)), g["convert_bgr_plab"])
+    out = np.zeros(N, np.float32)
+    O.rdo_edge_f_f(P(out), P(f), iw, ih)
+    assert np.array_equal(bits(out), bits(g["edge_f_f"]))
+    v = np.zeros(2 * N, np.float32)
+    O.rdo_edgevec_plab(P(v), P(plab), iw, ih)
+    assert np.array_equal(bits(v), bits(g["edgevec_f2_plab"]))
+    vf = np.zeros(2 * N, np.float32)
+    O.rdo_edgevec(P(vf), P(f), iw, ih)
+    assert np.array_equal(bits(vf), bits(g["edgevec_f2_f"]))
+    O.rdo_thincubic(P(out), P(f), P(vf), iw, ih)
+    assert np.array_equal(bits(out), bits(g["thincubic_f_f_f2"]))
+    O.rdo_thinthres(P(out), P(f), P(vf), iw, ih)
+    assert np.array_equal(bits(out), bits(g["thinthres_f_f_f2"]))
+    O.rdo_edge_plab(P(out), P(plab), iw, ih)
+    assert np.array_equal(bits(out), bits(g["edge_f_plab"]))
+    O.rdo_iirblur(P(out), P(f), iw, ih)
+    assert np.array_equal(bits(out), bits(g["iirblur_f_f"]))
+    pl = np.zeros(N, np.uint32)
+    O.rdo_bgr2plab(P(pl), P(np.ascontiguousarray(g["in_bgr"])), iw, ih, iw * 3)
+    assert np.array_equal(pl, g["convert_plab_bgr"])
+    u = [np.zeros(N, np.float32) for _ in range(3)]
+    O.rdo_unpack_plab(P(u[0]), P(u[1]), P(u[2]), P(plab), N)
+    for k in range(3):
+        assert np.array_equal(bits(u[k]), bits(g["unpack%d" % k]))
+    O.rdo_pack_plab(P(pl), P(u[0]), P(u[1]), P(u[2]), N)
+    assert np.array_equal(pl, g["pack_plab_f_f_f"])
+    acc = (np.arange(N, dtype=np.int32) % 3).astype(np.int32)
+    O.rdo_calc_strength(P(acc), P(f), P(lab), iw, ih)
+    assert np.array_equal(acc, g["calcStrength"])
+    l2 = lab.copy()
+    O.rdo_filter_strength(P(l2), P(acc), 5000, iw, ih)
+    assert np.array_equal(l2.ravel(), g["filterStrength"])

@@ -324,3 +324,20 @@ def test_polyline_overflow_takes_fallback_and_matches_oracle():
     assert helpers.segments_equal(det.last_segments(), orc.segments())
     det.close()
     orc.close()
+
+
+@pytest.mark.parametrize("name", ["ops_97x61", "ops_160x131"])
+def test_every_operator_against_reference_golden(name):
+    """all oclimgutil.h operators of this library, driven exactly like tools/make_golden_ops.py drove the reference's
+    (same call sequence, same seeded inputs): every output bit-identical to the reference's, floats included"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_ops", os.path.join(helpers.ROOT, "tools", "make_golden_ops.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    g = golden(name)
+    got = m.run_all(m.Ops(ra.lib()), int(g["iw"]), int(g["ih"]), int(g["seed"]))
+    for k in sorted(got):
+        a, b = np.ascontiguousarray(got[k]), np.ascontiguousarray(g[k])
+        if a.dtype == np.float32:
+            a, b = a.view(np.uint32), b.view(np.uint32)
+        assert a.shape == b.shape and np.array_equal(a, b), "%s differs in %d elements" % (k, int((a != b).sum()))
