@@ -103,7 +103,8 @@ def main():
             a = np.zeros((IH, IW, 3), np.uint8)
             L.rd_synth_frame(a.ctypes.data, IW, IH, IW * 3, synth.SEED0 + seed_stream, t, 1)
             frames.append(a)
-        det = ra.Detector(IW, IH, device=local, nslots=args.slots, nworkers=1)
+        dev = local % L.rd_device_count()     # identity on a full node; lets two ranks share the only GPU of a test box (gloo)
+        det = ra.Detector(IW, IH, device=dev, nslots=args.slots, nworkers=1)
         dframes = []
         for a in frames:
             p = L.rd_device_alloc(a.nbytes)

@@ -341,3 +341,46 @@ def test_every_operator_against_reference_golden(name):
         if a.dtype == np.float32:
             a, b = a.view(np.uint32), b.view(np.uint32)
         assert a.shape == b.shape and np.array_equal(a, b), "%s differs in %d elements" % (k, int((a != b).sum()))
+
+
+def test_largest_config_4k_against_oracle():
+    """BASELINE.json configs[3] size (3840x2160): the front-end planes bit-exact, the polyline stage (which overflows the
+    single-launch kernel's on-chip tables at this size and takes the multi-launch path) and its segments against the oracle"""
+    iw, ih = 3840, 2160
+    N = iw * ih
+    img = synth.frame(synth.SEED0 + 4, iw, ih, 2)
+    det = ra.Detector(iw, ih, nslots=1)
+    orc = helpers.OracleRect(iw, ih)
+    det.enqueue(img)
+    rects = det.poll(TAN36)
+    orc.frame(img)
+    for g, o, k in EXACT:
+        a = det.plane(g, np.uint32, N * k)
+        b = orc.plane(o).view(np.uint32)[: N * k]
+        assert np.array_equal(a, b), f"plane {g} differs in {int((a != b).sum())} elements"
+    assert helpers.segments_equal(det.last_segments(), orc.segments())
+    print("4K: redone", det.redone_frames(), "segments", int(det.last_segments()[0]["x0"].view(np.int32)) if False else len(det.last_segments()) - 1, "rectangles", len(rects))
+    det.close()
+    orc.close()
+
+
+@pytest.mark.parametrize("iw,ih", [(16, 16), (17, 19), (65, 16)])
+def test_smallest_frames(iw, ih):
+    """the smallest frames the detector accepts (one partial tile in every tiled kernel, blur blocks shorter than their
+    warm-up): same planes and segments as the oracle"""
+    N = iw * ih
+    rng = np.random.default_rng(iw * 100 + ih)
+    img = np.ascontiguousarray(np.repeat(np.repeat(rng.integers(0, 256, ((ih + 3) // 4, (iw + 3) // 4, 3), dtype=np.uint8), 4, 0), 4, 1)[:ih, :iw])
+    det = ra.Detector(iw, ih, nslots=1)
+    orc = helpers.OracleRect(iw, ih)
+    for _ in range(2):
+        det.enqueue(img)
+        det.poll(TAN36)
+        orc.frame(img)
+        for g, o, k in EXACT:
+            a = det.plane(g, np.uint32, N * k)
+            b = orc.plane(o).view(np.uint32)[: N * k]
+            assert np.array_equal(a, b), f"plane {g} differs in {int((a != b).sum())} elements"
+        assert helpers.segments_equal(det.last_segments(), orc.segments())
+    det.close()
+    orc.close()
