@@ -179,7 +179,10 @@ def main():
                          # HIP events on each frame's own stream over the timed region (rank 0): first kernel start -> last copy end.
                          # With several frames in flight these intervals overlap, which is why `achieved` is taken from the aggregate rate.
                          "frame_device_us_avg": round((dev1[0] - dev0[0]) / max(1, dev1[1] - dev0[1]), 1), "frames_in_flight": args.slots,
-                         "host_enqueue_us_avg": round((enq1 - enq0) / max(1, dev1[1] - dev0[1]), 1)},
+                         "host_enqueue_us_avg": round((enq1 - enq0) / max(1, dev1[1] - dev0[1]), 1),
+                         "region_round_budget": det.region_round_budget()[0] if det is not None else None,
+                         "frames_per_budget_8_12_16_20": [ra.lib().rd_detector_counter(det.h, 6 + k) for k in range(4)] if det is not None else None,
+                         "frames_repeated": {"round_budget": det.region_round_budget()[1], "polyline_overflow": det.redone_frames()} if det is not None else None},
         }
         if not args.dry_run and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(frames)

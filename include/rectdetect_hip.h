@@ -46,7 +46,9 @@ int rd_detector_last_segments(rd_detector *d, void *dst, int max_records);
 
 /* counters since creation: which 0 = frames whose polyline stage did not fit the single-launch kernel's on-chip tables and
  * was repeated with the multi-launch path (same results, slower); 1 = device microseconds summed over the polled frames
- * (HIP events on the frame's stream: first kernel start to last copy end, so concurrent frames overlap); 2 = frames in that sum; 3 = host microseconds spent inside rd_detector_enqueue */
+ * (HIP events on the frame's stream: first kernel start to last copy end, so concurrent frames overlap); 2 = frames in that sum; 3 = host microseconds spent inside rd_detector_enqueue;
+ * 4 = frames whose region merge had not settled within the launched round budget and were repeated with all 20 rounds;
+ * 5 = the current round budget (8, 12, 16 or 20) */
 long rd_detector_counter(rd_detector *d, int which);
 
 /* Test hook: copy an internal plane of the most recently completed frame to host memory.  Returns bytes written,

@@ -268,6 +268,10 @@ class Detector:
         """frames whose polyline stage overflowed the single-launch kernel and was repeated the long way"""
         return lib().rd_detector_counter(self.h, 0)
 
+    def region_round_budget(self):
+        """(current region-merge round budget, frames repeated with the full budget because theirs was too small)"""
+        return lib().rd_detector_counter(self.h, 5), lib().rd_detector_counter(self.h, 4)
+
     def device_time(self):
         """(summed device microseconds of the polled frames measured with HIP events, number of frames)"""
         return lib().rd_detector_counter(self.h, 1), lib().rd_detector_counter(self.h, 2)

@@ -280,7 +280,9 @@ struct Slot {
   long seq;
   int ws;
   // captured launch sequences (three segments, see enqueue_frame) and the stride they were captured for
-  hipGraphExec_t gexec[3]; int graph_ws;
+  hipGraphExec_t gexec[3]; int graph_ws;   // gexec[2] unused: the last segment has one graph per round budget (gexec2)
+  hipGraphExec_t gexec2[4];
+  int rounds;                             // region-merge round budget of the frame in flight
   // post-process worker
   pthread_t th; pthread_mutex_t mu; pthread_cond_t cv;
   int state;              // 0 idle, 1 submitted to the GPU, 2 result ready
@@ -298,7 +300,8 @@ struct rd_detector {
   long next_enqueue, next_poll;
   int last_polled_slot;
   void *last_segs; int last_nsegs;
-  int use_graph, poly_mode, force_redo, diag_no_post, diag_skip, fork_poly; long n_redo;
+  int use_graph, poly_mode, force_redo, diag_no_post, diag_skip, fork_poly, fixed_rounds; long n_redo, n_redo_rounds;
+  int rounds_budget, need_hist[64]; unsigned need_pos; long budget_count[4];
   long host_enqueue_ns;      // wall time the caller spent inside rd_detector_enqueue
   long dev_us, dev_frames;   // sum over polled frames of (last kernel end - first kernel start) on the frame's stream, HIP events
   double tan_aov; int have_tan;    // what the workers use ahead of the poll that asks for the result
@@ -321,7 +324,7 @@ static void slot_alloc(rd_detector *d, Slot *s) {
   int **ip[] = { &s->i0, &s->i1, &s->mask0, &s->tidy, &s->label1, &s->strsum, &s->edge500, &s->strong, &s->junction, &s->mergemask, &s->region, &s->rsize,
                  &s->boundarysrc, &s->boundary, &s->lsid, &s->region0 };
   for (size_t i = 0; i < sizeof(ip) / sizeof(ip[0]); i++) *ip[i] = dnew<int>(N);
-  s->scratch2 = dnew<int>(N * 3 + 64);
+  s->scratch2 = dnew<int>(N * 3 + 256);
   s->table = dnew<int>(N * 4); s->claim = dnew<int>(N); s->tlist = dnew<int>(N);
   rdk::reduce_ls_init(s->st, s->table, s->claim, s->tlist, (int)(N * 4 / 5));
   s->e8 = dnew<int8_t>(N);
@@ -335,7 +338,8 @@ static void slot_alloc(rd_detector *d, Slot *s) {
   RD_HIP(hipHostMalloc(&s->h_bgr, N * 4, hipHostMallocDefault));
   RD_HIP(hipHostMalloc(&s->h_segs, (size_t)RD_MAXREC * 56, hipHostMallocDefault));
   RD_HIP(hipHostMalloc((void **)&s->h_probes, (size_t)RD_MAXREC * 15 * 6 * sizeof(int), hipHostMallocDefault));
-  RD_HIP(hipHostMalloc((void **)&s->h_ctr, 32 * sizeof(int), hipHostMallocDefault)); memset(s->h_ctr, 0, 32 * sizeof(int));
+  RD_HIP(hipHostMalloc((void **)&s->h_ctr, 64 * sizeof(int), hipHostMallocDefault)); memset(s->h_ctr, 0, 64 * sizeof(int));
+  s->rounds = 20;
   s->seq = -1;
 }
 
@@ -376,11 +380,28 @@ static void frame_votes(rd_detector *d, Slot *s) {
   RD_HIP(hipMemcpyAsync(s->h_segs, s->lslist, (size_t)ncopy * 56, hipMemcpyDeviceToHost, st));
   RD_HIP(hipMemcpyAsync(s->h_probes, s->probes, (size_t)ncopy * 15 * 6 * sizeof(int), hipMemcpyDeviceToHost, st));
   RD_HIP(hipMemcpyAsync(s->h_ctr, rdk::poly_scratch_counters(s->ps), 32 * sizeof(int), hipMemcpyDeviceToHost, st));
+  RD_HIP(hipMemcpyAsync(s->h_ctr + 32, s->scratch2 + (size_t)N, 20 * sizeof(int), hipMemcpyDeviceToHost, st));   // "round r changed something" flags of the region merge
 }
 
 static void frame_tail(rd_detector *d, Slot *s, int mode) {   // both, in order, on the slot's main stream (overflow redo)
   frame_polyline(d, s, s->st, mode);
   frame_votes(d, s);
+}
+
+// regions, their sizes, absorption of small ones, boundaries and boundary components (oclrect.c:325-342).  Reads planes that
+// nothing later in the frame modifies (quant, mergemask, label1, junction), so it can be repeated with a larger round budget.
+static void frame_regions(rd_detector *d, Slot *s) {
+  const int iw = d->iw, ih = d->ih, N = d->N;
+  hipStream_t st = s->st;
+  // regions (oclrect.c:325-336)
+  rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih, (d->diag_skip & 2) ? 0 : s->rounds);
+  RD_HIP(hipMemcpyAsync(s->rsize, s->junction, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));   // H2: sizes start from the junction counts
+  rdk::region_size(st, s->rsize, s->region0, N);
+  rdk::despeckle2(st, s->region, s->region0, s->scratch2 + (size_t)N + 64, s->rsize, 16, iw, ih);   // (behind the round flags, which travel to the host at the end)
+
+  // region boundaries and their components (oclrect.c:340-342)
+  rdk::mark_boundary(st, s->boundarysrc, s->region, iw, ih);
+  rdk::label8(st, s->boundary, s->boundarysrc, -1, iw, ih);
 }
 
 static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
@@ -442,15 +463,7 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   rdk::junction(st, s->junction, s->label1, 0, iw, ih);
   rdk::merge_mask(st, s->mergemask, s->scratch2, s->junction, iw, ih);
 
-  // regions (oclrect.c:325-336)
-  rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih, (d->diag_skip & 2) ? 0 : 20);
-  RD_HIP(hipMemcpyAsync(s->rsize, s->junction, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));   // H2: sizes start from the junction counts
-  rdk::region_size(st, s->rsize, s->region0, N);
-  rdk::despeckle2(st, s->region, s->region0, s->scratch2, s->rsize, 16, iw, ih);
-
-  // region boundaries and their components (oclrect.c:340-342)
-  rdk::mark_boundary(st, s->boundarysrc, s->region, iw, ih);
-  rdk::label8(st, s->boundary, s->boundarysrc, -1, iw, ih);
+  frame_regions(d, s);
 
   if (d->diag_skip & 64) for (int i = 0; i < 100; i++) rdk::clear_i(st, s->i1, 64);   // diagnostics: what does a launch cost?
   if (d->fork_poly) RD_HIP(hipStreamWaitEvent(st, s->ev_join, 0));
@@ -458,22 +471,31 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   frame_votes(d, s);
 }
 
+// region-merge round budgets a frame can be launched with; the rounds stop changing anything after ~10 on typical frames
+// and every launched round costs two dispatches even when it exits at once, so the budget follows what recent frames
+// needed (+ margin).  A frame whose last launched round still changed something is repeated with the full budget
+// (slot_postprocess), so the result never depends on the budget.
+static const int kRoundBudgets[4] = { 8, 12, 16, 20 };
+
 static void run_segment(rd_detector *d, Slot *s, int ws, int seg) {
   if (!d->use_graph) { frame_segment(d, s, ws, seg); return; }
-  if (!s->gexec[seg]) {
+  hipGraphExec_t *ge = &s->gexec[seg];
+  if (seg == 2) for (int k = 0; k < 4; k++) if (kRoundBudgets[k] == s->rounds) ge = &s->gexec2[k];
+  if (!*ge) {
     hipGraph_t g = NULL;
     RD_HIP(hipStreamBeginCapture(s->st, hipStreamCaptureModeThreadLocal));
     frame_segment(d, s, ws, seg);
     RD_HIP(hipStreamEndCapture(s->st, &g));
-    RD_HIP(hipGraphInstantiate(&s->gexec[seg], g, NULL, NULL, 0));
+    RD_HIP(hipGraphInstantiate(ge, g, NULL, NULL, 0));
     RD_HIP(hipGraphDestroy(g));
   }
-  RD_HIP(hipGraphLaunch(s->gexec[seg], s->st));
+  RD_HIP(hipGraphLaunch(*ge, s->st));
 }
 
 static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   if (d->use_graph && s->graph_ws != ws) {
     for (int k = 0; k < 3; k++) if (s->gexec[k]) { RD_HIP(hipGraphExecDestroy(s->gexec[k])); s->gexec[k] = NULL; }
+    for (int k = 0; k < 4; k++) if (s->gexec2[k]) { RD_HIP(hipGraphExecDestroy(s->gexec2[k])); s->gexec2[k] = NULL; }
     s->graph_ws = ws;
   }
   RD_HIP(hipEventRecord(s->ev_begin, s->st));
@@ -482,6 +504,8 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   run_segment(d, s, ws, 1);
   RD_HIP(hipEventRecord(s->ev_strong, s->st));
   d->last_strong = s->ev_strong; d->have_last_strong = 1;
+  s->rounds = d->fixed_rounds ? d->fixed_rounds : __atomic_load_n(&d->rounds_budget, __ATOMIC_RELAXED);
+  for (int k = 0; k < 4; k++) if (kRoundBudgets[k] == s->rounds) d->budget_count[k]++;
   run_segment(d, s, ws, 2);
   RD_HIP(hipEventRecord(s->ev_done, s->st));
   rdrt::check_launch("rect frame");
@@ -489,6 +513,26 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
 
 // host post-process of one finished slot (on the polling thread or on the slot's worker)
 static void *slot_postprocess(rd_detector *d, Slot *s, double tanAOV, void **segs_out, int *nsegs_out) {
+  if (s->rounds < 20 && s->h_ctr[32 + s->rounds - 1] != 0) {   // the region merge was still changing in its last launched round: repeat with the full budget
+    s->rounds = 20;
+    frame_regions(d, s);
+    frame_votes(d, s);
+    RD_HIP(hipStreamSynchronize(s->st));
+    __atomic_add_fetch(&d->n_redo_rounds, 1, __ATOMIC_RELAXED);
+  }
+  {   // budget for the frames to come: what the last 64 frames needed (first round without a change, + 1 to see that) + 2.
+      // (A long window on purpose: alternating between two budgets - two graph instances - was measured to cost 15 %.)
+    int need = 20;
+    for (int r = 0; r < 20; r++) if (s->h_ctr[32 + r] == 0) { need = r + 1; break; }
+    pthread_mutex_lock(&d->tan_mu);
+    d->need_hist[d->need_pos++ & 63] = need;
+    int mx = 0;
+    for (int k = 0; k < 64; k++) mx = d->need_hist[k] > mx ? d->need_hist[k] : mx;
+    int b = 20;
+    for (int k = 3; k >= 0; k--) if (d->need_pos >= 8 && kRoundBudgets[k] >= mx + 2) b = kRoundBudgets[k];
+    __atomic_store_n(&d->rounds_budget, b, __ATOMIC_RELAXED);
+    pthread_mutex_unlock(&d->tan_mu);
+  }
   if (s->h_ctr[25] != 0 || d->force_redo) {   // the single-launch polyline stage overflowed: repeat the tail the long way
     frame_tail(d, s, 0);
     RD_HIP(hipStreamSynchronize(s->st));
@@ -559,6 +603,13 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->force_redo = getenv("RD_POLY_FORCE_REDO") ? 1 : 0;
   d->diag_no_post = getenv("RD_DIAG_NO_POST") ? 1 : 0;
   d->fork_poly = getenv("RD_NO_FORK") ? 0 : 1;
+  // round budget of the region merge: 20 (all launched rounds, the default) or, with RD_REGION_ROUNDS_ADAPTIVE, what recent frames
+  // needed + margin (8/12/16/20; frames that needed more are repeated).  The adaptive mode saves 1-2 % when it settles, but a
+  // second graph instance per slot changes how the runtime spreads the streams over its hardware queues, and the unlucky
+  // assignments cost 15 % (measured: 1068 vs 894 frames/s from run to run) - so it stays opt-in.
+  d->fixed_rounds = getenv("RD_REGION_ROUNDS_ADAPTIVE") ? 0 : 20;
+  if (getenv("RD_REGION_ROUNDS_FIXED")) { const int r = atoi(getenv("RD_REGION_ROUNDS_FIXED")); d->fixed_rounds = (r == 8 || r == 12 || r == 16) ? r : 20; }
+  d->rounds_budget = 20;
   d->diag_skip = getenv("RD_DIAG_SKIP") ? atoi(getenv("RD_DIAG_SKIP")) : 0;   // timing diagnostics only: leaves stages out (wrong results)
   pthread_mutex_init(&d->tan_mu, NULL); pthread_cond_init(&d->tan_cv, NULL);
   d->slots = (Slot *)calloc((size_t)nslots, sizeof(Slot));
@@ -587,6 +638,7 @@ void rd_detector_destroy(rd_detector *d) {
     }
     free(s->result); free(s->res_segs);
     for (int k = 0; k < 3; k++) if (s->gexec[k]) RD_HIP(hipGraphExecDestroy(s->gexec[k]));
+    for (int k = 0; k < 4; k++) if (s->gexec2[k]) RD_HIP(hipGraphExecDestroy(s->gexec2[k]));
     slot_free(s);
   }
   free(d->slots);
@@ -661,6 +713,9 @@ void rd_detector_drain(rd_detector *d) {
 long rd_detector_counter(rd_detector *d, int which) {
   if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_counter: bad handle\n");
   if (which == 3) return d->host_enqueue_ns / 1000;
+  if (which == 4) return __atomic_load_n(&d->n_redo_rounds, __ATOMIC_RELAXED);
+  if (which == 5) return __atomic_load_n(&d->rounds_budget, __ATOMIC_RELAXED);
+  if (which >= 6 && which <= 9) return d->budget_count[which - 6];   // frames launched with a budget of 8 / 12 / 16 / 20 rounds
   if (which == 1) return d->dev_us;
   if (which == 2) return d->dev_frames;
   return which == 0 ? __atomic_load_n(&d->n_redo, __ATOMIC_RELAXED) : -1;

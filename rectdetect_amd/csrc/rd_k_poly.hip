@@ -1010,6 +1010,7 @@ PolyScratch *poly_scratch_create(int iw, int ih) {
   ps->segaux = dalloc<int>(2 * (N * 16 / 56 + 2));
   ps->live = dalloc<int>(N);
   (void)hipMemset(ps->ctr, 0, 64 * sizeof(int));
+  (void)hipStreamSynchronize(0);   // the fill is asynchronous and the callers' streams do not wait for the null stream
   return ps;
 }
 

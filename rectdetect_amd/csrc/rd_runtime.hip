@@ -161,7 +161,11 @@ cl_mem clCreateBuffer(cl_context c, cl_mem_flags flags, size_t size, void *host,
   } else {
     RD_HIP(hipMalloc(&m->dptr, size ? size : 1));
     if ((flags & (CL_MEM_COPY_HOST_PTR | CL_MEM_USE_HOST_PTR)) && host) RD_HIP(hipMemcpy(m->dptr, host, size, hipMemcpyHostToDevice));
-    else RD_HIP(hipMemset(m->dptr, 0, size));   // fresh buffers read as zero (the detector relies on it)
+    else {   // fresh buffers read as zero (the detector relies on it).  hipMemset is asynchronous for device memory and
+      // the queues are non-blocking streams: without the wait the fill could land after a kernel's first writes
+      RD_HIP(hipMemset(m->dptr, 0, size));
+      RD_HIP(hipStreamSynchronize(0));
+    }
   }
   if (err) *err = CL_SUCCESS;
   return m;

@@ -384,3 +384,40 @@ def test_smallest_frames(iw, ih):
         assert helpers.segments_equal(det.last_segments(), orc.segments())
     det.close()
     orc.close()
+
+
+@pytest.mark.parametrize("iw,ih,mode", [(640, 480, {"RD_REGION_ROUNDS_ADAPTIVE": "1"}), (1920, 1080, {"RD_REGION_ROUNDS_FIXED": "8"})])
+def test_region_round_budget_does_not_change_results(iw, ih, mode):
+    """opt-in modes launch fewer region-merge rounds per frame (adaptive: what recent frames needed; fixed: 8) and repeat
+    the frames that needed more with the full budget: results must equal those of the default (always all 20 rounds)"""
+    nframes = 12 if iw < 1000 else 4
+    frames = [synth.frame(synth.SEED0 + 9, iw, ih, t) for t in range(nframes)]
+    rng = np.random.default_rng(3)
+    tiles = rng.integers(0, 256, (ih // 8, iw // 8, 3), dtype=np.uint8)
+    frames.insert(nframes - 2, np.ascontiguousarray(np.repeat(np.repeat(tiles, 8, 0), 8, 1)))   # a very different frame inside the stream
+    out = []
+    for env in (mode, {}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        det = ra.Detector(iw, ih, nslots=2, nworkers=1)
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        res, infl = [], 0
+        for f in frames:
+            if infl == 2:
+                res.append((det.poll(TAN36), det.last_segments(), det.plane("region").copy()))
+                infl -= 1
+            det.enqueue(f)
+            infl += 1
+        while infl:
+            res.append((det.poll(TAN36), det.last_segments(), det.plane("region").copy()))
+            infl -= 1
+        print("env", env, "budget, repeated frames:", det.region_round_budget())
+        if not env:
+            assert det.region_round_budget()[1] == 0      # nothing is ever repeated with the full budget (the default)
+        if "RD_REGION_ROUNDS_FIXED" in env:
+            assert det.region_round_budget()[1] > 0       # 8 rounds are not enough at this size: the repeat path must have run
+        det.close()
+        out.append(res)
+    for (r0, s0, p0), (r1, s1, p1) in zip(*out):
+        assert np.array_equal(p0, p1) and helpers.rects_equal(r0, r1) and helpers.segments_equal(s0, s1)
