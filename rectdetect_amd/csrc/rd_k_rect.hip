@@ -353,18 +353,47 @@ __global__ void k_quantize(uint32_t *__restrict__ out, const uint32_t *__restric
   }
 }
 
-// rc:218-244: pixels with a non-zero NMS response take the colour of the Lab-nearest 3x3 neighbour without one
+// rc:218-244: pixels with a non-zero NMS response take the colour of the Lab-nearest 3x3 neighbour without one.
+// Such pixels are a few per cent, on thin lines that cross a third of all waves: every block first copies its 64 x DS_ROWS
+// tile and collects the affected pixels in an LDS list, then works the list off with all lanes busy.
+#define DS_ROWS 16
 __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, const uint32_t *__restrict__ in, const float *__restrict__ edge, int iw, int ih) {
-  RD_XY;
-  if (x >= iw || y >= ih) return;
-  const int p0 = y * iw + x;
-  uint32_t r = in[p0];
-  if (!(edge[p0] < 1e-6f)) {
+  __shared__ int list[64 * DS_ROWS];
+  __shared__ int nlist;
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+  if (tid == 0) nlist = 0;
+  __syncthreads();
+  const int x = blockIdx.x * 64 + tx;
+#pragma unroll
+  for (int r = ty; r < DS_ROWS; r += 4) {
+    const int y = blockIdx.y * DS_ROWS + r;
+    bool hot = false;
+    int p0 = 0;
+    if (x < iw && y < ih) {
+      p0 = y * iw + x;
+      hot = !(edge[p0] < 1e-6f);
+      if (!hot) out[p0] = in[p0];
+    }
+    const unsigned long long m = __ballot(hot);
+    if (m) {
+      const int leader = __ffsll((long long)m) - 1;
+      int o = 0;
+      if (tx == leader) o = atomicAdd(&nlist, __popcll(m));
+      o = __shfl(o, leader);
+      if (hot) list[o + __popcll(m & ((1ull << tx) - 1))] = p0;
+    }
+  }
+  __syncthreads();
+  const int n = nlist;
+  for (int j = tid; j < n; j += 256) {
+    const int p0 = list[j];
+    const int px = p0 % iw, py = p0 / iw;
+    uint32_t r = in[p0];
     float dist = 1e+10f, l0, a0, b0;
     unpack_lab(r, l0, a0, b0);
     for (int yy = -1; yy <= 1; yy++)
       for (int xx = -1; xx <= 1; xx++) {
-        if (x + xx < 0 || x + xx >= iw || y + yy < 0 || y + yy >= ih) continue;
+        if (px + xx < 0 || px + xx >= iw || py + yy < 0 || py + yy >= ih) continue;
         const int p1 = p0 + yy * iw + xx;
         if (edge[p1] >= 1e-6f) continue;
         float l1, a1, b1;
@@ -374,8 +403,8 @@ __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, c
         const float d = sqrtf(dx * dx + dy * dy + dz * dz);
         if (d < dist) { r = v; dist = d; }
       }
+    out[p0] = r;
   }
-  out[p0] = r;
 }
 
 // ------------------------------------------------------------------------------------------------ merge mask
@@ -732,21 +761,53 @@ __global__ __launch_bounds__(256) void k_despeckle2_sparse(int *__restrict__ nxt
 }
 
 // rc:373-390
+// One 64 x MB_ROWS tile (+2 cells of halo) per block, staged in LDS.  "Some cell of the 5x5 window differs from the centre" is
+// evaluated separably: hu[y][x] = the five cells x-2..x+2 of row y all equal (x, y); the window is uniform exactly when the
+// five cells of the centre column equal the centre and their rows are uniform.  A tile whose staged cells are all equal
+// (the inside of a large region: most tiles) skips everything.
+#define MB_ROWS 16
+#define MB_P 68
 __global__ __launch_bounds__(256) void k_mark_boundary(int *__restrict__ out, const int *__restrict__ in, int iw, int ih) {
-  RD_XY;
-  if (x >= iw || y >= ih) return;
-  const int p0 = y * iw + x;
-  int r = -1;
-  if (x > 1 && y > 1 && x < iw - 2 && y < ih - 2) {
-    const int c0 = in[p0];
-    bool near = false;
-#pragma unroll
-    for (int yy = -2; yy <= 2; yy++)
-#pragma unroll
-      for (int xx = -2; xx <= 2; xx++) near = near || (in[p0 + yy * iw + xx] != c0);
-    if (near) r = c0;
+  __shared__ int t[(MB_ROWS + 4) * MB_P];
+  __shared__ uint8_t hu[(MB_ROWS + 4) * 64];
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * MB_ROWS;
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+  const int v00 = in[y0 * iw + x0];
+  bool uniform = true;
+  for (int k = tid; k < (MB_ROWS + 4) * MB_P; k += 256) {
+    const int r = k / MB_P, c = k % MB_P;
+    const int xx = x0 - 2 + c, yy = y0 - 2 + r;
+    const bool inside = xx >= 0 && xx < iw && yy >= 0 && yy < ih;
+    const int v = inside ? in[yy * iw + xx] : 0;
+    uniform = uniform && (!inside || v == v00);
+    t[k] = v;
   }
-  out[p0] = r;
+  const int x = x0 + tx;
+  if (__syncthreads_and(uniform)) {
+    // no differing cell anywhere in reach: interior pixels are not boundary pixels (-1), and so is the 2-px frame ring by definition
+    for (int r = ty; r < MB_ROWS; r += 4) { const int y = y0 + r; if (x < iw && y < ih) out[y * iw + x] = -1; }
+    return;
+  }
+  for (int r = ty; r < MB_ROWS + 4; r += 4) {
+    const int *row = t + r * MB_P + tx + 2;
+    const int c = row[0];
+    hu[r * 64 + tx] = (row[-2] == c && row[-1] == c && row[1] == c && row[2] == c) ? 1 : 0;
+  }
+  __syncthreads();
+  if (x >= iw) return;
+  for (int r = ty; r < MB_ROWS; r += 4) {
+    const int y = y0 + r;
+    if (y >= ih) break;
+    int res = -1;
+    if (x > 1 && y > 1 && x < iw - 2 && y < ih - 2) {
+      const int c0 = t[(r + 2) * MB_P + tx + 2];
+      bool same = true;
+#pragma unroll
+      for (int dy = 0; dy < 5; dy++) same = same && t[(r + dy) * MB_P + tx + 2] == c0 && hu[(r + dy) * 64 + tx] != 0;
+      if (!same) res = c0;
+    }
+    out[y * iw + x] = res;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ voting
@@ -1020,7 +1081,7 @@ void quantize(hipStream_t s, uint32_t *out, const uint32_t *in, int n0, int n1, 
   hipLaunchKernelGGL(k_quantize, dim3(ew_grid(n)), dim3(256), 0, s, out, in, n0, n1, n2, n);
 }
 void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih) {
-  hipLaunchKernelGGL(k_despeckle, grid2(iw, ih), block2, 0, s, out, in, edge, iw, ih);
+  hipLaunchKernelGGL(k_despeckle, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS)), dim3(64, 4), 0, s, out, in, edge, iw, ih);
 }
 // scratch: ih * ceil(iw/64) * 2 64-bit words
 void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih) {
@@ -1069,7 +1130,7 @@ void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int 
 }
 
 void mark_boundary(hipStream_t s, int *out, const int *in, int iw, int ih) {
-  hipLaunchKernelGGL(k_mark_boundary, grid2(iw, ih), block2, 0, s, out, in, iw, ih);
+  hipLaunchKernelGGL(k_mark_boundary, dim3(cdiv(iw, 64), cdiv(ih, MB_ROWS)), dim3(64, 4), 0, s, out, in, iw, ih);
 }
 
 // table: nentry*5 ints, claim: nentry ints, tlist: nentry+1 ints; all three are set up once by reduce_ls_init and kept
