@@ -287,13 +287,14 @@ __global__ __launch_bounds__(64) void k_iir_verify(P3c fwd, P3c bwd, const float
 // sweep BIT FOR BIT is checked on the device: each block records the 7 outputs it computed just before entering its rows
 // ("warm") and its own last 7 outputs ("true"), k_iir_fused_verify compares neighbours, and on any difference the
 // full-length sweeps run instead (rdk::iir_blur_pass).  TOUT = 1 writes the result transposed (through the LDS tile).
-#define IF_ROWS 64
-#define IF_LROWS 72           // a short remainder (< 8 rows) is merged into the last block
+#define IF_ROWS_T 64          // rows per block, pass with transposed output (the transposing tail wants longer runs per column)
+#define IF_ROWS_N 32          // rows per block, plain pass (more, smaller blocks: LDS is what limits the waves per CU)
+                              // (a remainder of fewer than 8 rows is merged into the last block: LDS tile = rows + 8)
 #define IF_WU 32              // warm-up rows (24 sufficed on every plane tried on the CPU; the on-device check is what guarantees the result)
 #define IF_PITCH 65
-__host__ __device__ inline int if_nchunks(int H) {
-  int n = (H + IF_ROWS - 1) / IF_ROWS;
-  if (n > 1 && H % IF_ROWS != 0 && H % IF_ROWS < 8) n--;
+__host__ __device__ inline int if_nchunks(int H, int rows) {
+  int n = (H + rows - 1) / rows;
+  if (n > 1 && H % rows != 0 && H % rows < 8) n--;
   return n;
 }
 
@@ -305,9 +306,9 @@ __host__ __device__ inline int if_nchunks(int H) {
   i7 = i6; i6 = i5; i5 = i4; i4 = i3; i3 = i2; i2 = i1; i1 = (i0v);                                                    \
   t6 = t5; t5 = t4; t4 = t3; t3 = t2; t2 = t1; t1 = t0; t0 = d;
 
-template <int TOUT>
+template <int TOUT, int IF_ROWS>
 __global__ __launch_bounds__(64) void k_iir_fused(P3 dst, P3c src, float *__restrict__ tails, int W, int H, int nchunks) {
-  __shared__ float fwt[IF_LROWS * IF_PITCH];
+  __shared__ float fwt[(IF_ROWS + 8) * IF_PITCH];
   const int lane = threadIdx.x;
   const int x = blockIdx.x * 64 + lane;
   const int k = blockIdx.y, c = blockIdx.z;
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(64) void k_iir_fused(P3 dst, P3c src, float *__rest
 }
 
 // the state a block reached after its warm-up must equal, bit for bit, what its neighbour computed for the same rows
-__global__ __launch_bounds__(64) void k_iir_fused_verify(const float *__restrict__ tails, int *bad, int W, int H, int nchunks) {
+__global__ __launch_bounds__(64) void k_iir_fused_verify(const float *__restrict__ tails, int *bad, int W, int H, int nchunks, int IF_ROWS) {
   const int x = blockIdx.x * 64 + threadIdx.x;
   const int k = blockIdx.y, c = blockIdx.z;
   if (x >= W) return;
@@ -402,16 +403,6 @@ __global__ __launch_bounds__(64) void k_iir_fused_verify(const float *__restrict
 }
 
 // iu:629-637: vertical result = anti-causal + causal - c0 * (horizontal result)
-// vertical result of the three planes, re-packed at once (iu:580-589 + iu:325-331); the blurred L plane is also kept as floats
-__global__ void k_iir_combine_pack(uint32_t *__restrict__ plab, float *__restrict__ Lout, P3c fwd, P3c bwd, P3c src, int n) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float v[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) v[k] = bwd.p[k][i] + fwd.p[k][i] - src.p[k][i] * IIR_C0;
-    Lout[i] = v[0];
-    plab[i] = pack_lab(v[0], v[1], v[2]);
-  }
-}
 __global__ void k_iir_combine(P3 dst, P3c fwd, P3c bwd, P3c src, int np, int n, const int *only_if) {
   if (only_if && *only_if == 0) return;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
@@ -549,9 +540,6 @@ __global__ void k_threshold_f(float *__restrict__ out, const float *__restrict__
 }
 __global__ void k_threshold_i(int *__restrict__ out, const int *__restrict__ in, int lo, int thr, int hi, int n) {
   ew4(n, [=](int i) { return in[i]; }, [=](int i, int v) { out[i] = v > thr ? hi : lo; });
-}
-__global__ void k_threshold_i2(int *__restrict__ out, int *__restrict__ out2, const int *__restrict__ in, int lo, int thr, int hi, int n) {
-  ew4(n, [=](int i) { return in[i]; }, [=](int i, int v) { const int r = v > thr ? hi : lo; out[i] = r; out2[i] = r; });
 }
 __global__ void k_cast_i_f(int *__restrict__ out, const float *__restrict__ in, float scale, int n) {
   ew4(n, [=](int i) { return in[i]; }, [=](int i, float v) { out[i] = (int)(v * scale); });
@@ -707,10 +695,6 @@ void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], 
   P3c z = { { nullptr, nullptr, nullptr } };
   hipLaunchKernelGGL(k_transpose<0>, dim3(cdiv(W, 64), cdiv(H, 64)), block2, 0, s, mk3(dst, np), mk3c(src, np), z, z, (const uint32_t *)nullptr, np, W, H, (const int *)nullptr);
 }
-void transpose_unpack(hipStream_t s, float *const dst[3], const uint32_t *plab, int W, int H) {
-  P3c z = { { nullptr, nullptr, nullptr } };
-  hipLaunchKernelGGL(k_transpose<1>, dim3(cdiv(W, 64), cdiv(H, 64)), block2, 0, s, mk3(dst, 3), z, z, z, plab, 3, W, H, (const int *)nullptr);
-}
 size_t iir_scratch_floats(int np, int W, int H) { return (size_t)np * 2 * cdiv(H + IIR_WARM + 1, IIR_CHUNK) * 7 * W; }
 
 void iir_columns(hipStream_t s, float *const fwd[3], float *const bwd[3], const float *const src[3], int np, int W, int H, float *tails, int *bad) {
@@ -730,22 +714,20 @@ void iir_combine_transpose(hipStream_t s, float *const dst[3], const float *cons
 void iir_combine(hipStream_t s, float *const dst[3], const float *const fwd[3], const float *const bwd[3], const float *const src[3], int np, int n) {
   hipLaunchKernelGGL(k_iir_combine, dim3(ew_grid(n)), dim3(256), 0, s, mk3(dst, np), mk3c(fwd, np), mk3c(bwd, np), mk3c(src, np), np, n, (const int *)nullptr);
 }
-void iir_combine_pack(hipStream_t s, uint32_t *plab, float *Lout, const float *const fwd[3], const float *const bwd[3], const float *const src[3], int n) {
-  hipLaunchKernelGGL(k_iir_combine_pack, dim3(ew_grid(n)), dim3(256), 0, s, plab, Lout, mk3c(fwd, 3), mk3c(bwd, 3), mk3c(src, 3), n);
-}
-size_t iir_pass_scratch_floats(int np, int W, int H) { return (size_t)np * if_nchunks(H) * 4 * 7 * W; }
+size_t iir_pass_scratch_floats(int np, int W, int H) { return (size_t)np * if_nchunks(H, IF_ROWS_N) * 4 * 7 * W; }   // (the finer blocking bounds both)
 
 // one blur pass (both sweeps + combination) down the columns of np planes (W columns, H rows); transpose_out: dst planes
 // are H wide, W tall.  fwd/bwd: scratch planes, only touched when the on-device check of the blocked evaluation fails
 // (*bad != 0) and the full-length sweeps have to run; tails: iir_pass_scratch_floats() floats; *bad must be 0 on entry.
 void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3], float *const fwd[3], float *const bwd[3], int np, int W, int H,
                    int transpose_out, float *tails, int *bad) {
-  const int nchunks = if_nchunks(H);
+  const int rows = transpose_out ? IF_ROWS_T : IF_ROWS_N;
+  const int nchunks = if_nchunks(H, rows);
   const dim3 grid(cdiv(W, 64), np, nchunks);
-  if (transpose_out) hipLaunchKernelGGL(k_iir_fused<1>, grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks);
-  else hipLaunchKernelGGL(k_iir_fused<0>, grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks);
+  if (transpose_out) hipLaunchKernelGGL((k_iir_fused<1, IF_ROWS_T>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks);
+  else hipLaunchKernelGGL((k_iir_fused<0, IF_ROWS_N>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks);
   if (nchunks > 1) {
-    hipLaunchKernelGGL(k_iir_fused_verify, grid, dim3(64), 0, s, (const float *)tails, bad, W, H, nchunks);
+    hipLaunchKernelGGL(k_iir_fused_verify, grid, dim3(64), 0, s, (const float *)tails, bad, W, H, nchunks, rows);
     // fallback (skipped on the device unless the check failed)
     const float *f[3] = { fwd[0], np > 1 ? fwd[1] : nullptr, np > 2 ? fwd[2] : nullptr }, *b[3] = { bwd[0], np > 1 ? bwd[1] : nullptr, np > 2 ? bwd[2] : nullptr };
     hipLaunchKernelGGL(k_iir_columns, dim3(cdiv(W, 64), np * 2), dim3(64), 0, s, mk3(fwd, np), mk3(bwd, np), mk3c(src, np), W, H, (const int *)bad);
@@ -783,9 +765,6 @@ void thinthres(hipStream_t s, float *out, const float *in, const float *vxy, int
 }
 void threshold_f(hipStream_t s, float *out, const float *in, float lo, float thr, float hi, int n) {
   hipLaunchKernelGGL(k_threshold_f, dim3(ew_grid(n)), dim3(256), 0, s, out, in, lo, thr, hi, n);
-}
-void threshold_i2(hipStream_t s, int *out, int *out2, const int *in, int lo, int thr, int hi, int n) {
-  hipLaunchKernelGGL(k_threshold_i2, dim3(ew_grid(n)), dim3(256), 0, s, out, out2, in, lo, thr, hi, n);
 }
 void threshold_i(hipStream_t s, int *out, const int *in, int lo, int thr, int hi, int n) {
   hipLaunchKernelGGL(k_threshold_i, dim3(ew_grid(n)), dim3(256), 0, s, out, in, lo, thr, hi, n);

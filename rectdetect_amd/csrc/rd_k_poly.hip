@@ -27,77 +27,14 @@ struct ls_rec { float x0, y0, x1, y1; int startIndex, endIndex, leftPtr, rightPt
 struct lsx_rec { long long mx00, mx01, mx11, my0, my1; short dx, dy, vx, vy; int d2, pad; };
 
 // ------------------------------------------------------------------------------------------------ dense tidy
-// pl:66-87 junction counts (`!= 0`)
-__global__ __launch_bounds__(256) void k_junction_nz(int *__restrict__ out, const int *__restrict__ in, int iw, int ih) {
-  RD_XY;
-  if (x >= iw || y >= ih) return;
-  const int p = y * iw + x;
-  int r = 0;
-  if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && in[p] != 0) {
-    int count = 1;
-#pragma unroll
-    for (int i = 0; i < 8; i++) if (in[p + nbr_dx(i) + nbr_dy(i) * iw] != 0) count++;
-    r = count == 1 ? 0 : count;
-  }
-  out[p] = r;
-}
-
-// pl:89-110: 1-px gaps between two curve ends are bridged (8 strict patterns).  The kernel of the reference does not
-// write the 2-px frame ring of its output plane, so the ring keeps the plane's previous content: here it
-// is taken from ring_src (the caller's plane) or, when that is null, set to ring_const.
-__global__ __launch_bounds__(256) void k_connect_poly(int *__restrict__ out, const int *__restrict__ in, const int *__restrict__ ring_src, int ring_const, int iw, int ih) {
-  RD_XY;
-  if (x >= iw || y >= ih) return;
-  const int p = y * iw + x;
-  int o;
-  if (x <= 1 || y <= 1 || x >= iw - 2 || y >= ih - 2) {
-    o = ring_src ? ring_src[p] : ring_const;
-  } else if (in[p] != 0) {
-    o = 1;
-  } else {
-    o = 0;
-    const int W = iw;
-    if (in[p - 2] != 0 && in[p - 1] == 2 && in[p + 1] == 2 && in[p + 2] != 0) o = 1;
-    if (in[p - W * 2] != 0 && in[p - W] == 2 && in[p + W] == 2 && in[p + W * 2] != 0) o = 1;
-    if (in[p - W * 2 - 2] != 0 && in[p - W - 1] == 2 && in[p + W + 1] == 2 && in[p + W * 2 + 2] != 0) o = 1;
-    if (in[p - W * 2 + 2] != 0 && in[p - W + 1] == 2 && in[p + W - 1] == 2 && in[p + W * 2 - 2] != 0) o = 1;
-    if (in[p + 2] != 0 && in[p + 1] == 2 && in[p + W - 1] == 2 && in[p + W - 2] != 0) o = 1;
-    if (in[p - 2] != 0 && in[p - 1] == 2 && in[p + W + 1] == 2 && in[p + W + 2] != 0) o = 1;
-    if (in[p - W * 2 + 1] != 0 && in[p - W + 1] == 2 && in[p + W] == 2 && in[p + W * 2] != 0) o = 1;
-    if (in[p - W * 2 - 1] != 0 && in[p - W - 1] == 2 && in[p + W] == 2 && in[p + W * 2] != 0) o = 1;
-  }
-  out[p] = o;
-}
-
-// pl:112-124
-__global__ __launch_bounds__(256) void k_stringify_p(int *__restrict__ out, const int *__restrict__ in, int mod2, int iw, int ih) {
-  RD_XY;
-  if (x >= iw || y >= ih) return;
-  const int p = y * iw + x;
-  int v = in[p];
-  if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && ((x + y) & 1) == mod2) {
-    const bool up = in[p - iw] != 0, dn = in[p + iw] != 0, lf = in[p - 1] != 0, rt = in[p + 1] != 0;
-    if ((up || dn) && (lf || rt)) v = 0;
-  }
-  out[p] = v;
-}
-
-// pl:126-147: keep on-pixels with at most two on-neighbours (cuts the curves at junctions)
-__global__ __launch_bounds__(256) void k_remove_branch(int *__restrict__ out, const int *__restrict__ in, int iw, int ih) {
-  RD_XY;
-  if (x >= iw || y >= ih) return;
-  const int p = y * iw + x;
-  int r = 0;
-  if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && in[p] != 0) {
-    int count = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) if (in[p + nbr_dx(i) + nbr_dy(i) * iw] != 0) count++;
-    r = count <= 2 ? 1 : 0;
-  }
-  out[p] = r;
-}
-
-// the five tidy stencils above for one 64 x PT_ROWS tile in LDS (6 cells of halo in total; after the bridging step only
+// Five stencils of the reference in one tile kernel:
+//   pl:66-87   junction counts (`!= 0`): on-pixels of the 3x3 block, isolated pixels -> 0, frame border 0
+//   pl:89-110  1-px gaps between two curve ends are bridged (8 strict patterns).  The kernel of the reference does not
+//              write the 2-px frame ring of its output plane, so the ring keeps the plane's previous content (SURVEY.md
+//              H3): here it is taken from ring_src (the caller's plane) or, when that is null, set to ring_const
+//   pl:112-124 checkerboard thinning, parity 0 then parity 1
+//   pl:126-147 keep on-pixels with at most two on-neighbours (cuts the curves at junctions)
+// one 64 x PT_ROWS tile per block, in LDS (6 cells of halo in total; after the bridging step only
 // "zero / non-zero" matters, so every intermediate is a byte)
 #define PT_ROWS 16
 #define PT_M 6
@@ -125,7 +62,7 @@ __global__ __launch_bounds__(256) void k_poly_tidy(int *__restrict__ out, const 
     B[i] = v;
   }
   __syncthreads();
-  PT_FOR(3) {   // pl:89-110 (ring: see k_connect_poly)
+  PT_FOR(3) {   // pl:89-110
     PT_CELL(3);
     uint8_t o = 0;
     if (in_img) {

@@ -39,46 +39,6 @@ __global__ __launch_bounds__(256) void k_junction(int *__restrict__ out, const i
   out[p] = r;
 }
 
-// rc:97-121: on-pixels stay, 1-px gaps next to a curve end (count == 2) are closed by ten patterns; 2-px ring -> 0
-__global__ __launch_bounds__(256) void k_connect_rect(int *__restrict__ out, const int *__restrict__ in, int iw, int ih) {
-  RD_XY;
-  if (x >= iw || y >= ih) return;
-  const int p = y * iw + x;
-  int o = 0;
-  if (x > 1 && y > 1 && x < iw - 2 && y < ih - 2) {
-    if (in[p] != 0) o = 1;
-    else {
-      const int w = in[p - 1], e = in[p + 1], n = in[p - iw], s = in[p + iw];
-      const int nw = in[p - iw - 1], ne = in[p - iw + 1], sw = in[p + iw - 1], se = in[p + iw + 1];
-      if (w == 2 && e != 0) o = 1;
-      if (w != 0 && e == 2) o = 1;
-      if (n == 2 && s != 0) o = 1;
-      if (n != 0 && s == 2) o = 1;
-      if (nw == 2 && se == 2) o = 1;
-      if (ne == 2 && sw == 2) o = 1;
-      if (e == 2 && sw == 2) o = 1;
-      if (w == 2 && se == 2) o = 1;
-      if (ne == 2 && s == 2) o = 1;
-      if (nw == 2 && s == 2) o = 1;
-    }
-  }
-  out[p] = o;
-}
-
-// rc:123-135 == pl:112-124: checkerboard thinning - a pixel of parity mod2 with an orthogonal L-shaped pair of
-// on-neighbours is removed; everything else (including the frame border) is copied
-__global__ __launch_bounds__(256) void k_stringify(int *__restrict__ out, const int *__restrict__ in, int mod2, int iw, int ih) {
-  RD_XY;
-  if (x >= iw || y >= ih) return;
-  const int p = y * iw + x;
-  int v = in[p];
-  if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && ((x + y) & 1) == mod2) {
-    const bool up = in[p - iw] != 0, dn = in[p + iw] != 0, lf = in[p - 1] != 0, rt = in[p + 1] != 0;
-    if ((up || dn) && (lf || rt)) v = 0;
-  }
-  out[p] = v;
-}
-
 // mask (NMS response > 0, rh:262-264) -> junction counts -> gap closing -> two thinning passes (rh:266-272) for one
 // 64 x TD_ROWS tile in LDS: the four 3x3 stencils need 4 cells of halo in total, every intermediate is a byte.
 #define TD_ROWS 16
@@ -113,7 +73,7 @@ __global__ __launch_bounds__(256) void k_rect_tidy(int *__restrict__ mask0, int 
     B[i] = v;
   }
   __syncthreads();
-  TD_FOR(2) {   // rc:97-121
+  TD_FOR(2) {   // rc:97-121: on-pixels stay, 1-px gaps next to a curve end (count == 2) are closed by ten patterns; 2-px ring -> 0
     TD_CELL(2);
     uint8_t o = 0;
     if (in_img && x > 1 && y > 1 && x < iw - 2 && y < ih - 2) {
@@ -128,7 +88,7 @@ __global__ __launch_bounds__(256) void k_rect_tidy(int *__restrict__ mask0, int 
     A[i] = o;
   }
   __syncthreads();
-  TD_FOR(1) {   // rc:123-135, parity 0
+  TD_FOR(1) {   // rc:123-135: checkerboard thinning - a pixel of this parity with an orthogonal L-shaped pair of on-neighbours goes; parity 0
     TD_CELL(1);
     uint8_t v = in_img ? A[i] : 0;
     if (in_img && x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && ((x + y) & 1) == 0) {
@@ -672,9 +632,15 @@ __global__ __launch_bounds__(256) void k_region_size(int *out, const int *__rest
   for (int i = threadIdx.x; i < RS_T; i += 256) { keys[i] = -1; vals[i] = 0; }
   __syncthreads();
   const int begin = blockIdx.x * 256 * RS_PER_THREAD;
-  for (int k = 0; k < RS_PER_THREAD; k++) {
+  int lks[RS_PER_THREAD];
+#pragma unroll
+  for (int k = 0; k < RS_PER_THREAD; k++) {     // all loads first: one block per CU would otherwise wait for them one by one
     const int i = begin + k * 256 + threadIdx.x;
-    const int lk = i < n ? label[i] : -1;
+    lks[k] = i < n ? label[i] : -1;
+  }
+#pragma unroll
+  for (int k = 0; k < RS_PER_THREAD; k++) {
+    const int lk = lks[k];
     const int l0 = __shfl(lk, 0);
     if (__all(lk == l0)) {          // the usual case: the whole wave lies inside one region
       if ((threadIdx.x & 63) == 0 && l0 != -1) rs_accum(keys, vals, out, l0, 64);
@@ -1060,12 +1026,6 @@ void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int i
 }
 void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, int ih) {
   hipLaunchKernelGGL(k_rect_tidy, dim3(cdiv(iw, 64), cdiv(ih, TD_ROWS)), dim3(64, 4), 0, s, mask0, tidy, nms, iw, ih);
-}
-void connect_rect(hipStream_t s, int *out, const int *in, int iw, int ih) {
-  hipLaunchKernelGGL(k_connect_rect, grid2(iw, ih), block2, 0, s, out, in, iw, ih);
-}
-void stringify(hipStream_t s, int *out, const int *in, int mod2, int iw, int ih) {
-  hipLaunchKernelGGL(k_stringify, grid2(iw, ih), block2, 0, s, out, in, mod2, iw, ih);
 }
 void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih) {
   hipLaunchKernelGGL(k_blblur_extents, dim3(cdiv(iw, 64), cdiv(ih, BE_ROWS)), dim3(64, 4), 0, s, ext, edge, iw, ih);

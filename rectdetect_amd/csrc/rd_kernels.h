@@ -10,13 +10,10 @@ namespace rdk {
 void bgr2plab(hipStream_t s, uint32_t *out, const uint8_t *bgr, int iw, int ih, int ws);
 // colour conversion that also leaves the unpacked L, a, b planes transposed (ih wide, iw tall) for the first blur sweep
 void bgr2plab_transposed(hipStream_t s, uint32_t *out, float *const dst[3], const uint8_t *bgr, int iw, int ih, int ws);
-// plab = pack(bwd + fwd - src * c0) over the three planes, Lout = the L plane of that
-void iir_combine_pack(hipStream_t s, uint32_t *plab, float *Lout, const float *const fwd[3], const float *const bwd[3], const float *const src[3], int n);
 void unpack_plab(hipStream_t s, float *L, float *a, float *b, const uint32_t *in, int n);
 void pack_plab(hipStream_t s, uint32_t *out, const float *L, const float *a, const float *b, int n);
 // transposes of `np` float planes (src planes W x H row-major -> dst planes H x W); src may be packed Lab (np = 3)
 void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], int np, int W, int H);
-void transpose_unpack(hipStream_t s, float *const dst[3], const uint32_t *plab, int W, int H);
 // causal + anti-causal sigma=1 IIR sweeps down the columns of np planes (W columns, H rows): fwd[k], bwd[k] <- src[k]
 // tails/bad: scratch for the chunked evaluation (iir_scratch_floats() floats, one int that must be 0 on entry and stays 0
 // unless a chunk failed its verification); pass nullptr for plain full-length sweeps
@@ -58,10 +55,8 @@ void strong_mask(hipStream_t s, int *out, int *out2, const int *label, const int
 
 // ---- rd_k_rect.hip: rect-path stages
 void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih);
-void connect_rect(hipStream_t s, int *out, const int *in, int iw, int ih);
-// mask0 = (nms > 0), tidy = stringify(stringify(connect_rect(junction(mask0)), 0), 1) in one launch
+// mask0 = (nms > 0), tidy = thin(thin(close_gaps(junction(mask0)), parity 0), parity 1) in one launch (oclrect.cl:74-135)
 void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, int ih);
-void stringify(hipStream_t s, int *out, const int *in, int mod2, int iw, int ih);
 // run extents of the edge-stopped blur (depend on the edge mask only): ext[p] = nl_h | nr_h<<3 | nl_v<<6 | nr_v<<9
 void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih);
 void blblur(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int vertical, int iw, int ih);
@@ -90,6 +85,5 @@ void polyline(hipStream_t s, PolyScratch *ps, void *lslist, int lslist_bytes, in
               float minerror, int sizeThre, int iw, int ih, int mode);
 // ids may be null (the dense id plane is then not produced); polyline_ids() materialises it later from the compact state
 void polyline_ids(hipStream_t s, PolyScratch *ps, int *ids, int n);
-void threshold_i2(hipStream_t s, int *out, int *out2, const int *in, int lo, int thr, int hi, int n);   // mode 0: always complete; 1: single persistent launch for the split/refine part, may set counter 25 (overflow: repeat with mode 0)
 
 }  // namespace rdk
