@@ -263,7 +263,7 @@ cl_event oclpolyline_execute(oclpolyline_t *thiz, cl_mem lsList, int lsListSize,
 struct Slot {
   hipStream_t st;
   hipStream_t st2;                        // second stream of the slot: polyline stage, parallel to the region stages
-  hipEvent_t ev_fork, ev_join;
+  hipEvent_t ev_fork, ev_mm, ev_join;
   hipEvent_t ev_begin, ev_done, ev_strong;   // ev_begin/ev_done carry timestamps: device time of the frame (rd_detector_counter)
   uint8_t *bgr;
   uint32_t *plab0, *plab1, *smooth, *quant;
@@ -314,6 +314,7 @@ static void slot_alloc(rd_detector *d, Slot *s) {
   RD_HIP(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
   RD_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   RD_HIP(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
+  RD_HIP(hipEventCreateWithFlags(&s->ev_mm, hipEventDisableTiming));
   RD_HIP(hipEventCreate(&s->ev_begin));
   RD_HIP(hipEventCreate(&s->ev_done));
   RD_HIP(hipEventCreateWithFlags(&s->ev_strong, hipEventDisableTiming));
@@ -352,7 +353,7 @@ static void slot_free(Slot *s) {
   rdk::poly_scratch_destroy(s->ps);
   RD_HIP(hipHostFree(s->h_bgr)); RD_HIP(hipHostFree(s->h_segs)); RD_HIP(hipHostFree(s->h_probes)); RD_HIP(hipHostFree(s->h_ctr));
   RD_HIP(hipEventDestroy(s->ev_begin)); RD_HIP(hipEventDestroy(s->ev_done)); RD_HIP(hipEventDestroy(s->ev_strong));
-  RD_HIP(hipEventDestroy(s->ev_fork)); RD_HIP(hipEventDestroy(s->ev_join));
+  RD_HIP(hipEventDestroy(s->ev_fork)); RD_HIP(hipEventDestroy(s->ev_mm)); RD_HIP(hipEventDestroy(s->ev_join));
   RD_HIP(hipStreamDestroy(s->st2));
   RD_HIP(hipStreamDestroy(s->st));
 }
@@ -437,19 +438,23 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   rdk::strong_mask(st, s->strong, d->prev_strong, s->label1, s->strsum, 2500, iw, ih);
   return;
   }
-  // the polyline stage needs nothing but the strong mask: it runs on the slot's second stream, beside the blur / region
-  // stages, and joins before the votes (inside a captured graph this becomes a parallel branch)
-  if (d->fork_poly) {
+  // Three chains leave this point and meet again before the region stage / the votes:
+  //   main stream: edge mask at 500 -> edge-stopped blur x20 -> quantise -> despeckle          (oclrect.c:277-303)
+  //   2nd stream : labels filtered at 2500 -> junction counts -> merge mask                  (oclrect.c:307-321)
+  //                then the polyline stage, which needs nothing but the strong mask          (oclrect.c:361)
+  // Filtering once at 2500 equals filtering at 500 and then at 2500; the mask at 500 is derived from the unfiltered labels
+  // (k_edge_mask) before the second stream may touch them.  Inside a captured graph the streams become parallel branches.
+  rdk::edge_mask(st, s->edge500, s->e8, s->label1, s->strsum, 500, iw, ih);
+  if (d->fork_poly) {      // (RD_NO_FORK: everything on the main stream, blur chain first)
     RD_HIP(hipEventRecord(s->ev_fork, st));
     RD_HIP(hipStreamWaitEvent(s->st2, s->ev_fork, 0));
+    rdk::filter_strength(s->st2, s->label1, s->strsum, 2500, iw, ih);
+    rdk::junction(s->st2, s->junction, s->label1, 0, iw, ih);
+    rdk::merge_mask(s->st2, s->mergemask, s->scratch2, s->junction, iw, ih);
+    RD_HIP(hipEventRecord(s->ev_mm, s->st2));
     if (!(d->diag_skip & 4)) frame_polyline(d, s, s->st2, d->poly_mode);
     RD_HIP(hipEventRecord(s->ev_join, s->st2));
   }
-
-  // filter at 500 (oclrect.c:277-284)
-  rdk::filter_strength(st, s->label1, s->strsum, 500, iw, ih);
-  rdk::threshold_i(st, s->edge500, s->label1, 0, 0, 1, N);
-  rdk::cast_c_i(st, s->e8, s->edge500, N);
 
   // edge-preserving smoothing x10, quantise, despeckle (oclrect.c:286-303)
   rdk::blblur_extents(st, s->ext, s->e8, iw, ih);
@@ -458,10 +463,12 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   rdk::quantize(st, (uint32_t *)s->i0, s->smooth, 24, 24, 24, N);
   rdk::despeckle(st, s->quant, (const uint32_t *)s->i0, s->nms, iw, ih);
 
-  // labels of the strong edges, junction counts, merge mask (oclrect.c:307-321)
-  rdk::filter_strength(st, s->label1, s->strsum, 2500, iw, ih);
-  rdk::junction(st, s->junction, s->label1, 0, iw, ih);
-  rdk::merge_mask(st, s->mergemask, s->scratch2, s->junction, iw, ih);
+  if (d->fork_poly) RD_HIP(hipStreamWaitEvent(st, s->ev_mm, 0));
+  else {
+    rdk::filter_strength(st, s->label1, s->strsum, 2500, iw, ih);
+    rdk::junction(st, s->junction, s->label1, 0, iw, ih);
+    rdk::merge_mask(st, s->mergemask, s->scratch2, s->junction, iw, ih);
+  }
 
   frame_regions(d, s);
 

@@ -230,6 +230,18 @@ __global__ __launch_bounds__(256) void k_strong_mask(int *__restrict__ out, int 
   out[p] = v; out2[p] = v;
 }
 
+// Edge mask at one threshold, as int and as int8, from the unfiltered labels: what k_filter_strength + `label > 0` + the
+// int -> int8 cast (oclrect.c:277-284) produce, without touching the label plane (which a parallel branch filters at 2500).
+__global__ __launch_bounds__(256) void k_edge_mask(int *__restrict__ out, int8_t *__restrict__ out8, const int *__restrict__ label, const int *__restrict__ str, int thre, int iw, int ih) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= iw || y >= ih) return;
+  const int p = y * iw + x;
+  const int l = label[p];
+  int v = l > 0 ? 1 : 0;
+  if (v && x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && str[l] < thre) v = 0;
+  out[p] = v; out8[p] = (int8_t)v;
+}
+
 }  // namespace
 
 namespace rdk {
@@ -250,6 +262,10 @@ void calc_strength(hipStream_t s, int *out, const float *edge, const int *label,
 
 void strong_mask(hipStream_t s, int *out, int *out2, const int *label, const int *str, int thre, int iw, int ih) {
   hipLaunchKernelGGL(k_strong_mask, grid2(iw, ih), block2, 0, s, out, out2, label, str, thre, iw, ih);
+}
+
+void edge_mask(hipStream_t s, int *out, int8_t *out8, const int *label, const int *str, int thre, int iw, int ih) {
+  hipLaunchKernelGGL(k_edge_mask, grid2(iw, ih), block2, 0, s, out, out8, label, str, thre, iw, ih);
 }
 
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih) {

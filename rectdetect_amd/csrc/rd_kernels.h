@@ -51,6 +51,8 @@ void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih);
 void calc_strength(hipStream_t s, int *out, const float *edge, const int *label, int iw, int ih);
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih);
 // out = out2 = (label > 0 after filter_strength at thresholds <= thre ... thre), from the UNFILTERED labels
+// out / out8 = (label > 0 after filter_strength at thre), as int and int8, from the unfiltered labels
+void edge_mask(hipStream_t s, int *out, int8_t *out8, const int *label, const int *str, int thre, int iw, int ih);
 void strong_mask(hipStream_t s, int *out, int *out2, const int *label, const int *str, int thre, int iw, int ih);
 
 // ---- rd_k_rect.hip: rect-path stages
