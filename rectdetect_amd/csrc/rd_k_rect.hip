@@ -785,30 +785,29 @@ __device__ __forceinline__ unsigned ls_slot(int id, int bid, int nentry) { retur
 
 // sparse: one thread per chain pixel left by the polyline stage (raster-ordered compact list, so the compact index orders
 // pixels like the pixel index does)
-// the distinct boundary ids (> 0) inside a 7x7 window and how often each occurs, in registers; a window with more than
-// RB_MAX of them (rare) reports overflow and is processed touch by touch instead
-#define RB_MAX 6
-__device__ __forceinline__ bool rb_collect(const int (&win)[49], int (&bs)[RB_MAX], int (&cnt)[RB_MAX], int &n) {
-  bool overflow = false;
-  n = 0;
+// The RB_MAX smallest distinct boundary ids greater than `floor` inside a 7x7 window, ascending, in registers (unused
+// entries 0x7fffffff); returns whether larger ids remain.  Callers loop: windows with more ids than fit (rare) simply take
+// another pass with floor = the largest id of the previous one, so every pass issues its dependent loads together.
+#define RB_MAX 8
+#define RB_NONE 0x7fffffff
+__device__ __forceinline__ bool rb_collect(const int (&win)[49], int floor, int (&bs)[RB_MAX]) {
+  bool more = false;
 #pragma unroll
-  for (int q = 0; q < RB_MAX; q++) { bs[q] = 0; cnt[q] = 0; }
+  for (int q = 0; q < RB_MAX; q++) bs[q] = RB_NONE;
 #pragma unroll
   for (int k = 0; k < 49; k++) {
     const int b = win[k];
-    if (b <= 0) continue;
-    bool found = false;
+    if (b <= floor) continue;
+    bool present = false;
 #pragma unroll
-    for (int q = 0; q < RB_MAX; q++) if (bs[q] == b) { cnt[q]++; found = true; }
-    if (!found) {
-      if (n < RB_MAX) {
+    for (int q = 0; q < RB_MAX; q++) present = present || bs[q] == b;
+    if (present) continue;
+    int v = b;
 #pragma unroll
-        for (int q = 0; q < RB_MAX; q++) if (q == n) { bs[q] = b; cnt[q] = 1; }
-        n++;
-      } else overflow = true;
-    }
+    for (int q = 0; q < RB_MAX; q++) { const int t = bs[q]; if (v < t) { bs[q] = v; v = t; } }   // sorted insert; v ends up as what fell off
+    more = more || v != RB_NONE;
   }
-  return overflow;
+  return more;
 }
 
 // slots that receive their first claim are appended to `tlist` (tlist[0] = count) so that the next frame can undo exactly
@@ -836,7 +835,7 @@ __global__ __launch_bounds__(1024) void k_reduce_clean(int *table, int *claim, i
   if (threadIdx.x == 0) tlist[0] = 0;
 }
 
-__global__ void k_reduce_claim(int *claim, int *tlist, const int *__restrict__ boundary, rdk::PolyScratch s, int iw, int ih, int nentry) {
+__global__ __launch_bounds__(256) void k_reduce_claim(int *claim, int *tlist, const int *__restrict__ boundary, rdk::PolyScratch s, int iw, int ih, int nentry) {
   const int nlive = s.ctr[24];
   const int stride = gridDim.x * blockDim.x;
   for (int j0 = blockIdx.x * blockDim.x; j0 < nlive; j0 += stride) {    // whole waves iterate together (ballots inside)
@@ -851,33 +850,28 @@ __global__ void k_reduce_claim(int *claim, int *tlist, const int *__restrict__ b
       const int xx = x + k % 7 - 3, yy = y + k / 7 - 3;
       win[k] = (act && xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? boundary[yy * iw + xx] : 0;
     }
-    int bs[RB_MAX], cnt[RB_MAX], nb;
-    if (!rb_collect(win, bs, cnt, nb)) {
+    int floor = 0;
+    bool more = true;
+    while (__any(more)) {               // one pass for all but a few pixels
+      int bs[RB_MAX];
+      const bool again = more && rb_collect(win, floor, bs);
       unsigned slot[RB_MAX];
       int cur[RB_MAX];
 #pragma unroll
-      for (int q = 0; q < RB_MAX; q++) { slot[q] = ls_slot(id, bs[q], nentry); cur[q] = ld_agent(&claim[slot[q]]); }   // independent loads
+      for (int q = 0; q < RB_MAX; q++) { slot[q] = ls_slot(id, bs[q] == RB_NONE ? 0 : bs[q], nentry); cur[q] = ld_agent(&claim[slot[q]]); }   // independent loads
 #pragma unroll
       for (int q = 0; q < RB_MAX; q++) {
         bool first = false;
-        if (q < nb && i < cur[q]) first = atomicMin(&claim[slot[q]], i) == 0x7f7f7f7f;
+        if (more && bs[q] != RB_NONE && i < cur[q]) first = atomicMin(&claim[slot[q]], i) == 0x7f7f7f7f;
         tlist_append(tlist, first, slot[q]);
       }
-    } else {
-      int lastb = 0;
-#pragma unroll
-      for (int k = 0; k < 49; k++) {
-        const int b = win[k];
-        if (b <= 0 || b == lastb) continue;      // the slot depends on (id, b) only
-        lastb = b;
-        const unsigned slot = ls_slot(id, b, nentry);
-        if (i < ld_agent(&claim[slot]) && atomicMin(&claim[slot], i) == 0x7f7f7f7f) tlist[1 + atomicAdd(&tlist[0], 1)] = (int)slot;
-      }
+      floor = bs[RB_MAX - 1];
+      more = again;
     }
   }
 }
 
-__global__ void k_reduce_box(int *table, const int *__restrict__ claim, const int *__restrict__ boundary, rdk::PolyScratch s, int iw, int ih, int nentry) {
+__global__ __launch_bounds__(256) void k_reduce_box(int *table, const int *__restrict__ claim, const int *__restrict__ boundary, rdk::PolyScratch s, int iw, int ih, int nentry) {
   const int nlive = s.ctr[24];
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nlive; j += gridDim.x * blockDim.x) {
     const int i = s.live[j];
@@ -890,84 +884,48 @@ __global__ void k_reduce_box(int *table, const int *__restrict__ claim, const in
       const int xx = x + k % 7 - 3, yy = y + k / 7 - 3;
       win[k] = (xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? boundary[yy * iw + xx] : 0;
     }
-    int bs[RB_MAX], cnt[RB_MAX], nb;
-    if (!rb_collect(win, bs, cnt, nb)) {
-      // per distinct slot: the claiming pixel's first touch only claims (rc:449-456), every other touch widens the box;
-      // max is idempotent, so "widen once if the slot's owner carries our id and we touched it often enough" is the same
+    // Per distinct slot: the claiming pixel's first touch only claims (rc:449-456), every other touch widens the box; max
+    // is idempotent, so "widen once if the slot's owner carries our id and we touched it often enough" is the same.
+    int floor = 0;
+    bool more = true;
+    while (more) {
+      int bs[RB_MAX];
+      more = rb_collect(win, floor, bs);
       unsigned slot[RB_MAX];
       int owner[RB_MAX], oid[RB_MAX];
 #pragma unroll
-      for (int q = 0; q < RB_MAX; q++) { slot[q] = ls_slot(id, bs[q], nentry); owner[q] = claim[slot[q]]; }
+      for (int q = 0; q < RB_MAX; q++) { slot[q] = ls_slot(id, bs[q] == RB_NONE ? 0 : bs[q], nentry); owner[q] = claim[slot[q]]; }
 #pragma unroll
-      for (int q = 0; q < RB_MAX; q++) oid[q] = (q < nb) ? s.id[owner[q]] : -1;
+      for (int q = 0; q < RB_MAX; q++) oid[q] = (bs[q] != RB_NONE) ? s.id[owner[q]] : -1;
+      unsigned wide = 0;
 #pragma unroll
       for (int q = 0; q < RB_MAX; q++) {
-        if (q >= nb || oid[q] != id) continue;
+        if (bs[q] == RB_NONE || oid[q] != id) continue;
         if (owner[q] == i) {
+          // we hold the claim (rare): count our touches of this slot through any boundary id
           int touches = 0;
-#pragma unroll
-          for (int q2 = 0; q2 < RB_MAX; q2++) if (q2 < nb && slot[q2] == slot[q]) touches += cnt[q2];
+          for (int k = 0; k < 49; k++) touches += (win[k] > 0 && ls_slot(id, win[k], nentry) == slot[q]);
           if (touches < 2) continue;
         }
+        wide |= 1u << q;
+      }
+      // the current box values of all slots to widen are requested together (they only guard the atomics against no-ops)
+      int c1[RB_MAX], c2[RB_MAX], c3[RB_MAX], c4[RB_MAX];
+#pragma unroll
+      for (int q = 0; q < RB_MAX; q++) {
+        const int *e = table + (size_t)slot[q] * 5;
+        c1[q] = ld_agent(&e[1]); c2[q] = ld_agent(&e[2]); c3[q] = ld_agent(&e[3]); c4[q] = ld_agent(&e[4]);   // (unused slots map to entry 0: a valid address)
+      }
+#pragma unroll
+      for (int q = 0; q < RB_MAX; q++) {
+        if (!((wide >> q) & 1)) continue;
         int *e = table + (size_t)slot[q] * 5;
-        if (iw - x > ld_agent(&e[1])) atomicMax(&e[1], iw - x);
-        if (x > ld_agent(&e[2])) atomicMax(&e[2], x);
-        if (ih - y > ld_agent(&e[3])) atomicMax(&e[3], ih - y);
-        if (y > ld_agent(&e[4])) atomicMax(&e[4], y);
+        if (iw - x > c1[q]) atomicMax(&e[1], iw - x);
+        if (x > c2[q]) atomicMax(&e[2], x);
+        if (ih - y > c3[q]) atomicMax(&e[3], ih - y);
+        if (y > c4[q]) atomicMax(&e[4], y);
       }
-      continue;
-    }
-    // state for the boundary id of the previous touch: the slot, whether its owner carries our segment id, whether we
-    // are the claiming pixel and still owe the "first touch only claims" skip (rc:449-456), whether we already widened it
-    int lastb = 0;
-    unsigned slot = 0;
-    bool ok = false, skip_first = false, done = false;
-    unsigned cons[4] = {0, 0, 0, 0};
-    int ncons = 0;
-#pragma unroll
-    for (int k = 0; k < 49; k++) {
-      const int b = win[k];
-      if (b <= 0) continue;
-      if (b != lastb) {
-        lastb = b;
-        slot = ls_slot(id, b, nentry);
-        const int owner = claim[slot];
-        ok = s.id[owner] == id;
-        done = false;
-        skip_first = false;
-        if (ok && owner == i) {
-          // claiming pixel (rare): was there an earlier touch of this slot, through any boundary id, in this window?
-          // Every such touch came through here, so a short register list of the slots already met answers it; a 7x7
-          // window holding more than 4 slots claimed by its own centre falls back to rescanning the window.
-          bool earlier = false;
-#pragma unroll
-          for (int q = 0; q < 4; q++) earlier |= (q < ncons && cons[q] == slot);
-          if (!earlier) {
-            if (ncons < 4) {
-#pragma unroll
-              for (int q = 0; q < 4; q++) if (q == ncons) cons[q] = slot;
-              ncons++;
-            } else {
-              for (int k2 = 0; k2 < k && !earlier; k2++) {
-                const int xx = x + k2 % 7 - 3, yy = y + k2 / 7 - 3;
-                if (xx < 0 || xx >= iw || yy < 0 || yy >= ih) continue;
-                const int b2 = boundary[yy * iw + xx];
-                if (b2 > 0 && ls_slot(id, b2, nentry) == slot) earlier = true;
-              }
-            }
-          }
-          skip_first = !earlier;
-        }
-      }
-      if (!ok) continue;
-      if (skip_first) { skip_first = false; continue; }
-      if (done) continue;               // max is idempotent: one widening per run of touches is enough
-      done = true;
-      int *e = table + (size_t)slot * 5;
-      if (iw - x > ld_agent(&e[1])) atomicMax(&e[1], iw - x);
-      if (x > ld_agent(&e[2])) atomicMax(&e[2], x);
-      if (ih - y > ld_agent(&e[3])) atomicMax(&e[3], ih - y);
-      if (y > ld_agent(&e[4])) atomicMax(&e[4], y);
+      floor = bs[RB_MAX - 1];
     }
   }
 }
