@@ -89,3 +89,11 @@ def test_product_does_not_reference_the_oracle():
     assert not bad, bad
     out = subprocess.check_output(["ldd", ra.LIB_PATH], text=True)
     assert "oracle" not in out and "rdref" not in out
+
+
+def test_example_programs_build_against_the_headers():
+    """examples/rdrect.c and rdvid.c are written against include/*.h only (the reference's API) and link with the library"""
+    import subprocess
+    subprocess.check_call(["make", "-C", os.path.join(helpers.ROOT, "examples")], stdout=subprocess.DEVNULL)
+    for exe in ("rdrect", "rdvid"):
+        assert os.access(os.path.join(helpers.ROOT, "examples", exe), os.X_OK)

@@ -421,3 +421,56 @@ def test_region_round_budget_does_not_change_results(iw, ih, mode):
         out.append(res)
     for (r0, s0, p0), (r1, s1, p1) in zip(*out):
         assert np.array_equal(p0, p1) and helpers.rects_equal(r0, r1) and helpers.segments_equal(s0, s1)
+
+
+def _write_png(path, rgb):
+    """8-bit RGB PNG with scanline filter 2 (Up) on every row but the first: exercises the example reader's unfiltering"""
+    import struct
+    ih, iw, _ = rgb.shape
+    raw = bytearray()
+    prev = np.zeros((iw, 3), np.uint8)
+    for y in range(ih):
+        row = rgb[y]
+        if y == 0:
+            raw += b"\x00" + row.tobytes()
+        else:
+            raw += b"\x02" + (row.astype(np.int16) - prev.astype(np.int16)).astype(np.uint8).tobytes()
+        prev = row
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", iw, ih, 8, 2, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(raw))) + chunk(b"IEND", b""))
+
+
+def test_example_program_on_ppm_and_png(tmp_path):
+    """examples/rdrect (C, reference API only, no OpenCV) on a PPM and on a PNG of a synthetic frame: same rectangles as the
+    Python front end at the same aperture (text output has 3 decimals)"""
+    import re
+    import subprocess
+    iw, ih = 640, 480
+    img = synth.frame(synth.SEED0 + 5, iw, ih, 1)
+    rgb = np.ascontiguousarray(img[:, :, ::-1])
+    ppm = tmp_path / "f.ppm"
+    with open(ppm, "wb") as f:
+        f.write(b"P6\n# comment line\n%d %d\n255\n" % (iw, ih) + rgb.tobytes())
+    png = tmp_path / "f.png"
+    _write_png(png, rgb)
+    det = ra.Detector(iw, ih, nslots=1)
+    det.enqueue(img)
+    want = det.poll(float(np.tan(36.0 / 180.0 * np.pi)))
+    det.close()
+    exe = os.path.join(helpers.ROOT, "examples", "rdrect")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(helpers.ROOT, "examples")], stdout=subprocess.DEVNULL)
+    for src in (ppm, png):
+        out = subprocess.run([exe, str(src), "0", str(tmp_path / "out.ppm")], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        lines = [l for l in out.stdout.splitlines() if l.startswith("status")]
+        assert len(lines) == len(want)
+        for l, w in zip(lines, want):
+            nums = [float(v) for v in re.findall(r"-?\d+\.\d+", l.split("corners")[1])]
+            assert int(l.split()[1]) == int(w["status"])
+            assert np.allclose(np.array(nums).reshape(4, 2), w["c2"], atol=1e-3)
+        assert os.path.getsize(tmp_path / "out.ppm") > iw * ih * 3
