@@ -95,5 +95,5 @@ def test_example_programs_build_against_the_headers():
     """examples/rdrect.c and rdvid.c are written against include/*.h only (the reference's API) and link with the library"""
     import subprocess
     subprocess.check_call(["make", "-C", os.path.join(helpers.ROOT, "examples")], stdout=subprocess.DEVNULL)
-    for exe in ("rdrect", "rdvid"):
+    for exe in ("rdrect", "rdvid", "rdpoly"):
         assert os.access(os.path.join(helpers.ROOT, "examples", exe), os.X_OK)

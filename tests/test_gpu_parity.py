@@ -474,3 +474,26 @@ def test_example_program_on_ppm_and_png(tmp_path):
             assert int(l.split()[1]) == int(w["status"])
             assert np.allclose(np.array(nums).reshape(4, 2), w["c2"], atol=1e-3)
         assert os.path.getsize(tmp_path / "out.ppm") > iw * ih * 3
+
+
+def test_polyline_example_program_matches_operator_api(ctx, tmp_path):
+    """examples/rdpoly (C; the operator sequence of BASELINE.json configs[0]) on a PNG: same valid segments as the Python
+    front end's poly_frame() and as the reference's golden segment list for this frame"""
+    import re
+    import subprocess
+    iw, ih = 640, 480
+    img = synth.frame(synth.SEED0, iw, ih, 0)
+    png = tmp_path / "f.png"
+    _write_png(png, np.ascontiguousarray(img[:, :, ::-1]))
+    segs, _ = ra.poly_frame(ctx, img)
+    g = golden("poly_640x480_s0")
+    assert helpers.segments_equal(segs, g["segments"])
+    exe = os.path.join(helpers.ROOT, "examples", "rdpoly")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(helpers.ROOT, "examples")], stdout=subprocess.DEVNULL)
+    out = subprocess.run([exe, str(png), "0", str(tmp_path / "out.ppm")], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    got = [[float(v) for v in re.findall(r"-?\d+\.\d+", l)] for l in out.stdout.splitlines() if l.startswith("segment ")]
+    want = [[s["x0"], s["y0"], s["x1"], s["y1"]] for s in segs[1:] if s["polyid"] != 0]
+    assert len(got) == len(want) > 0
+    assert np.allclose(np.array(got), np.array(want, dtype=np.float64), atol=1e-3)
