@@ -281,8 +281,10 @@ struct Slot {
   int ws;
   // captured launch sequences (three segments, see enqueue_frame) and the stride they were captured for
   hipGraphExec_t gexec[3]; int graph_ws;   // gexec[2] unused: the last segment has one graph per round budget (gexec2)
-  hipGraphExec_t gexec2[4];
+  hipGraphExec_t gexec2[8];                // [round budget index][polyline mode]
+  int poly_mode;                           // polyline mode of the frame in flight (1 = single launch, 0 = multi-launch)
   int rounds;                             // region-merge round budget of the frame in flight
+  int overflow_streak;
   // post-process worker
   pthread_t th; pthread_mutex_t mu; pthread_cond_t cv;
   int state;              // 0 idle, 1 submitted to the GPU, 2 result ready
@@ -301,6 +303,7 @@ struct rd_detector {
   int last_polled_slot;
   void *last_segs; int last_nsegs;
   int use_graph, poly_mode, force_redo, diag_no_post, diag_skip, fork_poly, fixed_rounds; long n_redo, n_redo_rounds;
+  int poly_overflows;                     // set once two frames in a row overflowed the single-launch polyline kernel: later frames go multi-launch
   int rounds_budget, need_hist[64]; unsigned need_pos; long budget_count[4];
   long host_enqueue_ns;      // wall time the caller spent inside rd_detector_enqueue
   long dev_us, dev_frames;   // sum over polled frames of (last kernel end - first kernel start) on the frame's stream, HIP events
@@ -452,7 +455,7 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
     rdk::junction(s->st2, s->junction, s->label1, 0, iw, ih);
     rdk::merge_mask(s->st2, s->mergemask, s->scratch2, s->junction, iw, ih);
     RD_HIP(hipEventRecord(s->ev_mm, s->st2));
-    if (!(d->diag_skip & 4)) frame_polyline(d, s, s->st2, d->poly_mode);
+    if (!(d->diag_skip & 4)) frame_polyline(d, s, s->st2, s->poly_mode);
     RD_HIP(hipEventRecord(s->ev_join, s->st2));
   }
 
@@ -474,7 +477,7 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
 
   if (d->diag_skip & 64) for (int i = 0; i < 100; i++) rdk::clear_i(st, s->i1, 64);   // diagnostics: what does a launch cost?
   if (d->fork_poly) RD_HIP(hipStreamWaitEvent(st, s->ev_join, 0));
-  else if (!(d->diag_skip & 4)) frame_polyline(d, s, st, d->poly_mode);
+  else if (!(d->diag_skip & 4)) frame_polyline(d, s, st, s->poly_mode);
   frame_votes(d, s);
 }
 
@@ -487,7 +490,7 @@ static const int kRoundBudgets[4] = { 8, 12, 16, 20 };
 static void run_segment(rd_detector *d, Slot *s, int ws, int seg) {
   if (!d->use_graph) { frame_segment(d, s, ws, seg); return; }
   hipGraphExec_t *ge = &s->gexec[seg];
-  if (seg == 2) for (int k = 0; k < 4; k++) if (kRoundBudgets[k] == s->rounds) ge = &s->gexec2[k];
+  if (seg == 2) for (int k = 0; k < 4; k++) if (kRoundBudgets[k] == s->rounds) ge = &s->gexec2[k * 2 + (s->poly_mode ? 1 : 0)];
   if (!*ge) {
     hipGraph_t g = NULL;
     RD_HIP(hipStreamBeginCapture(s->st, hipStreamCaptureModeThreadLocal));
@@ -502,7 +505,7 @@ static void run_segment(rd_detector *d, Slot *s, int ws, int seg) {
 static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   if (d->use_graph && s->graph_ws != ws) {
     for (int k = 0; k < 3; k++) if (s->gexec[k]) { RD_HIP(hipGraphExecDestroy(s->gexec[k])); s->gexec[k] = NULL; }
-    for (int k = 0; k < 4; k++) if (s->gexec2[k]) { RD_HIP(hipGraphExecDestroy(s->gexec2[k])); s->gexec2[k] = NULL; }
+    for (int k = 0; k < 8; k++) if (s->gexec2[k]) { RD_HIP(hipGraphExecDestroy(s->gexec2[k])); s->gexec2[k] = NULL; }
     s->graph_ws = ws;
   }
   RD_HIP(hipEventRecord(s->ev_begin, s->st));
@@ -512,6 +515,7 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   RD_HIP(hipEventRecord(s->ev_strong, s->st));
   d->last_strong = s->ev_strong; d->have_last_strong = 1;
   s->rounds = d->fixed_rounds ? d->fixed_rounds : __atomic_load_n(&d->rounds_budget, __ATOMIC_RELAXED);
+  s->poly_mode = (d->poly_mode && !__atomic_load_n(&d->poly_overflows, __ATOMIC_RELAXED)) ? 1 : 0;
   for (int k = 0; k < 4; k++) if (kRoundBudgets[k] == s->rounds) d->budget_count[k]++;
   run_segment(d, s, ws, 2);
   RD_HIP(hipEventRecord(s->ev_done, s->st));
@@ -540,7 +544,9 @@ static void *slot_postprocess(rd_detector *d, Slot *s, double tanAOV, void **seg
     __atomic_store_n(&d->rounds_budget, b, __ATOMIC_RELAXED);
     pthread_mutex_unlock(&d->tan_mu);
   }
-  if (s->h_ctr[25] != 0 || d->force_redo) {   // the single-launch polyline stage overflowed: repeat the tail the long way
+  if (s->poly_mode && s->h_ctr[25] != 0 && ++s->overflow_streak >= 2) __atomic_store_n(&d->poly_overflows, 1, __ATOMIC_RELAXED);   // this stream's frames do not fit the single-launch kernel (e.g. 4K): stop trying
+  if (s->poly_mode && s->h_ctr[25] == 0) s->overflow_streak = 0;
+  if ((s->poly_mode && s->h_ctr[25] != 0) || d->force_redo) {   // the single-launch polyline stage overflowed: repeat the tail the long way
     frame_tail(d, s, 0);
     RD_HIP(hipStreamSynchronize(s->st));
     __atomic_add_fetch(&d->n_redo, 1, __ATOMIC_RELAXED);
@@ -645,7 +651,7 @@ void rd_detector_destroy(rd_detector *d) {
     }
     free(s->result); free(s->res_segs);
     for (int k = 0; k < 3; k++) if (s->gexec[k]) RD_HIP(hipGraphExecDestroy(s->gexec[k]));
-    for (int k = 0; k < 4; k++) if (s->gexec2[k]) RD_HIP(hipGraphExecDestroy(s->gexec2[k]));
+    for (int k = 0; k < 8; k++) if (s->gexec2[k]) RD_HIP(hipGraphExecDestroy(s->gexec2[k]));
     slot_free(s);
   }
   free(d->slots);

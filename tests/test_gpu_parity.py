@@ -308,7 +308,8 @@ def test_polyline_single_launch_equals_multilaunch(iw, ih, seed):
 
 def test_polyline_overflow_takes_fallback_and_matches_oracle():
     """a frame with far more chains than the single-launch kernel's on-chip tables hold: the overflow flag must come
-    back, the stage is repeated with the multi-launch path, and the segments still equal the oracle's"""
+    back, the stage is repeated with the multi-launch path, and the segments still equal the oracle's; after two such
+    frames in a row the detector stops trying the single-launch kernel for this stream"""
     iw, ih = 1280, 720
     rng = np.random.default_rng(77)
     tiles = rng.integers(0, 256, (ih // 16, iw // 16, 3), dtype=np.uint8)
@@ -319,9 +320,17 @@ def test_polyline_overflow_takes_fallback_and_matches_oracle():
     det.poll(TAN36)
     orc.frame(img)
     ctr = det.plane("polyctr", np.int32, 64)
-    print("overflow frame: live pixels", int(ctr[24]), "chains", int(ctr[1]), "segments", int(det.last_segments()[0]["x0"].view(np.int32)) if False else "", "redone", det.redone_frames())
+    print("overflow frame: live pixels", int(ctr[24]), "chains", int(ctr[1]), "redone", det.redone_frames())
     assert det.redone_frames() == 1
     assert helpers.segments_equal(det.last_segments(), orc.segments())
+    first = det.last_segments()
+    for k in range(4):          # (same frame again: H1 makes frame 2 differ from frame 1, so compare frames 2.. among the two objects)
+        det.enqueue(img)
+        det.poll(TAN36)
+        orc.frame(img)
+        assert helpers.segments_equal(det.last_segments(), orc.segments())
+    assert det.redone_frames() == 2          # the second overflow in a row made the multi-launch path the default
+    assert len(first) > 1024                 # more records than the single-launch kernel holds
     det.close()
     orc.close()
 
