@@ -28,16 +28,18 @@ template <typename T> static T *dnew(size_t n) { void *p = NULL; RD_HIP(hipMallo
 static void dfree(void *p) { if (p) RD_HIP(hipFree(p)); }
 
 // ================================================================================================ oclimgutil
-struct ImgutilImpl { int N; float *s[3]; float *tails; int *flags; };
+struct ImgutilImpl { int N; size_t ntails; float *s[3]; float *tails; int *flags; };
 
-static void imgutil_scratch(oclimgutil_t *t, int N) {
+static void imgutil_scratch(oclimgutil_t *t, int iw, int ih) {
   ImgutilImpl *im = (ImgutilImpl *)t->impl;
-  if (im->N >= N) return;
+  const int N = iw * ih;
+  const size_t a = rdk::iir_pass_scratch_floats(1, ih, iw), b = rdk::iir_pass_scratch_floats(1, iw, ih), nt = a > b ? a : b;
+  if (im->N >= N && im->ntails >= nt) return;
   for (int k = 0; k < 3; k++) { dfree(im->s[k]); im->s[k] = dnew<float>((size_t)N); }
   dfree(im->tails); dfree(im->flags);
-  im->tails = dnew<float>((size_t)N);   // >= iir_scratch_floats(1, ., .) for any frame with both sides >= 64
+  im->tails = dnew<float>(nt);
   im->flags = dnew<int>(16);
-  im->N = N;
+  im->N = N; im->ntails = nt;
 }
 
 extern "C" {
@@ -117,27 +119,23 @@ cl_event oclimgutil_pack_plab_f_f_f(oclimgutil_t *thiz, cl_mem out, cl_mem in0, 
   IU_END("oclimgutil_pack_plab_f_f_f");
 }
 
-// oclimgutil.c:248-273.  obuf = vertical(horizontal(ibuf)); tmp0 / tmp1 end up holding the causal / anti-causal
-// vertical sweeps like in the reference.  Only r = 2 (sigma 1) is implemented - the only radius any caller uses.
+// oclimgutil.c:248-273.  obuf = vertical(horizontal(ibuf)); tmp0 / tmp1 are scratch (only written when the blocked
+// evaluation fails its on-device check).  Only r = 2 (sigma 1) is implemented - the only radius any caller uses.
 cl_event oclimgutil_iirblur_f_f(oclimgutil_t *thiz, cl_mem obuf, cl_mem ibuf, cl_mem tmp0, cl_mem tmp1, int r, int iw, int ih, cl_command_queue queue, const cl_event *events) {
   IU_BEGIN("oclimgutil_iirblur_f_f");
   if (r != 2) exitf(-1, "oclimgutil_iirblur_f_f: only r = 2 (sigma = 1) is implemented in this build, got r = %d\n", r);
-  imgutil_scratch(thiz, iw * ih);
+  imgutil_scratch(thiz, iw, ih);
   ImgutilImpl *im = (ImgutilImpl *)thiz->impl;
   float *o = (float *)dptr(obuf), *t0 = (float *)dptr(tmp0), *t1 = (float *)dptr(tmp1);
   const float *in = (const float *)dptr(ibuf);
   float *d1[3] = { im->s[0], NULL, NULL }; const float *s1[3] = { in, NULL, NULL };
   rdk::transpose_f(s, d1, s1, 1, iw, ih);                                   // s0 = in^T (ih wide)
-  float *f[3] = { im->s[1], NULL, NULL }, *b[3] = { im->s[2], NULL, NULL }; const float *c[3] = { im->s[0], NULL, NULL };
-  const bool chunked = rdk::iir_scratch_floats(1, ih, iw) <= (size_t)iw * ih && rdk::iir_scratch_floats(1, iw, ih) <= (size_t)iw * ih;
-  if (chunked) RD_HIP(hipMemsetAsync(im->flags, 0, 16 * sizeof(int), s));
-  rdk::iir_columns(s, f, b, c, 1, ih, iw, chunked ? im->tails : NULL, chunked ? im->flags : NULL);   // sweeps along x of the original
-  float *oo[3] = { o, NULL, NULL }; const float *fc[3] = { im->s[1], NULL, NULL }, *bc[3] = { im->s[2], NULL, NULL };
-  rdk::iir_combine_transpose(s, oo, fc, bc, c, 1, ih, iw);                  // o = horizontal result, original layout
-  float *f2[3] = { t0, NULL, NULL }, *b2[3] = { t1, NULL, NULL }; const float *c2[3] = { o, NULL, NULL };
-  rdk::iir_columns(s, f2, b2, c2, 1, iw, ih, chunked ? im->tails : NULL, chunked ? im->flags + 1 : NULL);
-  const float *f2c[3] = { t0, NULL, NULL }, *b2c[3] = { t1, NULL, NULL };
-  rdk::iir_combine(s, oo, f2c, b2c, c2, 1, iw * ih);
+  RD_HIP(hipMemsetAsync(im->flags, 0, 16 * sizeof(int), s));
+  float *fw[3] = { t0, NULL, NULL }, *bw[3] = { t1, NULL, NULL };
+  { float *dst[3] = { im->s[1], NULL, NULL }; const float *src[3] = { im->s[0], NULL, NULL };
+    rdk::iir_blur_pass(s, dst, src, fw, bw, 1, ih, iw, 1, im->tails, im->flags); }       // along x; s1 = horizontal result, original layout
+  { float *dst[3] = { o, NULL, NULL }; const float *src[3] = { im->s[1], NULL, NULL };
+    rdk::iir_blur_pass(s, dst, src, fw, bw, 1, iw, ih, 0, im->tails, im->flags + 1); }   // along y
   IU_END("oclimgutil_iirblur_f_f");
 }
 

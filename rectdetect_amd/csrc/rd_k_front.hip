@@ -214,75 +214,9 @@ __global__ __launch_bounds__(64) void k_iir_columns(P3 fwd, P3 bwd, P3c src, int
   }
 }
 
-// Chunked sweeps.  The feedback taps are small (c8 = 0.25, the rest below 0.01), so the recurrence forgets its state
-// within a few dozen steps: a sweep restarted IIR_WU steps early from zero state reproduces the full sweep BIT FOR BIT
-// (measured with the oracle: no differing sample on 14k chunk boundaries even with a 16-step warm-up).  Each lane
-// therefore runs only IIR_WU + IIR_CHUNK steps, and a sweep of ~2000 steps becomes ~15 independent chunks.  Exactness is
-// not assumed: every chunk stores the 7 outputs it computed just before its first real step (the complete recurrence
-// state together with the inputs) and k_iir_verify compares them with the neighbouring chunk's real outputs; on any
-// mismatch the flag makes k_iir_columns redo the whole launch serially.
-#define IIR_CHUNK 128
-#define IIR_WU 48
-
-__global__ __launch_bounds__(64) void k_iir_chunked(P3 fwd, P3 bwd, P3c src, float *__restrict__ tails, int W, int H, int nchunks) {
-  const int x = blockIdx.x * 64 + threadIdx.x;
-  const int kd = blockIdx.y, k = kd >> 1, dir = kd & 1, c = blockIdx.z;
-  if (x >= W) return;
-  const float *__restrict__ in = src.p[k] + x;
-  float *__restrict__ out = (dir ? bwd.p[k] : fwd.p[k]) + x;
-  float *__restrict__ tl = tails + ((size_t)(kd * nchunks + c) * 7) * W + x;
-  const int y0 = dir ? H + IIR_WARM : -IIR_WARM, step = dir ? -1 : 1;
-  const int count = H + IIR_WARM + dir;
-  const int c0 = c * IIR_CHUNK;
-  const int begin = c == 0 ? 0 : c0 - IIR_WU;
-  const int end = c0 + IIR_CHUNK < count ? c0 + IIR_CHUNK : count;
-  const int ylo = -IIR_WARM, yhi = H + IIR_WARM;
-  float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
-  float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
-  float cur[IIR_CH], nxt[IIR_CH];
-#pragma unroll
-  for (int j = 0; j < IIR_CH; j++) cur[j] = in[(size_t)mirror1(clampi(y0 + (begin + j) * step, ylo, yhi), H) * W];
-  for (int base = begin; base < end; base += IIR_CH) {
-#pragma unroll
-    for (int j = 0; j < IIR_CH; j++) nxt[j] = in[(size_t)mirror1(clampi(y0 + (base + IIR_CH + j) * step, ylo, yhi), H) * W];
-#pragma unroll
-    for (int j = 0; j < IIR_CH; j++) {
-      const int n = base + j;
-      const int yy = y0 + n * step;
-      const float i0 = cur[j];
-      float d = i0 * IIR_C0;
-      d += IIR_C1 * i1 + IIR_C2 * i2 + IIR_C3 * i3 + IIR_C4 * i4 + IIR_C5 * i5 + IIR_C6 * i6 + IIR_C7 * i7;
-      d += IIR_C8 * t0 + IIR_C9 * t1 + IIR_C10 * t2 + IIR_C11 * t3 + IIR_C12 * t4 + IIR_C13 * t5 + IIR_C14 * t6;
-      if (n >= c0 && n < end && yy >= 0 && yy < H) out[(size_t)yy * W] = d;
-      if (n < c0 && n >= c0 - 7) tl[(size_t)(n - (c0 - 7)) * W] = d;
-      i7 = i6; i6 = i5; i5 = i4; i4 = i3; i3 = i2; i2 = i1; i1 = i0;
-      t6 = t5; t5 = t4; t4 = t3; t3 = t2; t2 = t1; t1 = t0; t0 = d;
-    }
-#pragma unroll
-    for (int j = 0; j < IIR_CH; j++) cur[j] = nxt[j];
-  }
-}
-
-__global__ __launch_bounds__(64) void k_iir_verify(P3c fwd, P3c bwd, const float *__restrict__ tails, int *bad, int W, int H, int nchunks) {
-  const int x = blockIdx.x * 64 + threadIdx.x;
-  const int kd = blockIdx.y, k = kd >> 1, dir = kd & 1, c = blockIdx.z + 1;
-  if (x >= W || c >= nchunks) return;
-  const float *__restrict__ out = (dir ? bwd.p[k] : fwd.p[k]) + x;
-  const float *__restrict__ tl = tails + ((size_t)(kd * nchunks + c) * 7) * W + x;
-  const int y0 = dir ? H + IIR_WARM : -IIR_WARM, step = dir ? -1 : 1;
-  const int c0 = c * IIR_CHUNK;
-  bool differ = false;
-#pragma unroll
-  for (int j = 0; j < 7; j++) {
-    const int yy = y0 + (c0 - 7 + j) * step;
-    if (yy >= 0 && yy < H) differ = differ || (__float_as_uint(tl[(size_t)j * W]) != __float_as_uint(out[(size_t)yy * W]));
-  }
-  if (__any(differ) && threadIdx.x == 0) atomicOr(bad, 1);
-}
-
 // Both sweeps and the combination (iu:580-589 / iu:629-637: anti-causal + causal - c0 * input) for one 64-column x IF_ROWS
 // block of one plane in ONE wave: the causal outputs of the block wait in LDS while the anti-causal sweep runs over the same
-// rows and finishes each pixel, so neither sweep's result travels through HBM.  Both sweeps start IIR_WU rows outside the
+// rows and finishes each pixel, so neither sweep's result travels through HBM.  Both sweeps start IF_WU rows outside the
 // block from a zero state (or at the true beginning of the sweep when that is nearer); whether that reproduces the full
 // sweep BIT FOR BIT is checked on the device: each block records the 7 outputs it computed just before entering its rows
 // ("warm") and its own last 7 outputs ("true"), k_iir_fused_verify compares neighbours, and on any difference the
@@ -694,25 +628,6 @@ static P3c mk3c(const float *const p[3], int np) { P3c r = { { nullptr, nullptr,
 void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], int np, int W, int H) {
   P3c z = { { nullptr, nullptr, nullptr } };
   hipLaunchKernelGGL(k_transpose<0>, dim3(cdiv(W, 64), cdiv(H, 64)), block2, 0, s, mk3(dst, np), mk3c(src, np), z, z, (const uint32_t *)nullptr, np, W, H, (const int *)nullptr);
-}
-size_t iir_scratch_floats(int np, int W, int H) { return (size_t)np * 2 * cdiv(H + IIR_WARM + 1, IIR_CHUNK) * 7 * W; }
-
-void iir_columns(hipStream_t s, float *const fwd[3], float *const bwd[3], const float *const src[3], int np, int W, int H, float *tails, int *bad) {
-  if (!tails || !bad) {
-    hipLaunchKernelGGL(k_iir_columns, dim3(cdiv(W, 64), np * 2), dim3(64), 0, s, mk3(fwd, np), mk3(bwd, np), mk3c(src, np), W, H, (const int *)nullptr);
-    return;
-  }
-  const int nchunks = cdiv(H + IIR_WARM + 1, IIR_CHUNK);
-  const float *f[3] = { fwd[0], np > 1 ? fwd[1] : nullptr, np > 2 ? fwd[2] : nullptr }, *b[3] = { bwd[0], np > 1 ? bwd[1] : nullptr, np > 2 ? bwd[2] : nullptr };
-  hipLaunchKernelGGL(k_iir_chunked, dim3(cdiv(W, 64), np * 2, nchunks), dim3(64), 0, s, mk3(fwd, np), mk3(bwd, np), mk3c(src, np), tails, W, H, nchunks);
-  if (nchunks > 1) hipLaunchKernelGGL(k_iir_verify, dim3(cdiv(W, 64), np * 2, nchunks - 1), dim3(64), 0, s, mk3c(f, np), mk3c(b, np), (const float *)tails, bad, W, H, nchunks);
-  hipLaunchKernelGGL(k_iir_columns, dim3(cdiv(W, 64), np * 2), dim3(64), 0, s, mk3(fwd, np), mk3(bwd, np), mk3c(src, np), W, H, (const int *)bad);
-}
-void iir_combine_transpose(hipStream_t s, float *const dst[3], const float *const fwd[3], const float *const bwd[3], const float *const src[3], int np, int W, int H) {
-  hipLaunchKernelGGL(k_transpose<2>, dim3(cdiv(W, 64), cdiv(H, 64)), block2, 0, s, mk3(dst, np), mk3c(src, np), mk3c(fwd, np), mk3c(bwd, np), (const uint32_t *)nullptr, np, W, H, (const int *)nullptr);
-}
-void iir_combine(hipStream_t s, float *const dst[3], const float *const fwd[3], const float *const bwd[3], const float *const src[3], int np, int n) {
-  hipLaunchKernelGGL(k_iir_combine, dim3(ew_grid(n)), dim3(256), 0, s, mk3(dst, np), mk3c(fwd, np), mk3c(bwd, np), mk3c(src, np), np, n, (const int *)nullptr);
 }
 size_t iir_pass_scratch_floats(int np, int W, int H) { return (size_t)np * if_nchunks(H, IF_ROWS_N) * 4 * 7 * W; }   // (the finer blocking bounds both)
 

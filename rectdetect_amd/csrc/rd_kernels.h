@@ -14,15 +14,6 @@ void unpack_plab(hipStream_t s, float *L, float *a, float *b, const uint32_t *in
 void pack_plab(hipStream_t s, uint32_t *out, const float *L, const float *a, const float *b, int n);
 // transposes of `np` float planes (src planes W x H row-major -> dst planes H x W); src may be packed Lab (np = 3)
 void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], int np, int W, int H);
-// causal + anti-causal sigma=1 IIR sweeps down the columns of np planes (W columns, H rows): fwd[k], bwd[k] <- src[k]
-// tails/bad: scratch for the chunked evaluation (iir_scratch_floats() floats, one int that must be 0 on entry and stays 0
-// unless a chunk failed its verification); pass nullptr for plain full-length sweeps
-size_t iir_scratch_floats(int np, int W, int H);
-void iir_columns(hipStream_t s, float *const fwd[3], float *const bwd[3], const float *const src[3], int np, int W, int H, float *tails, int *bad);
-// dst[k] (H x W) = transpose( bwd[k] + fwd[k] - src[k] * c0 )   with fwd/bwd/src given as W x H planes
-void iir_combine_transpose(hipStream_t s, float *const dst[3], const float *const fwd[3], const float *const bwd[3], const float *const src[3], int np, int W, int H);
-// dst[k] = bwd[k] + fwd[k] - src[k] * c0   (no transpose)
-void iir_combine(hipStream_t s, float *const dst[3], const float *const fwd[3], const float *const bwd[3], const float *const src[3], int np, int n);
 // one complete blur pass (causal + anti-causal sweep + combination) in a single launch, see rd_k_front.hip
 size_t iir_pass_scratch_floats(int np, int W, int H);
 void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3], float *const fwd[3], float *const bwd[3], int np, int W, int H,
