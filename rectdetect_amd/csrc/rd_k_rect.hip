@@ -171,34 +171,6 @@ __global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ e
   }
 }
 
-// floor(s / w) for s <= 40950, 2 <= w <= 10 as a multiply-high with ceil(2^32 / w) (exact in that range; checked offline)
-__device__ __forceinline__ unsigned div_small(unsigned s, int w) {
-  const unsigned R[11] = { 0u, 0u, 2147483648u, 1431655766u, 1073741824u, 858993460u, 715827883u, 613566757u, 536870912u, 477218589u, 429496730u };
-  return w == 1 ? s : __umulhi(s, R[w]);
-}
-
-template <int VERT>
-__global__ __launch_bounds__(256) void k_blblur(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih) {
-  RD_XY;
-  if (x >= iw || y >= ih) return;
-  const int p = y * iw + x;
-  const unsigned e = ext[p] >> (VERT ? 6 : 0);
-  const int nl = e & 7, nr = (e >> 3) & 7;
-  const int st = VERT ? iw : 1;
-  unsigned s0 = 0, s1 = 0, s2 = 0;
-#pragma unroll
-  for (int d = 0; d < 5; d++)
-    if (d < nl) { const uint32_t v = in[p - d * st]; s0 += v & 4095; s1 += (v >> 12) & 1023; s2 += (v >> 22) & 1023; }
-#pragma unroll
-  for (int d = 0; d < 5; d++)
-    if (d < nr) { const uint32_t v = in[p + d * st]; s0 += v & 4095; s1 += (v >> 12) & 1023; s2 += (v >> 22) & 1023; }
-  const int w = nl + nr;
-  uint32_t r;
-  if (w == 0) r = in[p];
-  else r = (div_small(s2, w) << 22) | (div_small(s1, w) << 12) | div_small(s0, w);   // fields cannot exceed their range: no clamp needed
-  out[p] = r;
-}
-
 // One (horizontal, vertical) pair of passes (rh:286-296) in a single launch.  The block stages a (64+8) x (BP_ROWS+8)
 // tile of the input in LDS in EXPANDED form (uint2: L | a << 16, b - 16-bit fields, so that a sum of 10 samples is two
 // plain adds without carries between fields), runs the horizontal pass for the 64 x (BP_ROWS+8) strip into a second LDS
@@ -987,10 +959,6 @@ void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, i
 }
 void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih) {
   hipLaunchKernelGGL(k_blblur_extents, dim3(cdiv(iw, 64), cdiv(ih, BE_ROWS)), dim3(64, 4), 0, s, ext, edge, iw, ih);
-}
-void blblur(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int vertical, int iw, int ih) {
-  if (vertical) hipLaunchKernelGGL(k_blblur<1>, grid2(iw, ih), block2, 0, s, out, ext, in, iw, ih);
-  else hipLaunchKernelGGL(k_blblur<0>, grid2(iw, ih), block2, 0, s, out, ext, in, iw, ih);
 }
 void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih) {
   hipLaunchKernelGGL(k_blblur_pair, dim3(cdiv(iw, 64), cdiv(ih, BP_ROWS)), dim3(64, 16), 0, s, out, ext, in, iw, ih);

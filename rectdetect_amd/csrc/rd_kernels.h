@@ -52,7 +52,6 @@ void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int i
 void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, int ih);
 // run extents of the edge-stopped blur (depend on the edge mask only): ext[p] = nl_h | nr_h<<3 | nl_v<<6 | nr_v<<9
 void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih);
-void blblur(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int vertical, int iw, int ih);
 // one horizontal + vertical pass pair; out must not alias in
 void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih);
 void quantize(hipStream_t s, uint32_t *out, const uint32_t *in, int n0, int n1, int n2, int n);
