@@ -916,13 +916,22 @@ __global__ void k_reduce_owner(int *table, const int *__restrict__ claim, const 
 // host instead of the 4N-byte plane and the 16N-byte table.  Double precision, same operation order as the host code.
 struct ls_rec { float x0, y0, x1, y1; int startIndex, endIndex, leftPtr, rightPtr, startCount, endCount, maxDist, polyid, npix, level; };
 
+// The kernel also assembles the block that travels to the host in ONE copy (pack): [0,32) polyline counters, [32,52) region
+// round flags, [64, 64 + 14 * pack_records) segment records 0.., then 90 ints of probes per record.
 __global__ void k_sample_segments(int *__restrict__ out, const ls_rec *__restrict__ ls, int max_records, const int *__restrict__ boundary, const int *__restrict__ table,
-                                  int iw, int ih, int nentry) {
+                                  int iw, int ih, int nentry, int *__restrict__ pack, int pack_records, const int *__restrict__ polyctr, const int *__restrict__ rflags) {
   const int n = *(const int *)ls;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (pack) {
+    if (t < 32) pack[t] = polyctr[t];
+    else if (t < 52) pack[t] = rflags[t - 32];
+    if (t < 14) pack[64 + t] = ((const int *)ls)[t];        // header record
+  }
   const int i = t / 15 + 1, k = t % 15;
   if (i > n || i >= max_records) return;
   int *o = out + (size_t)(i * 15 + k) * 6;
+  const bool packed = pack && i < pack_records;
+  if (packed && k < 14) pack[64 + i * 14 + k] = ((const int *)ls)[i * 14 + k];   // the record itself (14 ints), one int per probe thread
   int segid = 0;
   if (ls[i].polyid != 0) {
     const double x0 = rint((double)ls[i].x0), y0 = rint((double)ls[i].y0), x1 = rint((double)ls[i].x1), y1 = rint((double)ls[i].y1);
@@ -937,13 +946,18 @@ __global__ void k_sample_segments(int *__restrict__ out, const ls_rec *__restric
     const int sx = (int)(cx + 0.5), sy = (int)(cy + 0.5);
     if (!(sx < 0 || sx >= iw || sy < 0 || sy >= ih)) segid = boundary[sx + sy * iw];
   }
-  o[0] = segid;
+  int v[6] = { segid, 0, 0, 0, 0, 0 };
   if (segid > 0) {
     const unsigned slot = ls_slot(i, segid, nentry);
     const int *e = table + (size_t)slot * 5;
-    o[1] = e[0]; o[2] = e[1]; o[3] = e[2]; o[4] = e[3]; o[5] = e[4];
-  } else {
-    o[1] = o[2] = o[3] = o[4] = o[5] = 0;
+    v[1] = e[0]; v[2] = e[1]; v[3] = e[2]; v[4] = e[3]; v[5] = e[4];
+  }
+#pragma unroll
+  for (int q = 0; q < 6; q++) o[q] = v[q];
+  if (packed) {
+    int *po = pack + 64 + pack_records * 14 + (size_t)(i * 15 + k) * 6;
+#pragma unroll
+    for (int q = 0; q < 6; q++) po[q] = v[q];
   }
 }
 
@@ -1034,9 +1048,11 @@ void reduce_ls(hipStream_t s, int *table, int *claim, int *tlist, const int *bou
   hipLaunchKernelGGL(k_reduce_box, dim3(512), dim3(256), 0, s, table, (const int *)claim, boundary, *ps, iw, ih, nentry);
 }
 
-void sample_segments(hipStream_t s, int *out, const void *lslist, int max_records, const int *boundary, const int *table, int iw, int ih, int nentry) {
+void sample_segments(hipStream_t s, int *out, const void *lslist, int max_records, const int *boundary, const int *table, int iw, int ih, int nentry,
+                     int *pack, int pack_records, const int *polyctr, const int *rflags) {
   const int threads = max_records * 15;
-  hipLaunchKernelGGL(k_sample_segments, dim3(cdiv(threads, 256)), dim3(256), 0, s, out, (const ls_rec *)lslist, max_records, boundary, table, iw, ih, nentry);
+  hipLaunchKernelGGL(k_sample_segments, dim3(cdiv(threads, 256)), dim3(256), 0, s, out, (const ls_rec *)lslist, max_records, boundary, table, iw, ih, nentry,
+                     pack, pack_records, polyctr, rflags);
 }
 
 }  // namespace rdk

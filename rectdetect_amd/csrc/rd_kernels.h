@@ -66,7 +66,9 @@ struct PolyScratch;
 void reduce_ls_init(hipStream_t s, int *table, int *claim, int *tlist, int nentry);   // once per allocation
 void reduce_ls(hipStream_t s, int *table, int *claim, int *tlist, const int *boundary, const PolyScratch *ps, int iw, int ih, int nentry);
 // per segment, 15 probe points: {boundary id, table slot owner, 4 box values} -> out[(seg*15 + k)*6 ..]
-void sample_segments(hipStream_t s, int *out, const void *lslist, int max_records, const int *boundary, const int *table, int iw, int ih, int nentry);
+// pack (may be null): the block for the host in one piece - 64 ints of counters / flags, pack_records records of 14 ints, then their probes
+void sample_segments(hipStream_t s, int *out, const void *lslist, int max_records, const int *boundary, const int *table, int iw, int ih, int nentry,
+                     int *pack, int pack_records, const int *polyctr, const int *rflags);
 
 // ---- rd_k_poly.hip: polyline stage on compacted chain pixels
 PolyScratch *poly_scratch_create(int iw, int ih);
