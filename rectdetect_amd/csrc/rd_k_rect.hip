@@ -524,7 +524,9 @@ __global__ __launch_bounds__(256) void k_region_propose(const int *__restrict__ 
   // (parent -> smallest proposal) pairs in a small LDS hash and then issues one guarded atomic per distinct parent.
 #pragma unroll
   for (int k = 0; k < RP_PX; k++) {
-    if (!todo[k]) continue;
+    // a lane whose (parent, proposal) pair repeats its left neighbour's adds nothing to a min: skip it (most lanes inside a region)
+    const int pog = __shfl_up(og[k], 1), pg = __shfl_up(g[k], 1), pt = __shfl_up((int)todo[k], 1);
+    if (!todo[k] || (threadIdx.x > 0 && pt && pog == og[k] && pg == g[k])) continue;
     unsigned h = ((unsigned)og[k] * 2654435761u) >> 23;
     int probes = 0;
     for (;;) {
