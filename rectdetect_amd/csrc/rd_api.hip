@@ -396,10 +396,11 @@ static void frame_regions(rd_detector *d, Slot *s) {
   const int iw = d->iw, ih = d->ih, N = d->N;
   hipStream_t st = s->st;
   // regions (oclrect.c:325-336)
-  rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih, (d->diag_skip & 2) ? 0 : s->rounds);
-  RD_HIP(hipMemcpyAsync(s->rsize, s->junction, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));   // H2: sizes start from the junction counts
-  rdk::region_size(st, s->rsize, s->region0, N);
-  rdk::despeckle2(st, s->region, s->region0, s->scratch2 + (size_t)N + 64, s->rsize, 16, iw, ih);   // (behind the round flags, which travel to the host at the end)
+  int *d2scratch = s->scratch2 + (size_t)N + 64;      // behind the round flags, which travel to the host at the end
+  rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih, (d->diag_skip & 2) ? 0 : s->rounds,
+                    s->rsize, s->junction);             // H2: the sizes start from the junction counts (copied by the first kernel)
+  rdk::region_size(st, s->rsize, s->region0, N, d2scratch + N);
+  rdk::despeckle2(st, s->region, s->region0, d2scratch, s->rsize, 16, iw, ih, 1);
 
   // region boundaries and their components (oclrect.c:340-342)
   rdk::mark_boundary(st, s->boundarysrc, s->region, iw, ih);

@@ -421,8 +421,10 @@ __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const 
 // pixel outside the tile on its way up/left; the few remaining tile-to-tile hops are left to k_region_flatten.
 #define RI_ROWS 32
 __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, int *__restrict__ prop, int *__restrict__ selfp, const int *__restrict__ pix, const int *__restrict__ mask,
-                                                     const int *__restrict__ edge, int iw, int ih) {
+                                                     const int *__restrict__ edge, int iw, int ih, int *__restrict__ flags, int *__restrict__ size_out, const int *__restrict__ size_init) {
   __shared__ int par[64 * RI_ROWS];     // >= 0: tile-local index of the parent; < 0: -(global index) - 1 of a parent outside the tile
+  // (also: the round / flatten flags start at zero, and the size plane starts from size_init - quirk H2 - without extra launches)
+  if (blockIdx.x == 0 && blockIdx.y == 0) { const int t = threadIdx.y * 64 + threadIdx.x; if (t < 64) flags[t] = 0; }
   const int tx = threadIdx.x, x = blockIdx.x * 64 + tx, y0 = blockIdx.y * RI_ROWS;
   for (int r = threadIdx.y; r < RI_ROWS; r += 4) {
     const int y = y0 + r;
@@ -445,6 +447,7 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
       allow[p] = (uint8_t)a;
       prop[p] = 0x7f7f7f7f;      // no proposal
       selfp[p] = 0x7f7f7f7f;
+      if (size_out) size_out[p] = size_init[p];
     }
     par[r * 64 + tx] = l;
   }
@@ -601,7 +604,8 @@ __device__ __forceinline__ void rs_accum(int *keys, int *vals, int *out, int lab
   }
 }
 
-__global__ __launch_bounds__(256) void k_region_size(int *out, const int *__restrict__ label, int n) {
+__global__ __launch_bounds__(256) void k_region_size(int *out, const int *__restrict__ label, int n, int *zero_me) {
+  if (zero_me && blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;     // (a counter of the next stage: saves a fill launch)
   __shared__ int keys[RS_T], vals[RS_T];
   for (int i = threadIdx.x; i < RS_T; i += 256) { keys[i] = -1; vals[i] = 0; }
   __syncthreads();
@@ -993,16 +997,15 @@ void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int 
 }
 
 // scratch: 3*N ints (hook proposals; round flags + allowed-direction bytes; self proposals)
-void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS) {
+void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS, int *size_out, const int *size_init) {
   const int n = iw * ih;
   // tile-to-tile hops left after k_region_init: at most ih/RI_ROWS + iw/64 + 2; each launch divides the depth by 4
   int FLAT = 1;
   for (long reach = 4; reach < ih / RI_ROWS + iw / 64 + 2; reach *= 4) FLAT++;
   int *prop = scratch, *flags = scratch + n, *fflags = flags + 32;
-  (void)hipMemsetAsync(flags, 0, sizeof(int) * 64, s);
   uint8_t *allow = (uint8_t *)(flags + 64);
   int *selfp = scratch + 2 * (size_t)n;
-  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, label, allow, prop, selfp, pix, mask, edge, iw, ih);
+  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, label, allow, prop, selfp, pix, mask, edge, iw, ih, flags, size_out, size_init);
   // the initial links are flattened first; the synchronous rounds then start from trees of depth 1
   for (int r = 0; r < FLAT; r++) hipLaunchKernelGGL(k_region_flatten, dim3(ew_grid(n)), dim3(256), 0, s, label, n, fflags, r);
   for (int r = 0; r < ROUNDS; r++) {
@@ -1011,16 +1014,16 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
   }
 }
 
-void region_size(hipStream_t s, int *out, const int *label, int n) {
-  hipLaunchKernelGGL(k_region_size, dim3(cdiv(n, 256 * RS_PER_THREAD)), dim3(256), 0, s, out, label, n);
+void region_size(hipStream_t s, int *out, const int *label, int n, int *zero_me) {
+  hipLaunchKernelGGL(k_region_size, dim3(cdiv(n, 256 * RS_PER_THREAD)), dim3(256), 0, s, out, label, n, zero_me);
 }
 
 // scratch: 2*N + 1 ints; out must not alias in.  Eight Jacobi rounds of the reference's in-place sweep (see DESIGN.md,
 // H6); only pixels of small regions can change, so rounds 2..8 run over their list.
-void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih) {
+void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih, int count_is_zero) {
   const int n = iw * ih, ROUNDS = 8;   // even: the last round writes into `out`
   int *tmp = scratch, *count = scratch + (size_t)n, *list = count + 1;
-  (void)hipMemsetAsync(count, 0, sizeof(int), s);
+  if (!count_is_zero) (void)hipMemsetAsync(count, 0, sizeof(int), s);
   // first round: tmp <- result, out <- input (both planes then agree on every pixel that is not in the list)
   hipLaunchKernelGGL(k_despeckle2_first, dim3(cdiv(iw, 64), cdiv(ih, D2_ROWS)), dim3(64, 4), 0, s, tmp, out, list, count, in, size, thre, iw, ih);
   const int *cur = tmp;
