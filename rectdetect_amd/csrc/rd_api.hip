@@ -462,8 +462,7 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   rdk::blblur_extents(st, s->ext, s->e8, iw, ih);
   { const uint32_t *src = s->plab0;     // ping-pong between i0 and smooth; the 10th pair lands in smooth
     for (int i = 0; i < ((d->diag_skip & 1) ? 2 : 10); i++) { uint32_t *dst = (i & 1) ? s->smooth : (uint32_t *)s->i0; rdk::blblur_pair(st, dst, s->ext, src, iw, ih); src = dst; } }
-  rdk::quantize(st, (uint32_t *)s->i0, s->smooth, 24, 24, 24, N);
-  rdk::despeckle(st, s->quant, (const uint32_t *)s->i0, s->nms, iw, ih);
+  rdk::despeckle(st, s->quant, s->smooth, s->nms, iw, ih, 1);      // quantisation to 24 levels per field (oclrect.c:298) happens on the fly
 
   if (d->fork_poly) RD_HIP(hipStreamWaitEvent(st, s->ev_mm, 0));
   else {

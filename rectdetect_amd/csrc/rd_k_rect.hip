@@ -263,32 +263,19 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
   }
 }
 
-// rc:207-216
-__global__ void k_quantize(uint32_t *__restrict__ out, const uint32_t *__restrict__ in, int n0, int n1, int n2, int n) {
-  const int stride = gridDim.x * blockDim.x;
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + 3 * stride < n; i += 4 * stride) {      // four independent loads in flight
-    uint32_t v[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = in[i + k * stride];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      float L, a, b;
-      unpack_lab(v[k], L, a, b);
-      out[i + k * stride] = pack_lab(roundf(L * n0) / (float)n0, roundf(a * n1) / (float)n1, roundf(b * n2) / (float)n2);
-    }
-  }
-  for (; i < n; i += stride) {
-    float L, a, b;
-    unpack_lab(in[i], L, a, b);
-    out[i] = pack_lab(roundf(L * n0) / (float)n0, roundf(a * n1) / (float)n1, roundf(b * n2) / (float)n2);
-  }
+// rc:207-216: each Lab field rounded to n levels
+__device__ __forceinline__ uint32_t quantize_plab(uint32_t v, int n0, int n1, int n2) {
+  float L, a, b;
+  unpack_lab(v, L, a, b);
+  return pack_lab(roundf(L * n0) / (float)n0, roundf(a * n1) / (float)n1, roundf(b * n2) / (float)n2);
 }
 
 // rc:218-244: pixels with a non-zero NMS response take the colour of the Lab-nearest 3x3 neighbour without one.
 // Such pixels are a few per cent, on thin lines that cross a third of all waves: every block first copies its 64 x DS_ROWS
 // tile and collects the affected pixels in an LDS list, then works the list off with all lanes busy.
 #define DS_ROWS 16
+// QN > 0: the input is quantised to QN levels per field on the fly (rc:207-216 fused in: no separate pass over the plane)
+template <int QN>
 __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, const uint32_t *__restrict__ in, const float *__restrict__ edge, int iw, int ih) {
   __shared__ int list[64 * DS_ROWS];
   __shared__ int nlist;
@@ -304,7 +291,7 @@ __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, c
     if (x < iw && y < ih) {
       p0 = y * iw + x;
       hot = !(edge[p0] < 1e-6f);
-      if (!hot) out[p0] = in[p0];
+      if (!hot) out[p0] = QN > 0 ? quantize_plab(in[p0], QN, QN, QN) : in[p0];
     }
     const unsigned long long m = __ballot(hot);
     if (m) {
@@ -320,7 +307,7 @@ __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, c
   for (int j = tid; j < n; j += 256) {
     const int p0 = list[j];
     const int px = p0 % iw, py = p0 / iw;
-    uint32_t r = in[p0];
+    uint32_t r = QN > 0 ? quantize_plab(in[p0], QN, QN, QN) : in[p0];
     float dist = 1e+10f, l0, a0, b0;
     unpack_lab(r, l0, a0, b0);
     for (int yy = -1; yy <= 1; yy++)
@@ -329,7 +316,7 @@ __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, c
         const int p1 = p0 + yy * iw + xx;
         if (edge[p1] >= 1e-6f) continue;
         float l1, a1, b1;
-        const uint32_t v = in[p1];
+        const uint32_t v = QN > 0 ? quantize_plab(in[p1], QN, QN, QN) : in[p1];
         unpack_lab(v, l1, a1, b1);
         const float dx = l1 - l0, dy = a1 - a0, dz = b1 - b0;
         const float d = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -983,11 +970,9 @@ void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, in
 void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih) {
   hipLaunchKernelGGL(k_blblur_pair, dim3(cdiv(iw, 64), cdiv(ih, BP_ROWS)), dim3(64, 16), 0, s, out, ext, in, iw, ih);
 }
-void quantize(hipStream_t s, uint32_t *out, const uint32_t *in, int n0, int n1, int n2, int n) {
-  hipLaunchKernelGGL(k_quantize, dim3(ew_grid(n)), dim3(256), 0, s, out, in, n0, n1, n2, n);
-}
-void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih) {
-  hipLaunchKernelGGL(k_despeckle, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS)), dim3(64, 4), 0, s, out, in, edge, iw, ih);
+void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih, int quantize24) {
+  if (quantize24) hipLaunchKernelGGL(k_despeckle<24>, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS)), dim3(64, 4), 0, s, out, in, edge, iw, ih);
+  else hipLaunchKernelGGL(k_despeckle<0>, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS)), dim3(64, 4), 0, s, out, in, edge, iw, ih);
 }
 // scratch: ih * ceil(iw/64) * 2 64-bit words
 void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih) {

@@ -54,8 +54,7 @@ void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, i
 void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih);
 // one horizontal + vertical pass pair; out must not alias in
 void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih);
-void quantize(hipStream_t s, uint32_t *out, const uint32_t *in, int n0, int n1, int n2, int n);
-void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih);
+void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih, int quantize24);   // quantize24: `in` is quantised to 24 levels per field on the fly
 void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih);   // scratch: >= ih*ceil(iw/64)*4 ints
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int rounds,
                   int *size_out, const int *size_init);   // rounds: 20 (at most; early-out on the device); size_out (optional) <- size_init, for region_size
