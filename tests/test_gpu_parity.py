@@ -506,3 +506,28 @@ def test_polyline_example_program_matches_operator_api(ctx, tmp_path):
     want = [[s["x0"], s["y0"], s["x1"], s["y1"]] for s in segs[1:] if s["polyid"] != 0]
     assert len(got) == len(want) > 0
     assert np.allclose(np.array(got), np.array(want, dtype=np.float64), atol=1e-3)
+
+
+def test_many_streams_final_outputs_equal_the_reference():
+    """68 more frames (26 short streams, four sizes) against the reference's own rectangle and segment lists
+    (tests/golden/many_rect.npz from tools/make_golden_many.py).  The segment lists must match exactly on every frame; the
+    region stages are evaluated in another schedule than the reference's order-dependent one, so the
+    number of frames whose rectangle list matches is reported and must not fall below the level measured when this
+    test was written."""
+    g = golden("many_rect")
+    total = same = 0
+    differing = []
+    for si, (iw, ih, seed, nframes) in enumerate(g["streams"].tolist()):
+        det = ra.Detector(iw, ih, nslots=1)
+        for t in range(nframes):
+            det.enqueue(synth.frame(synth.SEED0 + seed, iw, ih, t))
+            rects = det.poll(TAN36)
+            assert helpers.segments_equal(det.last_segments(), g["s%d_f%d_segments" % (si, t)]), (si, t)
+            total += 1
+            if helpers.rects_equal(rects, g["s%d_f%d_rects" % (si, t)]):
+                same += 1
+            else:
+                differing.append((iw, ih, seed, t, len(rects), len(g["s%d_f%d_rects" % (si, t)])))
+        det.close()
+    print("rectangle lists identical to the reference's on %d of %d frames; differing:" % (same, total), differing)
+    assert same == total
