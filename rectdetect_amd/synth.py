@@ -86,3 +86,37 @@ def frame(seed, iw, ih, t=0, noise=True):
             out[:, :, c] += (_noise_hash(xx, yy, t, c, s32) >> np.uint32(29)).astype(np.int32) - 4
         img = np.clip(out, 0, 255).astype(np.uint8)
     return img
+
+
+def hard_frame(kind, seed, iw, ih):
+    """Inputs that are much busier than the stream generator's flat quads (tests only; numpy's PCG64 streams are stable):
+    'tiles'  random colour tiles of 8..24 px (thousands of regions and junctions),
+    'noise'  independent uniform noise per pixel and channel,
+    'waves'  smooth sinusoidal colour fields with a few dark-rimmed bright rectangles on top,
+    'bars'   horizontal and vertical bars of varying width on a gradient."""
+    rng = np.random.default_rng([seed, iw, ih])
+    if kind == "tiles":
+        t = int(rng.integers(8, 25))
+        tiles = rng.integers(0, 256, ((ih + t - 1) // t, (iw + t - 1) // t, 3), dtype=np.uint8)
+        return np.ascontiguousarray(np.repeat(np.repeat(tiles, t, 0), t, 1)[:ih, :iw])
+    if kind == "noise":
+        return rng.integers(0, 256, (ih, iw, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:ih, 0:iw].astype(np.float64)
+    if kind == "waves":
+        img = np.stack([127 + 100 * np.sin(xx * rng.uniform(0.01, 0.05) + yy * rng.uniform(0.0, 0.03) + rng.uniform(0, 6)) for _ in range(3)], -1)
+        for _ in range(5):
+            x0, y0 = int(rng.integers(0, iw - 80)), int(rng.integers(0, ih - 60))
+            w, h = int(rng.integers(40, iw // 3)), int(rng.integers(30, ih // 3))
+            img[y0:y0 + h, x0:x0 + w] = 20
+            img[y0 + 3:y0 + h - 3, x0 + 3:x0 + w - 3] = rng.integers(150, 256, 3)
+        return np.clip(img, 0, 255).astype(np.uint8)
+    if kind == "bars":
+        img = np.stack([xx * 255 / iw, yy * 255 / ih, (xx + yy) * 255 / (iw + ih)], -1)
+        for _ in range(12):
+            c = rng.integers(0, 256, 3)
+            if rng.integers(0, 2):
+                x0 = int(rng.integers(0, iw - 4)); img[:, x0:x0 + int(rng.integers(2, 30))] = c
+            else:
+                y0 = int(rng.integers(0, ih - 4)); img[y0:y0 + int(rng.integers(2, 30)), :] = c
+        return np.clip(img, 0, 255).astype(np.uint8)
+    raise ValueError(kind)

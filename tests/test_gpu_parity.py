@@ -531,3 +531,31 @@ def test_many_streams_final_outputs_equal_the_reference():
         det.close()
     print("rectangle lists identical to the reference's on %d of %d frames; differing:" % (same, total), differing)
     assert same == total
+
+
+def test_busy_inputs_final_outputs_vs_reference():
+    """much busier inputs than the stream generator's (random tiles, pure noise, smooth waves with rimmed rectangles, bars on
+    gradients; up to 1500 segments and 66 rectangles per frame) against the reference's own lists
+    (tests/golden/hard_rect.npz).  Segments must match exactly; the rectangle lists are compared frame by frame and the
+    count of identical ones is reported (see test_many_streams_final_outputs_equal_the_reference for why this is a count)."""
+    g = golden("hard_rect")
+    same, total, differing = 0, 0, []
+    for hi, (kind, (seed, iw, ih)) in enumerate(zip(g["kinds"].tolist(), g["params"].tolist())):
+        det = ra.Detector(iw, ih, nslots=1)
+        det.enqueue(synth.hard_frame(kind, seed, iw, ih))
+        rects = det.poll(TAN36)
+        assert helpers.segments_equal(det.last_segments(), g["h%d_segments" % hi]), (kind, seed)
+        total += 1
+        want = g["h%d_rects" % hi]
+        if helpers.rects_equal(rects, want):
+            same += 1
+        else:
+            # how many of the reference's rectangles are present here (all four corners within 1e-4 px), and how many are extra
+            hit = sum(any(np.abs(r["c2"] - w["c2"]).max() <= 1e-4 for r in rects) for w in want)
+            differing.append((kind, seed, iw, ih, "reference %d, present %d, here %d" % (len(want), hit, len(rects))))
+        det.close()
+    print("busy inputs: rectangle lists identical to the reference's on %d of %d frames; differing:" % (same, total), differing)
+    assert same >= HARD_RECT_IDENTICAL_MIN
+
+
+HARD_RECT_IDENTICAL_MIN = 11   # of 14, measured when the test was written (the three 'tiles' frames with 600-1500 segments differ)
