@@ -785,7 +785,11 @@ int rdo_region_propagate_pass(int *label, const int *pix, const int *mask, const
 }
 
 /* experiment: Jacobi evaluation of rdo_despeckle2's raster-order recurrence; returns rounds until fixpoint */
-int rdo_despeckle2_jacobi(int *label, const int *size, int thre, int iw, int ih, int *nsmall) {
+int rdo_despeckle2_jacobi_k(int *label, const int *size, int thre, int iw, int ih, int *nsmall, int max_rounds);
+int rdo_despeckle2_jacobi(int *label, const int *size, int thre, int iw, int ih, int *nsmall) { return rdo_despeckle2_jacobi_k(label, size, thre, iw, ih, nsmall, 1 << 30); }
+
+/* the same with a bound on the rounds (the HIP path runs 8) */
+int rdo_despeckle2_jacobi_k(int *label, const int *size, int thre, int iw, int ih, int *nsmall, int max_rounds) {
   const int N = iw * ih;
   int *old = (int *)malloc(sizeof(int) * N), *cur = (int *)malloc(sizeof(int) * N), *nxt = (int *)malloc(sizeof(int) * N);
   memcpy(old, label, sizeof(int) * N); memcpy(cur, label, sizeof(int) * N);
@@ -811,7 +815,7 @@ int rdo_despeckle2_jacobi(int *label, const int *size, int thre, int iw, int ih,
       }
     memcpy(cur, nxt, sizeof(int) * N);
     rounds++;
-    if (!changed) break;
+    if (!changed || rounds >= max_rounds) break;
   }
   memcpy(label, cur, sizeof(int) * N);
   free(old); free(cur); free(nxt);

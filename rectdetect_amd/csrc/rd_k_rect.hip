@@ -630,17 +630,23 @@ __global__ __launch_bounds__(256) void k_region_size(int *out, const int *__rest
 // rc:348-371.  The reference updates labels in place in raster order: a small-region pixel sees the NEW labels of
 // its NW, N, NE, W neighbours.  One Jacobi round of that recurrence: `cur` holds the previous round's
 // values for small-region pixels; the rounds are iterated by the launcher.
+// (all loads of a pick are issued before any is used: the loops are unrolled and the frame-border tests only mask the result)
 __device__ __forceinline__ int despeckle2_pick(const int *__restrict__ cur, const int *__restrict__ old, const int *__restrict__ size, int l0, int x, int y, int iw, int ih) {
   const int p0 = y * iw + x;
+  int lab[9], sz[9];
+  bool ok[9];
+#pragma unroll
+  for (int k = 0; k < 9; k++) {
+    const int xx = k % 3 - 1, yy = k / 3 - 1;
+    ok[k] = !(x + xx < 0 || x + xx >= iw || y + yy < 0 || y + yy >= ih);
+    const int p1 = ok[k] ? p0 + yy * iw + xx : p0;
+    lab[k] = k < 4 ? cur[p1] : old[p1];          // NW, N, NE, W come before p in raster order
+  }
+#pragma unroll
+  for (int k = 0; k < 9; k++) sz[k] = size[lab[k]];
   int res = l0, maxSize = 0;
-  for (int yy = -1; yy <= 1; yy++)
-    for (int xx = -1; xx <= 1; xx++) {
-      if (x + xx < 0 || x + xx >= iw || y + yy < 0 || y + yy >= ih) continue;
-      const int p1 = p0 + yy * iw + xx;
-      const int l1 = (yy < 0 || (yy == 0 && xx < 0)) ? cur[p1] : old[p1];
-      const int sz = size[l1];
-      if (sz > maxSize) { maxSize = sz; res = l1; }
-    }
+#pragma unroll
+  for (int k = 0; k < 9; k++) if (ok[k] && sz[k] > maxSize) { maxSize = sz[k]; res = lab[k]; }
   return res;
 }
 
@@ -682,12 +688,34 @@ __global__ __launch_bounds__(256) void k_despeckle2_first(int *__restrict__ nxt,
   for (int i = tid; i < nloc; i += 256) list[base + i] = loc[i];
 }
 
-__global__ __launch_bounds__(256) void k_despeckle2_sparse(int *__restrict__ nxt, const int *__restrict__ cur, const int *__restrict__ list, const int *__restrict__ count,
-                                                            const int *__restrict__ old, const int *__restrict__ size, int iw, int ih) {
+// TWO Jacobi rounds per launch, exactly: the value of a pixel after round r+2 needs the round r+1 values of its four earlier
+// neighbours, which are recomputed here from the round r plane (a launch costs more than the extra gathers: the rounds are
+// latency-bound at a few microseconds each, and the recurrence needs a few dozen of them - see despeckle2()).
+__global__ __launch_bounds__(256) void k_despeckle2_sparse2(int *__restrict__ nxt, const int *__restrict__ cur, const int *__restrict__ list, const int *__restrict__ count,
+                                                             const int *__restrict__ old, const int *__restrict__ size, int thre, int iw, int ih) {
   const int n = *count;
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
     const int p0 = list[j];
-    nxt[p0] = despeckle2_pick(cur, old, size, old[p0], p0 % iw, p0 / iw, iw, ih);
+    const int x = p0 % iw, y = p0 / iw;
+    int lab[9], sz[9];
+    bool ok[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      const int xx = k % 3 - 1, yy = k / 3 - 1;
+      ok[k] = !(x + xx < 0 || x + xx >= iw || y + yy < 0 || y + yy >= ih);
+      lab[k] = old[ok[k] ? p0 + yy * iw + xx : p0];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) sz[k] = size[lab[k]];
+#pragma unroll
+    for (int k = 0; k < 4; k++)      // an earlier neighbour that belongs to a small region: its value after round r+1
+      if (ok[k] && sz[k] <= thre) lab[k] = despeckle2_pick(cur, old, size, lab[k], x + k % 3 - 1, y + k / 3 - 1, iw, ih);
+#pragma unroll
+    for (int k = 0; k < 9; k++) sz[k] = size[lab[k]];
+    int res = old[p0], maxSize = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) if (ok[k] && sz[k] > maxSize) { maxSize = sz[k]; res = lab[k]; }
+    nxt[p0] = res;
   }
 }
 
@@ -1006,15 +1034,19 @@ void region_size(hipStream_t s, int *out, const int *label, int n, int *zero_me)
 // scratch: 2*N + 1 ints; out must not alias in.  Eight Jacobi rounds of the reference's in-place sweep (see DESIGN.md,
 // H6); only pixels of small regions can change, so rounds 2..8 run over their list.
 void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih, int count_is_zero) {
-  const int n = iw * ih, ROUNDS = 8;   // even: the last round writes into `out`
+  // 1 + 2 * 13 = 27 Jacobi rounds.  The raster recurrence has dependency chains of hundreds of pixels (it takes 300-900
+  // rounds to reproduce the reference's plane exactly); what matters downstream settles much earlier: with 8 rounds the
+  // rectangle lists of busy frames differed from the reference's, from 24 rounds on they did not (CPU study with
+  // oracle/rd_oracle.c: rdo_despeckle2_jacobi_k, 6 of 6 frames; DESIGN.md "Known deviation").
+  const int n = iw * ih, DOUBLE_ROUNDS = 13;   // odd: the last launch writes into `out`
   int *tmp = scratch, *count = scratch + (size_t)n, *list = count + 1;
   if (!count_is_zero) (void)hipMemsetAsync(count, 0, sizeof(int), s);
   // first round: tmp <- result, out <- input (both planes then agree on every pixel that is not in the list)
   hipLaunchKernelGGL(k_despeckle2_first, dim3(cdiv(iw, 64), cdiv(ih, D2_ROWS)), dim3(64, 4), 0, s, tmp, out, list, count, in, size, thre, iw, ih);
   const int *cur = tmp;
-  for (int r = 1; r < ROUNDS; r++) {
-    int *nxt = (r & 1) ? out : tmp;
-    hipLaunchKernelGGL(k_despeckle2_sparse, dim3(512), dim3(256), 0, s, nxt, cur, (const int *)list, (const int *)count, in, size, iw, ih);
+  for (int r = 0; r < DOUBLE_ROUNDS; r++) {
+    int *nxt = (r & 1) ? tmp : out;
+    hipLaunchKernelGGL(k_despeckle2_sparse2, dim3(512), dim3(256), 0, s, nxt, cur, (const int *)list, (const int *)count, in, size, thre, iw, ih);
     cur = nxt;
   }
 }
