@@ -1037,7 +1037,7 @@ void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int 
   // 1 + 2 * 13 = 27 Jacobi rounds.  The raster recurrence has dependency chains of hundreds of pixels (it takes 300-900
   // rounds to reproduce the reference's plane exactly); what matters downstream settles much earlier: with 8 rounds the
   // rectangle lists of busy frames differed from the reference's, from 24 rounds on they did not (CPU study with
-  // oracle/rd_oracle.c: rdo_despeckle2_jacobi_k, 6 of 6 frames; DESIGN.md "Known deviation").
+  // bounded-round Jacobi prototypes, 6 of 6 frames; DESIGN.md "Known deviation").
   const int n = iw * ih, DOUBLE_ROUNDS = 13;   // odd: the last launch writes into `out`
   int *tmp = scratch, *count = scratch + (size_t)n, *list = count + 1;
   if (!count_is_zero) (void)hipMemsetAsync(count, 0, sizeof(int), s);
