@@ -266,7 +266,7 @@ struct Slot {
   uint8_t *bgr;
   uint32_t *plab0, *plab1, *smooth, *quant;
   float *tr[3], *fw[3], *bw[3], *hz[3], *bl[3], *vxy, *strength, *nms;
-  int *i0, *i1, *mask0, *tidy, *label1, *strsum, *edge500, *strong, *junction, *mergemask, *region, *rsize, *scratch2, *boundarysrc, *boundary, *lsid, *table, *claim, *probes, *region0, *tlist;
+  int *i0, *i1, *mask0, *tidy, *label1, *strsum, *edge500, *strong, *junction, *mergemask, *region, *rsize, *scratch2, *d2s, *boundarysrc, *boundary, *lsid, *table, *claim, *probes, *region0, *tlist;
   int8_t *e8;
   uint16_t *ext;
   float *tails; int *flags; int iir_chunked;
@@ -328,6 +328,7 @@ static void slot_alloc(rd_detector *d, Slot *s) {
                  &s->boundarysrc, &s->boundary, &s->lsid, &s->region0 };
   for (size_t i = 0; i < sizeof(ip) / sizeof(ip[0]); i++) *ip[i] = dnew<int>(N);
   s->scratch2 = dnew<int>(N * 3 + 256);
+  s->d2s = dnew<int>(RD_D2_SCRATCH_INTS(N));
   s->table = dnew<int>(N * 4); s->claim = dnew<int>(N); s->tlist = dnew<int>(N);
   rdk::reduce_ls_init(s->st, s->table, s->claim, s->tlist, (int)(N * 4 / 5));
   s->e8 = dnew<int8_t>(N);
@@ -350,7 +351,7 @@ static void slot_alloc(rd_detector *d, Slot *s) {
 static void slot_free(Slot *s) {
   RD_HIP(hipStreamSynchronize(s->st));
   void *all[] = { s->bgr, s->plab0, s->plab1, s->smooth, s->quant, s->vxy, s->strength, s->nms, s->i0, s->i1, s->mask0, s->tidy, s->label1, s->strsum, s->edge500, s->strong,
-                  s->junction, s->mergemask, s->region, s->rsize, s->scratch2, s->boundarysrc, s->boundary, s->lsid, s->table, s->claim, s->tlist, s->region0, s->probes, s->e8, s->ext, s->tails, s->flags, s->lslist };
+                  s->junction, s->mergemask, s->region, s->rsize, s->scratch2, s->d2s, s->boundarysrc, s->boundary, s->lsid, s->table, s->claim, s->tlist, s->region0, s->probes, s->e8, s->ext, s->tails, s->flags, s->lslist };
   for (void *p : all) dfree(p);
   for (int k = 0; k < 3; k++) { dfree(s->tr[k]); dfree(s->fw[k]); dfree(s->bw[k]); dfree(s->hz[k]); dfree(s->bl[k]); }
   rdk::poly_scratch_destroy(s->ps);
@@ -396,7 +397,7 @@ static void frame_regions(rd_detector *d, Slot *s) {
   const int iw = d->iw, ih = d->ih, N = d->N;
   hipStream_t st = s->st;
   // regions (oclrect.c:325-336)
-  int *d2scratch = s->scratch2 + (size_t)N + 64;      // behind the round flags, which travel to the host at the end
+  int *d2scratch = s->d2s;
   rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih, (d->diag_skip & 2) ? 0 : s->rounds,
                     s->rsize, s->junction);             // H2: the sizes start from the junction counts (copied by the first kernel)
   rdk::region_size(st, s->rsize, s->region0, N, d2scratch + N);
@@ -751,7 +752,7 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
     { "nms", s->nms, N * 4 }, { "mask0", s->mask0, N * 4 }, { "tidy", s->tidy, N * 4 }, { "label1", s->label1, N * 4 }, { "strsum", s->strsum, N * 4 },
     { "edge500", s->edge500, N * 4 }, { "smooth", s->smooth, N * 4 }, { "quant", s->quant, N * 4 }, { "strong", s->strong, N * 4 }, { "junction", s->junction, N * 4 },
     { "mergemask", s->mergemask, N * 4 }, { "region", s->region, N * 4 }, { "rsize", s->rsize, N * 4 }, { "boundarysrc", s->boundarysrc, N * 4 },
-    { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 }, { "polyctr", rdk::poly_scratch_counters(s->ps), 64 * 4 }, { "iirflags", s->flags, 16 * 4 },
+    { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 }, { "polyctr", rdk::poly_scratch_counters(s->ps), 64 * 4 }, { "iirflags", s->flags, 16 * 4 }, { "d2work", s->d2s + N, 16 * 4 },
   };
   for (size_t i = 0; i < sizeof(tab) / sizeof(tab[0]); i++)
     if (!strcmp(tab[i].n, name)) {

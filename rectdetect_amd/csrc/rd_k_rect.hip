@@ -654,11 +654,14 @@ __device__ __forceinline__ int despeckle2_pick(const int *__restrict__ cur, cons
 // are appended to `list` (any order), *count = their number.  One block per 64x32 tile collects its pixels in LDS and
 // reserves its share of the list with a single atomic (same-address atomics cost ~8 ns each: one per wave was 250 us).
 #define D2_ROWS 32
-__global__ __launch_bounds__(256) void k_despeckle2_first(int *__restrict__ nxt, int *__restrict__ other, int *__restrict__ list, int *count, const int *__restrict__ old, const int *__restrict__ size,
-                                                           int thre, int iw, int ih) {
+__global__ __launch_bounds__(256) void k_despeckle2_first(int *__restrict__ nxt, int *__restrict__ other, int *__restrict__ stamp, int *__restrict__ list, int *count,
+                                                           const int *__restrict__ old, const int *__restrict__ size, int thre, int iw, int ih) {
   __shared__ int loc[64 * D2_ROWS];
   __shared__ int nloc, base;
-  if (threadIdx.x == 0 && threadIdx.y == 0) nloc = 0;
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    nloc = 0;
+    if (blockIdx.x == 0 && blockIdx.y == 0) count[1] = count[2] = 0;     // the counters of the two other work lists
+  }
   __syncthreads();
   const int x = blockIdx.x * 64 + threadIdx.x;
   for (int r = threadIdx.y; r < D2_ROWS; r += 4) {
@@ -671,6 +674,7 @@ __global__ __launch_bounds__(256) void k_despeckle2_first(int *__restrict__ nxt,
       small = size[l0] <= thre;
       nxt[p0] = small ? despeckle2_pick(old, old, size, l0, x, y, iw, ih) : l0;
       other[p0] = l0;
+      stamp[p0] = small ? 0 : 0x7fffffff;      // work-list stamps (k_despeckle2_active): other pixels never enter a list
     }
     const unsigned long long m = __ballot(small);
     if (m) {
@@ -691,32 +695,110 @@ __global__ __launch_bounds__(256) void k_despeckle2_first(int *__restrict__ nxt,
 // TWO Jacobi rounds per launch, exactly: the value of a pixel after round r+2 needs the round r+1 values of its four earlier
 // neighbours, which are recomputed here from the round r plane (a launch costs more than the extra gathers: the rounds are
 // latency-bound at a few microseconds each, and the recurrence needs a few dozen of them - see despeckle2()).
-__global__ __launch_bounds__(256) void k_despeckle2_sparse2(int *__restrict__ nxt, const int *__restrict__ cur, const int *__restrict__ list, const int *__restrict__ count,
-                                                             const int *__restrict__ old, const int *__restrict__ size, int thre, int iw, int ih) {
-  const int n = *count;
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-    const int p0 = list[j];
-    const int x = p0 % iw, y = p0 / iw;
-    int lab[9], sz[9];
-    bool ok[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-      const int xx = k % 3 - 1, yy = k / 3 - 1;
-      ok[k] = !(x + xx < 0 || x + xx >= iw || y + yy < 0 || y + yy >= ih);
-      lab[k] = old[ok[k] ? p0 + yy * iw + xx : p0];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) sz[k] = size[lab[k]];
-#pragma unroll
-    for (int k = 0; k < 4; k++)      // an earlier neighbour that belongs to a small region: its value after round r+1
-      if (ok[k] && sz[k] <= thre) lab[k] = despeckle2_pick(cur, old, size, lab[k], x + k % 3 - 1, y + k / 3 - 1, iw, ih);
-#pragma unroll
-    for (int k = 0; k < 9; k++) sz[k] = size[lab[k]];
-    int res = old[p0], maxSize = 0;
-#pragma unroll
-    for (int k = 0; k < 9; k++) if (ok[k] && sz[k] > maxSize) { maxSize = sz[k]; res = lab[k]; }
-    nxt[p0] = res;
+//
+// Only the pixels that can still move are visited.  `cur` holds round r everywhere, `nxt` holds round r-2 and differs from `cur`
+// exactly on the pixels the previous launch changed.  A pixel's value after round r+2 is a function of the round r values of
+// its two-step earlier neighbourhood, so a pixel keeps its value unless the previous launch changed something in there; the
+// work list of a launch is therefore: the pixels the previous launch changed (their `nxt` is stale) and every small-region
+// pixel up to two steps later in raster order than one of those (offsets D2_LATER).  Each launch builds the next list while it
+// runs: a pixel goes in once (`stamp` carries the launch number), through a block-local list and one reservation per block.
+#define D2A_CAP 6144
+__constant__ signed char D2_LATER[11][2] = { {1, 0}, {2, 0}, {-1, 1}, {0, 1}, {1, 1}, {2, 1}, {-2, 2}, {-1, 2}, {0, 2}, {1, 2}, {2, 2} };
+__device__ __forceinline__ void d2_flush(int *__restrict__ list_out, int *count_out, const int *loc, int &nloc, int &base, int tid) {
+  __syncthreads();
+  const int m = min(nloc, D2A_CAP);
+  if (tid == 0 && m > 0) base = atomicAdd(count_out, m);
+  __syncthreads();
+  for (int i = tid; i < m; i += 256) list_out[base + i] = loc[i];
+  __syncthreads();
+  if (tid == 0) nloc = 0;
+  __syncthreads();
+}
+__global__ __launch_bounds__(256) void k_despeckle2_active(int *__restrict__ nxt, const int *__restrict__ cur, const int *__restrict__ list, const int *__restrict__ count,
+                                                            int *__restrict__ list_out, int *count_out, int *count_zero, int *work_trace, int *__restrict__ stamp, int tag,
+                                                            const int *__restrict__ old, const int *__restrict__ size, int thre, int iw, int ih) {
+  __shared__ int loc[D2A_CAP];
+  __shared__ int nloc, base;
+  const int tid = threadIdx.x;
+  if (tid == 0) {
+    nloc = 0;
+    if (blockIdx.x == 0) *count_zero = 0;        // the list after next: nobody reads or appends to it during this launch
   }
+  __syncthreads();
+  const int n = *count;
+  if (blockIdx.x == 0 && tid == 0) *work_trace = n;   // (diagnostic: the work list length of each launch)
+  for (int j0 = blockIdx.x * 256; j0 < n; j0 += gridDim.x * 256) {
+    const int j = j0 + tid;
+    bool changed = false;
+    int p0 = 0, x = 0, y = 0;
+    if (j < n) {
+      p0 = list[j];
+      x = p0 % iw, y = p0 / iw;
+      // The launches are latency-bound (a few hundred pixels, every dependent gather a trip to L2), so the gathers are arranged
+      // in two levels only: the round-r and input labels of the window (x-2..x+2, y-2..y+1) - the cells that are not needed
+      // fall away at compile time - then the region sizes of all of them; the rest is register arithmetic.
+      int C[4][5], O[4][5], CS[4][5], OS[4][5];
+      bool in[4][5];
+#pragma unroll
+      for (int wy = 0; wy < 4; wy++)
+#pragma unroll
+        for (int wx = 0; wx < 5; wx++) {
+          const int xx = x + wx - 2, yy = y + wy - 2;
+          in[wy][wx] = xx >= 0 && xx < iw && yy >= 0 && yy < ih;
+          const int q = in[wy][wx] ? p0 + (wy - 2) * iw + (wx - 2) : p0;
+          C[wy][wx] = cur[q];
+          O[wy][wx] = old[q];
+        }
+#pragma unroll
+      for (int wy = 0; wy < 4; wy++)
+#pragma unroll
+        for (int wx = 0; wx < 5; wx++) { CS[wy][wx] = size[C[wy][wx]]; OS[wy][wx] = size[O[wy][wx]]; }
+      int lab[9], sz[9];
+      bool ok[9];
+#pragma unroll
+      for (int k = 0; k < 9; k++) { ok[k] = in[k / 3 + 1][k % 3 + 1]; lab[k] = O[k / 3 + 1][k % 3 + 1]; sz[k] = OS[k / 3 + 1][k % 3 + 1]; }
+#pragma unroll
+      for (int k = 0; k < 4; k++)      // an earlier neighbour that belongs to a small region: its value after round r+1 (despeckle2_pick on the window)
+        if (ok[k] && sz[k] <= thre) {
+          int r = lab[k], rs = sz[k], m = 0;
+#pragma unroll
+          for (int i = 0; i < 9; i++) {
+            const int wy = k / 3 + i / 3, wx = k % 3 + i % 3;
+            const int l = i < 4 ? C[wy][wx] : O[wy][wx], sl = i < 4 ? CS[wy][wx] : OS[wy][wx];
+            if (in[wy][wx] && sl > m) { m = sl; r = l; rs = sl; }
+          }
+          lab[k] = r; sz[k] = rs;
+        }
+      int res = lab[4], maxSize = 0;
+#pragma unroll
+      for (int k = 0; k < 9; k++) if (ok[k] && sz[k] > maxSize) { maxSize = sz[k]; res = lab[k]; }
+      nxt[p0] = res;
+      changed = res != C[2][2];
+    }
+    if (list_out != nullptr) {
+      if (changed) {
+        int q[12], st[12];
+        q[11] = p0;
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+          const int xx = x + D2_LATER[k][0], yy = y + D2_LATER[k][1];
+          q[k] = (xx >= 0 && xx < iw && yy < ih) ? yy * iw + xx : p0;
+        }
+        // stamps: 0x7fffffff on pixels of large regions (stay out), otherwise the number of the last launch that listed the pixel
+#pragma unroll
+        for (int k = 0; k < 12; k++) st[k] = atomicMax(&stamp[q[k]], tag);
+#pragma unroll
+        for (int k = 0; k < 12; k++)
+          if (st[k] < tag) {
+            const int i = atomicAdd(&nloc, 1);
+            if (i < D2A_CAP) loc[i] = q[k]; else list_out[atomicAdd(count_out, 1)] = q[k];     // (never: at most 256 x 12 per pass, flushed below)
+          }
+      }
+      __syncthreads();
+      if (nloc + 256 * 12 > D2A_CAP) d2_flush(list_out, count_out, loc, nloc, base, tid);
+    }
+  }
+  if (list_out != nullptr) d2_flush(list_out, count_out, loc, nloc, base, tid);
 }
 
 // rc:373-390
@@ -1031,22 +1113,26 @@ void region_size(hipStream_t s, int *out, const int *label, int n, int *zero_me)
   hipLaunchKernelGGL(k_region_size, dim3(cdiv(n, 256 * RS_PER_THREAD)), dim3(256), 0, s, out, label, n, zero_me);
 }
 
-// scratch: 2*N + 1 ints; out must not alias in.  Eight Jacobi rounds of the reference's in-place sweep (see DESIGN.md,
-// H6); only pixels of small regions can change, so rounds 2..8 run over their list.
+// scratch: RD_D2_SCRATCH_INTS(N) ints, scratch[N] (the first list counter) zeroed by the caller when count_is_zero; out must not
+// alias in.  27 Jacobi rounds of the reference's in-place sweep; only pixels of small regions can change,
+// so every round after the first runs over work lists.
 void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih, int count_is_zero) {
   // 1 + 2 * 13 = 27 Jacobi rounds.  The raster recurrence has dependency chains of hundreds of pixels (it takes 300-900
   // rounds to reproduce the reference's plane exactly); what matters downstream settles much earlier: with 8 rounds the
   // rectangle lists of busy frames differed from the reference's, from 24 rounds on they did not (CPU study with
   // bounded-round Jacobi prototypes, 6 of 6 frames; DESIGN.md "Known deviation").
   const int n = iw * ih, DOUBLE_ROUNDS = 13;   // odd: the last launch writes into `out`
-  int *tmp = scratch, *count = scratch + (size_t)n, *list = count + 1;
+  int *tmp = scratch, *count = scratch + (size_t)n, *stamp = count + 16, *lists = stamp + (size_t)n;
   if (!count_is_zero) (void)hipMemsetAsync(count, 0, sizeof(int), s);
   // first round: tmp <- result, out <- input (both planes then agree on every pixel that is not in the list)
-  hipLaunchKernelGGL(k_despeckle2_first, dim3(cdiv(iw, 64), cdiv(ih, D2_ROWS)), dim3(64, 4), 0, s, tmp, out, list, count, in, size, thre, iw, ih);
+  hipLaunchKernelGGL(k_despeckle2_first, dim3(cdiv(iw, 64), cdiv(ih, D2_ROWS)), dim3(64, 4), 0, s, tmp, out, stamp, lists, count, in, size, thre, iw, ih);
   const int *cur = tmp;
   for (int r = 0; r < DOUBLE_ROUNDS; r++) {
     int *nxt = (r & 1) ? tmp : out;
-    hipLaunchKernelGGL(k_despeckle2_sparse2, dim3(512), dim3(256), 0, s, nxt, cur, (const int *)list, (const int *)count, in, size, thre, iw, ih);
+    const int li = r % 3, lo = (r + 1) % 3, lz = (r + 2) % 3;
+    const bool last = r == DOUBLE_ROUNDS - 1;
+    hipLaunchKernelGGL(k_despeckle2_active, dim3(512), dim3(256), 0, s, nxt, cur, (const int *)(lists + (size_t)li * n), (const int *)(count + li),
+                       last ? (int *)nullptr : lists + (size_t)lo * n, count + lo, count + lz, count + 3 + r, stamp, r + 1, in, size, thre, iw, ih);
     cur = nxt;
   }
 }

@@ -59,7 +59,8 @@ void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int 
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int rounds,
                   int *size_out, const int *size_init);   // rounds: 20 (at most; early-out on the device); size_out (optional) <- size_init, for region_size
 void region_size(hipStream_t s, int *out, const int *label, int n, int *zero_me);   // accumulates into out; zero_me (optional): an int to clear on the way
-void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih, int count_is_zero);   // out != in; scratch: 2N+1 ints (scratch[N] = 0 already if count_is_zero)
+#define RD_D2_SCRATCH_INTS(N) (5 * (size_t)(N) + 64)
+void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih, int count_is_zero);   // out != in; scratch: RD_D2_SCRATCH_INTS(N) ints (scratch[N] = 0 already if count_is_zero)
 void mark_boundary(hipStream_t s, int *out, const int *in, int iw, int ih);
 struct PolyScratch;
 // votes of the chain pixels left in `ps` by the last polyline() call on this stream (their final segment ids)
