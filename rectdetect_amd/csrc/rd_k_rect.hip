@@ -115,59 +115,85 @@ __global__ __launch_bounds__(256) void k_rect_tidy(int *__restrict__ mask0, int 
 // twice), each side stopping at transitions of the int8 edge mask.  The stopping positions depend on the mask only and
 // the mask is the same for all 20 passes (rh:286-296), so they are computed once per frame (k_blblur_extents: number of
 // samples taken towards smaller / larger coordinates, 0..5 each, for both axes) and every pass is a branch-free gather.
-#define BE_ROWS 16
-#define BE_PITCH 76
+//
+// The scans only ask "is the mask non-zero" of cells up to 5 away along the axis and 1 sideways, so the block turns its
+// (64+16) x (BE_ROWS+11) patch of the mask into bit rows (one ballot per 64 cells) and every stopping rule into one word
+// operation per row:
+//   towards smaller coordinates, cell c stops the scan before it is counted when
+//       c < 0, or c > 0 and (E[c] & !E[c-1]  |  !E[c] & E[c-1] & E[c, one step sideways]);
+//   towards larger coordinates when
+//       c > n-1, or (centre on an edge ? !E[c] : !E[c] & E[c+1]).
+// Cells outside the frame are staged as zero, which makes the reference's `c < n-1` and `has side cell` tests redundant.
+// A pixel then reads its five relevant stop bits per direction and counts the leading clear ones.
+#define BE_ROWS 32
+#define BE_NR (BE_ROWS + 11)          // rows y0-5 .. y0+BE_ROWS+5
 __global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ ext, const int8_t *__restrict__ edge, int iw, int ih) {
-  // the scans below look at most 5 cells away along their axis and 1 cell sideways: stage (64+10) x (BE_ROWS+10) mask bytes
-  __shared__ int8_t te[(BE_ROWS + 10) * BE_PITCH];
+  typedef unsigned long long u64;
+  __shared__ u64 EA[BE_NR + 1], EB[BE_NR + 1];   // mask != 0 for columns x0-8 .. x0+55 (A) and x0+56 .. x0+71 (B)
+  __shared__ u64 HLa[BE_NR], HLb[BE_NR], HRa[BE_NR], HRb[BE_NR];   // along x: stop bits towards smaller / larger x (centre not on an edge)
+  __shared__ u64 VL[BE_NR], VR[BE_NR], VE[BE_NR];                  // along y, tile columns only (bit = column - x0)
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BE_ROWS;
-  const int tid = threadIdx.y * 64 + threadIdx.x;
-  for (int t = tid; t < (BE_ROWS + 10) * 74; t += 256) {
-    const int r = t / 74, c = t % 74;
-    const int xx = x0 - 5 + c, yy = y0 - 5 + r;
-    te[r * BE_PITCH + c] = (xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? edge[yy * iw + xx] : (int8_t)0;
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+  for (int r = ty; r < BE_NR; r += 4) {
+    const int yy = y0 - 5 + r;
+    const bool rowin = yy >= 0 && yy < ih;
+    const int xa = x0 - 8 + tx, xb = x0 + 56 + tx;
+    const bool ea = rowin && xa >= 0 && xa < iw && edge[yy * iw + xa] != 0;
+    const bool eb = rowin && tx < 16 && xb < iw && edge[yy * iw + xb] != 0;
+    const u64 ba = __ballot(ea), bb = __ballot(eb);
+    if (tx == 0) { EA[r] = ba; EB[r] = bb; }
+  }
+  if (tid == 0) { EA[BE_NR] = 0; EB[BE_NR] = 0; }
+  __syncthreads();
+  if (tid < BE_NR) {
+    const int r = tid, yy = y0 - 5 + r;
+    const u64 A = EA[r], B = EB[r], SA = EA[r + 1], SB = EB[r + 1];
+    const u64 PA = A << 1, PB = (B << 1) | (A >> 63);            // E[c-1]
+    const u64 NA = (A >> 1) | (B << 63), NB = B >> 1;            // E[c+1]
+    u64 la = (A & ~PA) | (~A & PA & SA), lb = (B & ~PB) | (~B & PB & SB);
+    u64 ra = ~A & NA, rb = ~B & NB;
+    if (x0 == 0) { la &= ~(1ull << 8); la |= 0xffull; }          // column 0 never stops the scan itself; columns < 0 do
+    const int fa = iw - x0 + 8, fb = iw - x0 - 56;               // first bit index beyond the frame
+    if (fa < 64) ra |= ~0ull << fa;
+    if (fb <= 0) rb = ~0ull; else if (fb < 64) rb |= ~0ull << fb;
+    HLa[r] = la; HLb[r] = lb; HRa[r] = ra; HRb[r] = rb;
+    const u64 Et = (A >> 8) | (B << 56), En = (A >> 9) | (B << 55);                 // columns x0.., x0+1..
+    const u64 Ep = r > 0 ? (EA[r - 1] >> 8) | (EB[r - 1] << 56) : 0ull;             // row above
+    const u64 Es = (SA >> 8) | (SB << 56);                                           // row below
+    u64 vl = (Et & ~Ep) | (~Et & Ep & En);
+    if (yy == 0) vl = 0;
+    if (yy < 0) vl = ~0ull;
+    u64 vr = ~Et & Es;
+    if (yy >= ih) vr = ~0ull;
+    VL[r] = vl; VR[r] = vr; VE[r] = Et;
   }
   __syncthreads();
-  const int x = x0 + threadIdx.x;
+  const int x = x0 + tx;
   if (x >= iw) return;
-  for (int r = threadIdx.y; r < BE_ROWS; r += 4) {
-    const int y = y0 + r;
+  for (int rr = ty; rr < BE_ROWS; rr += 4) {
+    const int y = y0 + rr;
     if (y >= ih) break;
-    const int8_t *ctr = te + (r + 5) * BE_PITCH + threadIdx.x + 5;
-    const bool oe = ctr[0] != 0;
-    unsigned e = 0;
+    const int r = rr + 5;
+    // 64-bit windows starting at column x - 8: the pixel is bit 8
+    const int sh = tx, rs = (64 - tx) & 63;
+    const u64 keep = tx == 0 ? 0ull : ~0ull;
+    const u64 we = (EA[r] >> sh) | ((EB[r] << rs) & keep);
+    const u64 wl = (HLa[r] >> sh) | ((HLb[r] << rs) & keep);
+    const u64 wr1 = (HRa[r] >> sh) | ((HRb[r] << rs) & keep);
+    const bool oe = (we >> 8) & 1;
+    const u64 wr = oe ? ~we : wr1;
+    const unsigned tl = (unsigned)(wl >> 4) & 31u;                 // bit 4: the pixel's own column ... bit 0: four columns before
+    const int nl = __clz((int)tl) - 27;
+    const int nr = __ffs((int)(((unsigned)(wr >> 8) & 31u) | 32u)) - 1;
+    unsigned tv = 0, uv = 32u;
 #pragma unroll
-    for (int vert = 0; vert < 2; vert++) {
-      const int c0 = vert ? y : x, n = vert ? ih : iw, st = vert ? BE_PITCH : 1;
-      const bool has_side = vert ? (x < iw - 1) : (y < ih - 1);
-      const int side = vert ? 1 : BE_PITCH;
-      int nl = 0, nr = 0;
-#pragma unroll
-      for (int d = 0; d >= -4; d--) {
-        const int c = c0 + d;
-        if (c < 0) break;
-        const int8_t *q = ctr + d * st;
-        const int ec = q[0];
-        if (c > 0) {
-          const int em = q[-st];
-          if (ec != 0 && em == 0) break;
-          if (has_side && ec == 0 && em != 0 && q[side] != 0) break;
-        }
-        nl++;
-      }
-#pragma unroll
-      for (int d = 0; d <= 4; d++) {
-        const int c = c0 + d;
-        if (c > n - 1) break;
-        const int8_t *q = ctr + d * st;
-        const int ec = q[0];
-        if (c < n - 1 && ec == 0 && q[st] != 0) break;
-        if (oe && ec == 0) break;
-        nr++;
-      }
-      e |= (unsigned)(nl | (nr << 3)) << (vert * 6);
+    for (int d = 0; d < 5; d++) {
+      tv |= (unsigned)((VL[r - d] >> tx) & 1ull) << (4 - d);
+      const u64 w = oe ? ~VE[r + d] : VR[r + d];
+      uv |= (unsigned)((w >> tx) & 1ull) << d;
     }
-    ext[y * iw + x] = (uint16_t)e;
+    const int nlv = __clz((int)tv) - 27, nrv = __ffs((int)uv) - 1;
+    ext[y * iw + x] = (uint16_t)((unsigned)(nl | (nr << 3)) | ((unsigned)(nlv | (nrv << 3)) << 6));
   }
 }
 
