@@ -250,8 +250,13 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
     const int nl = e & 7, nr = (e >> 3) & 7;
     const int c = r * BP_SW + tx + 4;
     uint2 v[10];
+    // (byte addresses: a sample's address is `selected base + constant`, so the constant travels in the instruction)
+    const unsigned cb = (unsigned)c * 8u, zb = (unsigned)ZS * 8u;
 #pragma unroll
-    for (int d = 0; d < 5; d++) { v[d] = src[d < nl ? c - d : ZS]; v[5 + d] = src[d < nr ? c + d : ZS]; }
+    for (int d = 0; d < 5; d++) {
+      v[d] = *(const uint2 *)((const char *)src + ((d < nl ? cb - 32u : zb - (32u - 8u * d)) + (32u - 8u * d)));
+      v[5 + d] = *(const uint2 *)((const char *)src + ((d < nr ? cb : zb - 8u * d) + 8u * d));
+    }
     unsigned lo = 0, hi = 0;
 #pragma unroll
     for (int d = 0; d < 10; d++) { lo += v[d].x; hi += v[d].y; }
@@ -274,8 +279,12 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
     const int nl = e & 7, nr = (e >> 3) & 7;
     const int c = (r + 4) * 64 + tx;
     uint2 v[10];
+    const unsigned cb = (unsigned)c * 8u, zb = (unsigned)ZH * 8u;
 #pragma unroll
-    for (int d = 0; d < 5; d++) { v[d] = hz[d < nl ? c - d * 64 : ZH]; v[5 + d] = hz[d < nr ? c + d * 64 : ZH]; }
+    for (int d = 0; d < 5; d++) {
+      v[d] = *(const uint2 *)((const char *)hz + ((d < nl ? cb - 2048u : zb - (2048u - 512u * d)) + (2048u - 512u * d)));
+      v[5 + d] = *(const uint2 *)((const char *)hz + ((d < nr ? cb : zb - 512u * d) + 512u * d));
+    }
     unsigned lo = 0, hi = 0;
 #pragma unroll
     for (int d = 0; d < 10; d++) { lo += v[d].x; hi += v[d].y; }
