@@ -211,36 +211,50 @@ __device__ __forceinline__ unsigned div_small_f(unsigned s, float rw) { return (
 __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih) {
   __shared__ uint2 src[(BP_ROWS + 8) * BP_SW + 1];
   __shared__ uint2 hz[(BP_ROWS + 8) * 64 + 1];
-  __shared__ float rwt[16];                                      // 1 / w, correctly rounded (compile-time constants)
+  __shared__ float rwt[16];                                      // 1 / w, correctly rounded
   const int ZS = (BP_ROWS + 8) * BP_SW, ZH = (BP_ROWS + 8) * 64;   // zero slots
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BP_ROWS;
   const int x = x0 + tx;
-  if (tid == 0) { src[ZS] = make_uint2(0, 0); hz[ZH] = make_uint2(0, 0); }
-  if (tid < 16) {
-    const float t[16] = { 0.0f, 1.0f, 1.0f / 2.0f, 1.0f / 3.0f, 1.0f / 4.0f, 1.0f / 5.0f, 1.0f / 6.0f, 1.0f / 7.0f, 1.0f / 8.0f, 1.0f / 9.0f, 1.0f / 10.0f, 0, 0, 0, 0, 0 };
-    rwt[tid] = t[tid];
-  }
   // the run extents of this thread's pixels (3 rows of the horizontal strip, 2 rows of the output tile): requested first so
   // that their latency overlaps the staging of the tile
+  // (every load below is unconditional - the address of a cell outside the frame is clamped, its value replaced afterwards -
+  //  so that all eight are in flight together: a block's critical path holds one trip to memory, not one per staging step)
   unsigned eh[3], ev[2];
+  uint32_t q[3];
+  bool okh[3], okv[2], okq[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
     const int y = y0 - 4 + ty + 16 * k;
-    eh[k] = (ty + 16 * k < BP_ROWS + 8 && x < iw && y >= 0 && y < ih) ? ext[y * iw + x] : 0u;
+    okh[k] = ty + 16 * k < BP_ROWS + 8 && x < iw && y >= 0 && y < ih;
+    eh[k] = ext[okh[k] ? y * iw + x : 0];
   }
 #pragma unroll
   for (int k = 0; k < 2; k++) {
     const int y = y0 + ty + 16 * k;
-    ev[k] = (x < iw && y < ih) ? (unsigned)ext[y * iw + x] >> 6 : 0u;
+    okv[k] = x < iw && y < ih;
+    ev[k] = ext[okv[k] ? y * iw + x : 0];
   }
-  for (int t = tid; t < (BP_ROWS + 8) * 72; t += 1024) {
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int t = tid + 1024 * i;
     const int r = t / 72, c = t % 72;
     const int xx = x0 - 4 + c, yy = y0 - 4 + r;
-    uint32_t q = 0;
-    if (xx >= 0 && xx < iw && yy >= 0 && yy < ih) q = in[yy * iw + xx];
-    src[r * BP_SW + c] = make_uint2((q & 4095u) | ((q << 4) & 0x3ff0000u), q >> 22);
+    okq[i] = t < (BP_ROWS + 8) * 72 && xx >= 0 && xx < iw && yy >= 0 && yy < ih;
+    q[i] = in[okq[i] ? yy * iw + xx : 0];
   }
+  if (tid == 0) { src[ZS] = make_uint2(0, 0); hz[ZH] = make_uint2(0, 0); }
+  if (tid < 16) rwt[tid] = tid >= 1 && tid <= 10 ? 1.0f / (float)tid : 0.0f;      // 1 / w, correctly rounded
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int t = tid + 1024 * i;
+    const uint32_t v = okq[i] ? q[i] : 0u;
+    if (t < (BP_ROWS + 8) * 72) src[(t / 72) * BP_SW + t % 72] = make_uint2((v & 4095u) | ((v << 4) & 0x3ff0000u), v >> 22);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) if (!okh[k]) eh[k] = 0u;
+#pragma unroll
+  for (int k = 0; k < 2; k++) if (!okv[k]) ev[k] = 0u;
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < 3; k++) {
@@ -275,7 +289,7 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
     const int r = ty + 16 * k;
     const int y = y0 + r;
     if (y >= ih) break;
-    const unsigned e = ev[k];
+    const unsigned e = ev[k] >> 6;
     const int nl = e & 7, nr = (e >> 3) & 7;
     const int c = (r + 4) * 64 + tx;
     uint2 v[10];
