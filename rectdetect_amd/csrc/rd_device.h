@@ -74,6 +74,29 @@ __device__ __forceinline__ int pixel_rand(int p, uint64_t seed) {
   return (int)mix64(((uint64_t)(int64_t)p ^ 0xb21c2cb635b48285ULL) * 0x9b923b9cec745401ULL + (seed ^ 0x7bb93d75a79d2f15ULL) * 0x22cab58ada573a29ULL);
 }
 
+// Staging a tile: NCELLS cells, NT threads.  `where(t, a)` returns whether cell t has a source element and puts its index in
+// a; `put(t, ok, v)` stores it.  All loads of a thread are issued before any value is used (the address of a cell without a
+// source is clamped to element 0 and the value ignored): a block then waits for memory once, not once per step of a loop -
+// these kernels run a few microseconds, a trip to HBM takes about one.
+template <int NCELLS, int NT, typename T, typename Where, typename Put>
+__device__ __forceinline__ void stage_cells(int tid, const T *__restrict__ in, Where where, Put put) {
+  constexpr int IT = (NCELLS + NT - 1) / NT;
+  T v[IT];
+  bool ok[IT];
+#pragma unroll
+  for (int i = 0; i < IT; i++) {
+    const int t = tid + i * NT;
+    int a = 0;
+    ok[i] = (IT * NT == NCELLS || t < NCELLS) && where(t, a);
+    v[i] = in[ok[i] ? a : 0];
+  }
+#pragma unroll
+  for (int i = 0; i < IT; i++) {
+    const int t = tid + i * NT;
+    if (IT * NT == NCELLS || t < NCELLS) put(t, ok[i], v[i]);
+  }
+}
+
 // L2-coherent (device-scope) load: used to guard hot atomics so that later waves see an earlier wave's update instead of
 // a stale L1 line and skip the atomic
 __device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -443,18 +443,26 @@ __global__ __launch_bounds__(256) void k_thinthres(float *__restrict__ out, cons
   __shared__ float tile[(TT_ROWS + 7) * TT_PITCH];
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * TT_ROWS;
   const int tid = threadIdx.y * 64 + threadIdx.x;
-  for (int t = tid; t < (TT_ROWS + 7) * TT_PITCH; t += 256) {
-    const int r = t / TT_PITCH, c = t % TT_PITCH;
-    tile[t] = in[(size_t)mirror1(y0 - 3 + r, ih) * iw + mirror1(x0 - 3 + c, iw)];
-  }
-  __syncthreads();
   const int x = x0 + threadIdx.x;
+  // the directions of this thread's pixels are requested together with the tile (one wait for memory per block)
+  float2 dir[TT_ROWS / 4];
+#pragma unroll
+  for (int k = 0; k < TT_ROWS / 4; k++) {
+    const int y = y0 + threadIdx.y + 4 * k;
+    dir[k] = vxy[(x < iw && y < ih) ? y * iw + x : 0];
+  }
+  stage_cells<(TT_ROWS + 7) * TT_PITCH, 256>(tid, in,
+    [&](int t, int &a) { a = mirror1(y0 - 3 + t / TT_PITCH, ih) * iw + mirror1(x0 - 3 + t % TT_PITCH, iw); return true; },
+    [&](int t, bool, float v) { tile[t] = v; });
+  __syncthreads();
   if (x >= iw) return;
-  for (int r = threadIdx.y; r < TT_ROWS; r += 4) {
+#pragma unroll
+  for (int k = 0; k < TT_ROWS / 4; k++) {
+    const int r = threadIdx.y + 4 * k;
     const int y = y0 + r;
     if (y >= ih) break;
     const int p0 = y * iw + x;
-    const float2 v = vxy[p0];
+    const float2 v = dir[k];
     const float a0 = tile[(r + 3) * TT_PITCH + threadIdx.x + 3];
     const float am1 = bicubic_lds(tile, x - 1 * v.x, y - 1 * v.y, x0, y0);
     const float ap1 = bicubic_lds(tile, x + 1 * v.x, y + 1 * v.y, x0, y0);

@@ -45,10 +45,9 @@ __global__ __launch_bounds__(256) void k_poly_tidy(int *__restrict__ out, const 
   const int tid = threadIdx.y * 64 + threadIdx.x;
 #define PT_FOR(m) for (int t = tid; t < (PT_ROWS + 2 * (m)) * (64 + 2 * (m)); t += 256)
 #define PT_CELL(m) const int r = t / (64 + 2 * (m)) - (m), c = t % (64 + 2 * (m)) - (m); const int x = x0 + c, y = y0 + r; const int i = (r + PT_M) * PT_P + c + PT_M; const bool in_img = x >= 0 && x < iw && y >= 0 && y < ih
-  PT_FOR(6) {
-    PT_CELL(6);
-    A[i] = (in_img && in[y * iw + x] != 0) ? 1 : 0;
-  }
+  stage_cells<(PT_ROWS + 12) * (64 + 12), 256>(tid, in,
+    [&](int t, int &a) { PT_CELL(6); (void)i; a = y * iw + x; return in_img; },
+    [&](int t, bool ok, int v) { PT_CELL(6); (void)in_img; A[i] = (ok && v != 0) ? 1 : 0; });
   __syncthreads();
   PT_FOR(5) {   // pl:66-87
     PT_CELL(5);

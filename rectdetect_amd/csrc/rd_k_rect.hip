@@ -51,15 +51,14 @@ __global__ __launch_bounds__(256) void k_rect_tidy(int *__restrict__ mask0, int 
   // region with margin m around the tile, cell t -> (r, c) tile coordinates, (x, y) frame coordinates, i = LDS index
 #define TD_FOR(m) for (int t = tid; t < (TD_ROWS + 2 * (m)) * (64 + 2 * (m)); t += 256)
 #define TD_CELL(m) const int r = t / (64 + 2 * (m)) - (m), c = t % (64 + 2 * (m)) - (m); const int x = x0 + c, y = y0 + r; const int i = (r + TD_M) * TD_P + c + TD_M; const bool in_img = x >= 0 && x < iw && y >= 0 && y < ih
-  TD_FOR(4) {
-    TD_CELL(4);
-    uint8_t v = 0;
-    if (in_img) {
-      v = nms[y * iw + x] > 0.0f ? 1 : 0;
-      if (r >= 0 && r < TD_ROWS && c >= 0 && c < 64) mask0[y * iw + x] = v;
-    }
-    A[i] = v;
-  }
+  stage_cells<(TD_ROWS + 8) * (64 + 8), 256>(tid, nms,
+    [&](int t, int &a) { TD_CELL(4); (void)i; a = y * iw + x; return in_img; },
+    [&](int t, bool ok, float f) {
+      TD_CELL(4);
+      const uint8_t v = (ok && f > 0.0f) ? 1 : 0;
+      if (in_img && r >= 0 && r < TD_ROWS && c >= 0 && c < 64) mask0[y * iw + x] = v;
+      A[i] = v;
+    });
   __syncthreads();
   TD_FOR(3) {   // rc:67-95 (count of on-pixels in the 3x3 block, isolated pixels -> 0)
     TD_CELL(3);
@@ -134,14 +133,26 @@ __global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ e
   __shared__ u64 VL[BE_NR], VR[BE_NR], VE[BE_NR];                  // along y, tile columns only (bit = column - x0)
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BE_ROWS;
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
-  for (int r = ty; r < BE_NR; r += 4) {
-    const int yy = y0 - 5 + r;
-    const bool rowin = yy >= 0 && yy < ih;
+  {
+    constexpr int IT = (BE_NR + 3) / 4;
+    int8_t va[IT], vb[IT];
+    bool oka[IT], okb[IT];
     const int xa = x0 - 8 + tx, xb = x0 + 56 + tx;
-    const bool ea = rowin && xa >= 0 && xa < iw && edge[yy * iw + xa] != 0;
-    const bool eb = rowin && tx < 16 && xb < iw && edge[yy * iw + xb] != 0;
-    const u64 ba = __ballot(ea), bb = __ballot(eb);
-    if (tx == 0) { EA[r] = ba; EB[r] = bb; }
+#pragma unroll
+    for (int i = 0; i < IT; i++) {          // all loads first (see stage_cells)
+      const int yy = y0 - 5 + ty + 4 * i;
+      const bool rowin = ty + 4 * i < BE_NR && yy >= 0 && yy < ih;
+      oka[i] = rowin && xa >= 0 && xa < iw;
+      okb[i] = rowin && tx < 16 && xb < iw;
+      va[i] = edge[oka[i] ? yy * iw + xa : 0];
+      vb[i] = edge[okb[i] ? yy * iw + xb : 0];
+    }
+#pragma unroll
+    for (int i = 0; i < IT; i++) {
+      const int r = ty + 4 * i;
+      const u64 ba = __ballot(oka[i] && va[i] != 0), bb = __ballot(okb[i] && vb[i] != 0);
+      if (tx == 0 && r < BE_NR) { EA[r] = ba; EB[r] = bb; }
+    }
   }
   if (tid == 0) { EA[BE_NR] = 0; EB[BE_NR] = 0; }
   __syncthreads();
@@ -320,27 +331,51 @@ __device__ __forceinline__ uint32_t quantize_plab(uint32_t v, int n0, int n1, in
 }
 
 // rc:218-244: pixels with a non-zero NMS response take the colour of the Lab-nearest 3x3 neighbour without one.
-// Such pixels are a few per cent, on thin lines that cross a third of all waves: every block first copies its 64 x DS_ROWS
-// tile and collects the affected pixels in an LDS list, then works the list off with all lanes busy.
+// One block per 64 x DS_ROWS tile: the tile and a 1-cell halo of both inputs are staged in LDS (colours already quantised,
+// the response reduced to flags) with all loads of a thread in flight together; the affected pixels - a few per cent, on thin
+// lines that cross a third of all waves - are collected in an LDS list and worked off with all lanes busy, from LDS only.
 #define DS_ROWS 16
+#define DS_P 66
 // QN > 0: the input is quantised to QN levels per field on the fly (rc:207-216 fused in: no separate pass over the plane)
 template <int QN>
 __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, const uint32_t *__restrict__ in, const float *__restrict__ edge, int iw, int ih) {
+  constexpr int NC = (DS_ROWS + 2) * DS_P, IT = (NC + 255) / 256;
+  __shared__ uint32_t tq[NC];
+  __shared__ uint8_t tf[NC];        // bit 0: replaced as a centre (!(e < 1e-6)), bit 1: skipped as a neighbour (e >= 1e-6), bit 2: outside the frame
   __shared__ int list[64 * DS_ROWS];
   __shared__ int nlist;
-  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+  const int tx = threadIdx.x, tid = threadIdx.y * 64 + tx;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * DS_ROWS;
   if (tid == 0) nlist = 0;
-  __syncthreads();
-  const int x = blockIdx.x * 64 + tx;
+  {
+    uint32_t v[IT];
+    float e[IT];
+    bool ok[IT];
 #pragma unroll
-  for (int r = ty; r < DS_ROWS; r += 4) {
-    const int y = blockIdx.y * DS_ROWS + r;
+    for (int i = 0; i < IT; i++) {
+      const int t = tid + 256 * i;
+      const int xx = x0 - 1 + t % DS_P, yy = y0 - 1 + t / DS_P;
+      ok[i] = t < NC && xx >= 0 && xx < iw && yy >= 0 && yy < ih;
+      const int a = ok[i] ? yy * iw + xx : 0;
+      v[i] = in[a];
+      e[i] = edge[a];
+    }
+#pragma unroll
+    for (int i = 0; i < IT; i++) {
+      const int t = tid + 256 * i;
+      if (t >= NC) break;
+      tq[t] = ok[i] ? (QN > 0 ? quantize_plab(v[i], QN, QN, QN) : v[i]) : 0u;
+      tf[t] = ok[i] ? (uint8_t)((!(e[i] < 1e-6f) ? 1 : 0) | (e[i] >= 1e-6f ? 2 : 0)) : (uint8_t)4;
+    }
+  }
+  __syncthreads();
+  for (int r = threadIdx.y; r < DS_ROWS; r += 4) {
+    const int x = x0 + tx, y = y0 + r;
+    const int i = (r + 1) * DS_P + tx + 1;
     bool hot = false;
-    int p0 = 0;
     if (x < iw && y < ih) {
-      p0 = y * iw + x;
-      hot = !(edge[p0] < 1e-6f);
-      if (!hot) out[p0] = QN > 0 ? quantize_plab(in[p0], QN, QN, QN) : in[p0];
+      hot = tf[i] & 1;
+      if (!hot) out[y * iw + x] = tq[i];
     }
     const unsigned long long m = __ballot(hot);
     if (m) {
@@ -348,30 +383,28 @@ __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, c
       int o = 0;
       if (tx == leader) o = atomicAdd(&nlist, __popcll(m));
       o = __shfl(o, leader);
-      if (hot) list[o + __popcll(m & ((1ull << tx) - 1))] = p0;
+      if (hot) list[o + __popcll(m & ((1ull << tx) - 1))] = i;
     }
   }
   __syncthreads();
   const int n = nlist;
   for (int j = tid; j < n; j += 256) {
-    const int p0 = list[j];
-    const int px = p0 % iw, py = p0 / iw;
-    uint32_t r = QN > 0 ? quantize_plab(in[p0], QN, QN, QN) : in[p0];
+    const int i = list[j];
+    uint32_t r = tq[i];
     float dist = 1e+10f, l0, a0, b0;
     unpack_lab(r, l0, a0, b0);
-    for (int yy = -1; yy <= 1; yy++)
-      for (int xx = -1; xx <= 1; xx++) {
-        if (px + xx < 0 || px + xx >= iw || py + yy < 0 || py + yy >= ih) continue;
-        const int p1 = p0 + yy * iw + xx;
-        if (edge[p1] >= 1e-6f) continue;
-        float l1, a1, b1;
-        const uint32_t v = QN > 0 ? quantize_plab(in[p1], QN, QN, QN) : in[p1];
-        unpack_lab(v, l1, a1, b1);
-        const float dx = l1 - l0, dy = a1 - a0, dz = b1 - b0;
-        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-        if (d < dist) { r = v; dist = d; }
-      }
-    out[p0] = r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      const int q = i + (k / 3 - 1) * DS_P + k % 3 - 1;
+      if (tf[q] & 6) continue;          // outside the frame, or has a response itself
+      float l1, a1, b1;
+      const uint32_t v = tq[q];
+      unpack_lab(v, l1, a1, b1);
+      const float dx = l1 - l0, dy = a1 - a0, dz = b1 - b0;
+      const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+      if (d < dist) { r = v; dist = d; }
+    }
+    out[(y0 + i / DS_P - 1) * iw + x0 + i % DS_P - 1] = r;
   }
 }
 
@@ -864,14 +897,9 @@ __global__ __launch_bounds__(256) void k_mark_boundary(int *__restrict__ out, co
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
   const int v00 = in[y0 * iw + x0];
   bool uniform = true;
-  for (int k = tid; k < (MB_ROWS + 4) * MB_P; k += 256) {
-    const int r = k / MB_P, c = k % MB_P;
-    const int xx = x0 - 2 + c, yy = y0 - 2 + r;
-    const bool inside = xx >= 0 && xx < iw && yy >= 0 && yy < ih;
-    const int v = inside ? in[yy * iw + xx] : 0;
-    uniform = uniform && (!inside || v == v00);
-    t[k] = v;
-  }
+  stage_cells<(MB_ROWS + 4) * MB_P, 256>(tid, in,
+    [&](int k, int &a) { const int xx = x0 - 2 + k % MB_P, yy = y0 - 2 + k / MB_P; a = yy * iw + xx; return xx >= 0 && xx < iw && yy >= 0 && yy < ih; },
+    [&](int k, bool inside, int v) { uniform = uniform && (!inside || v == v00); t[k] = inside ? v : 0; });
   const int x = x0 + tx;
   if (__syncthreads_and(uniform)) {
     // no differing cell anywhere in reach: interior pixels are not boundary pixels (-1), and so is the 2-px frame ring by definition
