@@ -495,30 +495,54 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
   // (also: the round / flatten flags start at zero, and the size plane starts from size_init - quirk H2 - without extra launches)
   if (blockIdx.x == 0 && blockIdx.y == 0) { const int t = threadIdx.y * 64 + threadIdx.x; if (t < 64) flags[t] = 0; }
   const int tx = threadIdx.x, x = blockIdx.x * 64 + tx, y0 = blockIdx.y * RI_ROWS;
-  for (int r = threadIdx.y; r < RI_ROWS; r += 4) {
-    const int y = y0 + r;
-    int l = r * 64 + tx;
-    if (x < iw && y < ih) {
-      const int p = y * iw + x;
-      const int v = pix[p];
-      if (y > 0 && v == pix[p - iw]) l = r > 0 ? l - 64 : -(p - iw) - 1;
-      else if (x > 0 && v == pix[p - 1]) l = tx > 0 ? l - 1 : -(p - 1) - 1;
-      unsigned a = 0;
-      if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1) {
-        const bool any = mask[p] != 0;
-        const bool e0 = edge[p] <= 0;
-        if ((v == pix[p - iw] || any) && e0) a |= 1;
-        if ((v == pix[p - 1] || any) && e0) a |= 2;
-        if ((v == pix[p + 1] || any) && edge[p + 1] <= 0) a |= 4;
-        if ((v == pix[p + iw] || any) && edge[p + iw] <= 0) a |= 8;
-        a |= 16;   // interior
-      }
-      allow[p] = (uint8_t)a;
-      prop[p] = 0x7f7f7f7f;      // no proposal
-      selfp[p] = 0x7f7f7f7f;
-      if (size_out) size_out[p] = size_init[p];
+  // four rows at a time, all of their loads in flight together (clamped addresses; what a pixel may not use is ignored)
+#pragma unroll
+  for (int half = 0; half < RI_ROWS / 16; half++) {
+    int v[4], vu[4], vl[4], vr[4], vd[4], mk[4], e0[4], er[4], ed[4], si[4];
+    bool in[4], inter[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int y = y0 + threadIdx.y + 4 * (half * 4 + k);
+      in[k] = x < iw && y < ih;
+      inter[k] = in[k] && x > 0 && y > 0 && x < iw - 1 && y < ih - 1;
+      const int p = in[k] ? y * iw + x : 0;
+      v[k] = pix[p];
+      vu[k] = pix[(in[k] && y > 0) ? p - iw : p];
+      vl[k] = pix[(in[k] && x > 0) ? p - 1 : p];
+      vr[k] = pix[inter[k] ? p + 1 : p];
+      vd[k] = pix[inter[k] ? p + iw : p];
+      mk[k] = mask[p];
+      e0[k] = edge[p];
+      er[k] = edge[inter[k] ? p + 1 : p];
+      ed[k] = edge[inter[k] ? p + iw : p];
+      si[k] = size_out ? size_init[p] : 0;
     }
-    par[r * 64 + tx] = l;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int r = threadIdx.y + 4 * (half * 4 + k);
+      const int y = y0 + r;
+      int l = r * 64 + tx;
+      if (in[k]) {
+        const int p = y * iw + x;
+        if (y > 0 && v[k] == vu[k]) l = r > 0 ? l - 64 : -(p - iw) - 1;
+        else if (x > 0 && v[k] == vl[k]) l = tx > 0 ? l - 1 : -(p - 1) - 1;
+        unsigned a = 0;
+        if (inter[k]) {
+          const bool any = mk[k] != 0;
+          const bool z0 = e0[k] <= 0;
+          if ((v[k] == vu[k] || any) && z0) a |= 1;
+          if ((v[k] == vl[k] || any) && z0) a |= 2;
+          if ((v[k] == vr[k] || any) && er[k] <= 0) a |= 4;
+          if ((v[k] == vd[k] || any) && ed[k] <= 0) a |= 8;
+          a |= 16;   // interior
+        }
+        allow[p] = (uint8_t)a;
+        prop[p] = 0x7f7f7f7f;      // no proposal
+        selfp[p] = 0x7f7f7f7f;
+        if (size_out) size_out[p] = si[k];
+      }
+      par[r * 64 + tx] = l;
+    }
   }
   __syncthreads();
   // a chain inside the tile is at most RI_ROWS + 64 links long: 7 doublings (any interleaving only ever stores ancestors)
@@ -659,7 +683,8 @@ __global__ void k_region_apply(int *label, int *prop, int *selfp, int n, int *fl
 }
 
 // rc:336-346: out[label]++ for every pixel.  Most pixels belong to a handful of huge regions, so counts are
-// aggregated per wave (ballot of equal labels), then per block in an LDS hash, before touching global atomics.
+// aggregated per wave (runs of equal labels among its 64 consecutive pixels), then per block in an LDS hash, before touching
+// global atomics.
 #define RS_T 1024
 #define RS_PER_THREAD 32
 __device__ __forceinline__ void rs_accum(int *keys, int *vals, int *out, int label, int cnt) {
@@ -693,16 +718,12 @@ __global__ __launch_bounds__(256) void k_region_size(int *out, const int *__rest
       if ((threadIdx.x & 63) == 0 && l0 != -1) rs_accum(keys, vals, out, l0, 64);
       continue;
     }
-    bool todo = lk != -1;
-    while (__any(todo)) {
-      const unsigned long long m = __ballot(todo);
-      const int leader = __ffsll((long long)m) - 1;
-      const int ll = __shfl(lk, leader);
-      const bool mine = todo && lk == ll;
-      const int cnt = __popcll(__ballot(mine));
-      if ((int)(threadIdx.x & 63) == leader) rs_accum(keys, vals, out, ll, cnt);
-      if (mine) todo = false;
-    }
+    // the lanes are consecutive pixels: every run of equal labels is counted by its first lane
+    const int lane = threadIdx.x & 63;
+    const int prev = __shfl_up(lk, 1);
+    const bool start = lane == 0 || prev != lk;
+    const unsigned long long after = __ballot(start) & ~((2ull << lane) - 1ull);
+    if (start && lk != -1) rs_accum(keys, vals, out, lk, (after ? __ffsll((long long)after) - 1 : 64) - lane);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < RS_T; i += 256)
@@ -1011,6 +1032,17 @@ __global__ __launch_bounds__(256) void k_reduce_claim(int *claim, int *tlist, co
       int cur[RB_MAX];
 #pragma unroll
       for (int q = 0; q < RB_MAX; q++) { slot[q] = ls_slot(id, bs[q] == RB_NONE ? 0 : bs[q], nentry); cur[q] = ld_agent(&claim[slot[q]]); }   // independent loads
+      if (floor == 0 && j < nlive) {
+        // k_reduce_box visits the same slots: they are left for it (RB_MAX ints per chain pixel in the neighbour table of the
+        // polyline stage, which is dead by now); -1: no slot, first entry -2: the window holds more ids than fit - start over
+        int4 r0, r1;
+        r0.x = again ? -2 : (bs[0] == RB_NONE ? -1 : (int)slot[0]); r0.y = bs[1] == RB_NONE ? -1 : (int)slot[1];
+        r0.z = bs[2] == RB_NONE ? -1 : (int)slot[2]; r0.w = bs[3] == RB_NONE ? -1 : (int)slot[3];
+        r1.x = bs[4] == RB_NONE ? -1 : (int)slot[4]; r1.y = bs[5] == RB_NONE ? -1 : (int)slot[5];
+        r1.z = bs[6] == RB_NONE ? -1 : (int)slot[6]; r1.w = bs[7] == RB_NONE ? -1 : (int)slot[7];
+        int4 *rec = (int4 *)(s.nbr + (size_t)j * RB_MAX);
+        rec[0] = r0; rec[1] = r1;
+      }
 #pragma unroll
       for (int q = 0; q < RB_MAX; q++) {
         bool first = false;
@@ -1023,60 +1055,93 @@ __global__ __launch_bounds__(256) void k_reduce_claim(int *claim, int *tlist, co
   }
 }
 
+// widening for up to RB_MAX slots of one chain pixel (valid[q]: slot q is in use); `touches(slot)` counts how often the pixel's
+// window maps to a slot and is only evaluated for a pixel that holds the claim itself (rare)
+template <typename Touches>
+__device__ __forceinline__ void box_vote(int *table, const int *__restrict__ claim, const int *__restrict__ ids, const unsigned (&slot)[RB_MAX], const bool (&valid)[RB_MAX],
+                                         int i, int id, int x, int y, int iw, int ih, Touches touches) {
+  // Per distinct slot: the claiming pixel's first touch only claims (rc:449-456), every other touch widens the box; max
+  // is idempotent, so "widen once if the slot's owner carries our id and we touched it often enough" is the same.
+  int owner[RB_MAX], oid[RB_MAX];
+#pragma unroll
+  for (int q = 0; q < RB_MAX; q++) owner[q] = claim[slot[q]];
+#pragma unroll
+  for (int q = 0; q < RB_MAX; q++) oid[q] = valid[q] ? ids[owner[q]] : -1;
+  // the current box values are requested together with the owners (they only guard the atomics against no-ops)
+  int c1[RB_MAX], c2[RB_MAX], c3[RB_MAX], c4[RB_MAX];
+#pragma unroll
+  for (int q = 0; q < RB_MAX; q++) {
+    const int *e = table + (size_t)slot[q] * 5;
+    c1[q] = ld_agent(&e[1]); c2[q] = ld_agent(&e[2]); c3[q] = ld_agent(&e[3]); c4[q] = ld_agent(&e[4]);   // (unused slots map to entry 0: a valid address)
+  }
+#pragma unroll
+  for (int q = 0; q < RB_MAX; q++) {
+    if (!valid[q] || oid[q] != id) continue;
+    if (owner[q] == i && touches(slot[q]) < 2) continue;       // we hold the claim: our first touch does not count
+    int *e = table + (size_t)slot[q] * 5;
+    if (iw - x > c1[q]) atomicMax(&e[1], iw - x);
+    if (x > c2[q]) atomicMax(&e[2], x);
+    if (ih - y > c3[q]) atomicMax(&e[3], ih - y);
+    if (y > c4[q]) atomicMax(&e[4], y);
+  }
+}
+
 __global__ __launch_bounds__(256) void k_reduce_box(int *table, const int *__restrict__ claim, const int *__restrict__ boundary, rdk::PolyScratch s, int iw, int ih, int nentry) {
   const int nlive = s.ctr[24];
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nlive; j += gridDim.x * blockDim.x) {
     const int i = s.live[j];
+    const int4 *rec = (const int4 *)(s.nbr + (size_t)j * RB_MAX);      // left by k_reduce_claim
+    const int4 r0 = rec[0], r1 = rec[1];
     const int id = s.id[i];
     if (id <= 0) continue;
     const int p0 = s.pos[i], x = p0 % iw, y = p0 / iw;
+    if (r0.x != -2) {
+      const int rs[RB_MAX] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w };
+      unsigned slot[RB_MAX];
+      bool valid[RB_MAX];
+#pragma unroll
+      for (int q = 0; q < RB_MAX; q++) { valid[q] = rs[q] >= 0; slot[q] = valid[q] ? (unsigned)rs[q] : 0u; }
+      int win[49];
+      bool have = false;
+      box_vote(table, claim, s.id, slot, valid, i, id, x, y, iw, ih, [&](unsigned sl) {
+        if (!have) {           // the pixel holds a claim itself: now its window is needed after all (all 49 loads together)
+#pragma unroll
+          for (int k = 0; k < 49; k++) {
+            const int xx = x + k % 7 - 3, yy = y + k / 7 - 3;
+            const bool in = xx >= 0 && xx < iw && yy >= 0 && yy < ih;
+            win[k] = boundary[in ? yy * iw + xx : p0];
+            if (!in) win[k] = 0;
+          }
+          have = true;
+        }
+        int touches = 0;
+#pragma unroll
+        for (int k = 0; k < 49; k++) touches += (win[k] > 0 && ls_slot(id, win[k], nentry) == sl);
+        return touches;
+      });
+      continue;
+    }
+    // more distinct boundary ids in the window than one pass holds (rare): collect them again, pass by pass
     int win[49];
 #pragma unroll
     for (int k = 0; k < 49; k++) {
       const int xx = x + k % 7 - 3, yy = y + k / 7 - 3;
       win[k] = (xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? boundary[yy * iw + xx] : 0;
     }
-    // Per distinct slot: the claiming pixel's first touch only claims (rc:449-456), every other touch widens the box; max
-    // is idempotent, so "widen once if the slot's owner carries our id and we touched it often enough" is the same.
     int floor = 0;
     bool more = true;
     while (more) {
       int bs[RB_MAX];
       more = rb_collect(win, floor, bs);
       unsigned slot[RB_MAX];
-      int owner[RB_MAX], oid[RB_MAX];
+      bool valid[RB_MAX];
 #pragma unroll
-      for (int q = 0; q < RB_MAX; q++) { slot[q] = ls_slot(id, bs[q] == RB_NONE ? 0 : bs[q], nentry); owner[q] = claim[slot[q]]; }
-#pragma unroll
-      for (int q = 0; q < RB_MAX; q++) oid[q] = (bs[q] != RB_NONE) ? s.id[owner[q]] : -1;
-      unsigned wide = 0;
-#pragma unroll
-      for (int q = 0; q < RB_MAX; q++) {
-        if (bs[q] == RB_NONE || oid[q] != id) continue;
-        if (owner[q] == i) {
-          // we hold the claim (rare): count our touches of this slot through any boundary id
-          int touches = 0;
-          for (int k = 0; k < 49; k++) touches += (win[k] > 0 && ls_slot(id, win[k], nentry) == slot[q]);
-          if (touches < 2) continue;
-        }
-        wide |= 1u << q;
-      }
-      // the current box values of all slots to widen are requested together (they only guard the atomics against no-ops)
-      int c1[RB_MAX], c2[RB_MAX], c3[RB_MAX], c4[RB_MAX];
-#pragma unroll
-      for (int q = 0; q < RB_MAX; q++) {
-        const int *e = table + (size_t)slot[q] * 5;
-        c1[q] = ld_agent(&e[1]); c2[q] = ld_agent(&e[2]); c3[q] = ld_agent(&e[3]); c4[q] = ld_agent(&e[4]);   // (unused slots map to entry 0: a valid address)
-      }
-#pragma unroll
-      for (int q = 0; q < RB_MAX; q++) {
-        if (!((wide >> q) & 1)) continue;
-        int *e = table + (size_t)slot[q] * 5;
-        if (iw - x > c1[q]) atomicMax(&e[1], iw - x);
-        if (x > c2[q]) atomicMax(&e[2], x);
-        if (ih - y > c3[q]) atomicMax(&e[3], ih - y);
-        if (y > c4[q]) atomicMax(&e[4], y);
-      }
+      for (int q = 0; q < RB_MAX; q++) { valid[q] = bs[q] != RB_NONE; slot[q] = ls_slot(id, valid[q] ? bs[q] : 0, nentry); }
+      box_vote(table, claim, s.id, slot, valid, i, id, x, y, iw, ih, [&](unsigned sl) {
+        int touches = 0;
+        for (int k = 0; k < 49; k++) touches += (win[k] > 0 && ls_slot(id, win[k], nentry) == sl);
+        return touches;
+      });
       floor = bs[RB_MAX - 1];
     }
   }
