@@ -129,8 +129,10 @@ __device__ __forceinline__ void border_union(int *label, int p, int q, bool want
   }
 }
 
-__global__ __launch_bounds__(256) void k_label_border(int *label, const int *__restrict__ pix, int bgc, int iw, int ih, int horizontal) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+// (both kinds of border in one launch - unions commute: the first `hblocks` blocks take the horizontal borders)
+__global__ __launch_bounds__(256) void k_label_border(int *label, const int *__restrict__ pix, int bgc, int iw, int ih, int hblocks) {
+  const bool horizontal = (int)blockIdx.x < hblocks;
+  const int t = (horizontal ? blockIdx.x : blockIdx.x - hblocks) * blockDim.x + threadIdx.x;
   if (horizontal) {
     const int nb = (ih - 1) / LT_H;              // border rows
     const int x = t % iw, k = t / iw;
@@ -249,8 +251,8 @@ namespace rdk {
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih) {
   hipLaunchKernelGGL(k_label_tile, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, pix, bgc, iw, ih);
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
-  if (nh > 0) hipLaunchKernelGGL(k_label_border, dim3(cdiv(nh, 256)), dim3(256), 0, s, label, pix, bgc, iw, ih, 1);
-  if (nv > 0) hipLaunchKernelGGL(k_label_border, dim3(cdiv(nv, 256)), dim3(256), 0, s, label, pix, bgc, iw, ih, 0);
+  const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
+  if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb), dim3(256), 0, s, label, pix, bgc, iw, ih, hb);
   const int n = iw * ih;
   int g = cdiv(n, 256 * 4);
   hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n);

@@ -640,7 +640,7 @@ __global__ __launch_bounds__(256) void k_region_propose(const int *__restrict__ 
 }
 
 // In-place pointer jumping on the forest of initial links (parent index < child index): each launch replaces a
-// pixel's parent by its great-great-grandparent; any interleaving only ever stores ancestors, so the iteration ends
+// pixel's parent by an ancestor up to 16 links away (or the root); any interleaving only ever stores ancestors, so the iteration ends
 // with every pixel pointing at the root of its initial tree.
 __global__ void k_region_flatten(int *label, int n, int *flags, int round) {
   if (round > 0 && flags[round - 1] == 0) return;
@@ -649,7 +649,7 @@ __global__ void k_region_flatten(int *label, int n, int *flags, int round) {
     const int l = label[i];
     int a = label[l];
     if (a != l) {
-      a = label[a]; a = label[a];
+      for (int j = 0; j < 14; j++) { const int b = label[a]; if (b == a) break; a = b; }   // (most chains end after a jump or two)
       label[i] = a;
       changed = true;
     }
@@ -1236,9 +1236,9 @@ void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int 
 // scratch: 3*N ints (hook proposals; round flags + allowed-direction bytes; self proposals)
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS, int *size_out, const int *size_init) {
   const int n = iw * ih;
-  // tile-to-tile hops left after k_region_init: at most ih/RI_ROWS + iw/64 + 2; each launch divides the depth by 4
+  // tile-to-tile hops left after k_region_init: at most ih/RI_ROWS + iw/64 + 2; each launch divides the depth by 16
   int FLAT = 1;
-  for (long reach = 4; reach < ih / RI_ROWS + iw / 64 + 2; reach *= 4) FLAT++;
+  for (long reach = 16; reach < ih / RI_ROWS + iw / 64 + 2; reach *= 16) FLAT++;
   int *prop = scratch, *flags = scratch + n, *fflags = flags + 32;
   uint8_t *allow = (uint8_t *)(flags + 64);
   int *selfp = scratch + 2 * (size_t)n;
