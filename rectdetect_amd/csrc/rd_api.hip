@@ -614,7 +614,12 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : 1;
   d->force_redo = getenv("RD_POLY_FORCE_REDO") ? 1 : 0;
   d->diag_no_post = getenv("RD_DIAG_NO_POST") ? 1 : 0;
-  d->fork_poly = getenv("RD_NO_FORK") ? 0 : 1;
+  // The device runs four hardware queues side by side (more are time-sliced: measured 2x slower per frame).  With one or two
+  // frames in flight a frame spreads over two streams (polyline chain beside the blur chain: shortest latency); from three
+  // frames on every frame keeps to one stream, so that four frames occupy the four queues (highest throughput).
+  d->fork_poly = nslots <= 2 ? 1 : 0;
+  if (getenv("RD_NO_FORK")) d->fork_poly = 0;
+  if (getenv("RD_FORK")) d->fork_poly = 1;
   // round budget of the region merge: 20 (all launched rounds, the default) or, with RD_REGION_ROUNDS_ADAPTIVE, what recent frames
   // needed + margin (8/12/16/20; frames that needed more are repeated).  The adaptive mode saves 1-2 % when it settles, but a
   // second graph instance per slot changes how the runtime spreads the streams over its hardware queues, and the unlucky
