@@ -38,7 +38,7 @@ static void imgutil_scratch(oclimgutil_t *t, int iw, int ih) {
   for (int k = 0; k < 3; k++) { dfree(im->s[k]); im->s[k] = dnew<float>((size_t)N); }
   dfree(im->tails); dfree(im->flags);
   im->tails = dnew<float>(nt);
-  im->flags = dnew<int>(16);
+  im->flags = dnew<int>(16); RD_HIP(hipMemset(im->flags, 0, 16 * sizeof(int))); RD_HIP(hipStreamSynchronize(0));
   im->N = N; im->ntails = nt;
 }
 
@@ -130,7 +130,6 @@ cl_event oclimgutil_iirblur_f_f(oclimgutil_t *thiz, cl_mem obuf, cl_mem ibuf, cl
   const float *in = (const float *)dptr(ibuf);
   float *d1[3] = { im->s[0], NULL, NULL }; const float *s1[3] = { in, NULL, NULL };
   rdk::transpose_f(s, d1, s1, 1, iw, ih);                                   // s0 = in^T (ih wide)
-  RD_HIP(hipMemsetAsync(im->flags, 0, 16 * sizeof(int), s));
   float *fw[3] = { t0, NULL, NULL }, *bw[3] = { t1, NULL, NULL };
   { float *dst[3] = { im->s[1], NULL, NULL }; const float *src[3] = { im->s[0], NULL, NULL };
     rdk::iir_blur_pass(s, dst, src, fw, bw, 1, ih, iw, 1, im->tails, im->flags); }       // along x; s1 = horizontal result, original layout
@@ -334,7 +333,7 @@ static void slot_alloc(rd_detector *d, Slot *s) {
   s->e8 = dnew<int8_t>(N);
   s->ext = dnew<uint16_t>(N);
   { size_t a = rdk::iir_pass_scratch_floats(3, d->ih, d->iw), b = rdk::iir_pass_scratch_floats(3, d->iw, d->ih); s->tails = dnew<float>(a > b ? a : b); }
-  s->flags = dnew<int>(16);
+  s->flags = dnew<int>(16); RD_HIP(hipMemset(s->flags, 0, 16 * sizeof(int))); RD_HIP(hipStreamSynchronize(0));
   s->iir_chunked = 1;
   s->lslist = dnew<uint8_t>(N * 16);
   s->probes = dnew<int>((size_t)d->maxrec_dev * 15 * 6);
@@ -415,7 +414,6 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
 
   // colour -> sigma=1 blur of L, a, b -> packed blurred Lab (oclrect.c:245-251)
   rdk::bgr2plab_transposed(st, s->plab0, s->tr, s->bgr, iw, ih, ws);
-  RD_HIP(hipMemsetAsync(s->flags, 0, 16 * sizeof(int), st));
   { const float *c[3] = { s->tr[0], s->tr[1], s->tr[2] }; rdk::iir_blur_pass(st, s->hz, c, s->fw, s->bw, 3, ih, iw, 1, s->tails, s->flags); }       // along x
   { const float *c[3] = { s->hz[0], s->hz[1], s->hz[2] }; rdk::iir_blur_pass(st, s->bl, c, s->fw, s->bw, 3, iw, ih, 0, s->tails, s->flags + 1); }   // along y
   rdk::pack_plab(st, s->plab1, s->bl[0], s->bl[1], s->bl[2], N);

@@ -3,6 +3,7 @@
 //
 // Reference behaviour being reproduced (file:line into the reference): oclimgutil.cl ("iu").
 // Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off  (see rd_device.h for the arithmetic contract).
+#include <stdlib.h>
 #include "rd_device.h"
 #include "rd_kernels.h"
 
@@ -176,51 +177,13 @@ __global__ __launch_bounds__(256) void k_transpose(P3 dst, P3c src, P3c fwd, P3c
 #define IIR_WARM 11
 #define IIR_CH 16
 
-__global__ __launch_bounds__(64) void k_iir_columns(P3 fwd, P3 bwd, P3c src, int W, int H, const int *only_if) {
-  if (only_if && *only_if == 0) return;   // fallback after a failed chunk verification
-  const int x = blockIdx.x * 64 + threadIdx.x;
-  const int k = blockIdx.y >> 1, dir = blockIdx.y & 1;
-  if (x >= W) return;
-  const float *__restrict__ in = src.p[k] + x;
-  float *__restrict__ out = (dir ? bwd.p[k] : fwd.p[k]) + x;
-  const int y0 = dir ? H + IIR_WARM : -IIR_WARM, step = dir ? -1 : 1;
-  const int count = H + IIR_WARM + dir;   // down: -11..H-1, up: H+11..0
-  float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
-  float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
-  // Loads and recurrence steps are unconditional (indices clamped into the mirrored range; steps past the end of the
-  // sweep compute garbage that is never stored), so the compiler keeps IIR_CH independent loads in flight while the
-  // previous chunk's dependent chain runs.
-  const int ylo = -IIR_WARM, yhi = H + IIR_WARM;
-  float cur[IIR_CH], nxt[IIR_CH];
-#pragma unroll
-  for (int j = 0; j < IIR_CH; j++) cur[j] = in[(size_t)mirror1(clampi(y0 + j * step, ylo, yhi), H) * W];
-  for (int base = 0; base < count; base += IIR_CH) {
-#pragma unroll
-    for (int j = 0; j < IIR_CH; j++) nxt[j] = in[(size_t)mirror1(clampi(y0 + (base + IIR_CH + j) * step, ylo, yhi), H) * W];
-#pragma unroll
-    for (int j = 0; j < IIR_CH; j++) {
-      const int n = base + j;
-      const int yy = y0 + n * step;
-      const float i0 = cur[j];
-      float d = i0 * IIR_C0;
-      d += IIR_C1 * i1 + IIR_C2 * i2 + IIR_C3 * i3 + IIR_C4 * i4 + IIR_C5 * i5 + IIR_C6 * i6 + IIR_C7 * i7;
-      d += IIR_C8 * t0 + IIR_C9 * t1 + IIR_C10 * t2 + IIR_C11 * t3 + IIR_C12 * t4 + IIR_C13 * t5 + IIR_C14 * t6;
-      if (n < count && yy >= 0 && yy < H) out[(size_t)yy * W] = d;
-      i7 = i6; i6 = i5; i5 = i4; i4 = i3; i3 = i2; i2 = i1; i1 = i0;
-      t6 = t5; t5 = t4; t4 = t3; t3 = t2; t2 = t1; t1 = t0; t0 = d;
-    }
-#pragma unroll
-    for (int j = 0; j < IIR_CH; j++) cur[j] = nxt[j];
-  }
-}
-
 // Both sweeps and the combination (iu:580-589 / iu:629-637: anti-causal + causal - c0 * input) for one 64-column x IF_ROWS
 // block of one plane in ONE wave: the causal outputs of the block wait in LDS while the anti-causal sweep runs over the same
 // rows and finishes each pixel, so neither sweep's result travels through HBM.  Both sweeps start IF_WU rows outside the
 // block from a zero state (or at the true beginning of the sweep when that is nearer); whether that reproduces the full
 // sweep BIT FOR BIT is checked on the device: each block records the 7 outputs it computed just before entering its rows
-// ("warm") and its own last 7 outputs ("true"), k_iir_fused_verify compares neighbours, and on any difference the
-// full-length sweeps run instead (rdk::iir_blur_pass).  TOUT = 1 writes the result transposed (through the LDS tile).
+// ("warm") and its own last 7 outputs ("true"), k_iir_check_fix compares neighbours and evaluates a column with any
+// difference again by full-length sweeps (rdk::iir_blur_pass).  TOUT = 1 writes the result transposed (through the LDS tile).
 #define IF_ROWS_T 64          // rows per block, pass with transposed output (the transposing tail wants longer runs per column)
 #define IF_ROWS_N 32          // rows per block, plain pass (more, smaller blocks: LDS is what limits the waves per CU)
                               // (a remainder of fewer than 8 rows is merged into the last block: LDS tile = rows + 8)
@@ -241,9 +204,10 @@ __host__ __device__ inline int if_nchunks(int H, int rows) {
   t6 = t5; t5 = t4; t4 = t3; t3 = t2; t2 = t1; t1 = t0; t0 = d;
 
 template <int TOUT, int IF_ROWS>
-__global__ __launch_bounds__(64) void k_iir_fused(P3 dst, P3c src, float *__restrict__ tails, int W, int H, int nchunks) {
+__global__ __launch_bounds__(64) void k_iir_fused(P3 dst, P3c src, float *__restrict__ tails, int W, int H, int nchunks, int *bad) {
   __shared__ float fwt[(IF_ROWS + 8) * IF_PITCH];
   const int lane = threadIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) *bad = 0;      // diagnostics flag of the check that follows this launch
   const int x = blockIdx.x * 64 + lane;
   const int k = blockIdx.y, c = blockIdx.z;
   const bool xin = x < W;
@@ -315,14 +279,19 @@ __global__ __launch_bounds__(64) void k_iir_fused(P3 dst, P3c src, float *__rest
   }
 }
 
-// the state a block reached after its warm-up must equal, bit for bit, what its neighbour computed for the same rows
-__global__ __launch_bounds__(64) void k_iir_fused_verify(const float *__restrict__ tails, int *bad, int W, int H, int nchunks, int IF_ROWS) {
+// The state a block reached after its warm-up must equal, bit for bit, what its neighbour computed for the same rows.  One
+// wave per (64 columns, plane, chunk) compares the chunk's two borders; a column with a difference - none has been seen, the
+// check is what guarantees the result - is evaluated again by the full-length sweeps (iu:580-589 / iu:629-637, mirrored ends,
+// IIR_WARM rows of run-in) by the lane that found it, through the `fwd` scratch plane (two chunks of one column may both do
+// that: they write the same values).  `force` (diagnostics) treats every column of chunk 0 as different.
+template <int TOUT>
+__global__ __launch_bounds__(64) void k_iir_check_fix(P3 dst, P3c src, P3 fwd, const float *__restrict__ tails, int *bad, int W, int H, int nchunks, int IF_ROWS, int force) {
   const int x = blockIdx.x * 64 + threadIdx.x;
   const int k = blockIdx.y, c = blockIdx.z;
   if (x >= W) return;
   const int s0 = c * IF_ROWS, s1 = (c == nchunks - 1) ? H : s0 + IF_ROWS;
   const float *me = tails + ((size_t)(k * nchunks + c) * 4 * 7) * W + x;
-  bool differ = false;
+  bool differ = force != 0 && c == 0;
   if (c > 0 && s0 - IF_WU > -IIR_WARM) {                 // causal: my warm rows s0-7..s0-1 against the previous block's last rows
     const float *pv = tails + ((size_t)(k * nchunks + c - 1) * 4 * 7) * W + x;
 #pragma unroll
@@ -333,14 +302,33 @@ __global__ __launch_bounds__(64) void k_iir_fused_verify(const float *__restrict
 #pragma unroll
     for (int j = 0; j < 7; j++) differ = differ || (__float_as_uint(me[(size_t)(2 * 7 + j) * W]) != __float_as_uint(nx[(size_t)(3 * 7 + j) * W]));
   }
-  if (__any(differ) && threadIdx.x == 0) atomicOr(bad, 1);
-}
-
-// iu:629-637: vertical result = anti-causal + causal - c0 * (horizontal result)
-__global__ void k_iir_combine(P3 dst, P3c fwd, P3c bwd, P3c src, int np, int n, const int *only_if) {
-  if (only_if && *only_if == 0) return;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    for (int k = 0; k < np; k++) dst.p[k][i] = bwd.p[k][i] + fwd.p[k][i] - src.p[k][i] * IIR_C0;
+  if (!differ) return;
+  atomicOr(bad, 1);
+  const float *__restrict__ in = src.p[k] + x;
+  float *fw = fwd.p[k] + x;
+  {
+    float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
+    float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+    for (int yy = -IIR_WARM; yy < H; yy++) {
+      const float i0 = in[(size_t)mirror1(yy, H) * W];
+      IIR_STEP(i0);
+      if (yy >= 0) fw[(size_t)yy * W] = d;
+      IIR_SHIFT(i0);
+    }
+  }
+  {
+    float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
+    float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+    for (int yy = H + IIR_WARM; yy >= 0; yy--) {
+      const float i0 = in[(size_t)mirror1(yy, H) * W];
+      IIR_STEP(i0);
+      if (yy < H) {
+        const float o = d + fw[(size_t)yy * W] - i0 * IIR_C0;
+        if (TOUT) dst.p[k][(size_t)x * H + yy] = o; else dst.p[k][(size_t)yy * W + x] = o;
+      }
+      IIR_SHIFT(i0);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ gradient direction
@@ -640,23 +628,22 @@ void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], 
 size_t iir_pass_scratch_floats(int np, int W, int H) { return (size_t)np * if_nchunks(H, IF_ROWS_N) * 4 * 7 * W; }   // (the finer blocking bounds both)
 
 // one blur pass (both sweeps + combination) down the columns of np planes (W columns, H rows); transpose_out: dst planes
-// are H wide, W tall.  fwd/bwd: scratch planes, only touched when the on-device check of the blocked evaluation fails
-// (*bad != 0) and the full-length sweeps have to run; tails: iir_pass_scratch_floats() floats; *bad must be 0 on entry.
+// are H wide, W tall.  fwd: scratch planes, only touched by columns whose blocked evaluation fails its on-device check and
+// which are then evaluated by full-length sweeps (*bad is set to 1: diagnostics; bwd is not used any more); tails:
+// iir_pass_scratch_floats() floats.
 void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3], float *const fwd[3], float *const bwd[3], int np, int W, int H,
                    int transpose_out, float *tails, int *bad) {
   const int rows = transpose_out ? IF_ROWS_T : IF_ROWS_N;
   const int nchunks = if_nchunks(H, rows);
   const dim3 grid(cdiv(W, 64), np, nchunks);
-  if (transpose_out) hipLaunchKernelGGL((k_iir_fused<1, IF_ROWS_T>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks);
-  else hipLaunchKernelGGL((k_iir_fused<0, IF_ROWS_N>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks);
+  if (transpose_out) hipLaunchKernelGGL((k_iir_fused<1, IF_ROWS_T>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks, bad);
+  else hipLaunchKernelGGL((k_iir_fused<0, IF_ROWS_N>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks, bad);
   if (nchunks > 1) {
-    hipLaunchKernelGGL(k_iir_fused_verify, grid, dim3(64), 0, s, (const float *)tails, bad, W, H, nchunks, rows);
-    // fallback (skipped on the device unless the check failed)
-    const float *f[3] = { fwd[0], np > 1 ? fwd[1] : nullptr, np > 2 ? fwd[2] : nullptr }, *b[3] = { bwd[0], np > 1 ? bwd[1] : nullptr, np > 2 ? bwd[2] : nullptr };
-    hipLaunchKernelGGL(k_iir_columns, dim3(cdiv(W, 64), np * 2), dim3(64), 0, s, mk3(fwd, np), mk3(bwd, np), mk3c(src, np), W, H, (const int *)bad);
-    if (transpose_out) hipLaunchKernelGGL(k_transpose<2>, dim3(cdiv(W, 64), cdiv(H, 64)), block2, 0, s, mk3(dst, np), mk3c(src, np), mk3c(f, np), mk3c(b, np), (const uint32_t *)nullptr, np, W, H, (const int *)bad);
-    else hipLaunchKernelGGL(k_iir_combine, dim3(ew_grid(W * H)), dim3(256), 0, s, mk3(dst, np), mk3c(f, np), mk3c(b, np), mk3c(src, np), np, W * H, (const int *)bad);
+    const int force = getenv("RD_IIR_FORCE_FIX") ? 1 : 0;             // diagnostics: every column takes the full-length path
+    if (transpose_out) hipLaunchKernelGGL(k_iir_check_fix<1>, grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force);
+    else hipLaunchKernelGGL(k_iir_check_fix<0>, grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force);
   }
+  (void)bwd;
 }
 
 void convert_bgr_lumaf(hipStream_t s, uint8_t *out, const float *in, float f, int iw, int ih, int ws) {

@@ -245,6 +245,28 @@ def test_chunked_blur_verifies_and_counters():
     det.close()
 
 
+def test_blur_columns_that_fail_the_check_are_evaluated_again(monkeypatch):
+    """RD_IIR_FORCE_FIX makes every column fail the on-device check of the chunked IIR evaluation: the full-length sweeps
+    that then replace the result must reproduce the same planes bit for bit (both passes, transposed and plain output)"""
+    iw, ih = 640, 480
+    img = synth.frame(synth.SEED0 + 2, iw, ih, 1)
+    det = ra.Detector(iw, ih, nslots=1)
+    det.enqueue(img)
+    want_rects = det.poll(TAN36)
+    want = {n: det.plane(n, np.uint32) for n in ("plab1", "lblur", "nms")}
+    assert det.plane("iirflags", np.int32, 16)[:2].tolist() == [0, 0]
+    det.close()
+    monkeypatch.setenv("RD_IIR_FORCE_FIX", "1")
+    det = ra.Detector(iw, ih, nslots=1)
+    det.enqueue(img)
+    got_rects = det.poll(TAN36)
+    assert det.plane("iirflags", np.int32, 16)[:2].tolist() == [1, 1]
+    for n in want:
+        assert np.array_equal(det.plane(n, np.uint32), want[n]), n
+    assert helpers.rects_equal(got_rects, want_rects)
+    det.close()
+
+
 def test_pipelined_workers_equal_sequential():
     """several frames in flight + post-process on worker threads + captured graphs == one frame at a time, inline"""
     iw, ih = 640, 480
