@@ -39,10 +39,11 @@ struct lsx_rec { long long mx00, mx01, mx11, my0, my1; short dx, dy, vx, vy; int
 #define PT_ROWS 16
 #define PT_M 6
 #define PT_P (64 + 2 * PT_M)
-__global__ __launch_bounds__(256) void k_poly_tidy(int *__restrict__ out, const int *__restrict__ in, const int *__restrict__ ring_src, int ring_const, int iw, int ih) {
+__global__ __launch_bounds__(256) void k_poly_tidy(int *__restrict__ out, const int *__restrict__ in, const int *__restrict__ ring_src, int ring_const, int iw, int ih, int *gen) {
   __shared__ uint8_t A[(PT_ROWS + 2 * PT_M) * PT_P], B[(PT_ROWS + 2 * PT_M) * PT_P];
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * PT_ROWS;
   const int tid = threadIdx.y * 64 + threadIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) gen[0] = gen[0] + 1;      // generation of this frame's compaction state words (k_compact1)
 #define PT_FOR(m) for (int t = tid; t < (PT_ROWS + 2 * (m)) * (64 + 2 * (m)); t += 256)
 #define PT_CELL(m) const int r = t / (64 + 2 * (m)) - (m), c = t % (64 + 2 * (m)) - (m); const int x = x0 + c, y = y0 + r; const int i = (r + PT_M) * PT_P + c + PT_M; const bool in_img = x >= 0 && x < iw && y >= 0 && y < ih
   stage_cells<(PT_ROWS + 12) * (64 + 12), 256>(tid, in,
@@ -118,76 +119,80 @@ __global__ __launch_bounds__(256) void k_poly_tidy(int *__restrict__ out, const 
 
 // ------------------------------------------------------------------------------------------------ raster-order compaction
 #define CP_PER_BLOCK 2048
-// Stable (index-ordered) compaction of the non-zero elements of `plane` in three launches: per-block counts, exclusive
-// scan of the counts by one block, scatter.  The element count may live on the device (nptr).  Outputs (each optional):
-// pos[rank] = index, cidx[index] = rank or -1, rank1[index] = rank + 1 for non-zero elements.
-__global__ __launch_bounds__(256) void k_compact_count(int *__restrict__ blk, const int *__restrict__ plane, int n, const int *nptr) {
-  __shared__ int total;
+// Stable (index-ordered) compaction of the non-zero elements of `plane` in ONE launch (chained scan with decoupled look-back):
+// a block counts the non-zero elements among its CP_PER_BLOCK, publishes the count, adds up the published counts / running
+// totals of the blocks before it (one wave looks at 64 predecessors per step; workgroups are dispatched in index order, so the
+// blocks waited for are running) and publishes its own running total; then it scatters.  Blocks beyond the element count -
+// which may live on the device (nptr) - leave at once.  The state words carry a generation number (*gen, advanced once per
+// frame by k_poly_tidy; every call site has its own state array), so nothing has to be cleared between launches.  Outputs (each
+// optional): pos[rank] = index, cidx[index] = rank or -1, rank1[index] = rank + 1 for non-zero elements; *cnt = their number.
+#define CP_K (CP_PER_BLOCK / 256)
+__device__ __forceinline__ unsigned long long cp_word(unsigned gen, unsigned status, unsigned value) { return ((unsigned long long)(gen & 0xffffffu) << 40) | ((unsigned long long)status << 38) | value; }
+__global__ __launch_bounds__(256) void k_compact1(int *__restrict__ pos, int *__restrict__ cidx, int *__restrict__ rank1, const int *__restrict__ plane, int n, const int *nptr,
+                                                  int *cnt, unsigned long long *state, const int *genp) {
+  __shared__ int wcount[CP_K * 4 + 1];
+  __shared__ int s_excl;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = blockIdx.x;
   if (nptr) n = *nptr;
-  if (threadIdx.x == 0) total = 0;
+  if (b * CP_PER_BLOCK >= n) { if (b == 0 && tid == 0 && cnt) *cnt = 0; return; }
+  const unsigned gen = (unsigned)*genp;
+  // flags of this thread's CP_K elements (all loads in flight together), wave counts per row of 256 elements
+  unsigned on = 0;
+  {
+    int v[CP_K];
+#pragma unroll
+    for (int k = 0; k < CP_K; k++) { const int i = b * CP_PER_BLOCK + k * 256 + tid; v[k] = plane[i < n ? i : 0]; }
+#pragma unroll
+    for (int k = 0; k < CP_K; k++) { const int i = b * CP_PER_BLOCK + k * 256 + tid; if (i < n && v[k] != 0) on |= 1u << k; }
+  }
+  unsigned long long m[CP_K];
+#pragma unroll
+  for (int k = 0; k < CP_K; k++) { m[k] = __ballot((on >> k) & 1u); if (lane == 0) wcount[k * 4 + w] = __popcll(m[k]); }
   __syncthreads();
-  int c = 0;
-  if (blockIdx.x * CP_PER_BLOCK < n)
-    for (int k = 0; k < CP_PER_BLOCK / 256; k++) {
-      const int i = blockIdx.x * CP_PER_BLOCK + k * 256 + threadIdx.x;
-      c += __popcll(__ballot(i < n && plane[i] != 0));
-    }
-  if ((threadIdx.x & 63) == 0) atomicAdd(&total, c);
-  __syncthreads();
-  if (threadIdx.x == 0) blk[blockIdx.x] = total;
-}
-
-// exclusive scan of nblk block counts by one 1024-thread block; total -> *cnt
-__global__ __launch_bounds__(1024) void k_compact_scan(int *blk, int nblk, int *cnt) {
-  __shared__ int wsum[16];
-  __shared__ int carry;
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int base = 0; base < nblk; base += 1024) {
-    const int i = base + threadIdx.x;
-    const int v = i < nblk ? blk[i] : 0;
-    int inc = v;
+  if (w == 0) {
+    // exclusive scan of the CP_K * 4 wave counts (element order: row k, then wave, then lane)
+    const int c = lane < CP_K * 4 ? wcount[lane] : 0;
+    int inc = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    int woff = 0;
-    for (int k = 0; k < w; k++) woff += wsum[k];
-    const int c0 = carry;
-    if (i < nblk) blk[i] = c0 + woff + inc - v;
-    __syncthreads();
-    if (threadIdx.x == 1023) carry = c0 + woff + inc;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) *cnt = carry;
-}
-
-__global__ __launch_bounds__(256) void k_compact_scatter(int *__restrict__ pos, int *__restrict__ cidx, int *__restrict__ rank1, const int *__restrict__ blk,
-                                                         const int *__restrict__ plane, int n, const int *nptr) {
-  __shared__ int wcount[4];
-  __shared__ int running;
-  if (nptr) n = *nptr;
-  if (blockIdx.x * CP_PER_BLOCK >= n) return;
-  if (threadIdx.x == 0) running = blk[blockIdx.x];
-  __syncthreads();
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int k = 0; k < CP_PER_BLOCK / 256; k++) {
-    const int i = blockIdx.x * CP_PER_BLOCK + k * 256 + threadIdx.x;
-    const bool on = i < n && plane[i] != 0;
-    const unsigned long long m = __ballot(on);
-    if (lane == 0) wcount[w] = __popcll(m);
-    __syncthreads();
-    int off = running;
-    for (int q = 0; q < w; q++) off += wcount[q];
-    const int rank = off + __popcll(m & ((1ull << lane) - 1ull));
-    if (i < n) {
-      if (on) { if (pos) pos[rank] = i; if (rank1) rank1[i] = rank + 1; }
-      if (cidx) cidx[i] = on ? rank : -1;
+    if (lane < CP_K * 4) wcount[lane] = inc - c;
+    const int total = __shfl(inc, 63);
+    if (lane == 0) __hip_atomic_store(&state[b], cp_word(gen, b == 0 ? 2u : 1u, (unsigned)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // look-back
+    int excl = 0;
+    for (int j = b - 1; j >= 0; j -= 64) {
+      const int idx = j - lane;
+      unsigned long long st;
+      bool ready;
+      do {
+        st = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : cp_word(gen, 2u, 0u);
+        ready = (unsigned)(st >> 40) == (gen & 0xffffffu) && ((st >> 38) & 3ull) != 0ull;
+      } while (!__all(ready));
+      const unsigned long long pm = __ballot(((st >> 38) & 3ull) == 2ull);      // predecessors whose running total is known
+      const int upto = pm ? __ffsll((long long)pm) - 1 : 63;
+      int v = lane <= upto ? (int)(st & 0x3fffffffffull) : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+      excl += v;
+      if (pm) break;
     }
-    __syncthreads();
-    if (threadIdx.x == 0) running += wcount[0] + wcount[1] + wcount[2] + wcount[3];
-    __syncthreads();
+    if (lane == 0) {
+      s_excl = excl;
+      if (b > 0) __hip_atomic_store(&state[b], cp_word(gen, 2u, (unsigned)(excl + total)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((b + 1) * CP_PER_BLOCK >= n && cnt) *cnt = excl + total;      // the last block with elements
+    }
+  }
+  __syncthreads();
+  const int excl = s_excl;
+#pragma unroll
+  for (int k = 0; k < CP_K; k++) {
+    const int i = b * CP_PER_BLOCK + k * 256 + tid;
+    if (i >= n) continue;
+    const bool o = (on >> k) & 1u;
+    const int rank = excl + wcount[k * 4 + w] + __popcll(m[k] & ((1ull << lane) - 1ull));
+    if (o) { if (pos) pos[rank] = i; if (rank1) rank1[i] = rank + 1; }
+    if (cidx) cidx[i] = o ? rank : -1;
   }
 }
 
@@ -358,9 +363,18 @@ __global__ void k_sub_union(PolyScratch s, const int *number) {
 }
 
 // pl:357-378 sizes of the sub-chains
+// (the lanes of a wave are consecutive chain pixels in raster order: a run of equal roots - a horizontal stretch of one chain -
+//  is counted by its first lane; same-address atomics are served one after the other, a long chain was thousands of them)
 __global__ void k_sub_size(PolyScratch s) {
   const int cnt = s.ctr[0];
-  SPARSE_LOOP(i, cnt) if (s.lab2[i] >= 0) atomicAdd(&s.size[s.lab2[i]], 1);
+  for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; i0 < cnt; i0 += gridDim.x * blockDim.x) {     // whole waves together
+    const int lane = threadIdx.x & 63, i = i0 + lane;
+    const int l = i < cnt ? s.lab2[i] : -1;
+    const int prev = __shfl_up(l, 1);
+    const bool start = lane == 0 || prev != l;
+    const unsigned long long after = __ballot(start) & ~((2ull << lane) - 1ull);
+    if (start && l >= 0) atomicAdd(&s.size[l], (after ? __ffsll((long long)after) - 1 : 64) - lane);
+  }
 }
 
 // pl:380-420: surviving roots are numbered 1..K in raster order (= compact order): one block, ballot prefix scan
@@ -934,7 +948,7 @@ PolyScratch *poly_scratch_create(int iw, int ih) {
   ps->cap = (int)N;
   ps->planeA = dalloc<int>(N); ps->planeB = dalloc<int>(N); ps->planeC = dalloc<int>(N);
   ps->cidx = dalloc<int>(N);
-  ps->blk = dalloc<int>(N / CP_PER_BLOCK + 2);
+  ps->cstate = dalloc<unsigned long long>(3 * (N / CP_PER_BLOCK + 2)); ps->csync = dalloc<int>(4);
   ps->pos = dalloc<int>(N); ps->nbr = dalloc<int>(N * 8);
   ps->lab = dalloc<int>(N); ps->alive = dalloc<int>(N); ps->ends = dalloc<int>(N);
   for (int k = 0; k < 2; k++) { ps->nx[k] = dalloc<int>(N); ps->pv[k] = dalloc<int>(N); ps->num[k] = dalloc<int>(N); ps->link[k] = dalloc<int>(N); }
@@ -946,6 +960,8 @@ PolyScratch *poly_scratch_create(int iw, int ih) {
   ps->segaux = dalloc<int>(2 * (N * 16 / 56 + 2));
   ps->live = dalloc<int>(N);
   (void)hipMemset(ps->ctr, 0, 64 * sizeof(int));
+  (void)hipMemset(ps->cstate, 0, 3 * (N / CP_PER_BLOCK + 2) * sizeof(unsigned long long));
+  (void)hipMemset(ps->csync, 0, 4 * sizeof(int));      // [0]: generation of the compaction state words (k_poly_tidy advances it before use)
   (void)hipStreamSynchronize(0);   // the fill is asynchronous and the callers' streams do not wait for the null stream
   return ps;
 }
@@ -954,7 +970,7 @@ const int *poly_scratch_counters(const PolyScratch *ps) { return ps->ctr; }
 
 void poly_scratch_destroy(PolyScratch *ps) {
   if (!ps) return;
-  void *all[] = { ps->planeA, ps->planeB, ps->planeC, ps->cidx, ps->blk, ps->pos, ps->nbr, ps->lab, ps->alive, ps->ends, ps->nx[0], ps->nx[1], ps->pv[0], ps->pv[1],
+  void *all[] = { ps->planeA, ps->planeB, ps->planeC, ps->cidx, ps->cstate, ps->csync, ps->pos, ps->nbr, ps->lab, ps->alive, ps->ends, ps->nx[0], ps->nx[1], ps->pv[0], ps->pv[1],
                   ps->num[0], ps->num[1], ps->link[0], ps->link[1], ps->flag, ps->flag2, ps->lab2, ps->size, ps->rootid, ps->id, ps->dist, ps->cand, ps->ctr, ps->lsx, ps->segaux, ps->live };
   for (void *p : all) if (p) (void)hipFree(p);
   delete ps;
@@ -969,13 +985,11 @@ void polyline(hipStream_t st, PolyScratch *ps, void *lslist, int lslist_bytes, i
   const dim3 sg(SPARSE_GRID), sb(256);
 
   // tidy (oclpolyline.c:222-235)
-  hipLaunchKernelGGL(k_poly_tidy, dim3(cdiv(iw, 64), cdiv(ih, PT_ROWS)), dim3(64, 4), 0, st, s.planeC, in, ring_src, ring_const, iw, ih);
+  hipLaunchKernelGGL(k_poly_tidy, dim3(cdiv(iw, 64), cdiv(ih, PT_ROWS)), dim3(64, 4), 0, st, s.planeC, in, ring_src, ring_const, iw, ih, s.csync);
 
   // compaction of the chain pixels in raster order
   const int nblk = cdiv(N, CP_PER_BLOCK);
-  hipLaunchKernelGGL(k_compact_count, dim3(nblk), dim3(256), 0, st, s.blk, (const int *)s.planeC, N, (const int *)nullptr);
-  hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, s.blk, nblk, s.ctr);
-  hipLaunchKernelGGL(k_compact_scatter, dim3(nblk), dim3(256), 0, st, s.pos, s.cidx, (int *)nullptr, (const int *)s.blk, (const int *)s.planeC, N, (const int *)nullptr);
+  hipLaunchKernelGGL(k_compact1, dim3(nblk), dim3(256), 0, st, s.pos, s.cidx, (int *)nullptr, (const int *)s.planeC, N, (const int *)nullptr, s.ctr, s.cstate, (const int *)s.csync);
 
   // chains, loops, ends (oclpolyline.c:237-266)
   hipLaunchKernelGGL(k_build_nbr, sg, sb, 0, st, s, iw);
@@ -998,13 +1012,9 @@ void polyline(hipStream_t st, PolyScratch *ps, void *lslist, int lslist_bytes, i
   hipLaunchKernelGGL(k_sub_size, sg, sb, 0, st, s);
   // (the chain-pixel count lives on the device: launch for the worst case, blocks beyond it exit at once)
   hipLaunchKernelGGL(k_root_flags, sg, sb, 0, st, s, sizeThre);
-  hipLaunchKernelGGL(k_compact_count, dim3(nblk), dim3(256), 0, st, s.blk, (const int *)s.flag2, N, (const int *)s.ctr);
-  hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, s.blk, nblk, s.ctr + 1);
-  hipLaunchKernelGGL(k_compact_scatter, dim3(nblk), dim3(256), 0, st, (int *)nullptr, (int *)nullptr, s.rootid, (const int *)s.blk, (const int *)s.flag2, N, (const int *)s.ctr);
+  hipLaunchKernelGGL(k_compact1, dim3(nblk), dim3(256), 0, st, (int *)nullptr, (int *)nullptr, s.rootid, (const int *)s.flag2, N, (const int *)s.ctr, s.ctr + 1, s.cstate + (size_t)nblk, (const int *)s.csync);
   hipLaunchKernelGGL(k_assign_ids, sg, sb, 0, st, s);
-  hipLaunchKernelGGL(k_compact_count, dim3(nblk), dim3(256), 0, st, s.blk, (const int *)s.id, N, (const int *)s.ctr);
-  hipLaunchKernelGGL(k_compact_scan, dim3(1), dim3(1024), 0, st, s.blk, nblk, s.ctr + 24);
-  hipLaunchKernelGGL(k_compact_scatter, dim3(nblk), dim3(256), 0, st, s.live, (int *)nullptr, (int *)nullptr, (const int *)s.blk, (const int *)s.id, N, (const int *)s.ctr);
+  hipLaunchKernelGGL(k_compact1, dim3(nblk), dim3(256), 0, st, s.live, (int *)nullptr, (int *)nullptr, (const int *)s.id, N, (const int *)s.ctr, s.ctr + 24, s.cstate + 2 * (size_t)nblk, (const int *)s.csync);
 
   if (mode == 1) {
     // fast path: initial segments, 15 subdivision rounds and the refinement in one persistent launch (overflow -> ctr[25])

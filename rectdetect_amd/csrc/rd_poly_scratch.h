@@ -7,7 +7,8 @@ struct PolyScratch {
   int cap;            // = iw*ih, capacity of every per-pixel array
   int *planeA, *planeB, *planeC;   // dense int planes
   int *cidx;          // dense: pixel -> compact index or -1
-  int *blk;           // per-block counts / offsets for the compaction
+  unsigned long long *cstate;   // compaction: one state word per block and call site (generation | status | count or running total)
+  int *csync;         // compaction: [0] generation, advanced once per frame
   int *pos;           // compact: pixel index, ascending
   int *nbr;           // compact: 8 neighbour compact indices (E,NE,N,NW,W,SW,S,SE), -1 = none
   int *lab, *alive, *ends;
