@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-step", type=int, default=64)
-    ap.add_argument("--slots", type=int, default=4, help="frames in flight per GPU")
+    ap.add_argument("--slots", type=int, default=8, help="frames in flight per GPU (from three on: one stream per frame on four shared streams)")
     ap.add_argument("--host-frames", action="store_true", help="hand over host buffers (PCIe upload inside the timed region); not the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercises sharding/aggregation only (CPU tests)")

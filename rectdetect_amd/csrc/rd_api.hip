@@ -260,6 +260,7 @@ cl_event oclpolyline_execute(oclpolyline_t *thiz, cl_mem lsList, int lsListSize,
 struct Slot {
   hipStream_t st;
   hipStream_t st2;                        // second stream of the slot: polyline stage, parallel to the region stages
+  int shares_streams;                     // st / st2 belong to another slot (see rd_detector_create)
   hipEvent_t ev_fork, ev_mm, ev_join;
   hipEvent_t ev_begin, ev_done, ev_strong;   // ev_begin/ev_done carry timestamps: device time of the frame (rd_detector_counter)
   uint8_t *bgr;
@@ -309,10 +310,15 @@ struct rd_detector {
   pthread_mutex_t tan_mu; pthread_cond_t tan_cv;
 };
 
-static void slot_alloc(rd_detector *d, Slot *s) {
+// share: the slot whose streams this one uses as well (NULL: own streams)
+static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
   const size_t N = (size_t)d->N;
-  RD_HIP(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
-  RD_HIP(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
+  s->shares_streams = share != NULL;
+  if (share) { s->st = share->st; s->st2 = share->st2; }
+  else {
+    RD_HIP(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+    RD_HIP(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
+  }
   RD_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   RD_HIP(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
   RD_HIP(hipEventCreateWithFlags(&s->ev_mm, hipEventDisableTiming));
@@ -357,8 +363,10 @@ static void slot_free(Slot *s) {
   RD_HIP(hipHostFree(s->h_bgr)); RD_HIP(hipHostFree(s->h_pack)); dfree(s->pack);
   RD_HIP(hipEventDestroy(s->ev_begin)); RD_HIP(hipEventDestroy(s->ev_done)); RD_HIP(hipEventDestroy(s->ev_strong));
   RD_HIP(hipEventDestroy(s->ev_fork)); RD_HIP(hipEventDestroy(s->ev_mm)); RD_HIP(hipEventDestroy(s->ev_join));
-  RD_HIP(hipStreamDestroy(s->st2));
-  RD_HIP(hipStreamDestroy(s->st));
+  if (!s->shares_streams) {
+    RD_HIP(hipStreamDestroy(s->st2));
+    RD_HIP(hipStreamDestroy(s->st));
+  }
 }
 
 // The device part of one frame (reference oclrect.c:235-381), enqueued on the slot's stream in three segments so that
@@ -628,9 +636,14 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->diag_skip = getenv("RD_DIAG_SKIP") ? atoi(getenv("RD_DIAG_SKIP")) : 0;   // timing diagnostics only: leaves stages out (wrong results)
   pthread_mutex_init(&d->tan_mu, NULL); pthread_cond_init(&d->tan_cv, NULL);
   d->slots = (Slot *)calloc((size_t)nslots, sizeof(Slot));
+  // One stream per frame: the frames beyond the fourth queue up behind earlier ones on the same four streams (slot i uses the
+  // streams of slot i mod 4) - a stream of its own would be time-sliced onto the same four hardware queues and stall frames
+  // that have nothing to do with each other, while a queued frame keeps its queue busy as soon as its predecessor is done
+  // (the host's turn-around between "frame polled" and "next frame enqueued" otherwise idles a quarter of the device).
+  const int nstreams = getenv("RD_STREAMS") ? atoi(getenv("RD_STREAMS")) : 4;
   for (int i = 0; i < nslots; i++) {
     Slot *s = &d->slots[i];
-    slot_alloc(d, s);
+    slot_alloc(d, s, (!d->fork_poly && nstreams > 0 && i >= nstreams) ? &d->slots[i % nstreams] : NULL);
     s->owner = d;
     pthread_mutex_init(&s->mu, NULL); pthread_cond_init(&s->cv, NULL);
     if (nworkers > 0 && pthread_create(&s->th, NULL, slot_worker, s) != 0) exitf(-1, "rd_detector_create: cannot start worker thread\n");
@@ -644,7 +657,7 @@ void rd_detector_destroy(rd_detector *d) {
   if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_destroy: bad handle\n");
   RD_HIP(hipSetDevice(d->device));
   RD_HIP(hipDeviceSynchronize());
-  for (int i = 0; i < d->nslots; i++) {
+  for (int i = d->nslots - 1; i >= 0; i--) {      // (slots that borrowed streams go before the slots that own them)
     Slot *s = &d->slots[i];
     if (d->nworkers > 0) {
       pthread_mutex_lock(&s->mu); s->quit = 1; pthread_cond_broadcast(&s->cv); pthread_mutex_unlock(&s->mu);

@@ -267,20 +267,22 @@ def test_blur_columns_that_fail_the_check_are_evaluated_again(monkeypatch):
     det.close()
 
 
-def test_pipelined_workers_equal_sequential():
-    """several frames in flight + post-process on worker threads + captured graphs == one frame at a time, inline"""
+@pytest.mark.parametrize("nslots", [2, 3, 8])
+def test_pipelined_workers_equal_sequential(nslots):
+    """several frames in flight + post-process on worker threads + captured graphs == one frame at a time, inline
+    (2: two streams per frame; 3: one stream per frame; 8: slots 4..7 queue up on the streams of slots 0..3)"""
     iw, ih = 640, 480
-    frames = [synth.frame(synth.SEED0 + 8, iw, ih, t) for t in range(7)]
+    frames = [synth.frame(synth.SEED0 + 8, iw, ih, t) for t in range(19)]
     seq = ra.Detector(iw, ih, nslots=1, nworkers=0)
     want = []
     for f in frames:
         seq.enqueue(f)
         want.append((seq.poll(TAN36), seq.last_segments()))
     seq.close()
-    par = ra.Detector(iw, ih, nslots=3, nworkers=1)
+    par = ra.Detector(iw, ih, nslots=nslots, nworkers=1)
     got, inflight = [], 0
     for f in frames:
-        if inflight == 3:
+        if inflight == nslots:
             got.append((par.poll(TAN36), par.last_segments()))
             inflight -= 1
         par.enqueue(f)
