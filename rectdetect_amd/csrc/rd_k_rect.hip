@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ e
 // tile (4 extra rows above and below) and the vertical pass from there: the intermediate plane never travels through
 // HBM, every sample is one unconditional ds_read_b64 (samples beyond the run read a zero slot), and all reads of a pixel
 // are in flight together.
-#define BP_ROWS 32
+#define BP_ROWS 64
 #define BP_SW 73              // row pitch of the staged input (72 used)
 // floor(s / w) for 0 <= s <= 40950, 1 <= w <= 10 (exhaustively checked: tools/check_div_small.py)
 __device__ __forceinline__ unsigned div_small_f(unsigned s, float rw) { return (unsigned)(((float)s + 0.5f) * rw); }
@@ -231,23 +231,24 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
   // that their latency overlaps the staging of the tile
   // (every load below is unconditional - the address of a cell outside the frame is clamped, its value replaced afterwards -
   //  so that all eight are in flight together: a block's critical path holds one trip to memory, not one per staging step)
-  unsigned eh[3], ev[2];
-  uint32_t q[3];
-  bool okh[3], okv[2], okq[3];
+  constexpr int NH = (BP_ROWS + 8 + 15) / 16, NV = BP_ROWS / 16, NQ = ((BP_ROWS + 8) * 72 + 1023) / 1024;
+  unsigned eh[NH], ev[NV];
+  uint32_t q[NQ];
+  bool okh[NH], okv[NV], okq[NQ];
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < NH; k++) {
     const int y = y0 - 4 + ty + 16 * k;
     okh[k] = ty + 16 * k < BP_ROWS + 8 && x < iw && y >= 0 && y < ih;
     eh[k] = ext[okh[k] ? y * iw + x : 0];
   }
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < NV; k++) {
     const int y = y0 + ty + 16 * k;
     okv[k] = x < iw && y < ih;
     ev[k] = ext[okv[k] ? y * iw + x : 0];
   }
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
+  for (int i = 0; i < NQ; i++) {
     const int t = tid + 1024 * i;
     const int r = t / 72, c = t % 72;
     const int xx = x0 - 4 + c, yy = y0 - 4 + r;
@@ -257,18 +258,18 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
   if (tid == 0) { src[ZS] = make_uint2(0, 0); hz[ZH] = make_uint2(0, 0); }
   if (tid < 16) rwt[tid] = tid >= 1 && tid <= 10 ? 1.0f / (float)tid : 0.0f;      // 1 / w, correctly rounded
 #pragma unroll
-  for (int i = 0; i < 3; i++) {
+  for (int i = 0; i < NQ; i++) {
     const int t = tid + 1024 * i;
     const uint32_t v = okq[i] ? q[i] : 0u;
     if (t < (BP_ROWS + 8) * 72) src[(t / 72) * BP_SW + t % 72] = make_uint2((v & 4095u) | ((v << 4) & 0x3ff0000u), v >> 22);
   }
 #pragma unroll
-  for (int k = 0; k < 3; k++) if (!okh[k]) eh[k] = 0u;
+  for (int k = 0; k < NH; k++) if (!okh[k]) eh[k] = 0u;
 #pragma unroll
-  for (int k = 0; k < 2; k++) if (!okv[k]) ev[k] = 0u;
+  for (int k = 0; k < NV; k++) if (!okv[k]) ev[k] = 0u;
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < NH; k++) {
     const int r = ty + 16 * k;
     if (r >= BP_ROWS + 8) break;
     const unsigned e = eh[k];
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
   __syncthreads();
   if (x >= iw) return;
 #pragma unroll
-  for (int k = 0; k < 2; k++) {
+  for (int k = 0; k < NV; k++) {
     const int r = ty + 16 * k;
     const int y = y0 + r;
     if (y >= ih) break;
