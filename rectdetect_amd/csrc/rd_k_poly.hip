@@ -118,11 +118,12 @@ __global__ __launch_bounds__(256) void k_poly_tidy(int *__restrict__ out, const 
 }
 
 // ------------------------------------------------------------------------------------------------ raster-order compaction
-#define CP_PER_BLOCK 2048
+#define CP_PER_BLOCK 8192
 // Stable (index-ordered) compaction of the non-zero elements of `plane` in ONE launch (chained scan with decoupled look-back):
 // a block counts the non-zero elements among its CP_PER_BLOCK, publishes the count, adds up the published counts / running
-// totals of the blocks before it (one wave looks at 64 predecessors per step; workgroups are dispatched in index order, so the
-// blocks waited for are running) and publishes its own running total; then it scatters.  Blocks beyond the element count -
+// totals of the blocks before it (one wave looks at 64 predecessors per step; workgroups are dispatched in index order and a
+// launch has so few of them - CP_PER_BLOCK elements each - that the launches of all hardware queues together cannot fill a
+// die with waiting blocks: the blocks waited for get to run) and publishes its own running total; then it scatters.  Blocks beyond the element count -
 // which may live on the device (nptr) - leave at once.  The state words carry a generation number (*gen, advanced once per
 // frame by k_poly_tidy; every call site has its own state array), so nothing has to be cleared between launches.  Outputs (each
 // optional): pos[rank] = index, cidx[index] = rank or -1, rank1[index] = rank + 1 for non-zero elements; *cnt = their number.
@@ -146,17 +147,21 @@ __global__ __launch_bounds__(256) void k_compact1(int *__restrict__ pos, int *__
 #pragma unroll
     for (int k = 0; k < CP_K; k++) { const int i = b * CP_PER_BLOCK + k * 256 + tid; if (i < n && v[k] != 0) on |= 1u << k; }
   }
-  unsigned long long m[CP_K];
 #pragma unroll
-  for (int k = 0; k < CP_K; k++) { m[k] = __ballot((on >> k) & 1u); if (lane == 0) wcount[k * 4 + w] = __popcll(m[k]); }
+  for (int k = 0; k < CP_K; k++) { const unsigned long long m = __ballot((on >> k) & 1u); if (lane == 0) wcount[k * 4 + w] = __popcll(m); }
   __syncthreads();
   if (w == 0) {
-    // exclusive scan of the CP_K * 4 wave counts (element order: row k, then wave, then lane)
-    const int c = lane < CP_K * 4 ? wcount[lane] : 0;
+    // exclusive scan of the CP_K * 4 wave counts (element order: row k, then wave, then lane); CP_E consecutive entries per lane
+    constexpr int CP_E = (CP_K * 4 + 63) / 64;
+    int e[CP_E], c = 0;
+#pragma unroll
+    for (int q = 0; q < CP_E; q++) { e[q] = lane * CP_E + q < CP_K * 4 ? wcount[lane * CP_E + q] : 0; c += e[q]; }
     int inc = c;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
-    if (lane < CP_K * 4) wcount[lane] = inc - c;
+    int run = inc - c;
+#pragma unroll
+    for (int q = 0; q < CP_E; q++) { if (lane * CP_E + q < CP_K * 4) wcount[lane * CP_E + q] = run; run += e[q]; }
     const int total = __shfl(inc, 63);
     if (lane == 0) __hip_atomic_store(&state[b], cp_word(gen, b == 0 ? 2u : 1u, (unsigned)total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // look-back
@@ -165,9 +170,11 @@ __global__ __launch_bounds__(256) void k_compact1(int *__restrict__ pos, int *__
       const int idx = j - lane;
       unsigned long long st;
       bool ready;
+      int spins = 0;
       do {
         st = idx >= 0 ? __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : cp_word(gen, 2u, 0u);
         ready = (unsigned)(st >> 40) == (gen & 0xffffffu) && ((st >> 38) & 3ull) != 0ull;
+        if (++spins > (1 << 24)) abort();       // (seconds: an earlier block never came - fail loudly rather than hang)
       } while (!__all(ready));
       const unsigned long long pm = __ballot(((st >> 38) & 3ull) == 2ull);      // predecessors whose running total is known
       const int upto = pm ? __ffsll((long long)pm) - 1 : 63;
@@ -188,9 +195,10 @@ __global__ __launch_bounds__(256) void k_compact1(int *__restrict__ pos, int *__
 #pragma unroll
   for (int k = 0; k < CP_K; k++) {
     const int i = b * CP_PER_BLOCK + k * 256 + tid;
-    if (i >= n) continue;
     const bool o = (on >> k) & 1u;
-    const int rank = excl + wcount[k * 4 + w] + __popcll(m[k] & ((1ull << lane) - 1ull));
+    const unsigned long long m = __ballot(o);
+    if (i >= n) continue;
+    const int rank = excl + wcount[k * 4 + w] + __popcll(m & ((1ull << lane) - 1ull));
     if (o) { if (pos) pos[rank] = i; if (rank1) rank1[i] = rank + 1; }
     if (cidx) cidx[i] = o ? rank : -1;
   }
