@@ -444,20 +444,19 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   // short segment is the whole frame-to-frame dependency chain
   RD_HIP(hipMemcpyAsync(s->strsum, d->prev_strong, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));
   rdk::calc_strength(st, s->strsum, s->nms, s->label1, iw, ih);
-  rdk::strong_mask(st, s->strong, d->prev_strong, s->label1, s->strsum, 2500, iw, ih);
+  // (the same pass also yields the edge mask at 500 of oclrect.c:277-284 and filters the labels at 2500, oclrect.c:307-313:
+  //  filtering once at 2500 equals filtering at 500 and then at 2500, and both masks come from the unfiltered labels)
+  rdk::strength_masks(st, s->strong, d->prev_strong, s->edge500, s->e8, s->label1, s->strsum, 500, 2500, iw, ih);
   return;
   }
   // Three chains leave this point and meet again before the region stage / the votes:
-  //   main stream: edge mask at 500 -> edge-stopped blur x20 -> quantise -> despeckle          (oclrect.c:277-303)
-  //   2nd stream : labels filtered at 2500 -> junction counts -> merge mask                  (oclrect.c:307-321)
+  //   main stream: edge-stopped blur x20 -> quantise -> despeckle                              (oclrect.c:286-303)
+  //   2nd stream : junction counts of the filtered labels -> merge mask                      (oclrect.c:315-321)
   //                then the polyline stage, which needs nothing but the strong mask          (oclrect.c:361)
-  // Filtering once at 2500 equals filtering at 500 and then at 2500; the mask at 500 is derived from the unfiltered labels
-  // (k_edge_mask) before the second stream may touch them.  Inside a captured graph the streams become parallel branches.
-  rdk::edge_mask(st, s->edge500, s->e8, s->label1, s->strsum, 500, iw, ih);
+  // Inside a captured graph the streams become parallel branches.
   if (d->fork_poly) {      // (RD_NO_FORK: everything on the main stream, blur chain first)
     RD_HIP(hipEventRecord(s->ev_fork, st));
     RD_HIP(hipStreamWaitEvent(s->st2, s->ev_fork, 0));
-    rdk::filter_strength(s->st2, s->label1, s->strsum, 2500, iw, ih);
     rdk::junction(s->st2, s->junction, s->label1, 0, iw, ih);
     rdk::merge_mask(s->st2, s->mergemask, s->scratch2, s->junction, iw, ih);
     RD_HIP(hipEventRecord(s->ev_mm, s->st2));
@@ -473,7 +472,6 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
 
   if (d->fork_poly) RD_HIP(hipStreamWaitEvent(st, s->ev_mm, 0));
   else {
-    rdk::filter_strength(st, s->label1, s->strsum, 2500, iw, ih);
     rdk::junction(st, s->junction, s->label1, 0, iw, ih);
     rdk::merge_mask(st, s->mergemask, s->scratch2, s->junction, iw, ih);
   }

@@ -244,6 +244,24 @@ __global__ __launch_bounds__(256) void k_edge_mask(int *__restrict__ out, int8_t
   out[p] = v; out8[p] = (int8_t)v;
 }
 
+// What the frame path needs of the three kernels above in one pass over (label, strength sum): the strong mask at t_strong
+// (twice: this frame's copy and the plane handed to the next frame), the edge mask at t_edge as int and int8 - both from the
+// unfiltered labels - and the labels filtered at t_strong in place (filtering at t_edge first changes nothing: t_edge <= t_strong).
+__global__ __launch_bounds__(256) void k_strength_masks(int *__restrict__ strong, int *__restrict__ strong2, int *__restrict__ edge, int8_t *__restrict__ edge8,
+                                                         int *__restrict__ label, const int *__restrict__ str, int t_edge, int t_strong, int iw, int ih) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= iw || y >= ih) return;
+  const int p = y * iw + x;
+  const int l = label[p];
+  const bool interior = x > 0 && y > 0 && x < iw - 1 && y < ih - 1;
+  const int sum = (l > 0 && interior) ? str[l] : 0;
+  const int vs = (l > 0 && !(interior && sum < t_strong)) ? 1 : 0;
+  const int ve = (l > 0 && !(interior && sum < t_edge)) ? 1 : 0;
+  strong[p] = vs; strong2[p] = vs;
+  edge[p] = ve; edge8[p] = (int8_t)ve;
+  if (interior && l != -1 && (l <= 0 || sum < t_strong)) label[p] = -1;
+}
+
 }  // namespace
 
 namespace rdk {
@@ -268,6 +286,10 @@ void strong_mask(hipStream_t s, int *out, int *out2, const int *label, const int
 
 void edge_mask(hipStream_t s, int *out, int8_t *out8, const int *label, const int *str, int thre, int iw, int ih) {
   hipLaunchKernelGGL(k_edge_mask, grid2(iw, ih), block2, 0, s, out, out8, label, str, thre, iw, ih);
+}
+
+void strength_masks(hipStream_t s, int *strong, int *strong2, int *edge, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih) {
+  hipLaunchKernelGGL(k_strength_masks, grid2(iw, ih), block2, 0, s, strong, strong2, edge, edge8, label, str, t_edge, t_strong, iw, ih);
 }
 
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih) {

@@ -329,21 +329,26 @@ __global__ void k_find_ends2(PolyScratch s) {
 }
 
 // pl:287-310: 32-hop pointer-jumping prefix sum of the hop counts
-__global__ void k_number(PolyScratch s, int src) {
+// (init_sub: the last round also sets up the sub-chain labelling that follows - pl:312-355 - from the final numbers)
+__global__ void k_number(PolyScratch s, int src, int init_sub) {
   const int cnt = s.ctr[0];
   const int *ni = s.num[src], *li = s.link[src];
   int *no = s.num[src ^ 1], *lo_ = s.link[src ^ 1];
   SPARSE_LOOP(i, cnt) {
-    if (li[i] == -1) { no[i] = ni[i]; lo_[i] = -1; continue; }
     int n = ni[i], l = li[i];
-    bool ok = true;
-    for (int h = 0; h < 32; h++) {
-      if (l < 0) { ok = false; break; }
-      n += ni[l];
-      l = li[l];
+    if (l != -1) {
+      bool ok = true;
+      for (int h = 0; h < 32; h++) {
+        if (l < 0) { ok = false; break; }
+        n += ni[l];
+        l = li[l];
+      }
+      n = ok ? n : 0;
+      l = ok ? l : -1;
     }
-    no[i] = ok ? n : 0;
-    lo_[i] = ok ? l : -1;
+    no[i] = n;
+    lo_[i] = l;
+    if (init_sub) { s.lab2[i] = n == 0 ? -1 : i; s.size[i] = 0; s.rootid[i] = 0; }
   }
 }
 
@@ -393,9 +398,17 @@ __global__ void k_root_flags(PolyScratch s, int sizeThre) {
 }
 
 // ids of the surviving chains for every chain pixel (0 = dropped)
-__global__ void k_assign_ids(PolyScratch s) {
+// (ls != nullptr: also what k_seg_clear does for the single-launch stage - header record, counters ctr[2..23], ctr[25])
+__global__ void k_assign_ids(PolyScratch s, ls_rec *ls) {
   const int cnt = s.ctr[0];
   SPARSE_LOOP(i, cnt) { const int l = s.lab2[i]; s.id[i] = l >= 0 ? s.rootid[l] : 0; }
+  if (ls != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    ls_rec z = {};
+    ls[0] = z;
+    s.segaux[0] = -1; s.segaux[1] = 0x7fffffff;
+    for (int k = 2; k < 24; k++) s.ctr[k] = 0;
+    s.ctr[25] = 0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ initial segments (pl:439-506)
@@ -1010,25 +1023,23 @@ void polyline(hipStream_t st, PolyScratch *ps, void *lslist, int lslist_bytes, i
   for (int r = 0; r < 4; r++) hipLaunchKernelGGL(k_find_ends1, sg, sb, 0, st, s, r & 1);
   hipLaunchKernelGGL(k_find_ends2, sg, sb, 0, st, s);
   // numbering (oclpolyline.c:268-275): three rounds 0->1->0->1
-  for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k_number, sg, sb, 0, st, s, r & 1);
+  for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k_number, sg, sb, 0, st, s, r & 1, r == 2 ? 1 : 0);
   const int *number = s.num[1];
 
   // split at numbering jumps, size filter, compact ids (oclpolyline.c:277-295)
-  hipLaunchKernelGGL(k_sub_init, sg, sb, 0, st, s, number);
   hipLaunchKernelGGL(k_sub_union, sg, sb, 0, st, s, number);
   hipLaunchKernelGGL(k_flatten, sg, sb, 0, st, s.lab2, (const int *)s.ctr);
   hipLaunchKernelGGL(k_sub_size, sg, sb, 0, st, s);
   // (the chain-pixel count lives on the device: launch for the worst case, blocks beyond it exit at once)
   hipLaunchKernelGGL(k_root_flags, sg, sb, 0, st, s, sizeThre);
   hipLaunchKernelGGL(k_compact1, dim3(nblk), dim3(256), 0, st, (int *)nullptr, (int *)nullptr, s.rootid, (const int *)s.flag2, N, (const int *)s.ctr, s.ctr + 1, s.cstate + (size_t)nblk, (const int *)s.csync);
-  hipLaunchKernelGGL(k_assign_ids, sg, sb, 0, st, s);
+  hipLaunchKernelGGL(k_assign_ids, sg, sb, 0, st, s, mode == 1 ? ls : (ls_rec *)nullptr);
   hipLaunchKernelGGL(k_compact1, dim3(nblk), dim3(256), 0, st, s.live, (int *)nullptr, (int *)nullptr, (const int *)s.id, N, (const int *)s.ctr, s.ctr + 24, s.cstate + 2 * (size_t)nblk, (const int *)s.csync);
 
   if (mode == 1) {
     // fast path: initial segments, 15 subdivision rounds and the refinement in one persistent launch (overflow -> ctr[25])
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_poly_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pp_lds)); attr_set = true; }
-    hipLaunchKernelGGL(k_seg_clear, dim3(1), dim3(64), 0, st, s, ls, 56);     // resets the counters (ctr[2..23], ctr[25])
     hipLaunchKernelGGL(k_poly_persistent, dim3(1), dim3(PP_T), sizeof(pp_lds), st, s, ls, lslist_bytes, number, minerror, iw);
     if (ids) polyline_ids(st, ps, ids, N);
     return;

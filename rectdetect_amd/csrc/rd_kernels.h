@@ -45,6 +45,8 @@ void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw
 // out / out8 = (label > 0 after filter_strength at thre), as int and int8, from the unfiltered labels
 void edge_mask(hipStream_t s, int *out, int8_t *out8, const int *label, const int *str, int thre, int iw, int ih);
 void strong_mask(hipStream_t s, int *out, int *out2, const int *label, const int *str, int thre, int iw, int ih);
+// strong_mask at t_strong (two copies) + edge_mask at t_edge + filter_strength at t_strong (label in place), one pass; t_edge <= t_strong
+void strength_masks(hipStream_t s, int *strong, int *strong2, int *edge, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih);
 
 // ---- rd_k_rect.hip: rect-path stages
 void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih);
