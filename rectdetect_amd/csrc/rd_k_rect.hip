@@ -1078,8 +1078,11 @@ __device__ __forceinline__ void box_vote(int *table, const int *__restrict__ cla
 #pragma unroll
   for (int q = 0; q < RB_MAX; q++) {
     if (!valid[q] || oid[q] != id) continue;
-    if (owner[q] == i && touches(slot[q]) < 2) continue;       // we hold the claim: our first touch does not count
     int *e = table + (size_t)slot[q] * 5;
+    if (owner[q] == i) {
+      e[0] = id;                                  // the slot's id is its claimant's (exactly one pixel holds the claim)
+      if (touches(slot[q]) < 2) continue;         // our first touch does not count
+    }
     if (iw - x > c1[q]) atomicMax(&e[1], iw - x);
     if (x > c2[q]) atomicMax(&e[2], x);
     if (ih - y > c3[q]) atomicMax(&e[3], ih - y);
@@ -1145,14 +1148,6 @@ __global__ __launch_bounds__(256) void k_reduce_box(int *table, const int *__res
       });
       floor = bs[RB_MAX - 1];
     }
-  }
-}
-
-__global__ void k_reduce_owner(int *table, const int *__restrict__ claim, const int *__restrict__ tlist, rdk::PolyScratch s) {
-  const int n = tlist[0];
-  for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < n; j += gridDim.x * blockDim.x) {
-    const int slot = tlist[1 + j];
-    table[(size_t)slot * 5] = s.id[claim[slot]];
   }
 }
 
@@ -1295,7 +1290,6 @@ void reduce_ls_init(hipStream_t s, int *table, int *claim, int *tlist, int nentr
 void reduce_ls(hipStream_t s, int *table, int *claim, int *tlist, const int *boundary, const PolyScratch *ps, int iw, int ih, int nentry) {
   hipLaunchKernelGGL(k_reduce_clean, dim3(1), dim3(1024), 0, s, table, claim, tlist);       // undo the previous use
   hipLaunchKernelGGL(k_reduce_claim, dim3(512), dim3(256), 0, s, claim, tlist, boundary, *ps, iw, ih, nentry);
-  hipLaunchKernelGGL(k_reduce_owner, dim3(64), dim3(256), 0, s, table, (const int *)claim, (const int *)tlist, *ps);
   hipLaunchKernelGGL(k_reduce_box, dim3(512), dim3(256), 0, s, table, (const int *)claim, boundary, *ps, iw, ih, nentry);
 }
 
