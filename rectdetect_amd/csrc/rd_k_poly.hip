@@ -767,15 +767,21 @@ __global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec 
 #define PP_NUM(k) ((int)((unsigned)pk[k] >> 11))
 #define PP_CI(k) (s.live[tid + (k) * PP_T])
 #define PP_SEQ __builtin_amdgcn_sched_barrier(0)
+  {   // two levels of gathers, each issued for all PP_PX pixels together
+    int cc[PP_PX];
 #pragma unroll
-  for (int k = 0; k < PP_PX; k++) {
-    const int j = tid + k * PP_T;
-    pk[k] = 0; xy[k] = 0; dreg[k] = 0;
-    if (j < nlive) {
-      const int c = s.live[j];
-      const int p = s.pos[c];
-      pk[k] = s.id[c] | (number[c] << 11);
-      xy[k] = (p % iw) | ((p / iw) << 16);
+    for (int k = 0; k < PP_PX; k++) { const int j = tid + k * PP_T; cc[k] = s.live[j < nlive ? j : 0]; }
+#pragma unroll
+    for (int k = 0; k < PP_PX; k++) { const int j = tid + k * PP_T; if (j >= nlive) cc[k] = 0; }
+#pragma unroll
+    for (int k = 0; k < PP_PX; k++) { xy[k] = s.pos[cc[k]]; pk[k] = s.id[cc[k]]; dreg[k] = number[cc[k]]; }
+#pragma unroll
+    for (int k = 0; k < PP_PX; k++) {
+      const int j = tid + k * PP_T;
+      const int p = xy[k];
+      pk[k] = j < nlive ? (pk[k] | (dreg[k] << 11)) : 0;
+      xy[k] = j < nlive ? ((p % iw) | ((p / iw) << 16)) : 0;
+      dreg[k] = 0;
     }
   }
   for (int g = tid; g < PP_MAXSEG; g += PP_T) L.done[g] = 0;   // during the rounds: round in which the segment has to be looked at again
