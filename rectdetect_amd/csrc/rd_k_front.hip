@@ -217,6 +217,53 @@ __global__ __launch_bounds__(64) void k_iir_fused(P3 dst, P3c src, float *__rest
   float *__restrict__ tl = tails + ((size_t)(k * nchunks + c) * 4 * 7) * W + (xin ? x : W - 1);
   const int ylo = -IIR_WARM, yhi = H + IIR_WARM;
   float cur[IIR_CH], nxt[IIR_CH];
+  static_assert(IIR_CH == 16 && IF_WU % IIR_CH == 0 && IF_ROWS % IIR_CH == 0, "the interior path walks whole chunks");
+  if (s0 - IF_WU >= 0 && s1 + IF_WU <= H && s1 - s0 == IF_ROWS) {
+    // Interior block (all but the first and last of a column): no mirrored rows, no clamping, a full block - the same steps
+    // as below with every row test resolved at compile time (the scalar address and branch work of the general form costs
+    // as many issue slots as the recurrence itself).  A chunk = IIR_CH rows; rows one chunk past either end are fetched
+    // and dropped (they exist: IF_WU >= IIR_CH).
+    // IIR_CHUNK(row pointer of the chunk's first row, row step, STORE: what to do with an output row, TAIL: tails set or -1)
+#define IIR_CHUNK(PTR, STEP, STORE, TAIL, TIDX)                                                                         \
+    {                                                                                                                    \
+      _Pragma("unroll") for (int j = 0; j < IIR_CH; j++) nxt[j] = (PTR)[((long)(IIR_CH + j) * (STEP)) * W];              \
+      _Pragma("unroll") for (int j = 0; j < IIR_CH; j++) {                                                               \
+        IIR_STEP(cur[j]);                                                                                                \
+        STORE;                                                                                                           \
+        if ((TAIL) >= 0 && j >= IIR_CH - 7 && xin) tl[(size_t)((TAIL) * 7 + (TIDX)) * W] = d;                            \
+        IIR_SHIFT(cur[j]);                                                                                               \
+      }                                                                                                                  \
+      _Pragma("unroll") for (int j = 0; j < IIR_CH; j++) cur[j] = nxt[j];                                                \
+    }
+    {   // causal: rows s0 - IF_WU .. s1 - 1
+      float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
+      float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+      const float *p = in + (size_t)(s0 - IF_WU) * W;
+#pragma unroll
+      for (int j = 0; j < IIR_CH; j++) cur[j] = p[(size_t)j * W];
+      for (int c = 0; c < IF_WU / IIR_CH - 1; c++) { IIR_CHUNK(p, 1, (void)0, -1, 0); p += (size_t)IIR_CH * W; }
+      IIR_CHUNK(p, 1, (void)0, 0, j - (IIR_CH - 7)); p += (size_t)IIR_CH * W;                    // rows s0-16 .. s0-1: "warm" tails
+      float *f = fwt + lane;
+      for (int c = 0; c < IF_ROWS / IIR_CH - 1; c++) { IIR_CHUNK(p, 1, f[j * IF_PITCH] = d, -1, 0); p += (size_t)IIR_CH * W; f += IIR_CH * IF_PITCH; }
+      IIR_CHUNK(p, 1, f[j * IF_PITCH] = d, 1, j - (IIR_CH - 7));                                  // rows s1-16 .. s1-1: "true" tails
+    }
+    {   // anti-causal: rows s1 - 1 + IF_WU .. s0, finishing the block's pixels
+      float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
+      float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+      const float *p = in + (size_t)(s1 - 1 + IF_WU) * W;
+#pragma unroll
+      for (int j = 0; j < IIR_CH; j++) cur[j] = p[-(long)j * W];
+      for (int c = 0; c < IF_WU / IIR_CH - 1; c++) { IIR_CHUNK(p, -1, (void)0, -1, 0); p -= (size_t)IIR_CH * W; }
+      IIR_CHUNK(p, -1, (void)0, 2, (IIR_CH - 1) - j); p -= (size_t)IIR_CH * W;                   // rows s1+15 .. s1: "warm" tails (index = row - s1)
+      float *f = fwt + (IF_ROWS - 1) * IF_PITCH + lane;
+      float *o = TOUT ? nullptr : dst.p[k] + (size_t)(s1 - 1) * W + (xin ? x : W - 1);
+#define IIR_FINISH { const float r = d + f[-j * IF_PITCH] - cur[j] * IIR_C0; if (TOUT) f[-j * IF_PITCH] = r; else if (xin) o[-(long)j * W] = r; }
+      for (int c = 0; c < IF_ROWS / IIR_CH - 1; c++) { IIR_CHUNK(p, -1, IIR_FINISH, -1, 0); p -= (size_t)IIR_CH * W; f -= IIR_CH * IF_PITCH; if (!TOUT) o -= (size_t)IIR_CH * W; }
+      IIR_CHUNK(p, -1, IIR_FINISH, 3, (IIR_CH - 1) - j);                                           // rows s0+15 .. s0: "true" tails (index = row - s0)
+#undef IIR_FINISH
+    }
+#undef IIR_CHUNK
+  } else {
   {   // ---------------- causal sweep: rows fb .. s1-1
     const int fb = (s0 - IF_WU <= ylo) ? ylo : s0 - IF_WU;
     const int total = s1 - fb;
@@ -266,6 +313,7 @@ __global__ __launch_bounds__(64) void k_iir_fused(P3 dst, P3c src, float *__rest
 #pragma unroll
       for (int j = 0; j < IIR_CH; j++) cur[j] = nxt[j];
     }
+  }
   }
   if (TOUT) {
     __syncthreads();
