@@ -184,8 +184,7 @@ __global__ __launch_bounds__(256) void k_transpose(P3 dst, P3c src, P3c fwd, P3c
 // sweep BIT FOR BIT is checked on the device: each block records the 7 outputs it computed just before entering its rows
 // ("warm") and its own last 7 outputs ("true"), k_iir_check_fix compares neighbours and evaluates a column with any
 // difference again by full-length sweeps (rdk::iir_blur_pass).  TOUT = 1 writes the result transposed (through the LDS tile).
-#define IF_ROWS_T 64          // rows per block, pass with transposed output (the transposing tail wants longer runs per column)
-#define IF_ROWS_N 32          // rows per block, plain pass (more, smaller blocks: LDS is what limits the waves per CU)
+#define IF_ROWS_MIN 32         // rows per block: 32 ... 128, chosen per launch (if_pick_rows)
                               // (a remainder of fewer than 8 rows is merged into the last block: LDS tile = rows + 8)
 #define IF_WU 32              // warm-up rows (24 sufficed on every plane tried on the CPU; the on-device check is what guarantees the result)
 #define IF_PITCH 65
@@ -673,7 +672,19 @@ void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], 
   P3c z = { { nullptr, nullptr, nullptr } };
   hipLaunchKernelGGL(k_transpose<0>, dim3(cdiv(W, 64), cdiv(H, 64)), block2, 0, s, mk3(dst, np), mk3c(src, np), z, z, (const uint32_t *)nullptr, np, W, H, (const int *)nullptr);
 }
-size_t iir_pass_scratch_floats(int np, int W, int H) { return (size_t)np * if_nchunks(H, IF_ROWS_N) * 4 * 7 * W; }   // (the finer blocking bounds both)
+// Block height per launch.  One wave per block, each a serial recurrence of 2 x (rows + IF_WU) steps whose dependent chain is
+// longer than its issue time: several waves per SIMD hide that, so short blocks win although they repeat the run-in more often
+// (measured at 1080p, one wave per SIMD with 96 / 112 rows: 62 / 55 us; 32, 48, 64 rows: 48, 45, 50 us with transposed output,
+// 37, 38, 40 us without).  RD_IIR_ROWS
+// overrides (32, 48, 64, 96, 112, 128).
+static int if_pick_rows(int np, int W, int H, int transpose_out) {
+  (void)np; (void)W; (void)H;
+  static const int forced = getenv("RD_IIR_ROWS") ? atoi(getenv("RD_IIR_ROWS")) : 0;
+  if (forced == 32 || forced == 48 || forced == 64 || forced == 96 || forced == 112 || forced == 128) return forced;
+  return transpose_out ? 48 : 32;
+}
+
+size_t iir_pass_scratch_floats(int np, int W, int H) { return (size_t)np * if_nchunks(H, IF_ROWS_MIN) * 4 * 7 * W; }   // (the finest blocking bounds all)
 
 // one blur pass (both sweeps + combination) down the columns of np planes (W columns, H rows); transpose_out: dst planes
 // are H wide, W tall.  fwd: scratch planes, only touched by columns whose blocked evaluation fails its on-device check and
@@ -681,11 +692,21 @@ size_t iir_pass_scratch_floats(int np, int W, int H) { return (size_t)np * if_nc
 // iir_pass_scratch_floats() floats.
 void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3], float *const fwd[3], float *const bwd[3], int np, int W, int H,
                    int transpose_out, float *tails, int *bad) {
-  const int rows = transpose_out ? IF_ROWS_T : IF_ROWS_N;
+  const int rows = if_pick_rows(np, W, H, transpose_out);
   const int nchunks = if_nchunks(H, rows);
   const dim3 grid(cdiv(W, 64), np, nchunks);
-  if (transpose_out) hipLaunchKernelGGL((k_iir_fused<1, IF_ROWS_T>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks, bad);
-  else hipLaunchKernelGGL((k_iir_fused<0, IF_ROWS_N>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks, bad);
+#define IF_LAUNCH(T, R) hipLaunchKernelGGL((k_iir_fused<T, R>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks, bad)
+#define IF_LAUNCH_R(R) { if (transpose_out) IF_LAUNCH(1, R); else IF_LAUNCH(0, R); }
+  switch (rows) {
+    case 32: IF_LAUNCH_R(32); break;
+    case 48: IF_LAUNCH_R(48); break;
+    case 64: IF_LAUNCH_R(64); break;
+    case 96: IF_LAUNCH_R(96); break;
+    case 112: IF_LAUNCH_R(112); break;
+    default: IF_LAUNCH_R(128); break;
+  }
+#undef IF_LAUNCH_R
+#undef IF_LAUNCH
   if (nchunks > 1) {
     const int force = getenv("RD_IIR_FORCE_FIX") ? 1 : 0;             // diagnostics: every column takes the full-length path
     if (transpose_out) hipLaunchKernelGGL(k_iir_check_fix<1>, grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force);
