@@ -45,11 +45,18 @@ __global__ __launch_bounds__(256) void k_label_tile(int *__restrict__ label, con
   const bool xin = x < iw;
   const int v00 = pix[(size_t)y0 * iw + blockIdx.x * LT_W];   // the tile's first pixel is always inside the frame
   bool uniform = true;
+  int pv8[LT_H / LT_TY];            // this thread's pixels, requested together (one wait for memory instead of one per row)
 #pragma unroll
-  for (int r = threadIdx.y; r < LT_H; r += LT_TY) {
+  for (int k = 0; k < LT_H / LT_TY; k++) {
+    const int y = y0 + threadIdx.y + k * LT_TY;
+    pv8[k] = pix[(xin && y < ih) ? y * iw + x : 0];
+  }
+#pragma unroll
+  for (int k = 0; k < LT_H / LT_TY; k++) {
+    const int r = threadIdx.y + k * LT_TY;
     const int y = y0 + r;
     const bool valid = xin && y < ih;
-    const int v = valid ? pix[y * iw + x] : 0;
+    const int v = valid ? pv8[k] : 0;
     uniform = uniform && (!valid || v == v00);
     const int vl = __shfl_up(v, 1);
     const bool lvalid = __shfl_up((int)valid, 1) != 0;
@@ -108,8 +115,9 @@ __global__ __launch_bounds__(256) void k_label_tile(int *__restrict__ label, con
 // y = 32k (k >= 1) against the row above; 0: the pixels of columns x = 64k (k >= 1) against column x-1 and the pixels of
 // columns x = 64k-1 against their NE neighbour; lanes are consecutive pixels ALONG the border so that a lane whose
 // (label, neighbour label) pair equals its predecessor's can leave the union to that lane.
-__device__ __forceinline__ void border_union(int *label, int p, int q, bool want) {
-  const int la = want ? label[p] : -1, lb = want ? label[q] : -2;   // the tile roots (constant during this kernel unless roots themselves)
+// la, lb: label[p], label[q] (the tile roots: constant during this kernel unless roots themselves; any value when !want)
+__device__ __forceinline__ void border_union(int *label, int la, int lb, bool want) {
+  if (!want) { la = -1; lb = -2; }
   const int pa = __shfl_up(la, 1), pb = __shfl_up(lb, 1);
   if (want && !(__lane_id() > 0 && pa == la && pb == lb)) {
     int a = la, b = lb;
@@ -146,9 +154,12 @@ __global__ __launch_bounds__(256) void k_label_border(int *label, const int *__r
     const bool nwSame = act && x > 0 && pix[p - iw - 1] == v;
     const bool neSame = act && x < iw - 1 && pix[p - iw + 1] == v;
     const bool eSame = act && x < iw - 1 && pix[p + 1] == v;
-    border_union(label, p, p - iw, nSame && !(wSame && nwSame));
-    border_union(label, p, p - iw - 1, !nSame && nwSame && !wSame);
-    border_union(label, p, p - iw + 1, !nSame && neSame && !eSame);
+    // (the labels of all three candidate pairs are requested together: clamped addresses, used only where wanted)
+    const int pc = in ? p : 0;
+    const int l0 = label[pc], ln = label[in ? p - iw : 0], lnw = label[(in && x > 0) ? p - iw - 1 : 0], lne = label[(in && x < iw - 1) ? p - iw + 1 : 0];
+    border_union(label, l0, ln, nSame && !(wSame && nwSame));
+    border_union(label, l0, lnw, !nSame && nwSame && !wSame);
+    border_union(label, l0, lne, !nSame && neSame && !eSame);
   } else {
     const int nb = (iw - 1) / LT_W;              // border columns
     const int y = t % ih, k = t / ih;
@@ -160,8 +171,11 @@ __global__ __launch_bounds__(256) void k_label_border(int *label, const int *__r
     const bool wSame = act && pix[p - 1] == v;
     const bool nSame = act && y > 0 && pix[p - iw] == v;
     const bool nwSame = act && y > 0 && pix[p - iw - 1] == v;
-    border_union(label, p, p - 1, wSame);
-    border_union(label, p, p - iw - 1, nwSame && !nSame && !wSame);
+    const int pc = in ? p : 0;
+    const int l0 = label[pc], lw = label[in ? p - 1 : 0], lnw = label[(in && y > 0) ? p - iw - 1 : 0];
+    const int ll0 = label[in ? p - 1 : 0], llne = label[(in && y > 0) ? p - 1 - iw + 1 : 0];
+    border_union(label, l0, lw, wSame);
+    border_union(label, l0, lnw, nwSame && !nSame && !wSame);
     // the pixel left of the border and its NE neighbour (x, y-1)
     const int pl = p - 1;
     const int vl = in ? pix[pl] : bgc;
@@ -169,7 +183,7 @@ __global__ __launch_bounds__(256) void k_label_border(int *label, const int *__r
     const bool lne = actl && pix[pl - iw + 1] == vl;
     const bool ln = actl && pix[pl - iw] == vl;
     const bool le = actl && pix[pl + 1] == vl;
-    border_union(label, pl, pl - iw + 1, lne && !ln && !le);
+    border_union(label, ll0, llne, lne && !ln && !le);
   }
 }
 
