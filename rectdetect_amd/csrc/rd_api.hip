@@ -534,8 +534,8 @@ static void *slot_postprocess(rd_detector *d, Slot *s, double tanAOV, void **seg
     RD_HIP(hipStreamSynchronize(s->st));
     __atomic_add_fetch(&d->n_redo_rounds, 1, __ATOMIC_RELAXED);
   }
-  {   // budget for the frames to come: what the last 64 frames needed (first round without a change, + 1 to see that) + 2.
-      // (A long window on purpose: alternating between two budgets - two graph instances - was measured to cost 15 %.)
+  {   // budget for the frames to come: what the last 64 frames needed (first round without a change, + 1 to see that) + 1.
+      // (A long window on purpose: a frame that needs more than the budget is computed twice.)
     int need = 20;
     for (int r = 0; r < 20; r++) if (s->h_ctr[32 + r] == 0) { need = r + 1; break; }
     pthread_mutex_lock(&d->tan_mu);
@@ -543,7 +543,7 @@ static void *slot_postprocess(rd_detector *d, Slot *s, double tanAOV, void **seg
     int mx = 0;
     for (int k = 0; k < 64; k++) mx = d->need_hist[k] > mx ? d->need_hist[k] : mx;
     int b = 20;
-    for (int k = 3; k >= 0; k--) if (d->need_pos >= 8 && kRoundBudgets[k] >= mx + 2) b = kRoundBudgets[k];
+    for (int k = 3; k >= 0; k--) if (d->need_pos >= 8 && kRoundBudgets[k] >= mx + 1) b = kRoundBudgets[k];
     __atomic_store_n(&d->rounds_budget, b, __ATOMIC_RELAXED);
     pthread_mutex_unlock(&d->tan_mu);
   }
@@ -624,11 +624,10 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->fork_poly = nslots <= 2 ? 1 : 0;
   if (getenv("RD_NO_FORK")) d->fork_poly = 0;
   if (getenv("RD_FORK")) d->fork_poly = 1;
-  // round budget of the region merge: 20 (all launched rounds, the default) or, with RD_REGION_ROUNDS_ADAPTIVE, what recent frames
-  // needed + margin (8/12/16/20; frames that needed more are repeated).  The adaptive mode saves 1-2 % when it settles, but a
-  // second graph instance per slot changes how the runtime spreads the streams over its hardware queues, and the unlucky
-  // assignments cost 15 % (measured: 1068 vs 894 frames/s from run to run) - so it stays opt-in.
-  d->fixed_rounds = getenv("RD_REGION_ROUNDS_ADAPTIVE") ? 0 : 20;
+  // round budget of the region merge: what the last 64 frames needed + margin (8 / 12 / 16 / 20 launched rounds; the rounds after
+  // the merge has settled are no-ops, but each still costs two launches of a thousand blocks), frames that turn out to need more
+  // are repeated with all 20; RD_REGION_ROUNDS_FIXED=8|12|16|20 pins the budget (20: never repeat anything).
+  d->fixed_rounds = 0;
   if (getenv("RD_REGION_ROUNDS_FIXED")) { const int r = atoi(getenv("RD_REGION_ROUNDS_FIXED")); d->fixed_rounds = (r == 8 || r == 12 || r == 16) ? r : 20; }
   d->rounds_budget = 20;
   d->diag_skip = getenv("RD_DIAG_SKIP") ? atoi(getenv("RD_DIAG_SKIP")) : 0;   // timing diagnostics only: leaves stages out (wrong results)

@@ -419,17 +419,17 @@ def test_smallest_frames(iw, ih):
     orc.close()
 
 
-@pytest.mark.parametrize("iw,ih,mode", [(640, 480, {"RD_REGION_ROUNDS_ADAPTIVE": "1"}), (1920, 1080, {"RD_REGION_ROUNDS_FIXED": "8"})])
+@pytest.mark.parametrize("iw,ih,mode", [(640, 480, {}), (1920, 1080, {"RD_REGION_ROUNDS_FIXED": "8"})])
 def test_region_round_budget_does_not_change_results(iw, ih, mode):
-    """opt-in modes launch fewer region-merge rounds per frame (adaptive: what recent frames needed; fixed: 8) and repeat
-    the frames that needed more with the full budget: results must equal those of the default (always all 20 rounds)"""
+    """fewer region-merge rounds are launched per frame than the full 20 (default: what recent frames needed + margin; fixed: 8)
+    and the frames that needed more are repeated with the full budget: results must equal those with all 20 rounds always"""
     nframes = 12 if iw < 1000 else 4
     frames = [synth.frame(synth.SEED0 + 9, iw, ih, t) for t in range(nframes)]
     rng = np.random.default_rng(3)
     tiles = rng.integers(0, 256, (ih // 8, iw // 8, 3), dtype=np.uint8)
     frames.insert(nframes - 2, np.ascontiguousarray(np.repeat(np.repeat(tiles, 8, 0), 8, 1)))   # a very different frame inside the stream
     out = []
-    for env in (mode, {}):
+    for env in (mode, {"RD_REGION_ROUNDS_FIXED": "20"}):
         old = {k: os.environ.get(k) for k in env}
         os.environ.update(env)
         det = ra.Detector(iw, ih, nslots=2, nworkers=1)
@@ -446,9 +446,9 @@ def test_region_round_budget_does_not_change_results(iw, ih, mode):
             res.append((det.poll(TAN36), det.last_segments(), det.plane("region").copy()))
             infl -= 1
         print("env", env, "budget, repeated frames:", det.region_round_budget())
-        if not env:
-            assert det.region_round_budget()[1] == 0      # nothing is ever repeated with the full budget (the default)
-        if "RD_REGION_ROUNDS_FIXED" in env:
+        if env.get("RD_REGION_ROUNDS_FIXED") == "20":
+            assert det.region_round_budget()[1] == 0      # nothing is ever repeated with the full budget
+        if env.get("RD_REGION_ROUNDS_FIXED") == "8":
             assert det.region_round_budget()[1] > 0       # 8 rounds are not enough at this size: the repeat path must have run
         det.close()
         out.append(res)
