@@ -112,13 +112,15 @@ def main():
             dframes.append(p)
 
     nrect = 0
+    inflight = 0
 
     def step():
-        nonlocal nrect
+        """one pass over the batch of F frames: every frame is handed to the detector; it is a stream, so the results of the
+        last frames in flight are collected at the beginning of the next step (or by sync() at the end of the timed region)"""
+        nonlocal nrect, inflight
         if args.dry_run:
             time.sleep(0.01 * (1 + rank))
             return
-        inflight = 0
         for i in range(F):
             if inflight == args.slots:
                 nrect += len(det.poll(TAN_AOV))
@@ -128,12 +130,14 @@ def main():
             else:
                 det.enqueue(dframes[i], ws=IW * 3, on_device=True)
             inflight += 1
-        while inflight:
-            nrect += len(det.poll(TAN_AOV))
-            inflight -= 1
 
     def sync():
+        """all frames handed over so far are finished, post-processed and their rectangles collected"""
+        nonlocal nrect, inflight
         if not args.dry_run:
+            while inflight:
+                nrect += len(det.poll(TAN_AOV))
+                inflight -= 1
             det.drain()
             if dist is not None and dist.get_backend() == "nccl":
                 import torch
