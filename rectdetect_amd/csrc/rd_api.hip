@@ -432,7 +432,7 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   rdk::thinthres(st, s->nms, s->strength, s->vxy, iw, ih);
 
   // mask of positive responses and the rect-path tidy (oclrect.c:262-272)
-  rdk::rect_tidy(st, s->mask0, s->tidy, s->nms, iw, ih);
+  rdk::rect_tidy(st, s->mask0, s->tidy, s->nms, iw, ih, s->strsum);     // (also clears the strength sums for the H1 segment)
 
   // components (background included)
   rdk::label8(st, s->label1, s->tidy, -1, iw, ih);
@@ -442,8 +442,7 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   // strength sums on top of last frame's strong mask (H1, oclrect.c:274-275) and - at once - this frame's strong mask
   // (what oclrect.c:307-313 derives from the sums later): nothing else of a frame is needed by the next one, so this
   // short segment is the whole frame-to-frame dependency chain
-  RD_HIP(hipMemcpyAsync(s->strsum, d->prev_strong, sizeof(int) * (size_t)N, hipMemcpyDeviceToDevice, st));
-  rdk::calc_strength(st, s->strsum, s->nms, s->label1, iw, ih);
+  rdk::calc_strength(st, s->strsum, s->nms, s->label1, iw, ih, d->prev_strong);
   // (the same pass also yields the edge mask at 500 of oclrect.c:277-284 and filters the labels at 2500, oclrect.c:307-313:
   //  filtering once at 2500 equals filtering at 500 and then at 2500, and both masks come from the unfiltered labels)
   rdk::strength_masks(st, s->strong, d->prev_strong, s->edge500, s->e8, s->label1, s->strsum, 500, 2500, iw, ih);

@@ -201,8 +201,11 @@ __global__ __launch_bounds__(256) void k_label_flatten(int *label, int n) {
 // oclimgutil.cl:641-649: out[label] += (int)(e*e*10000) for interior pixels with label > 0.  Lanes of a wave that
 // share a label are summed with a ballot/shuffle loop first, so a big component costs one atomic per wave instead of
 // one per pixel; zero contributions (most pixels) are skipped.  Integer addition: order independent.
-__global__ __launch_bounds__(256) void k_calc_strength(int *out, const float *__restrict__ edge, const int *__restrict__ label, int iw, int ih) {
+__global__ __launch_bounds__(256) void k_calc_strength(int *out, const float *__restrict__ edge, const int *__restrict__ label, int iw, int ih, const int *__restrict__ add) {
   const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  // (quirk H1 without a copy launch: the sums start from last frame's strong mask - `out` arrives zeroed and the mask is added
+  //  element by element with the same commutative atomics as the sums)
+  if (add != nullptr && x < iw && y < ih) { const int a = add[y * iw + x]; if (a != 0) atomicAdd(&out[y * iw + x], a); }
   int l = -1, val = 0;
   if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1) {
     const int p = y * iw + x;
@@ -290,8 +293,8 @@ void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih) 
   hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n);
 }
 
-void calc_strength(hipStream_t s, int *out, const float *edge, const int *label, int iw, int ih) {
-  hipLaunchKernelGGL(k_calc_strength, grid2(iw, ih), block2, 0, s, out, edge, label, iw, ih);
+void calc_strength(hipStream_t s, int *out, const float *edge, const int *label, int iw, int ih, const int *add) {
+  hipLaunchKernelGGL(k_calc_strength, grid2(iw, ih), block2, 0, s, out, edge, label, iw, ih, add);
 }
 
 void strong_mask(hipStream_t s, int *out, int *out2, const int *label, const int *str, int thre, int iw, int ih) {

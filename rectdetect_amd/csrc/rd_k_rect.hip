@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_junction(int *__restrict__ out, const i
 #define TD_ROWS 16
 #define TD_M 4
 #define TD_P (64 + 2 * TD_M)
-__global__ __launch_bounds__(256) void k_rect_tidy(int *__restrict__ mask0, int *__restrict__ tidy, const float *__restrict__ nms, int iw, int ih) {
+__global__ __launch_bounds__(256) void k_rect_tidy(int *__restrict__ mask0, int *__restrict__ tidy, const float *__restrict__ nms, int iw, int ih, int *__restrict__ zero_plane) {
   __shared__ uint8_t A[(TD_ROWS + 2 * TD_M) * TD_P], B[(TD_ROWS + 2 * TD_M) * TD_P];
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * TD_ROWS;
   const int tid = threadIdx.y * 64 + threadIdx.x;
@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void k_rect_tidy(int *__restrict__ mask0, int 
       if ((B[i - TD_P] != 0 || B[i + TD_P] != 0) && (B[i - 1] != 0 || B[i + 1] != 0)) v = 0;
     }
     tidy[y * iw + x] = v;
+    if (zero_plane) zero_plane[y * iw + x] = 0;
   }
 #undef TD_FOR
 #undef TD_CELL
@@ -1209,8 +1210,8 @@ namespace rdk {
 void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih) {
   hipLaunchKernelGGL(k_junction, grid2(iw, ih), block2, 0, s, out, in, nonzero_variant, iw, ih);
 }
-void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, int ih) {
-  hipLaunchKernelGGL(k_rect_tidy, dim3(cdiv(iw, 64), cdiv(ih, TD_ROWS)), dim3(64, 4), 0, s, mask0, tidy, nms, iw, ih);
+void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, int ih, int *zero_plane) {
+  hipLaunchKernelGGL(k_rect_tidy, dim3(cdiv(iw, 64), cdiv(ih, TD_ROWS)), dim3(64, 4), 0, s, mask0, tidy, nms, iw, ih, zero_plane);
 }
 void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih) {
   hipLaunchKernelGGL(k_blblur_extents, dim3(cdiv(iw, 64), cdiv(ih, BE_ROWS)), dim3(64, 4), 0, s, ext, edge, iw, ih);

@@ -39,7 +39,8 @@ void rand_i(hipStream_t s, int *out, uint64_t seed, int n);
 // ---- rd_k_label.hip: connected components and per-label reductions
 // 8-connected components of equal `pix` value, pixels equal to bgc -> -1, label = smallest pixel index
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih);
-void calc_strength(hipStream_t s, int *out, const float *edge, const int *label, int iw, int ih);
+// add (optional): a plane whose non-zero elements are added to out element by element in the same launch (out = zeros + add + sums)
+void calc_strength(hipStream_t s, int *out, const float *edge, const int *label, int iw, int ih, const int *add = nullptr);
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih);
 // out = out2 = (label > 0 after filter_strength at thresholds <= thre ... thre), from the UNFILTERED labels
 // out / out8 = (label > 0 after filter_strength at thre), as int and int8, from the unfiltered labels
@@ -51,7 +52,7 @@ void strength_masks(hipStream_t s, int *strong, int *strong2, int *edge, int8_t 
 // ---- rd_k_rect.hip: rect-path stages
 void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih);
 // mask0 = (nms > 0), tidy = thin(thin(close_gaps(junction(mask0)), parity 0), parity 1) in one launch (oclrect.cl:74-135)
-void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, int ih);
+void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, int ih, int *zero_plane = nullptr);   // zero_plane (optional): cleared on the way
 // run extents of the edge-stopped blur (depend on the edge mask only): ext[p] = nl_h | nr_h<<3 | nl_v<<6 | nr_v<<9
 void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih);
 // one horizontal + vertical pass pair; out must not alias in
