@@ -201,28 +201,42 @@ __global__ __launch_bounds__(256) void k_label_flatten(int *label, int n) {
 // oclimgutil.cl:641-649: out[label] += (int)(e*e*10000) for interior pixels with label > 0.  Lanes of a wave that
 // share a label are summed with a ballot/shuffle loop first, so a big component costs one atomic per wave instead of
 // one per pixel; zero contributions (most pixels) are skipped.  Integer addition: order independent.
+#define CS_ROWS 4      // rows per thread: their loads are in flight together
 __global__ __launch_bounds__(256) void k_calc_strength(int *out, const float *__restrict__ edge, const int *__restrict__ label, int iw, int ih, const int *__restrict__ add) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-  // (quirk H1 without a copy launch: the sums start from last frame's strong mask - `out` arrives zeroed and the mask is added
-  //  element by element with the same commutative atomics as the sums)
-  if (add != nullptr && x < iw && y < ih) { const int a = add[y * iw + x]; if (a != 0) atomicAdd(&out[y * iw + x], a); }
-  int l = -1, val = 0;
-  if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1) {
-    const int p = y * iw + x;
-    l = label[p];
-    if (l > 0) { const float e = edge[p]; val = (int)(e * e * 10000.0f); }
-  }
-  bool todo = l > 0 && val != 0;
-  while (__any(todo)) {
-    unsigned long long m = __ballot(todo);
-    const int leader = __ffsll((long long)m) - 1;
-    const int ll = __shfl(l, leader);
-    const bool mine = todo && l == ll;
-    int sum = mine ? val : 0;
+  const int x = blockIdx.x * 64 + threadIdx.x, yb = blockIdx.y * (4 * CS_ROWS) + threadIdx.y;
+  int ls[CS_ROWS], as[CS_ROWS];
+  float es[CS_ROWS];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-    if ((int)threadIdx.x == leader) atomicAdd(&out[ll], sum);
-    if (mine) todo = false;
+  for (int k = 0; k < CS_ROWS; k++) {
+    const int y = yb + 4 * k;
+    const int p = (x < iw && y < ih) ? y * iw + x : 0;
+    ls[k] = label[p];
+    es[k] = edge[p];
+    as[k] = add != nullptr ? add[p] : 0;
+  }
+#pragma unroll
+  for (int k = 0; k < CS_ROWS; k++) {
+    const int y = yb + 4 * k;
+    // (quirk H1 without a copy launch: the sums start from last frame's strong mask - `out` arrives zeroed and the mask is added
+    //  element by element with the same commutative atomics as the sums)
+    if (x < iw && y < ih && as[k] != 0) atomicAdd(&out[y * iw + x], as[k]);
+    int l = -1, val = 0;
+    if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1) {
+      l = ls[k];
+      if (l > 0) { const float e = es[k]; val = (int)(e * e * 10000.0f); }
+    }
+    bool todo = l > 0 && val != 0;
+    while (__any(todo)) {
+      unsigned long long m = __ballot(todo);
+      const int leader = __ffsll((long long)m) - 1;
+      const int ll = __shfl(l, leader);
+      const bool mine = todo && l == ll;
+      int sum = mine ? val : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+      if ((int)threadIdx.x == leader) atomicAdd(&out[ll], sum);
+      if (mine) todo = false;
+    }
   }
 }
 
@@ -294,7 +308,7 @@ void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih) 
 }
 
 void calc_strength(hipStream_t s, int *out, const float *edge, const int *label, int iw, int ih, const int *add) {
-  hipLaunchKernelGGL(k_calc_strength, grid2(iw, ih), block2, 0, s, out, edge, label, iw, ih, add);
+  hipLaunchKernelGGL(k_calc_strength, dim3(cdiv(iw, 64), cdiv(ih, 4 * CS_ROWS)), block2, 0, s, out, edge, label, iw, ih, add);
 }
 
 void strong_mask(hipStream_t s, int *out, int *out2, const int *label, const int *str, int thre, int iw, int ih) {
