@@ -26,7 +26,10 @@ void rd_download(void *host, const void *dptr, size_t bytes);
 /* ---- one detector instance = one stream of frames (state carried between frames) */
 typedef struct rd_detector rd_detector;
 
-/* nslots frames in flight (>= 1), nworkers host threads for the post-process (0 = run it on the polling thread) */
+/* nslots frames in flight (>= 1), nworkers host threads for the post-process (0 = run it on the polling thread).
+ * 1-2 frames in flight: a frame spreads over two HIP streams (shortest latency); from 3 on: one stream per frame, and frames
+ * beyond the fourth queue up on the same four streams (the device runs four hardware queues side by side) - 8 gives the highest
+ * rate ("Execution"). */
 rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nworkers);
 void rd_detector_destroy(rd_detector *d);
 
