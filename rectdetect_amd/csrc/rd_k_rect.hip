@@ -966,21 +966,25 @@ __device__ __forceinline__ unsigned ls_slot(int id, int bid, int nentry) { retur
 #define RB_MAX 8
 #define RB_NONE 0x7fffffff
 __device__ __forceinline__ bool rb_collect(const int (&win)[49], int floor, int (&bs)[RB_MAX]) {
-  bool more = false;
+  // repeated minimum extraction: pass q finds the smallest id above the one of pass q-1; windows hold one to three distinct ids
+  // as a rule, and the passes stop as soon as no lane of the wave finds another one
 #pragma unroll
   for (int q = 0; q < RB_MAX; q++) bs[q] = RB_NONE;
+  int cur = floor;
 #pragma unroll
-  for (int k = 0; k < 49; k++) {
-    const int b = win[k];
-    if (b <= floor) continue;
-    bool present = false;
+  for (int q = 0; q < RB_MAX; q++) {
+    int m = RB_NONE;
 #pragma unroll
-    for (int q = 0; q < RB_MAX; q++) present = present || bs[q] == b;
-    if (present) continue;
-    int v = b;
+    for (int k = 0; k < 49; k++) { const int b = win[k]; m = (b > cur && b < m) ? b : m; }
+    bs[q] = m;
+    cur = m;                              // (RB_NONE once exhausted: nothing is larger)
+    if (!__any(m != RB_NONE)) break;
+  }
+  bool more = false;
+  if (__any(bs[RB_MAX - 1] != RB_NONE)) {
+    const int last = bs[RB_MAX - 1];
 #pragma unroll
-    for (int q = 0; q < RB_MAX; q++) { const int t = bs[q]; if (v < t) { bs[q] = v; v = t; } }   // sorted insert; v ends up as what fell off
-    more = more || v != RB_NONE;
+    for (int k = 0; k < 49; k++) more = more || (last != RB_NONE && win[k] > last);
   }
   return more;
 }
