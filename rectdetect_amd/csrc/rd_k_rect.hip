@@ -989,6 +989,20 @@ __device__ __forceinline__ bool rb_collect(const int (&win)[49], int floor, int 
   return more;
 }
 
+// how often each collected id occurs in the window (entries without an id: 0)
+__device__ __forceinline__ void rb_counts(const int (&win)[49], const int (&bs)[RB_MAX], int (&cnt)[RB_MAX]) {
+#pragma unroll
+  for (int q = 0; q < RB_MAX; q++) cnt[q] = 0;
+#pragma unroll
+  for (int q = 0; q < RB_MAX; q++) {
+    if (!__any(bs[q] != RB_NONE)) break;
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 49; k++) c += win[k] == bs[q] ? 1 : 0;
+    cnt[q] = bs[q] != RB_NONE ? c : 0;
+  }
+}
+
 // slots that receive their first claim are appended to `tlist` (tlist[0] = count) so that the next frame can undo exactly
 // these instead of clearing the whole 20-bytes-per-entry table
 __device__ __forceinline__ void tlist_append(int *tlist, bool first, unsigned slot) {
@@ -1041,13 +1055,16 @@ __global__ __launch_bounds__(256) void k_reduce_claim(int *claim, int *tlist, co
       if (floor == 0 && j < nlive) {
         // k_reduce_box visits the same slots: they are left for it (RB_MAX ints per chain pixel in the neighbour table of the
         // polyline stage, which is dead by now); -1: no slot, first entry -2: the window holds more ids than fit - start over
-        int4 r0, r1;
-        r0.x = again ? -2 : (bs[0] == RB_NONE ? -1 : (int)slot[0]); r0.y = bs[1] == RB_NONE ? -1 : (int)slot[1];
-        r0.z = bs[2] == RB_NONE ? -1 : (int)slot[2]; r0.w = bs[3] == RB_NONE ? -1 : (int)slot[3];
-        r1.x = bs[4] == RB_NONE ? -1 : (int)slot[4]; r1.y = bs[5] == RB_NONE ? -1 : (int)slot[5];
-        r1.z = bs[6] == RB_NONE ? -1 : (int)slot[6]; r1.w = bs[7] == RB_NONE ? -1 : (int)slot[7];
+        // an entry also carries, in bits 28-29, how many cells of the window hold its id (capped at 3): with that the box kernel
+        // can tell "the claiming pixel touched the slot at least twice" without reading the window again
+        int cnt[RB_MAX], e[RB_MAX];
+        rb_counts(win, bs, cnt);
+#pragma unroll
+        for (int q = 0; q < RB_MAX; q++) e[q] = bs[q] == RB_NONE ? -1 : (int)(slot[q] | ((unsigned)(cnt[q] < 3 ? cnt[q] : 3) << 28));
+        if (again) e[0] = -2;
         int4 *rec = (int4 *)(s.nbr + (size_t)j * RB_MAX);
-        rec[0] = r0; rec[1] = r1;
+        rec[0] = make_int4(e[0], e[1], e[2], e[3]); rec[1] = make_int4(e[4], e[5], e[6], e[7]);
+        s.lab[j] = id; s.alive[j] = p0;       // (dead arrays of the polyline stage as well: saves the box kernel a level of gathers)
       }
 #pragma unroll
       for (int q = 0; q < RB_MAX; q++) {
@@ -1063,69 +1080,72 @@ __global__ __launch_bounds__(256) void k_reduce_claim(int *claim, int *tlist, co
 
 // widening for up to RB_MAX slots of one chain pixel (valid[q]: slot q is in use); `touches(slot)` counts how often the pixel's
 // window maps to a slot and is only evaluated for a pixel that holds the claim itself (rare)
+// Block-local aggregation of the box updates: hundreds of pixels of one segment widen the same slot, and atomics on one address
+// are served one after the other (measured: the longest segment of a frame set the duration of the kernel).  The block keeps a
+// small hash (slot -> the four maxima) in LDS and touches each of its slots once in global memory at the end.
+#define BA_T 512
+struct BoxAgg { int keys[BA_T]; int vals[BA_T * 4]; };
+__device__ __forceinline__ void boxagg_add(BoxAgg &A, int *table, unsigned slot, int v1, int v2, int v3, int v4) {
+  unsigned h = (slot * 2654435761u) >> 23;
+  for (int probes = 0; probes < 16; probes++) {
+    const int kprev = atomicCAS(&A.keys[h], -1, (int)slot);
+    if (kprev == -1 || kprev == (int)slot) {
+      atomicMax(&A.vals[h * 4 + 0], v1); atomicMax(&A.vals[h * 4 + 1], v2); atomicMax(&A.vals[h * 4 + 2], v3); atomicMax(&A.vals[h * 4 + 3], v4);
+      return;
+    }
+    h = (h + 1) & (BA_T - 1);
+  }
+  int *e = table + (size_t)slot * 5;      // table full of other slots: straight to memory
+  atomicMax(&e[1], v1); atomicMax(&e[2], v2); atomicMax(&e[3], v3); atomicMax(&e[4], v4);
+}
+
+// widening for up to RB_MAX slots of one chain pixel (valid[q]: slot q is in use); `touches(slot)` counts how often the pixel's
+// window maps to a slot and is only evaluated for a pixel that holds the claim itself
 template <typename Touches>
-__device__ __forceinline__ void box_vote(int *table, const int *__restrict__ claim, const int *__restrict__ ids, const unsigned (&slot)[RB_MAX], const bool (&valid)[RB_MAX],
+__device__ __forceinline__ void box_vote(BoxAgg &A, int *table, const int *__restrict__ claim, const int *__restrict__ ids, const unsigned (&slot)[RB_MAX], const bool (&valid)[RB_MAX],
                                          int i, int id, int x, int y, int iw, int ih, Touches touches) {
   // Per distinct slot: the claiming pixel's first touch only claims (rc:449-456), every other touch widens the box; max
   // is idempotent, so "widen once if the slot's owner carries our id and we touched it often enough" is the same.
   int owner[RB_MAX], oid[RB_MAX];
 #pragma unroll
-  for (int q = 0; q < RB_MAX; q++) owner[q] = claim[slot[q]];
+  for (int q = 0; q < RB_MAX; q++) owner[q] = claim[slot[q]];          // (unused slots map to entry 0: a valid address)
 #pragma unroll
   for (int q = 0; q < RB_MAX; q++) oid[q] = valid[q] ? ids[owner[q]] : -1;
-  // the current box values are requested together with the owners (they only guard the atomics against no-ops)
-  int c1[RB_MAX], c2[RB_MAX], c3[RB_MAX], c4[RB_MAX];
-#pragma unroll
-  for (int q = 0; q < RB_MAX; q++) {
-    const int *e = table + (size_t)slot[q] * 5;
-    c1[q] = ld_agent(&e[1]); c2[q] = ld_agent(&e[2]); c3[q] = ld_agent(&e[3]); c4[q] = ld_agent(&e[4]);   // (unused slots map to entry 0: a valid address)
-  }
 #pragma unroll
   for (int q = 0; q < RB_MAX; q++) {
     if (!valid[q] || oid[q] != id) continue;
-    int *e = table + (size_t)slot[q] * 5;
     if (owner[q] == i) {
-      e[0] = id;                                  // the slot's id is its claimant's (exactly one pixel holds the claim)
+      table[(size_t)slot[q] * 5] = id;            // the slot's id is its claimant's (exactly one pixel holds the claim)
       if (touches(slot[q]) < 2) continue;         // our first touch does not count
     }
-    if (iw - x > c1[q]) atomicMax(&e[1], iw - x);
-    if (x > c2[q]) atomicMax(&e[2], x);
-    if (ih - y > c3[q]) atomicMax(&e[3], ih - y);
-    if (y > c4[q]) atomicMax(&e[4], y);
+    boxagg_add(A, table, slot[q], iw - x, x, ih - y, y);
   }
 }
 
 __global__ __launch_bounds__(256) void k_reduce_box(int *table, const int *__restrict__ claim, const int *__restrict__ boundary, rdk::PolyScratch s, int iw, int ih, int nentry) {
+  __shared__ BoxAgg A;
   const int nlive = s.ctr[24];
+  if ((int)(blockIdx.x * blockDim.x) >= nlive) return;       // (whole block without pixels)
+  for (int t = threadIdx.x; t < BA_T; t += 256) { A.keys[t] = -1; A.vals[t * 4] = 0; A.vals[t * 4 + 1] = 0; A.vals[t * 4 + 2] = 0; A.vals[t * 4 + 3] = 0; }
+  __syncthreads();
   for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < nlive; j += gridDim.x * blockDim.x) {
     const int i = s.live[j];
-    const int4 *rec = (const int4 *)(s.nbr + (size_t)j * RB_MAX);      // left by k_reduce_claim
+    const int4 *rec = (const int4 *)(s.nbr + (size_t)j * RB_MAX);      // left by k_reduce_claim, like the pixel's id and position
     const int4 r0 = rec[0], r1 = rec[1];
-    const int id = s.id[i];
+    const int id = s.lab[j];
+    const int p0 = s.alive[j], x = p0 % iw, y = p0 / iw;
     if (id <= 0) continue;
-    const int p0 = s.pos[i], x = p0 % iw, y = p0 / iw;
     if (r0.x != -2) {
       const int rs[RB_MAX] = { r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w };
       unsigned slot[RB_MAX];
       bool valid[RB_MAX];
+      int cnt[RB_MAX];
 #pragma unroll
-      for (int q = 0; q < RB_MAX; q++) { valid[q] = rs[q] >= 0; slot[q] = valid[q] ? (unsigned)rs[q] : 0u; }
-      int win[49];
-      bool have = false;
-      box_vote(table, claim, s.id, slot, valid, i, id, x, y, iw, ih, [&](unsigned sl) {
-        if (!have) {           // the pixel holds a claim itself: now its window is needed after all (all 49 loads together)
+      for (int q = 0; q < RB_MAX; q++) { valid[q] = rs[q] >= 0; slot[q] = valid[q] ? (unsigned)rs[q] & 0x0fffffffu : 0u; cnt[q] = valid[q] ? rs[q] >> 28 : 0; }
+      box_vote(A, table, claim, s.id, slot, valid, i, id, x, y, iw, ih, [&](unsigned sl) {
+        int touches = 0;          // cells of the window whose id maps to this slot (several ids may: same slot value in the record)
 #pragma unroll
-          for (int k = 0; k < 49; k++) {
-            const int xx = x + k % 7 - 3, yy = y + k / 7 - 3;
-            const bool in = xx >= 0 && xx < iw && yy >= 0 && yy < ih;
-            win[k] = boundary[in ? yy * iw + xx : p0];
-            if (!in) win[k] = 0;
-          }
-          have = true;
-        }
-        int touches = 0;
-#pragma unroll
-        for (int k = 0; k < 49; k++) touches += (win[k] > 0 && ls_slot(id, win[k], nentry) == sl);
+        for (int q = 0; q < RB_MAX; q++) touches += (valid[q] && slot[q] == sl) ? cnt[q] : 0;
         return touches;
       });
       continue;
@@ -1146,13 +1166,21 @@ __global__ __launch_bounds__(256) void k_reduce_box(int *table, const int *__res
       bool valid[RB_MAX];
 #pragma unroll
       for (int q = 0; q < RB_MAX; q++) { valid[q] = bs[q] != RB_NONE; slot[q] = ls_slot(id, valid[q] ? bs[q] : 0, nentry); }
-      box_vote(table, claim, s.id, slot, valid, i, id, x, y, iw, ih, [&](unsigned sl) {
+      box_vote(A, table, claim, s.id, slot, valid, i, id, x, y, iw, ih, [&](unsigned sl) {
         int touches = 0;
         for (int k = 0; k < 49; k++) touches += (win[k] > 0 && ls_slot(id, win[k], nentry) == sl);
         return touches;
       });
       floor = bs[RB_MAX - 1];
     }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < BA_T; t += 256) {
+    const int key = A.keys[t];
+    if (key == -1) continue;
+    int *e = table + (size_t)key * 5;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int v = A.vals[t * 4 + k]; if (v > ld_agent(&e[1 + k])) atomicMax(&e[1 + k], v); }
   }
 }
 
