@@ -1028,8 +1028,15 @@ __global__ __launch_bounds__(1024) void k_reduce_clean(int *table, int *claim, i
   if (threadIdx.x == 0) tlist[0] = 0;
 }
 
+// (claims are aggregated per block like the box updates below: slot -> smallest claiming pixel in an LDS hash, one atomicMin per
+//  slot and block at the end; the one that finds the slot unclaimed appends it to tlist)
+#define CA_T 1024
 __global__ __launch_bounds__(256) void k_reduce_claim(int *claim, int *tlist, const int *__restrict__ boundary, rdk::PolyScratch s, int iw, int ih, int nentry) {
+  __shared__ int keys[CA_T], vals[CA_T];
   const int nlive = s.ctr[24];
+  if ((int)(blockIdx.x * blockDim.x) >= nlive) return;       // (whole block without pixels)
+  for (int t = threadIdx.x; t < CA_T; t += 256) { keys[t] = -1; vals[t] = 0x7f7f7f7f; }
+  __syncthreads();
   const int stride = gridDim.x * blockDim.x;
   for (int j0 = blockIdx.x * blockDim.x; j0 < nlive; j0 += stride) {    // whole waves iterate together (ballots inside)
     const int j = j0 + threadIdx.x;
@@ -1049,9 +1056,8 @@ __global__ __launch_bounds__(256) void k_reduce_claim(int *claim, int *tlist, co
       int bs[RB_MAX];
       const bool again = more && rb_collect(win, floor, bs);
       unsigned slot[RB_MAX];
-      int cur[RB_MAX];
 #pragma unroll
-      for (int q = 0; q < RB_MAX; q++) { slot[q] = ls_slot(id, bs[q] == RB_NONE ? 0 : bs[q], nentry); cur[q] = ld_agent(&claim[slot[q]]); }   // independent loads
+      for (int q = 0; q < RB_MAX; q++) slot[q] = ls_slot(id, bs[q] == RB_NONE ? 0 : bs[q], nentry);
       if (floor == 0 && j < nlive) {
         // k_reduce_box visits the same slots: they are left for it (RB_MAX ints per chain pixel in the neighbour table of the
         // polyline stage, which is dead by now); -1: no slot, first entry -2: the window holds more ids than fit - start over
@@ -1068,18 +1074,32 @@ __global__ __launch_bounds__(256) void k_reduce_claim(int *claim, int *tlist, co
       }
 #pragma unroll
       for (int q = 0; q < RB_MAX; q++) {
-        bool first = false;
-        if (more && bs[q] != RB_NONE && i < cur[q]) first = atomicMin(&claim[slot[q]], i) == 0x7f7f7f7f;
-        tlist_append(tlist, first, slot[q]);
+        if (!(more && bs[q] != RB_NONE)) continue;
+        unsigned h = (slot[q] * 2654435761u) >> 22;
+        int probes = 0;
+        for (;;) {
+          const int kprev = atomicCAS(&keys[h], -1, (int)slot[q]);
+          if (kprev == -1 || kprev == (int)slot[q]) { atomicMin(&vals[h], i); break; }
+          h = (h + 1) & (CA_T - 1);
+          if (++probes == 32) {         // table full of other slots: straight to memory
+            if (atomicMin(&claim[slot[q]], i) == 0x7f7f7f7f) tlist[1 + atomicAdd(&tlist[0], 1)] = (int)slot[q];
+            break;
+          }
+        }
       }
       floor = bs[RB_MAX - 1];
       more = again;
     }
   }
+  __syncthreads();
+  for (int t = threadIdx.x; t < CA_T; t += 256) {       // (CA_T is a multiple of 256: whole waves call tlist_append together)
+    const int key = keys[t];
+    bool first = false;
+    if (key != -1) { const int v = vals[t]; if (v < ld_agent(&claim[key])) first = atomicMin(&claim[key], v) == 0x7f7f7f7f; }
+    tlist_append(tlist, first, (unsigned)key);
+  }
 }
 
-// widening for up to RB_MAX slots of one chain pixel (valid[q]: slot q is in use); `touches(slot)` counts how often the pixel's
-// window maps to a slot and is only evaluated for a pixel that holds the claim itself (rare)
 // Block-local aggregation of the box updates: hundreds of pixels of one segment widen the same slot, and atomics on one address
 // are served one after the other (measured: the longest segment of a frame set the duration of the kernel).  The block keeps a
 // small hash (slot -> the four maxima) in LDS and touches each of its slots once in global memory at the end.
