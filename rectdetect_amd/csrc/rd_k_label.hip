@@ -249,35 +249,11 @@ __global__ __launch_bounds__(256) void k_filter_strength(int *label, const int *
   if (l <= 0 || str[l] < thre) label[p] = -1;
 }
 
-// The strong-edge mask that two k_filter_strength passes (thresholds t1 <= t2) followed by `label > 0` would produce,
-// computed directly from the unfiltered labels: interior pixels keep a label > 0 exactly when their sum reaches t2, the
-// frame ring is never filtered.  This mask is all the next frame needs from this one, so producing it
-// first takes everything else off the frame-to-frame dependency chain.
-__global__ __launch_bounds__(256) void k_strong_mask(int *__restrict__ out, int *__restrict__ out2, const int *__restrict__ label, const int *__restrict__ str, int thre, int iw, int ih) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-  if (x >= iw || y >= ih) return;
-  const int p = y * iw + x;
-  const int l = label[p];
-  int v = l > 0 ? 1 : 0;
-  if (v && x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && str[l] < thre) v = 0;
-  out[p] = v; out2[p] = v;
-}
-
-// Edge mask at one threshold, as int and as int8, from the unfiltered labels: what k_filter_strength + `label > 0` + the
-// int -> int8 cast (oclrect.c:277-284) produce, without touching the label plane (which a parallel branch filters at 2500).
-__global__ __launch_bounds__(256) void k_edge_mask(int *__restrict__ out, int8_t *__restrict__ out8, const int *__restrict__ label, const int *__restrict__ str, int thre, int iw, int ih) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-  if (x >= iw || y >= ih) return;
-  const int p = y * iw + x;
-  const int l = label[p];
-  int v = l > 0 ? 1 : 0;
-  if (v && x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && str[l] < thre) v = 0;
-  out[p] = v; out8[p] = (int8_t)v;
-}
-
-// What the frame path needs of the three kernels above in one pass over (label, strength sum): the strong mask at t_strong
-// (twice: this frame's copy and the plane handed to the next frame), the edge mask at t_edge as int and int8 - both from the
-// unfiltered labels - and the labels filtered at t_strong in place (filtering at t_edge first changes nothing: t_edge <= t_strong).
+// What the frame path needs of the strength sums in one pass over (label, sum): the strong mask that two k_filter_strength
+// passes (thresholds t_edge <= t_strong) followed by `label > 0` would produce (twice: this frame's copy and the plane handed to
+// the next frame - all the next frame needs from this one; interior pixels keep a label > 0 exactly when their sum
+// reaches t_strong, the frame ring is never filtered), the edge mask at t_edge as int and int8 (oclrect.c:277-284) - both from
+// the unfiltered labels - and the labels filtered at t_strong in place (filtering at t_edge first changes nothing).
 __global__ __launch_bounds__(256) void k_strength_masks(int *__restrict__ strong, int *__restrict__ strong2, int *__restrict__ edge, int8_t *__restrict__ edge8,
                                                          int *__restrict__ label, const int *__restrict__ str, int t_edge, int t_strong, int iw, int ih) {
   const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
@@ -309,14 +285,6 @@ void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih) 
 
 void calc_strength(hipStream_t s, int *out, const float *edge, const int *label, int iw, int ih, const int *add) {
   hipLaunchKernelGGL(k_calc_strength, dim3(cdiv(iw, 64), cdiv(ih, 4 * CS_ROWS)), block2, 0, s, out, edge, label, iw, ih, add);
-}
-
-void strong_mask(hipStream_t s, int *out, int *out2, const int *label, const int *str, int thre, int iw, int ih) {
-  hipLaunchKernelGGL(k_strong_mask, grid2(iw, ih), block2, 0, s, out, out2, label, str, thre, iw, ih);
-}
-
-void edge_mask(hipStream_t s, int *out, int8_t *out8, const int *label, const int *str, int thre, int iw, int ih) {
-  hipLaunchKernelGGL(k_edge_mask, grid2(iw, ih), block2, 0, s, out, out8, label, str, thre, iw, ih);
 }
 
 void strength_masks(hipStream_t s, int *strong, int *strong2, int *edge, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih) {

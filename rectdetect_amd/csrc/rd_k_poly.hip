@@ -352,12 +352,7 @@ __global__ void k_number(PolyScratch s, int src, int init_sub) {
   }
 }
 
-// pl:312-355 to convergence: split chains where the numbering jumps by more than one
-__global__ void k_sub_init(PolyScratch s, const int *number) {
-  const int cnt = s.ctr[0];
-  SPARSE_LOOP(i, cnt) { s.lab2[i] = number[i] == 0 ? -1 : i; s.size[i] = 0; s.rootid[i] = 0; }
-}
-
+// pl:312-355 to convergence: split chains where the numbering jumps by more than one (set up by the last k_number launch)
 __global__ void k_sub_union(PolyScratch s, const int *number) {
   const int cnt = s.ctr[0];
   SPARSE_LOOP(i, cnt) {

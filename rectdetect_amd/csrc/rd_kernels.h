@@ -42,11 +42,7 @@ void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih);
 // add (optional): a plane whose non-zero elements are added to out element by element in the same launch (out = zeros + add + sums)
 void calc_strength(hipStream_t s, int *out, const float *edge, const int *label, int iw, int ih, const int *add = nullptr);
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih);
-// out = out2 = (label > 0 after filter_strength at thresholds <= thre ... thre), from the UNFILTERED labels
-// out / out8 = (label > 0 after filter_strength at thre), as int and int8, from the unfiltered labels
-void edge_mask(hipStream_t s, int *out, int8_t *out8, const int *label, const int *str, int thre, int iw, int ih);
-void strong_mask(hipStream_t s, int *out, int *out2, const int *label, const int *str, int thre, int iw, int ih);
-// strong_mask at t_strong (two copies) + edge_mask at t_edge + filter_strength at t_strong (label in place), one pass; t_edge <= t_strong
+// strong mask at t_strong (two copies) + edge mask at t_edge (int, int8), both from the unfiltered labels, + filter_strength at t_strong (label in place), one pass; t_edge <= t_strong
 void strength_masks(hipStream_t s, int *strong, int *strong2, int *edge, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih);
 
 // ---- rd_k_rect.hip: rect-path stages
