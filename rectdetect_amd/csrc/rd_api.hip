@@ -332,7 +332,7 @@ static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
   int **ip[] = { &s->i0, &s->i1, &s->mask0, &s->tidy, &s->label1, &s->strsum, &s->edge500, &s->strong, &s->junction, &s->mergemask, &s->region, &s->rsize,
                  &s->boundarysrc, &s->boundary, &s->lsid, &s->region0 };
   for (size_t i = 0; i < sizeof(ip) / sizeof(ip[0]); i++) *ip[i] = dnew<int>(N);
-  s->scratch2 = dnew<int>(N * 3 + 256);
+  s->scratch2 = dnew<int>(N * 5 + 256);      // region_merge: two sets of proposal planes + flags + allow bytes
   s->d2s = dnew<int>(RD_D2_SCRATCH_INTS(N));
   s->table = dnew<int>(N * 4); s->claim = dnew<int>(N); s->tlist = dnew<int>(N);
   rdk::reduce_ls_init(s->st, s->table, s->claim, s->tlist, (int)(N * 4 / 5));
@@ -605,7 +605,7 @@ extern "C" {
 rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nworkers) {
   if (rd_device_count() <= 0) exitf(-1, "rd_detector_create: no HIP device available - this library has no CPU path\n");
   if (iw < 16 || ih < 16) exitf(-1, "rd_detector_create: frame %dx%d too small\n", iw, ih);
-  if ((long long)iw * ih >= (1ll << 28)) exitf(-1, "rd_detector_create: frame %dx%d too large (vote records keep table slots in 28 bits)\n", iw, ih);
+  if ((long long)iw * ih >= (1ll << 25)) exitf(-1, "rd_detector_create: frame %dx%d too large (region-merge proposals keep labels in 25 bits)\n", iw, ih);
   if (nslots < 1) nslots = 1;
   RD_HIP(hipSetDevice(device));
   rd_detector *d = (rd_detector *)calloc(1, sizeof(*d));

@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const 
 // so every pixel leaves pointing either at the root of its initial tree (if that root lies in the tile) or at the first
 // pixel outside the tile on its way up/left; the few remaining tile-to-tile hops are left to k_region_flatten.
 #define RI_ROWS 32
-__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, int *__restrict__ prop, int *__restrict__ selfp, const int *__restrict__ pix, const int *__restrict__ mask,
+__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, int *__restrict__ prop, int *__restrict__ selfp, int *__restrict__ prop1, int *__restrict__ selfp1, const int *__restrict__ pix, const int *__restrict__ mask,
                                                      const int *__restrict__ edge, int iw, int ih, int *__restrict__ flags, int *__restrict__ size_out, const int *__restrict__ size_init) {
   __shared__ int par[64 * RI_ROWS];     // >= 0: tile-local index of the parent; < 0: -(global index) - 1 of a parent outside the tile
   // (also: the round / flatten flags start at zero, and the size plane starts from size_init - quirk H2 - without extra launches)
@@ -539,8 +539,10 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
           a |= 16;   // interior
         }
         allow[p] = (uint8_t)a;
-        prop[p] = 0x7f7f7f7f;      // no proposal
+        prop[p] = 0x7f7f7f7f;      // no proposal (round tag 63: never current)
         selfp[p] = 0x7f7f7f7f;
+        prop1[p] = 0x7f7f7f7f;
+        selfp1[p] = 0x7f7f7f7f;
         if (size_out) size_out[p] = si[k];
       }
       par[r * 64 + tx] = l;
@@ -566,62 +568,104 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
 }
 
 // rc:300-334 per-pixel rule, evaluated in SYNCHRONOUS rounds on the flattened initial forest: every pixel reads the labels of the previous round,
-// proposes `min` updates for itself and for its old parent, and the proposals are applied between rounds.  The
+// proposes `min` updates for itself and for its old parent, and the proposals take effect between rounds.  The
 // reference applies the same rule in place for 8 launches, which makes its result depend on the work-item order
 // (SURVEY.md H5); synchronous rounds to convergence are the order-free reading of the same rule.
-// Memory-latency bound: every thread handles 4 pixels (64 columns apart, so each load instruction stays coalesced) and
-// issues all of their label / neighbour loads before using any, then the 4 first pointer jumps together.
-#define RP_PX 8
-__global__ __launch_bounds__(256) void k_region_propose(const int *__restrict__ label, int *prop, int *__restrict__ selfp, const uint8_t *__restrict__ allow, int iw, int ih, const int *flags, int round) {
-  if (round > 0 && flags[round - 1] == 0) return;
+//
+// One launch per round.  The proposals of a round are not applied by a launch of their own: they stay in their planes
+// (selfp: a pixel's own update, written by its thread; prop: updates for tree parents, atomicMin) and the next round reads every
+// label as  E(q) = min(label[q], prop[q], selfp[q])  - what an apply pass would have left in label[q].  The thread of pixel q
+// also stores E(q) back into label[q]; that store needs no ordering against the other threads' reads, because E(q) comes out
+// the same whether they see the old or the new label[q].  Two sets of proposal planes alternate (a round reads the previous
+// round's set while writing its own), and a proposal word carries the number of its round in its upper bits - (40 - round) <<
+// 25 | label - so that words left over from two rounds ago lose against every new proposal in the atomicMin and are ignored by
+// the readers: nothing is ever cleared between rounds.  flags[round] = "this round proposed something" (a proposal always lowers
+// its pixel's own label), which is what the next round and the host test.
+// Memory-latency bound: every thread handles RR_PX pixels (64 columns apart, so each load instruction stays coalesced) and
+// issues all of their label / proposal loads before using any, then the first pointer jumps together.
+#define RR_PX 4
+#define RR_VBITS 25
+#define RR_NONE 0x7fffffff
+__device__ __forceinline__ int rr_val(int w, int tag) { return (w >> RR_VBITS) == tag ? (w & ((1 << RR_VBITS) - 1)) : RR_NONE; }
+__device__ __forceinline__ int rr_min3(int l, int wp, int ws, int tag) { const int a = rr_val(wp, tag), b = rr_val(ws, tag); const int m = a < b ? a : b; return l < m ? l : m; }
+template <bool FIRST>
+__device__ __forceinline__ int rr_eff(const int *label, const int *propP, const int *selfP, int q, int tag) {
+  if (FIRST) return label[q];
+  return rr_min3(label[q], propP[q], selfP[q], tag);
+}
+
+template <bool FIRST>
+__global__ __launch_bounds__(256) void k_region_round(int *label, const int *__restrict__ propP, const int *__restrict__ selfP, int *propW, int *__restrict__ selfW,
+                                                       const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round) {
+  if (!FIRST && flags[round - 1] == 0) return;
   __shared__ int hk[512], hv[512];
   const int tid = threadIdx.y * 64 + threadIdx.x;
   for (int t = tid; t < 512; t += 256) { hk[t] = -1; hv[t] = 0x7fffffff; }
   __syncthreads();
+  const int tagP = 41 - round, tagW = 40 - round;
   const int y = blockIdx.y * 4 + threadIdx.y;
-  const int xb = blockIdx.x * (64 * RP_PX) + threadIdx.x;
-  int p0[RP_PX], og[RP_PX], g[RP_PX], nx[RP_PX];
-  unsigned a[RP_PX];
-  int lu[RP_PX], ll[RP_PX], lr[RP_PX], ld[RP_PX];
-  bool valid[RP_PX], todo[RP_PX];
+  const int xb = blockIdx.x * (64 * RR_PX) + threadIdx.x;
+  int p0[RR_PX], og[RR_PX], g[RR_PX], nx[RR_PX];
+  unsigned a[RR_PX];
+  bool valid[RR_PX], todo[RR_PX];
+  {
+    int q[RR_PX][5], l[RR_PX][5], wp[RR_PX][5], ws[RR_PX][5];
 #pragma unroll
-  for (int k = 0; k < RP_PX; k++) {
-    const int x = xb + k * 64;
-    valid[k] = x < iw && y < ih;
-    p0[k] = valid[k] ? y * iw + x : 0;
-    a[k] = valid[k] ? allow[p0[k]] : 0u;
-    // neighbour addresses clamped into the plane: the loads are unconditional, their use depends on the allow bits
-    og[k] = label[p0[k]];
-    lu[k] = label[(valid[k] && y > 0) ? p0[k] - iw : p0[k]];
-    ll[k] = label[(valid[k] && x > 0) ? p0[k] - 1 : p0[k]];
-    lr[k] = label[(valid[k] && x < iw - 1) ? p0[k] + 1 : p0[k]];
-    ld[k] = label[(valid[k] && y < ih - 1) ? p0[k] + iw : p0[k]];
+    for (int k = 0; k < RR_PX; k++) {
+      const int x = xb + k * 64;
+      valid[k] = x < iw && y < ih;
+      p0[k] = valid[k] ? y * iw + x : 0;
+      a[k] = valid[k] ? allow[p0[k]] : 0u;
+      // neighbour addresses clamped into the plane: the loads are unconditional, their use depends on the allow bits
+      q[k][0] = p0[k];
+      q[k][1] = (valid[k] && y > 0) ? p0[k] - iw : p0[k];
+      q[k][2] = (valid[k] && x > 0) ? p0[k] - 1 : p0[k];
+      q[k][3] = (valid[k] && x < iw - 1) ? p0[k] + 1 : p0[k];
+      q[k][4] = (valid[k] && y < ih - 1) ? p0[k] + iw : p0[k];
+#pragma unroll
+      for (int c = 0; c < 5; c++) {
+        l[k][c] = label[q[k][c]];
+        if (!FIRST) { wp[k][c] = propP[q[k][c]]; ws[k][c] = selfP[q[k][c]]; }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < RR_PX; k++) {
+      int e[5];
+#pragma unroll
+      for (int c = 0; c < 5; c++) e[c] = FIRST ? l[k][c] : rr_min3(l[k][c], wp[k][c], ws[k][c], tagP);
+      og[k] = e[0];
+      if (!FIRST && valid[k] && e[0] < l[k][0]) label[p0[k]] = e[0];     // what the apply pass would have stored
+      int m = e[0];
+      if ((a[k] & 1) && e[1] < m) m = e[1];
+      if ((a[k] & 2) && e[2] < m) m = e[2];
+      if ((a[k] & 4) && e[3] < m) m = e[3];
+      if ((a[k] & 8) && e[4] < m) m = e[4];
+      g[k] = (a[k] & 16) ? m : e[0];
+    }
   }
+  {
+    int l[RR_PX], wp[RR_PX], ws[RR_PX];
 #pragma unroll
-  for (int k = 0; k < RP_PX; k++) {
-    int m = og[k];
-    if ((a[k] & 1) && lu[k] < m) m = lu[k];
-    if ((a[k] & 2) && ll[k] < m) m = ll[k];
-    if ((a[k] & 4) && lr[k] < m) m = lr[k];
-    if ((a[k] & 8) && ld[k] < m) m = ld[k];
-    g[k] = (a[k] & 16) ? m : og[k];
+    for (int k = 0; k < RR_PX; k++) { l[k] = label[g[k]]; if (!FIRST) { wp[k] = propP[g[k]]; ws[k] = selfP[g[k]]; } }     // rc:328: first of the eight pointer jumps (a root maps to itself)
+#pragma unroll
+    for (int k = 0; k < RR_PX; k++) nx[k] = FIRST ? l[k] : rr_min3(l[k], wp[k], ws[k], tagP);
   }
+  bool any_todo = false;
 #pragma unroll
-  for (int k = 0; k < RP_PX; k++) nx[k] = label[g[k]];     // rc:328: first of the eight pointer jumps (a root maps to itself)
-#pragma unroll
-  for (int k = 0; k < RP_PX; k++) {
+  for (int k = 0; k < RR_PX; k++) {
     if (a[k] & 16) {
       int n = nx[k];
-      for (int j = 1; j < 8 && n != g[k]; j++) { g[k] = n; n = label[n]; }
+      for (int j = 1; j < 8 && n != g[k]; j++) { g[k] = n; n = rr_eff<FIRST>(label, propP, selfP, n, tagP); }
       if (n != g[k]) g[k] = n;          // (the eighth jump)
     }
     todo[k] = (a[k] & 16) && g[k] != og[k];
-    if (todo[k]) selfp[p0[k]] = g[k];   // own update: nobody else writes this word; k_region_apply resets it after use
+    if (todo[k]) selfW[p0[k]] = (tagW << RR_VBITS) | g[k];   // own update: nobody else writes this word
+    any_todo = any_todo || todo[k];
   }
   // Hooking the old parent: after flattening, all pixels of a tree share one parent, so the block first reduces its
   // (parent -> smallest proposal) pairs in a small LDS hash and then issues one guarded atomic per distinct parent.
 #pragma unroll
-  for (int k = 0; k < RP_PX; k++) {
+  for (int k = 0; k < RR_PX; k++) {
     // a lane whose (parent, proposal) pair repeats its left neighbour's adds nothing to a min: skip it (most lanes inside a region)
     const int pog = __shfl_up(og[k], 1), pg = __shfl_up(g[k], 1), pt = __shfl_up((int)todo[k], 1);
     if (!todo[k] || (threadIdx.x > 0 && pt && pog == og[k] && pg == g[k])) continue;
@@ -631,13 +675,25 @@ __global__ __launch_bounds__(256) void k_region_propose(const int *__restrict__ 
       const int kprev = atomicCAS(&hk[h], -1, og[k]);
       if (kprev == -1 || kprev == og[k]) { atomicMin(&hv[h], g[k]); break; }
       h = (h + 1) & 511;
-      if (++probes == 16) { if (g[k] < ld_agent(&prop[og[k]])) atomicMin(&prop[og[k]], g[k]); break; }
+      if (++probes == 16) { const int w = (tagW << RR_VBITS) | g[k]; if (w < ld_agent(&propW[og[k]])) atomicMin(&propW[og[k]], w); break; }
     }
   }
+  if (__any(any_todo) && threadIdx.x == 0) flags[round] = 1;
   __syncthreads();
   for (int t = tid; t < 512; t += 256) {
     const int key = hk[t];
-    if (key != -1) { const int v = hv[t]; if (v < ld_agent(&prop[key])) atomicMin(&prop[key], v); }
+    if (key != -1) { const int w = (tagW << RR_VBITS) | hv[t]; if (w < ld_agent(&propW[key])) atomicMin(&propW[key], w); }
+  }
+}
+
+// the proposals of the last launched round (if it made any) take effect
+__global__ void k_region_finish(int *label, const int *__restrict__ propP, const int *__restrict__ selfP, int n, const int *flags, int last_round) {
+  if (flags[last_round] == 0) return;
+  const int tag = 40 - last_round;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int l = label[i];
+    const int e = rr_min3(l, propP[i], selfP[i], tag);
+    if (e < l) label[i] = e;
   }
 }
 
@@ -654,31 +710,6 @@ __global__ void k_region_flatten(int *label, int n, int *flags, int round) {
       for (int j = 0; j < 14; j++) { const int b = label[a]; if (b == a) break; a = b; }   // (most chains end after a jump or two)
       label[i] = a;
       changed = true;
-    }
-  }
-  if (__any(changed) && (threadIdx.x & 63) == 0) flags[round] = 1;
-}
-
-__global__ void k_region_apply(int *label, int *prop, int *selfp, int n, int *flags, int round) {
-  if (round > 0 && flags[round - 1] == 0) return;
-  bool changed = false;
-  const int stride = gridDim.x * blockDim.x;
-  for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * 4) {
-    int m[4], sp[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int i = i0 + k * stride;
-      const bool in = i < n;
-      m[k] = in ? prop[i] : 0x7f7f7f7f; sp[k] = in ? selfp[i] : 0x7f7f7f7f;
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int i = i0 + k * stride;
-      const int v = sp[k] < m[k] ? sp[k] : m[k];
-      if (v == 0x7f7f7f7f) continue;               // nothing proposed for this pixel: its label is not even read
-      if (m[k] != 0x7f7f7f7f) prop[i] = 0x7f7f7f7f;
-      if (sp[k] != 0x7f7f7f7f) selfp[i] = 0x7f7f7f7f;
-      if (v < label[i]) { label[i] = v; changed = true; }
     }
   }
   if (__any(changed) && (threadIdx.x & 63) == 0) flags[round] = 1;
@@ -1288,16 +1319,19 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
   // tile-to-tile hops left after k_region_init: at most ih/RI_ROWS + iw/64 + 2; each launch divides the depth by 16
   int FLAT = 1;
   for (long reach = 16; reach < ih / RI_ROWS + iw / 64 + 2; reach *= 16) FLAT++;
-  int *prop = scratch, *flags = scratch + n, *fflags = flags + 32;
+  int *flags = scratch + n, *fflags = flags + 32;
   uint8_t *allow = (uint8_t *)(flags + 64);
-  int *selfp = scratch + 2 * (size_t)n;
-  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, label, allow, prop, selfp, pix, mask, edge, iw, ih, flags, size_out, size_init);
+  int *prop[2] = { scratch, scratch + 3 * (size_t)n }, *selfp[2] = { scratch + 2 * (size_t)n, scratch + 4 * (size_t)n };
+  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, label, allow, prop[0], selfp[0], prop[1], selfp[1], pix, mask, edge, iw, ih, flags, size_out, size_init);
   // the initial links are flattened first; the synchronous rounds then start from trees of depth 1
   for (int r = 0; r < FLAT; r++) hipLaunchKernelGGL(k_region_flatten, dim3(ew_grid(n)), dim3(256), 0, s, label, n, fflags, r);
+  const dim3 grid(cdiv(iw, 64 * RR_PX), cdiv(ih, 4));
   for (int r = 0; r < ROUNDS; r++) {
-    hipLaunchKernelGGL(k_region_propose, dim3(cdiv(iw, 64 * RP_PX), cdiv(ih, 4)), block2, 0, s, (const int *)label, prop, selfp, (const uint8_t *)allow, iw, ih, (const int *)flags, r);
-    hipLaunchKernelGGL(k_region_apply, dim3(ew_grid(n)), dim3(256), 0, s, label, prop, selfp, n, flags, r);
+    const int w = r & 1, p = w ^ 1;
+    if (r == 0) hipLaunchKernelGGL(k_region_round<true>, grid, block2, 0, s, label, (const int *)prop[p], (const int *)selfp[p], prop[w], selfp[w], (const uint8_t *)allow, iw, ih, flags, r);
+    else hipLaunchKernelGGL(k_region_round<false>, grid, block2, 0, s, label, (const int *)prop[p], (const int *)selfp[p], prop[w], selfp[w], (const uint8_t *)allow, iw, ih, flags, r);
   }
+  if (ROUNDS > 0) hipLaunchKernelGGL(k_region_finish, dim3(ew_grid(n)), dim3(256), 0, s, label, (const int *)prop[(ROUNDS - 1) & 1], (const int *)selfp[(ROUNDS - 1) & 1], n, (const int *)flags, ROUNDS - 1);
 }
 
 void region_size(hipStream_t s, int *out, const int *label, int n, int *zero_me) {
