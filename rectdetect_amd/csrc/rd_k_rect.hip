@@ -586,8 +586,13 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
 #define RR_PX 4
 #define RR_VBITS 25
 #define RR_NONE 0x7fffffff
-__device__ __forceinline__ int rr_val(int w, int tag) { return (w >> RR_VBITS) == tag ? (w & ((1 << RR_VBITS) - 1)) : RR_NONE; }
-__device__ __forceinline__ int rr_min3(int l, int wp, int ws, int tag) { const int a = rr_val(wp, tag), b = rr_val(ws, tag); const int m = a < b ? a : b; return l < m ? l : m; }
+// (the set a round reads holds only words of that round's predecessor - tag `tag` - or of earlier rounds / the initial fill, whose
+//  tags are larger: the smaller of the two words is the valid one if there is any)
+__device__ __forceinline__ int rr_min3(int l, int wp, int ws, int tag) {
+  const int m = wp < ws ? wp : ws;
+  const int v = m < ((tag + 1) << RR_VBITS) ? (m & ((1 << RR_VBITS) - 1)) : RR_NONE;
+  return l < v ? l : v;
+}
 template <bool FIRST>
 __device__ __forceinline__ int rr_eff(const int *label, const int *propP, const int *selfP, int q, int tag) {
   if (FIRST) return label[q];
