@@ -405,9 +405,10 @@ static void frame_regions(rd_detector *d, Slot *s) {
   hipStream_t st = s->st;
   // regions (oclrect.c:325-336)
   int *d2scratch = s->d2s;
+  rdk::RegionPending pending;
   rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih, (d->diag_skip & 2) ? 0 : s->rounds,
-                    s->rsize, s->junction);             // H2: the sizes start from the junction counts (copied by the first kernel)
-  rdk::region_size(st, s->rsize, s->region0, N, d2scratch + N);
+                    s->rsize, s->junction, &pending);   // H2: the sizes start from the junction counts (copied by the first kernel)
+  rdk::region_size(st, s->rsize, s->region0, N, d2scratch + N, &pending);      // (also lets the last round's proposals take effect)
   rdk::despeckle2(st, s->region, s->region0, d2scratch, s->rsize, 16, iw, ih, 1);
 
   // region boundaries and their components (oclrect.c:340-342)

@@ -736,7 +736,9 @@ __device__ __forceinline__ void rs_accum(int *keys, int *vals, int *out, int lab
   }
 }
 
-__global__ __launch_bounds__(256) void k_region_size(int *out, const int *__restrict__ label, int n, int *zero_me) {
+// (pend_*: the proposals of the region merge's last launched round, applied here on the way - see k_region_round / k_region_finish)
+__global__ __launch_bounds__(256) void k_region_size(int *out, int *__restrict__ label, int n, int *zero_me, const int *__restrict__ pend_prop, const int *__restrict__ pend_self,
+                                                      const int *__restrict__ pend_flags, int pend_round) {
   if (zero_me && blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;     // (a counter of the next stage: saves a fill launch)
   __shared__ int keys[RS_T], vals[RS_T];
   for (int i = threadIdx.x; i < RS_T; i += 256) { keys[i] = -1; vals[i] = 0; }
@@ -747,6 +749,14 @@ __global__ __launch_bounds__(256) void k_region_size(int *out, const int *__rest
   for (int k = 0; k < RS_PER_THREAD; k++) {     // all loads first: one block per CU would otherwise wait for them one by one
     const int i = begin + k * 256 + threadIdx.x;
     lks[k] = i < n ? label[i] : -1;
+  }
+  if (pend_flags != nullptr && pend_flags[pend_round] != 0) {
+    const int tag = 40 - pend_round;
+#pragma unroll
+    for (int k = 0; k < RS_PER_THREAD; k++) {
+      const int i = begin + k * 256 + threadIdx.x;
+      if (i < n) { const int e = rr_min3(lks[k], pend_prop[i], pend_self[i], tag); if (e < lks[k]) { label[i] = e; lks[k] = e; } }
+    }
   }
 #pragma unroll
   for (int k = 0; k < RS_PER_THREAD; k++) {
@@ -1319,7 +1329,7 @@ void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int 
 }
 
 // scratch: 3*N ints (hook proposals; round flags + allowed-direction bytes; self proposals)
-void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS, int *size_out, const int *size_init) {
+void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS, int *size_out, const int *size_init, RegionPending *pending) {
   const int n = iw * ih;
   // tile-to-tile hops left after k_region_init: at most ih/RI_ROWS + iw/64 + 2; each launch divides the depth by 16
   int FLAT = 1;
@@ -1336,11 +1346,13 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
     if (r == 0) hipLaunchKernelGGL(k_region_round<true>, grid, block2, 0, s, label, (const int *)prop[p], (const int *)selfp[p], prop[w], selfp[w], (const uint8_t *)allow, iw, ih, flags, r);
     else hipLaunchKernelGGL(k_region_round<false>, grid, block2, 0, s, label, (const int *)prop[p], (const int *)selfp[p], prop[w], selfp[w], (const uint8_t *)allow, iw, ih, flags, r);
   }
-  if (ROUNDS > 0) hipLaunchKernelGGL(k_region_finish, dim3(ew_grid(n)), dim3(256), 0, s, label, (const int *)prop[(ROUNDS - 1) & 1], (const int *)selfp[(ROUNDS - 1) & 1], n, (const int *)flags, ROUNDS - 1);
+  if (pending) { pending->prop = ROUNDS > 0 ? prop[(ROUNDS - 1) & 1] : nullptr; pending->selfp = ROUNDS > 0 ? selfp[(ROUNDS - 1) & 1] : nullptr; pending->flags = ROUNDS > 0 ? flags : nullptr; pending->last_round = ROUNDS - 1; }
+  else if (ROUNDS > 0) hipLaunchKernelGGL(k_region_finish, dim3(ew_grid(n)), dim3(256), 0, s, label, (const int *)prop[(ROUNDS - 1) & 1], (const int *)selfp[(ROUNDS - 1) & 1], n, (const int *)flags, ROUNDS - 1);
 }
 
-void region_size(hipStream_t s, int *out, const int *label, int n, int *zero_me) {
-  hipLaunchKernelGGL(k_region_size, dim3(cdiv(n, 256 * RS_PER_THREAD)), dim3(256), 0, s, out, label, n, zero_me);
+void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, const RegionPending *pending) {
+  hipLaunchKernelGGL(k_region_size, dim3(cdiv(n, 256 * RS_PER_THREAD)), dim3(256), 0, s, out, label, n, zero_me,
+                     pending ? pending->prop : (const int *)nullptr, pending ? pending->selfp : (const int *)nullptr, pending ? pending->flags : (const int *)nullptr, pending ? pending->last_round : 0);
 }
 
 // scratch: RD_D2_SCRATCH_INTS(N) ints, scratch[N] (the first list counter) zeroed by the caller when count_is_zero; out must not
