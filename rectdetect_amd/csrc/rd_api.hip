@@ -255,7 +255,7 @@ cl_event oclpolyline_execute(oclpolyline_t *thiz, cl_mem lsList, int lsListSize,
 }  // extern "C"
 
 // ================================================================================================ detector
-#define RD_MAXREC 2048      // records copied back per frame without a second transfer
+#define RD_MAXREC 512       // records copied back per frame without a second transfer (the copy runs at PCIe speed: 16 us for 2048)
 
 struct Slot {
   hipStream_t st;
