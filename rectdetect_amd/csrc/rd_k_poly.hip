@@ -684,7 +684,7 @@ struct pp_lds {
   int ncand, count, fail, progress;
 };
 
-__device__ __noinline__ int2 pp_move_dist(pp_lds &L, int pk, int xyv, int dreg, bool move_only, int iw, int round) {
+__device__ __noinline__ int2 pp_move_dist(pp_lds &L, int pk, int xyv, int dreg, bool move_only, int rnd13, int round) {
   int g = pk & 0x7ff;
   // a segment untouched by the previous round keeps its end index, its maximum and its pixels' distances: nothing to redo
   if (L.done[g] != round) return make_int2(pk, dreg);
@@ -706,7 +706,7 @@ __device__ __noinline__ int2 pp_move_dist(pp_lds &L, int pk, int xyv, int dreg, 
   }
   const float a = cx - (float)x, b = cy - (float)y;
   int d = (int)((float)sqrt((double)a * (double)a + (double)b * (double)b) * 65536);
-  d ^= pixel_rand(y * iw + x, 0) & 0x1fff;
+  d ^= rnd13;                  // pixel_rand(pixel, 0) & 0x1fff: the same in every round, computed once (see the kernel)
   dreg = d;
   atomicMax(&L.rec[g].maxDist, d);
   return make_int2(pk, dreg);
@@ -757,7 +757,7 @@ __global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec 
   if (nlive > PP_T * PP_PX || K >= PP_MAXSEG - 1 || K >= maxrec - 1) { if (tid == 0) s.ctr[25] = 1; return; }
 
   // per-pixel state in registers: id (11 bits) | position along the chain << 11, x | y << 16, last distance
-  int pk[PP_PX], xy[PP_PX], dreg[PP_PX];
+  int pk[PP_PX], xy[PP_PX], dreg[PP_PX], rnd[PP_PX / 2];
 #define PP_ID(k) (pk[k] & 0x7ff)
 #define PP_NUM(k) ((int)((unsigned)pk[k] >> 11))
 #define PP_CI(k) (s.live[tid + (k) * PP_T])
@@ -777,6 +777,10 @@ __global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec 
       pk[k] = j < nlive ? (pk[k] | (dreg[k] << 11)) : 0;
       xy[k] = j < nlive ? ((p % iw) | ((p / iw) << 16)) : 0;
       dreg[k] = 0;
+      // the tie-breaking bits of the pixel's distance (pl:870-889 mixing function): two per register
+      if ((k & 1) == 0) rnd[k >> 1] = 0;
+      rnd[k >> 1] |= (j < nlive ? (pixel_rand(p, 0) & 0x1fff) : 0) << (16 * (k & 1));
+      PP_SEQ;
     }
   }
   for (int g = tid; g < PP_MAXSEG; g += PP_T) L.done[g] = 0;   // during the rounds: round in which the segment has to be looked at again
@@ -818,10 +822,11 @@ __global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec 
   if (tid == 0) s.ctr[41] = (int)wall_clock64();
   // subdivision rounds (pl:509-646); round 15 only moves pixels
   for (int round = 0; round <= 15; round++) {
+    if (tid == 0) { s.ctr[46 + round] = (int)wall_clock64(); s.ctr[38] = round + 1; }      // (diagnostics: start of every round, rounds run)
     // (pixels in segments that the previous round did not change return at once: see pp_move_dist)
 #pragma unroll
     for (int k = 0; k < PP_PX; k++) {
-      const int2 r2 = pp_move_dist(L, pk[k], xy[k], dreg[k], round == 15, iw, round);
+      const int2 r2 = pp_move_dist(L, pk[k], xy[k], dreg[k], round == 15, (rnd[k >> 1] >> (16 * (k & 1))) & 0x1fff, round);
       pk[k] = r2.x; dreg[k] = r2.y;
       PP_SEQ;
     }

@@ -13,5 +13,8 @@ for f in range(4):
     det.poll(1.0)
     c = det.plane("polyctr", count=64)
     t = c[39:46].astype(np.int64)
-    print(f, "segments", int(c[0]), "chains", int(c[1]), "cand/round", c[2:19].tolist(), "phases us:", (np.diff(t) / 100.0).round(1).tolist(), "total", (t[-1] - t[0]) / 100.0)
+    nr = int(c[38])
+    rs = np.append(c[46:46 + nr].astype(np.int64), t[3])
+    print(f, "chain pixels", int(c[0]), "chains", int(c[1]), "live", int(c[24]), "phases us:", (np.diff(t) / 100.0).round(1).tolist(), "total", (t[-1] - t[0]) / 100.0,
+          "| rounds", nr, "us each:", ((np.diff(rs) & 0xffffffff) / 100.0).round(1).tolist())
 det.close()
