@@ -412,8 +412,7 @@ static void frame_regions(rd_detector *d, Slot *s) {
   rdk::despeckle2(st, s->region, s->region0, d2scratch, s->rsize, 16, iw, ih, 1);
 
   // region boundaries and their components (oclrect.c:340-342)
-  rdk::mark_boundary(st, s->boundarysrc, s->region, iw, ih);
-  rdk::label8(st, s->boundary, s->boundarysrc, -1, iw, ih);
+  rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, iw, ih);
 }
 
 static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {

@@ -38,18 +38,71 @@ __device__ __forceinline__ void lt_union(int *lab, int a, int b) {
 }
 
 #define LT_TY 4       // thread rows per block (16 is ~20% faster run alone, but costs 50% more wave-cycles: worse with frames in flight)
-__global__ __launch_bounds__(256) void k_label_tile(int *__restrict__ label, const int *__restrict__ pix, int bgc, int iw, int ih) {
+#define LT_MP 68      // row pitch of the staged region tile of the boundary variant (64 + 2 x 2 cells of halo)
+// BOUNDARY = false: the pixel values are read from `pix`.  BOUNDARY = true: they are the region-boundary marks of oclrect.cl:373-390,
+// computed here from the region plane `src` (a pixel of the interior whose 5x5 window holds another label carries its own label,
+// every other pixel -1; evaluated separably like this: hu = "the five cells x-2..x+2 of a row equal the one at x", window uniform
+// iff the five cells of the centre column equal the centre and their rows are uniform) and also written to `pix_out` for the
+// border kernel - one launch and one pass over the plane less than marking first and labelling then.
+template <bool BOUNDARY>
+__global__ __launch_bounds__(256) void k_label_tile(int *__restrict__ label, const int *__restrict__ pix, int bgc, int iw, int ih, int *__restrict__ pix_out) {
   __shared__ int lab[LT_W * LT_H];
   __shared__ int pv[LT_W * LT_H];
   const int tx = threadIdx.x, x = blockIdx.x * LT_W + tx, y0 = blockIdx.y * LT_H;
   const bool xin = x < iw;
-  const int v00 = pix[(size_t)y0 * iw + blockIdx.x * LT_W];   // the tile's first pixel is always inside the frame
+  int v00;
   bool uniform = true;
   int pv8[LT_H / LT_TY];            // this thread's pixels, requested together (one wait for memory instead of one per row)
+  if (!BOUNDARY) {
+    v00 = pix[(size_t)y0 * iw + blockIdx.x * LT_W];   // the tile's first pixel is always inside the frame
 #pragma unroll
-  for (int k = 0; k < LT_H / LT_TY; k++) {
-    const int y = y0 + threadIdx.y + k * LT_TY;
-    pv8[k] = pix[(xin && y < ih) ? y * iw + x : 0];
+    for (int k = 0; k < LT_H / LT_TY; k++) {
+      const int y = y0 + threadIdx.y + k * LT_TY;
+      pv8[k] = pix[(xin && y < ih) ? y * iw + x : 0];
+    }
+  } else {
+    __shared__ int t[(LT_H + 4) * LT_MP];
+    __shared__ uint8_t hu[(LT_H + 4) * 64];
+    const int x0 = blockIdx.x * LT_W, tid = threadIdx.y * 64 + tx;
+    const int r00 = pix[(size_t)y0 * iw + x0];
+    bool flat = true;
+    stage_cells<(LT_H + 4) * LT_MP, 256>(tid, pix,
+      [&](int c, int &a) { const int xx = x0 - 2 + c % LT_MP, yy = y0 - 2 + c / LT_MP; a = yy * iw + xx; return xx >= 0 && xx < iw && yy >= 0 && yy < ih; },
+      [&](int c, bool inside, int v) { flat = flat && (!inside || v == r00); t[c] = inside ? v : 0; });
+    if (__syncthreads_and(flat)) {
+      // no differing cell anywhere in reach: nothing is a boundary pixel, nothing to label
+#pragma unroll
+      for (int k = 0; k < LT_H / LT_TY; k++) {
+        const int y = y0 + threadIdx.y + k * LT_TY;
+        if (xin && y < ih) { pix_out[y * iw + x] = -1; label[y * iw + x] = -1; }
+      }
+      return;
+    }
+    for (int r = threadIdx.y; r < LT_H + 4; r += LT_TY) {
+      const int *row = t + r * LT_MP + tx + 2;
+      const int c = row[0];
+      hu[r * 64 + tx] = (row[-2] == c && row[-1] == c && row[1] == c && row[2] == c) ? 1 : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < LT_H / LT_TY; k++) {
+      const int r = threadIdx.y + k * LT_TY;
+      const int y = y0 + r;
+      int res = -1;
+      if (xin && y < ih && x > 1 && y > 1 && x < iw - 2 && y < ih - 2) {
+        const int c0 = t[(r + 2) * LT_MP + tx + 2];
+        bool same = true;
+#pragma unroll
+        for (int dy = 0; dy < 5; dy++) same = same && t[(r + dy) * LT_MP + tx + 2] == c0 && hu[(r + dy) * 64 + tx] != 0;
+        if (!same) res = c0;
+      }
+      pv8[k] = res;
+      if (xin && y < ih) pix_out[y * iw + x] = res;
+    }
+    __shared__ int s_v00;            // the mark of the tile's first pixel, for the uniform-tile test below
+    if (threadIdx.y == 0 && tx == 0) s_v00 = pv8[0];
+    __syncthreads();
+    v00 = s_v00;
   }
 #pragma unroll
   for (int k = 0; k < LT_H / LT_TY; k++) {
@@ -274,10 +327,21 @@ __global__ __launch_bounds__(256) void k_strength_masks(int *__restrict__ strong
 namespace rdk {
 
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih) {
-  hipLaunchKernelGGL(k_label_tile, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, pix, bgc, iw, ih);
+  hipLaunchKernelGGL(k_label_tile<false>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, pix, bgc, iw, ih, (int *)nullptr);
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
   if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb), dim3(256), 0, s, label, pix, bgc, iw, ih, hb);
+  const int n = iw * ih;
+  int g = cdiv(n, 256 * 4);
+  hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n);
+}
+
+// region boundaries (oclrect.cl:373-390) marked into `marks` and their 8-connected components labelled into `label`
+void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih) {
+  hipLaunchKernelGGL(k_label_tile<true>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, region, -1, iw, ih, marks);
+  const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
+  const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
+  if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb), dim3(256), 0, s, label, (const int *)marks, -1, iw, ih, hb);
   const int n = iw * ih;
   int g = cdiv(n, 256 * 4);
   hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n);

@@ -952,50 +952,7 @@ __global__ __launch_bounds__(256) void k_despeckle2_active(int *__restrict__ nxt
   if (list_out != nullptr) d2_flush(list_out, count_out, loc, nloc, base, tid);
 }
 
-// rc:373-390
-// One 64 x MB_ROWS tile (+2 cells of halo) per block, staged in LDS.  "Some cell of the 5x5 window differs from the centre" is
-// evaluated separably: hu[y][x] = the five cells x-2..x+2 of row y all equal (x, y); the window is uniform exactly when the
-// five cells of the centre column equal the centre and their rows are uniform.  A tile whose staged cells are all equal
-// (the inside of a large region: most tiles) skips everything.
-#define MB_ROWS 16
-#define MB_P 68
-__global__ __launch_bounds__(256) void k_mark_boundary(int *__restrict__ out, const int *__restrict__ in, int iw, int ih) {
-  __shared__ int t[(MB_ROWS + 4) * MB_P];
-  __shared__ uint8_t hu[(MB_ROWS + 4) * 64];
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * MB_ROWS;
-  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
-  const int v00 = in[y0 * iw + x0];
-  bool uniform = true;
-  stage_cells<(MB_ROWS + 4) * MB_P, 256>(tid, in,
-    [&](int k, int &a) { const int xx = x0 - 2 + k % MB_P, yy = y0 - 2 + k / MB_P; a = yy * iw + xx; return xx >= 0 && xx < iw && yy >= 0 && yy < ih; },
-    [&](int k, bool inside, int v) { uniform = uniform && (!inside || v == v00); t[k] = inside ? v : 0; });
-  const int x = x0 + tx;
-  if (__syncthreads_and(uniform)) {
-    // no differing cell anywhere in reach: interior pixels are not boundary pixels (-1), and so is the 2-px frame ring by definition
-    for (int r = ty; r < MB_ROWS; r += 4) { const int y = y0 + r; if (x < iw && y < ih) out[y * iw + x] = -1; }
-    return;
-  }
-  for (int r = ty; r < MB_ROWS + 4; r += 4) {
-    const int *row = t + r * MB_P + tx + 2;
-    const int c = row[0];
-    hu[r * 64 + tx] = (row[-2] == c && row[-1] == c && row[1] == c && row[2] == c) ? 1 : 0;
-  }
-  __syncthreads();
-  if (x >= iw) return;
-  for (int r = ty; r < MB_ROWS; r += 4) {
-    const int y = y0 + r;
-    if (y >= ih) break;
-    int res = -1;
-    if (x > 1 && y > 1 && x < iw - 2 && y < ih - 2) {
-      const int c0 = t[(r + 2) * MB_P + tx + 2];
-      bool same = true;
-#pragma unroll
-      for (int dy = 0; dy < 5; dy++) same = same && t[(r + dy) * MB_P + tx + 2] == c0 && hu[(r + dy) * 64 + tx] != 0;
-      if (!same) res = c0;
-    }
-    out[y * iw + x] = res;
-  }
-}
+// (rc:373-390, the region-boundary marks, are computed inside the labelling kernel: rd_k_label.hip, k_label_tile<true>)
 
 // ------------------------------------------------------------------------------------------------ voting
 // rc:426-464 in its canonical (raster) reading, SURVEY.md H9: a table slot is owned by the first pixel in raster order
@@ -1379,10 +1336,6 @@ void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int 
                        last ? (int *)nullptr : lists + (size_t)lo * n, count + lo, count + lz, count + 3 + r, stamp, r + 1, in, size, thre, iw, ih);
     cur = nxt;
   }
-}
-
-void mark_boundary(hipStream_t s, int *out, const int *in, int iw, int ih) {
-  hipLaunchKernelGGL(k_mark_boundary, dim3(cdiv(iw, 64), cdiv(ih, MB_ROWS)), dim3(64, 4), 0, s, out, in, iw, ih);
 }
 
 // table: nentry*5 ints, claim: nentry ints, tlist: nentry+1 ints; all three are set up once by reduce_ls_init and kept

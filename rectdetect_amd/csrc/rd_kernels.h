@@ -39,6 +39,7 @@ void rand_i(hipStream_t s, int *out, uint64_t seed, int n);
 // ---- rd_k_label.hip: connected components and per-label reductions
 // 8-connected components of equal `pix` value, pixels equal to bgc -> -1, label = smallest pixel index
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih);
+void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih);   // mark_boundary + label8(marks, background -1) with the marking fused into the tile kernel
 // add (optional): a plane whose non-zero elements are added to out element by element in the same launch (out = zeros + add + sums)
 void calc_strength(hipStream_t s, int *out, const float *edge, const int *label, int iw, int ih, const int *add = nullptr);
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih);
@@ -62,7 +63,6 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
 void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, const RegionPending *pending = nullptr);   // accumulates into out; zero_me (optional): an int to clear on the way
 #define RD_D2_SCRATCH_INTS(N) (5 * (size_t)(N) + 64)
 void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih, int count_is_zero);   // out != in; scratch: RD_D2_SCRATCH_INTS(N) ints (scratch[N] = 0 already if count_is_zero)
-void mark_boundary(hipStream_t s, int *out, const int *in, int iw, int ih);
 struct PolyScratch;
 // votes of the chain pixels left in `ps` by the last polyline() call on this stream (their final segment ids)
 void reduce_ls_init(hipStream_t s, int *table, int *claim, int *tlist, int nentry);   // once per allocation
