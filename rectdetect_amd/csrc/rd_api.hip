@@ -456,8 +456,8 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   if (d->fork_poly) {      // (RD_NO_FORK: everything on the main stream, blur chain first)
     RD_HIP(hipEventRecord(s->ev_fork, st));
     RD_HIP(hipStreamWaitEvent(s->st2, s->ev_fork, 0));
-    rdk::junction(s->st2, s->junction, s->label1, 0, iw, ih);
-    rdk::merge_mask(s->st2, s->mergemask, s->scratch2, s->junction, iw, ih);
+    rdk::junction(s->st2, s->junction, s->label1, 0, iw, ih, s->scratch2);
+    rdk::merge_mask(s->st2, s->mergemask, s->scratch2, NULL, iw, ih);
     RD_HIP(hipEventRecord(s->ev_mm, s->st2));
     if (!(d->diag_skip & 4)) frame_polyline(d, s, s->st2, s->poly_mode);
     RD_HIP(hipEventRecord(s->ev_join, s->st2));
@@ -471,8 +471,8 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
 
   if (d->fork_poly) RD_HIP(hipStreamWaitEvent(st, s->ev_mm, 0));
   else {
-    rdk::junction(st, s->junction, s->label1, 0, iw, ih);
-    rdk::merge_mask(st, s->mergemask, s->scratch2, s->junction, iw, ih);
+    rdk::junction(st, s->junction, s->label1, 0, iw, ih, s->scratch2);
+    rdk::merge_mask(st, s->mergemask, s->scratch2, NULL, iw, ih);
   }
 
   frame_regions(d, s);

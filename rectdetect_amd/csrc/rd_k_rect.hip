@@ -19,12 +19,13 @@ inline int ew_grid(int n) { int g = cdiv(n, 256 * 4); return g < 1 ? 1 : (g > 40
 
 // ------------------------------------------------------------------------------------------------ edge tidy
 // rc:74-95 (`> 0`) and pl:66-87 (`!= 0`): 3x3 population count of on-pixels, 1 -> 0, frame border 0
-__global__ __launch_bounds__(256) void k_junction(int *__restrict__ out, const int *__restrict__ in, int nz, int iw, int ih) {
+// (bits, optional: the two bit rows per 64 pixels that k_mm_gather reads - "counted pixel", "curve end" - see k_mm_bits)
+__global__ __launch_bounds__(256) void k_junction(int *__restrict__ out, const int *__restrict__ in, int nz, int iw, int ih, unsigned long long *__restrict__ bits, int wpr) {
   RD_XY;
-  if (x >= iw || y >= ih) return;
-  const int p = y * iw + x;
+  const bool inside = x < iw && y < ih;
+  const int p = inside ? y * iw + x : 0;
   int r = 0;
-  if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1) {
+  if (inside && x > 0 && y > 0 && x < iw - 1 && y < ih - 1) {
     const int c = in[p];
     if (nz ? c != 0 : c > 0) {
       int count = 1;
@@ -36,7 +37,14 @@ __global__ __launch_bounds__(256) void k_junction(int *__restrict__ out, const i
       r = count == 1 ? 0 : count;
     }
   }
-  out[p] = r;
+  if (inside) out[p] = r;
+  if (bits != nullptr) {
+    const unsigned long long any = __ballot(inside && r != 0), end = __ballot(inside && r == 2);
+    if (threadIdx.x == 0 && y < ih) {
+      unsigned long long *o = bits + ((size_t)y * wpr + blockIdx.x) * 2;
+      o[0] = any; o[1] = end;
+    }
+  }
 }
 
 // mask (NMS response > 0, rh:262-264) -> junction counts -> gap closing -> two thinning passes (rh:266-272) for one
@@ -1262,8 +1270,8 @@ __global__ void k_sample_segments(int *__restrict__ out, const ls_rec *__restric
 
 namespace rdk {
 
-void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih) {
-  hipLaunchKernelGGL(k_junction, grid2(iw, ih), block2, 0, s, out, in, nonzero_variant, iw, ih);
+void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih, int *merge_mask_scratch) {
+  hipLaunchKernelGGL(k_junction, grid2(iw, ih), block2, 0, s, out, in, nonzero_variant, iw, ih, (unsigned long long *)merge_mask_scratch, cdiv(iw, 64));
 }
 void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, int ih, int *zero_plane) {
   hipLaunchKernelGGL(k_rect_tidy, dim3(cdiv(iw, 64), cdiv(ih, TD_ROWS)), dim3(64, 4), 0, s, mask0, tidy, nms, iw, ih, zero_plane);
@@ -1281,11 +1289,11 @@ void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *ed
 // scratch: ih * ceil(iw/64) * 2 64-bit words
 void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih) {
   const int wpr = cdiv(iw, 64);
-  hipLaunchKernelGGL(k_mm_bits, grid2(iw, ih), block2, 0, s, (unsigned long long *)scratch, junction, iw, ih, wpr);
+  if (junction != nullptr) hipLaunchKernelGGL(k_mm_bits, grid2(iw, ih), block2, 0, s, (unsigned long long *)scratch, junction, iw, ih, wpr);   // (nullptr: rdk::junction has left the bit rows in scratch)
   hipLaunchKernelGGL(k_mm_gather, dim3(wpr, cdiv(ih, MM_ROWS)), dim3(64, 4), 0, s, out, (const unsigned long long *)scratch, iw, ih, wpr);
 }
 
-// scratch: 3*N ints (hook proposals; round flags + allowed-direction bytes; self proposals)
+// scratch: 5*N + 256 ints (hook proposals; round flags + allowed-direction bytes; self proposals; the second set of proposals)
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS, int *size_out, const int *size_init, RegionPending *pending) {
   const int n = iw * ih;
   // tile-to-tile hops left after k_region_init: at most ih/RI_ROWS + iw/64 + 2; each launch divides the depth by 16

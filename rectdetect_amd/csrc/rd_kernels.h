@@ -47,7 +47,7 @@ void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw
 void strength_masks(hipStream_t s, int *strong, int *strong2, int *edge, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih);
 
 // ---- rd_k_rect.hip: rect-path stages
-void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih);
+void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih, int *merge_mask_scratch = nullptr);   // merge_mask_scratch (optional): also leaves merge_mask's bit rows there (then call merge_mask with junction = nullptr)
 // mask0 = (nms > 0), tidy = thin(thin(close_gaps(junction(mask0)), parity 0), parity 1) in one launch (oclrect.cl:74-135)
 void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, int ih, int *zero_plane = nullptr);   // zero_plane (optional): cleared on the way
 // run extents of the edge-stopped blur (depend on the edge mask only): ext[p] = nl_h | nr_h<<3 | nl_v<<6 | nr_v<<9
