@@ -391,9 +391,11 @@ __device__ __forceinline__ float v5c(int i) {
   return t[i];
 }
 
-__global__ __launch_bounds__(256) void k_edgevec(float2 *__restrict__ dst, const float *__restrict__ in, int iw, int ih) {
+// (pack_out, optional: the packed Lab of the pixel's own blurred L, a, b - iu:28-34 - on the way: saves the frame path a launch)
+__global__ __launch_bounds__(256) void k_edgevec(float2 *__restrict__ dst, const float *__restrict__ in, int iw, int ih, uint32_t *__restrict__ pack_out, const float *__restrict__ pa, const float *__restrict__ pb) {
   const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
   if (x >= iw || y >= ih) return;
+  if (pack_out != nullptr) { const int p = y * iw + x; pack_out[p] = pack_lab(in[p], pa[p], pb[p]); }
   float vx = 0, vy = 0;
 #pragma unroll
   for (int yy = -2; yy <= 2; yy++) {
@@ -733,8 +735,8 @@ void edgevec_plab(hipStream_t s, float *vxy, const uint32_t *in, int iw, int ih)
 void thincubic(hipStream_t s, float *out, const float *in, const float *vxy, int iw, int ih) {
   hipLaunchKernelGGL(k_thincubic, grid2(iw, ih), block2, 0, s, out, in, (const float2 *)vxy, iw, ih);
 }
-void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih) {
-  hipLaunchKernelGGL(k_edgevec, grid2(iw, ih), block2, 0, s, (float2 *)vxy, in, iw, ih);
+void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih, uint32_t *pack_out, const float *a, const float *b) {
+  hipLaunchKernelGGL(k_edgevec, grid2(iw, ih), block2, 0, s, (float2 *)vxy, in, iw, ih, pack_out, a, b);
 }
 void edge_plab(hipStream_t s, float *out, const uint32_t *in, int iw, int ih) {
   hipLaunchKernelGGL(k_edge_plab, grid2(iw, ih), block2, 0, s, out, in, iw, ih);

@@ -18,7 +18,7 @@ void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], 
 size_t iir_pass_scratch_floats(int np, int W, int H);
 void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3], float *const fwd[3], float *const bwd[3], int np, int W, int H,
                    int transpose_out, float *tails, int *bad);
-void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih);
+void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih, uint32_t *pack_out = nullptr, const float *a = nullptr, const float *b = nullptr);   // pack_out (optional): pack_plab(in, a, b) on the way
 // visualisers / operators no application calls (oclimgutil.h:84-98)
 void convert_bgr_lumaf(hipStream_t s, uint8_t *out, const float *in, float f, int iw, int ih, int ws);
 void convert_bgr_labeli(hipStream_t s, uint8_t *out, const int *in, int bgc, int iw, int ih, int ws);
