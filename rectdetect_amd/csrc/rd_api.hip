@@ -162,7 +162,7 @@ cl_event oclimgutil_label8x_int_int(oclimgutil_t *thiz, cl_mem out, cl_mem in, c
 }
 cl_event oclimgutil_calcStrength(oclimgutil_t *thiz, cl_mem out, cl_mem edge, cl_mem label, int iw, int ih, cl_command_queue queue, const cl_event *events) {
   IU_BEGIN("oclimgutil_calcStrength");
-  rdk::calc_strength(s, (int *)dptr(out), (const float *)dptr(edge), (const int *)dptr(label), iw, ih);
+  rdk::calc_strength(s, (int *)dptr(out), (const float *)dptr(edge), (int *)dptr(label), iw, ih);
   IU_END("oclimgutil_calcStrength");
 }
 cl_event oclimgutil_filterStrength(oclimgutil_t *thiz, cl_mem labelinout, cl_mem str, int thre, int iw, int ih, cl_command_queue queue, const cl_event *events) {
@@ -433,14 +433,14 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   rdk::rect_tidy(st, s->mask0, s->tidy, s->nms, iw, ih, s->strsum);     // (also clears the strength sums for the H1 segment)
 
   // components (background included)
-  rdk::label8(st, s->label1, s->tidy, -1, iw, ih);
+  rdk::label8(st, s->label1, s->tidy, -1, iw, ih, 1);      // (the walk to the roots happens in the first kernel of the next segment)
   return;
   }
   if (seg == 1) {
   // strength sums on top of last frame's strong mask (H1, oclrect.c:274-275) and - at once - this frame's strong mask
   // (what oclrect.c:307-313 derives from the sums later): nothing else of a frame is needed by the next one, so this
   // short segment is the whole frame-to-frame dependency chain
-  rdk::calc_strength(st, s->strsum, s->nms, s->label1, iw, ih, d->prev_strong);
+  rdk::calc_strength(st, s->strsum, s->nms, s->label1, iw, ih, d->prev_strong, 1);
   // (the same pass also yields the edge mask at 500 of oclrect.c:277-284 and filters the labels at 2500, oclrect.c:307-313:
   //  filtering once at 2500 equals filtering at 500 and then at 2500, and both masks come from the unfiltered labels)
   rdk::strength_masks(st, s->strong, d->prev_strong, s->edge500, s->e8, s->label1, s->strsum, 500, 2500, iw, ih);

@@ -255,7 +255,9 @@ __global__ __launch_bounds__(256) void k_label_flatten(int *label, int n) {
 // share a label are summed with a ballot/shuffle loop first, so a big component costs one atomic per wave instead of
 // one per pixel; zero contributions (most pixels) are skipped.  Integer addition: order independent.
 #define CS_ROWS 4      // rows per thread: their loads are in flight together
-__global__ __launch_bounds__(256) void k_calc_strength(int *out, const float *__restrict__ edge, const int *__restrict__ label, int iw, int ih, const int *__restrict__ add) {
+// (flatten: the labels arrive as the trees the border kernel left - phase 3 of the labelling, k_label_flatten, is done here on the way:
+//  each pixel walks to its root and stores it; any interleaving only ever stores roots)
+__global__ __launch_bounds__(256) void k_calc_strength(int *out, const float *__restrict__ edge, int *label, int iw, int ih, const int *__restrict__ add, int flatten) {
   const int x = blockIdx.x * 64 + threadIdx.x, yb = blockIdx.y * (4 * CS_ROWS) + threadIdx.y;
   int ls[CS_ROWS], as[CS_ROWS];
   float es[CS_ROWS];
@@ -266,6 +268,16 @@ __global__ __launch_bounds__(256) void k_calc_strength(int *out, const float *__
     ls[k] = label[p];
     es[k] = edge[p];
     as[k] = add != nullptr ? add[p] : 0;
+  }
+  if (flatten) {
+#pragma unroll
+    for (int k = 0; k < CS_ROWS; k++) {
+      const int y = yb + 4 * k;
+      if (x < iw && y < ih && ls[k] >= 0) {
+        const int r = uf_find(label, ls[k]);
+        if (r != ls[k]) { label[y * iw + x] = r; ls[k] = r; }
+      }
+    }
   }
 #pragma unroll
   for (int k = 0; k < CS_ROWS; k++) {
@@ -326,11 +338,12 @@ __global__ __launch_bounds__(256) void k_strength_masks(int *__restrict__ strong
 
 namespace rdk {
 
-void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih) {
+void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, int skip_flatten) {
   hipLaunchKernelGGL(k_label_tile<false>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, pix, bgc, iw, ih, (int *)nullptr);
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
   if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb), dim3(256), 0, s, label, pix, bgc, iw, ih, hb);
+  if (skip_flatten) return;        // (the caller's next kernel walks to the roots itself: calc_strength)
   const int n = iw * ih;
   int g = cdiv(n, 256 * 4);
   hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n);
@@ -347,8 +360,8 @@ void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, i
   hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n);
 }
 
-void calc_strength(hipStream_t s, int *out, const float *edge, const int *label, int iw, int ih, const int *add) {
-  hipLaunchKernelGGL(k_calc_strength, dim3(cdiv(iw, 64), cdiv(ih, 4 * CS_ROWS)), block2, 0, s, out, edge, label, iw, ih, add);
+void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int iw, int ih, const int *add, int flatten) {
+  hipLaunchKernelGGL(k_calc_strength, dim3(cdiv(iw, 64), cdiv(ih, 4 * CS_ROWS)), block2, 0, s, out, edge, label, iw, ih, add, flatten);
 }
 
 void strength_masks(hipStream_t s, int *strong, int *strong2, int *edge, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih) {

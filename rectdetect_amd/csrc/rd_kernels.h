@@ -38,10 +38,10 @@ void rand_i(hipStream_t s, int *out, uint64_t seed, int n);
 
 // ---- rd_k_label.hip: connected components and per-label reductions
 // 8-connected components of equal `pix` value, pixels equal to bgc -> -1, label = smallest pixel index
-void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih);
+void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, int skip_flatten = 0);   // label = smallest index of the 8-connected component of equal value, -1 for bgc; skip_flatten: the final walk to the roots is left to calc_strength(flatten = 1)
 void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih);   // mark_boundary + label8(marks, background -1) with the marking fused into the tile kernel
 // add (optional): a plane whose non-zero elements are added to out element by element in the same launch (out = zeros + add + sums)
-void calc_strength(hipStream_t s, int *out, const float *edge, const int *label, int iw, int ih, const int *add = nullptr);
+void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int iw, int ih, const int *add = nullptr, int flatten = 0);
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih);
 // strong mask at t_strong (two copies) + edge mask at t_edge (int, int8), both from the unfiltered labels, + filter_strength at t_strong (label in place), one pass; t_edge <= t_strong
 void strength_masks(hipStream_t s, int *strong, int *strong2, int *edge, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih);
