@@ -380,12 +380,13 @@ static void frame_polyline(rd_detector *d, Slot *s, hipStream_t st, int mode) {
   rdk::polyline(st, s->ps, s->lslist, d->N * 16, NULL, s->strong, NULL, 1, 4.0f, 20, d->iw, d->ih, mode);   // the dense id plane is only produced on request (debug plane)
 }
 
-static void frame_votes(rd_detector *d, Slot *s) {
+// tables_are_clean: frame_regions() ran just before (its last kernel undoes the previous entries of the vote tables)
+static void frame_votes(rd_detector *d, Slot *s, int tables_are_clean) {
   const int iw = d->iw, ih = d->ih, N = d->N;
   hipStream_t st = s->st;
   // segment / boundary votes (oclrect.c:365-367) and the probes the host needs (oclrect.c:1066-1098)
   const int nentry = N * 4 / 5;
-  rdk::reduce_ls(st, s->table, s->claim, s->tlist, s->boundary, s->ps, iw, ih, nentry);
+  rdk::reduce_ls(st, s->table, s->claim, s->tlist, s->boundary, s->ps, iw, ih, nentry, tables_are_clean);
   const int ncopy = d->maxrec_dev < RD_MAXREC ? d->maxrec_dev : RD_MAXREC;
   rdk::sample_segments(st, s->probes, s->lslist, d->maxrec_dev, s->boundary, s->table, iw, ih, nentry,
                        s->pack, RD_MAXREC, rdk::poly_scratch_counters(s->ps), s->scratch2 + (size_t)N);
@@ -395,7 +396,7 @@ static void frame_votes(rd_detector *d, Slot *s) {
 
 static void frame_tail(rd_detector *d, Slot *s, int mode) {   // both, in order, on the slot's main stream (overflow redo)
   frame_polyline(d, s, s->st, mode);
-  frame_votes(d, s);
+  frame_votes(d, s, 0);
 }
 
 // regions, their sizes, absorption of small ones, boundaries and boundary components (oclrect.c:325-342).  Reads planes that
@@ -412,7 +413,7 @@ static void frame_regions(rd_detector *d, Slot *s) {
   rdk::despeckle2(st, s->region, s->region0, d2scratch, s->rsize, 16, iw, ih, 1);
 
   // region boundaries and their components (oclrect.c:340-342)
-  rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, iw, ih);
+  rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, iw, ih, s->table, s->claim, s->tlist);   // (also undoes the previous frame's vote-table entries)
 }
 
 static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
@@ -478,7 +479,7 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   if (d->diag_skip & 64) for (int i = 0; i < 100; i++) rdk::clear_i(st, s->i1, 64);   // diagnostics: what does a launch cost?
   if (d->fork_poly) RD_HIP(hipStreamWaitEvent(st, s->ev_join, 0));
   else if (!(d->diag_skip & 4)) frame_polyline(d, s, st, s->poly_mode);
-  frame_votes(d, s);
+  frame_votes(d, s, 1);
 }
 
 // region-merge round budgets a frame can be launched with; the rounds stop changing anything after ~10 on typical frames
@@ -527,7 +528,7 @@ static void *slot_postprocess(rd_detector *d, Slot *s, double tanAOV, void **seg
   if (s->rounds < 20 && s->h_ctr[32 + s->rounds - 1] != 0) {   // the region merge was still changing in its last launched round: repeat with the full budget
     s->rounds = 20;
     frame_regions(d, s);
-    frame_votes(d, s);
+    frame_votes(d, s, 1);
     RD_HIP(hipStreamSynchronize(s->st));
     __atomic_add_fetch(&d->n_redo_rounds, 1, __ATOMIC_RELAXED);
   }

@@ -241,13 +241,26 @@ __global__ __launch_bounds__(256) void k_label_border(int *label, const int *__r
 }
 
 // Phase 3: path compression to the root
-__global__ __launch_bounds__(256) void k_label_flatten(int *label, int n) {
+// (vt_*, optional: block 0 also undoes the previous frame's entries of the vote tables - what k_reduce_clean does - so that the
+//  vote kernels that follow the boundary labelling find them clean without a launch of their own)
+__global__ __launch_bounds__(256) void k_label_flatten(int *label, int n, int *vt_table, int *vt_claim, int *vt_list) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int l = label[i];
     if (l >= 0) {
       const int r = uf_find(label, l);
       if (r != l) label[i] = r;
     }
+  }
+  if (vt_list != nullptr && blockIdx.x == 0) {
+    const int m = vt_list[0];
+    for (int j = threadIdx.x; j < m; j += blockDim.x) {
+      const int slot = vt_list[1 + j];
+      int *e = vt_table + (size_t)slot * 5;
+      e[0] = 0; e[1] = 0; e[2] = 0; e[3] = 0; e[4] = 0;
+      vt_claim[slot] = 0x7f7f7f7f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) vt_list[0] = 0;
   }
 }
 
@@ -346,18 +359,18 @@ void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, 
   if (skip_flatten) return;        // (the caller's next kernel walks to the roots itself: calc_strength)
   const int n = iw * ih;
   int g = cdiv(n, 256 * 4);
-  hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n);
+  hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n, (int *)nullptr, (int *)nullptr, (int *)nullptr);
 }
 
 // region boundaries (oclrect.cl:373-390) marked into `marks` and their 8-connected components labelled into `label`
-void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih) {
+void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih, int *vt_table, int *vt_claim, int *vt_list) {
   hipLaunchKernelGGL(k_label_tile<true>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, region, -1, iw, ih, marks);
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
   if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb), dim3(256), 0, s, label, (const int *)marks, -1, iw, ih, hb);
   const int n = iw * ih;
   int g = cdiv(n, 256 * 4);
-  hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n);
+  hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n, vt_table, vt_claim, vt_list);
 }
 
 void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int iw, int ih, const int *add, int flatten) {

@@ -1354,8 +1354,8 @@ void reduce_ls_init(hipStream_t s, int *table, int *claim, int *tlist, int nentr
   (void)hipMemsetAsync(tlist, 0, sizeof(int), s);
 }
 
-void reduce_ls(hipStream_t s, int *table, int *claim, int *tlist, const int *boundary, const PolyScratch *ps, int iw, int ih, int nentry) {
-  hipLaunchKernelGGL(k_reduce_clean, dim3(1), dim3(1024), 0, s, table, claim, tlist);       // undo the previous use
+void reduce_ls(hipStream_t s, int *table, int *claim, int *tlist, const int *boundary, const PolyScratch *ps, int iw, int ih, int nentry, int tables_are_clean) {
+  if (!tables_are_clean) hipLaunchKernelGGL(k_reduce_clean, dim3(1), dim3(1024), 0, s, table, claim, tlist);       // undo the previous use
   hipLaunchKernelGGL(k_reduce_claim, dim3(512), dim3(256), 0, s, claim, tlist, boundary, *ps, iw, ih, nentry);
   hipLaunchKernelGGL(k_reduce_box, dim3(512), dim3(256), 0, s, table, (const int *)claim, boundary, *ps, iw, ih, nentry);
 }

@@ -39,7 +39,7 @@ void rand_i(hipStream_t s, int *out, uint64_t seed, int n);
 // ---- rd_k_label.hip: connected components and per-label reductions
 // 8-connected components of equal `pix` value, pixels equal to bgc -> -1, label = smallest pixel index
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, int skip_flatten = 0);   // label = smallest index of the 8-connected component of equal value, -1 for bgc; skip_flatten: the final walk to the roots is left to calc_strength(flatten = 1)
-void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih);   // mark_boundary + label8(marks, background -1) with the marking fused into the tile kernel
+void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih, int *vt_table = nullptr, int *vt_claim = nullptr, int *vt_list = nullptr);   // mark_boundary + label8(marks, background -1) with the marking fused into the tile kernel
 // add (optional): a plane whose non-zero elements are added to out element by element in the same launch (out = zeros + add + sums)
 void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int iw, int ih, const int *add = nullptr, int flatten = 0);
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih);
@@ -66,7 +66,7 @@ void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int 
 struct PolyScratch;
 // votes of the chain pixels left in `ps` by the last polyline() call on this stream (their final segment ids)
 void reduce_ls_init(hipStream_t s, int *table, int *claim, int *tlist, int nentry);   // once per allocation
-void reduce_ls(hipStream_t s, int *table, int *claim, int *tlist, const int *boundary, const PolyScratch *ps, int iw, int ih, int nentry);
+void reduce_ls(hipStream_t s, int *table, int *claim, int *tlist, const int *boundary, const PolyScratch *ps, int iw, int ih, int nentry, int tables_are_clean = 0);   // tables_are_clean: label8_boundary(vt_*) has undone the previous use already
 // per segment, 15 probe points: {boundary id, table slot owner, 4 box values} -> out[(seg*15 + k)*6 ..]
 // pack (may be null): the block for the host in one piece - 64 ints of counters / flags, pack_records records of 14 ints, then their probes
 void sample_segments(hipStream_t s, int *out, const void *lslist, int max_records, const int *boundary, const int *table, int iw, int ih, int nentry,
