@@ -235,18 +235,29 @@ __global__ void k_chain_union(PolyScratch s) {
   }
 }
 
-__global__ void k_flatten(int *lab, const int *ctr) {
+// Optional work on the way, with the root each pixel has just found (saves a launch each):
+//   ends / deg: pl:149-155 - a pixel with junction count 2 (itself + one neighbour, deg == 1) is a chain end; count the ends per chain;
+//   size: pl:357-378 - pixels per sub-chain.  The lanes of a wave are consecutive chain pixels in raster order: a run of equal roots
+//         (a horizontal stretch of one chain) is counted by its first lane - same-address atomics are served one after the other,
+//         a long chain was thousands of them.
+__global__ void k_flatten(int *lab, const int *ctr, int *ends, const int *deg, int *size) {
   const int cnt = ctr[0];
-  SPARSE_LOOP(i, cnt) {
-    const int l = lab[i];
-    if (l >= 0) { const int r = uf_find(lab, l); if (r != l) lab[i] = r; }
+  for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; i0 < cnt; i0 += gridDim.x * blockDim.x) {     // whole waves together
+    const int lane = threadIdx.x & 63, i = i0 + lane;
+    int r = -1;
+    if (i < cnt) {
+      const int l = lab[i];
+      r = l;
+      if (l >= 0) { r = uf_find(lab, l); if (r != l) lab[i] = r; }
+      if (ends != nullptr && deg[i] == 1) atomicAdd(&ends[r], 1);
+    }
+    if (size != nullptr) {
+      const int prev = __shfl_up(r, 1);
+      const bool start = lane == 0 || prev != r;
+      const unsigned long long after = __ballot(start) & ~((2ull << lane) - 1ull);
+      if (start && r >= 0) atomicAdd(&size[r], (after ? __ffsll((long long)after) - 1 : 64) - lane);
+    }
   }
-}
-
-// pl:149-155: a pixel with junction count 2 (itself + one neighbour) is a chain end; count ends per chain
-__global__ void k_count_ends(PolyScratch s) {
-  const int cnt = s.ctr[0];
-  SPARSE_LOOP(i, cnt) if (s.flag2[i] == 1) atomicAdd(&s.ends[s.lab[i]], 1);
 }
 
 // pl:157-167: a chain without ends is a closed loop: open it by deleting its root pixel
@@ -283,14 +294,16 @@ __global__ void k_find_ends0_flags(PolyScratch s) {
 }
 
 // pl:222-267: eight hops towards both chain ends with orientation-reversal tracking; page selects the flag bit pair
-__global__ void k_find_ends1(PolyScratch s, int page) {
+// (final: the last of the four launches also does pl:269-285 for its pixel - link towards the end with the smaller index, the
+//  end itself gets number 0 - with the two ends it has just found)
+__global__ void k_find_ends1(PolyScratch s, int page, int final) {
   const int cnt = s.ctr[0];
   const int *ni = s.nx[page], *pi = s.pv[page];
   int *no = s.nx[page ^ 1], *po = s.pv[page ^ 1];
   const int *fin = page == 0 ? s.flag : s.flag2;
   int *fout = page == 0 ? s.flag2 : s.flag;
   SPARSE_LOOP(i, cnt) {
-    if (!s.alive[i]) { no[i] = i; po[i] = i; fout[i] = fin[i]; continue; }
+    if (!s.alive[i]) { no[i] = i; po[i] = i; fout[i] = fin[i]; if (final) { s.num[0][i] = 0; s.link[0][i] = -1; } continue; }
     const int f0 = fin[i];
     bool revn = page == 0 ? (f0 & 1) != 0 : (f0 & 4) != 0;
     bool revp = page == 0 ? (f0 & 2) != 0 : (f0 & 8) != 0;
@@ -309,22 +322,13 @@ __global__ void k_find_ends1(PolyScratch s, int page) {
     if (page == 0) { f &= 3; f |= revn ? 4 : 0; f |= revp ? 8 : 0; }
     else { f &= (3 << 2); f |= revn ? 1 : 0; f |= revp ? 2 : 0; }
     fout[i] = f;
-  }
-}
-
-// pl:269-285: link towards the end with the smaller index; the end itself gets number 0
-__global__ void k_find_ends2(PolyScratch s) {
-  const int cnt = s.ctr[0];
-  SPARSE_LOOP(i, cnt) {
-    int lk = -1, nm = 0;
-    if (s.alive[i]) {
+    if (final) {
       int a = i, b = i, k = 0;
       for (; k < 8; k++) { const int j = s.nbr[i * 8 + k]; if (j >= 0 && s.alive[j]) { a = j; break; } }
       for (k++; k < 8; k++) { const int j = s.nbr[i * 8 + k]; if (j >= 0 && s.alive[j]) { b = j; break; } }
-      lk = s.nx[0][i] < s.pv[0][i] ? a : b;
-      nm = lk == i ? 0 : 1;
+      const int lk = nn < pp ? a : b;
+      s.num[0][i] = lk == i ? 0 : 1; s.link[0][i] = lk;
     }
-    s.num[0][i] = nm; s.link[0][i] = lk;
   }
 }
 
@@ -367,21 +371,6 @@ __global__ void k_sub_union(PolyScratch s, const int *number) {
       const int d = a > b ? a - b : b - a;
       if (d <= 1) uf_union(s.lab2, i, j);
     }
-  }
-}
-
-// pl:357-378 sizes of the sub-chains
-// (the lanes of a wave are consecutive chain pixels in raster order: a run of equal roots - a horizontal stretch of one chain -
-//  is counted by its first lane; same-address atomics are served one after the other, a long chain was thousands of them)
-__global__ void k_sub_size(PolyScratch s) {
-  const int cnt = s.ctr[0];
-  for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; i0 < cnt; i0 += gridDim.x * blockDim.x) {     // whole waves together
-    const int lane = threadIdx.x & 63, i = i0 + lane;
-    const int l = i < cnt ? s.lab2[i] : -1;
-    const int prev = __shfl_up(l, 1);
-    const bool start = lane == 0 || prev != l;
-    const unsigned long long after = __ballot(start) & ~((2ull << lane) - 1ull);
-    if (start && l >= 0) atomicAdd(&s.size[l], (after ? __ffsll((long long)after) - 1 : 64) - lane);
   }
 }
 
@@ -1021,21 +1010,18 @@ void polyline(hipStream_t st, PolyScratch *ps, void *lslist, int lslist_bytes, i
   // chains, loops, ends (oclpolyline.c:237-266)
   hipLaunchKernelGGL(k_build_nbr, sg, sb, 0, st, s, iw);
   hipLaunchKernelGGL(k_chain_union, sg, sb, 0, st, s);
-  hipLaunchKernelGGL(k_flatten, sg, sb, 0, st, s.lab, (const int *)s.ctr);
-  hipLaunchKernelGGL(k_count_ends, sg, sb, 0, st, s);
+  hipLaunchKernelGGL(k_flatten, sg, sb, 0, st, s.lab, (const int *)s.ctr, s.ends, (const int *)s.flag2, (int *)nullptr);      // + ends per chain
   hipLaunchKernelGGL(k_break_loops, sg, sb, 0, st, s);
   hipLaunchKernelGGL(k_find_ends0, sg, sb, 0, st, s);
   hipLaunchKernelGGL(k_find_ends0_flags, sg, sb, 0, st, s);
-  for (int r = 0; r < 4; r++) hipLaunchKernelGGL(k_find_ends1, sg, sb, 0, st, s, r & 1);
-  hipLaunchKernelGGL(k_find_ends2, sg, sb, 0, st, s);
+  for (int r = 0; r < 4; r++) hipLaunchKernelGGL(k_find_ends1, sg, sb, 0, st, s, r & 1, r == 3 ? 1 : 0);      // (the last one also links and numbers: pl:269-285)
   // numbering (oclpolyline.c:268-275): three rounds 0->1->0->1
   for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k_number, sg, sb, 0, st, s, r & 1, r == 2 ? 1 : 0);
   const int *number = s.num[1];
 
   // split at numbering jumps, size filter, compact ids (oclpolyline.c:277-295)
   hipLaunchKernelGGL(k_sub_union, sg, sb, 0, st, s, number);
-  hipLaunchKernelGGL(k_flatten, sg, sb, 0, st, s.lab2, (const int *)s.ctr);
-  hipLaunchKernelGGL(k_sub_size, sg, sb, 0, st, s);
+  hipLaunchKernelGGL(k_flatten, sg, sb, 0, st, s.lab2, (const int *)s.ctr, (int *)nullptr, (const int *)nullptr, s.size);     // + sub-chain sizes
   // (the chain-pixel count lives on the device: launch for the worst case, blocks beyond it exit at once)
   hipLaunchKernelGGL(k_root_flags, sg, sb, 0, st, s, sizeThre);
   hipLaunchKernelGGL(k_compact1, dim3(nblk), dim3(256), 0, st, (int *)nullptr, (int *)nullptr, s.rootid, (const int *)s.flag2, N, (const int *)s.ctr, s.ctr + 1, s.cstate + (size_t)nblk, (const int *)s.csync);
