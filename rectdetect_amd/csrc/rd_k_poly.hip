@@ -129,8 +129,20 @@ __global__ __launch_bounds__(256) void k_poly_tidy(int *__restrict__ out, const 
 // optional): pos[rank] = index, cidx[index] = rank or -1, rank1[index] = rank + 1 for non-zero elements; *cnt = their number.
 #define CP_K (CP_PER_BLOCK / 256)
 __device__ __forceinline__ unsigned long long cp_word(unsigned gen, unsigned status, unsigned value) { return ((unsigned long long)(gen & 0xffffffu) << 40) | ((unsigned long long)status << 38) | value; }
+// MODE 0: the elements are `plane`.  MODE 1: element i is "chain pixel i is the root of a sub-chain of more than size_thre pixels"
+// (pl:380-420: surviving roots are numbered 1..K in raster order = compact order).  MODE 2: element i is the id of chain pixel i's
+// sub-chain (0 = dropped), computed and stored on the way; block 0 also resets what the single-launch stage expects cleared
+// (header record, counters ctr[2..23], ctr[25]) when ls != nullptr.
+template <int MODE>
 __global__ __launch_bounds__(256) void k_compact1(int *__restrict__ pos, int *__restrict__ cidx, int *__restrict__ rank1, const int *__restrict__ plane, int n, const int *nptr,
-                                                  int *cnt, unsigned long long *state, const int *genp) {
+                                                  int *cnt, unsigned long long *state, const int *genp, PolyScratch s, int size_thre, ls_rec *ls) {
+  if (MODE == 2 && ls != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+    ls_rec z = {};
+    ls[0] = z;
+    s.segaux[0] = -1; s.segaux[1] = 0x7fffffff;
+    for (int k = 2; k < 24; k++) s.ctr[k] = 0;
+    s.ctr[25] = 0;
+  }
   __shared__ int wcount[CP_K * 4 + 1];
   __shared__ int s_excl;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -140,12 +152,26 @@ __global__ __launch_bounds__(256) void k_compact1(int *__restrict__ pos, int *__
   const unsigned gen = (unsigned)*genp;
   // flags of this thread's CP_K elements (all loads in flight together), wave counts per row of 256 elements
   unsigned on = 0;
-  {
+  if (MODE == 0) {
     int v[CP_K];
 #pragma unroll
     for (int k = 0; k < CP_K; k++) { const int i = b * CP_PER_BLOCK + k * 256 + tid; v[k] = plane[i < n ? i : 0]; }
 #pragma unroll
     for (int k = 0; k < CP_K; k++) { const int i = b * CP_PER_BLOCK + k * 256 + tid; if (i < n && v[k] != 0) on |= 1u << k; }
+  } else if (MODE == 1) {
+    int l[CP_K], sz[CP_K];
+#pragma unroll
+    for (int k = 0; k < CP_K; k++) { const int i = b * CP_PER_BLOCK + k * 256 + tid; const int q = i < n ? i : 0; l[k] = s.lab2[q]; sz[k] = s.size[q]; }
+#pragma unroll
+    for (int k = 0; k < CP_K; k++) { const int i = b * CP_PER_BLOCK + k * 256 + tid; if (i < n && l[k] == i && sz[k] > size_thre) on |= 1u << k; }
+  } else {
+    int l[CP_K];
+#pragma unroll
+    for (int k = 0; k < CP_K; k++) { const int i = b * CP_PER_BLOCK + k * 256 + tid; l[k] = s.lab2[i < n ? i : 0]; }
+#pragma unroll
+    for (int k = 0; k < CP_K; k++) l[k] = l[k] >= 0 ? s.rootid[l[k]] : 0;      // ids of the surviving chains for every chain pixel (0 = dropped)
+#pragma unroll
+    for (int k = 0; k < CP_K; k++) { const int i = b * CP_PER_BLOCK + k * 256 + tid; if (i < n) { s.id[i] = l[k]; if (l[k] != 0) on |= 1u << k; } }
   }
 #pragma unroll
   for (int k = 0; k < CP_K; k++) { const unsigned long long m = __ballot((on >> k) & 1u); if (lane == 0) wcount[k * 4 + w] = __popcll(m); }
@@ -260,21 +286,21 @@ __global__ void k_flatten(int *lab, const int *ctr, int *ends, const int *deg, i
   }
 }
 
-// pl:157-167: a chain without ends is a closed loop: open it by deleting its root pixel
-__global__ void k_break_loops(PolyScratch s) {
-  const int cnt = s.ctr[0];
-  SPARSE_LOOP(i, cnt) if (s.lab[i] == i && s.ends[i] == 0) s.alive[i] = 0;
-}
-
-// pl:169-220: the first two living neighbours (order E,NE,N,NW,W,SW,S,SE) become next / prev; self if missing
+// pl:157-167: a chain without ends is a closed loop: it is opened by deleting its root pixel.
+// pl:169-220: the first two living neighbours (order E,NE,N,NW,W,SW,S,SE) become next / prev; self if missing.
+// (one launch: whether a pixel is such a root is read off the labels and end counts directly; the pixel's own verdict is stored
+//  in alive[] for the launches that follow)
 __global__ void k_find_ends0(PolyScratch s) {
   const int cnt = s.ctr[0];
   SPARSE_LOOP(i, cnt) {
+    auto living = [&](int j) { return !(s.lab[j] == j && s.ends[j] == 0); };
     int a = i, b = i;
-    if (s.alive[i]) {
+    const bool me = living(i);
+    s.alive[i] = me ? 1 : 0;
+    if (me) {
       int k = 0;
-      for (; k < 8; k++) { const int j = s.nbr[i * 8 + k]; if (j >= 0 && s.alive[j]) { a = j; break; } }
-      for (k++; k < 8; k++) { const int j = s.nbr[i * 8 + k]; if (j >= 0 && s.alive[j]) { b = j; break; } }
+      for (; k < 8; k++) { const int j = s.nbr[i * 8 + k]; if (j >= 0 && living(j)) { a = j; break; } }
+      for (k++; k < 8; k++) { const int j = s.nbr[i * 8 + k]; if (j >= 0 && living(j)) { b = j; break; } }
     }
     s.nx[0][i] = a; s.pv[0][i] = b;
   }
@@ -371,27 +397,6 @@ __global__ void k_sub_union(PolyScratch s, const int *number) {
       const int d = a > b ? a - b : b - a;
       if (d <= 1) uf_union(s.lab2, i, j);
     }
-  }
-}
-
-// pl:380-420: surviving roots are numbered 1..K in raster order (= compact order): one block, ballot prefix scan
-// pl:380-420: surviving roots are numbered 1..K in raster order (= compact order): flag them, rank them by compaction
-__global__ void k_root_flags(PolyScratch s, int sizeThre) {
-  const int cnt = s.ctr[0];
-  SPARSE_LOOP(i, cnt) s.flag2[i] = (s.lab2[i] == i && s.size[i] > sizeThre) ? 1 : 0;
-}
-
-// ids of the surviving chains for every chain pixel (0 = dropped)
-// (ls != nullptr: also what k_seg_clear does for the single-launch stage - header record, counters ctr[2..23], ctr[25])
-__global__ void k_assign_ids(PolyScratch s, ls_rec *ls) {
-  const int cnt = s.ctr[0];
-  SPARSE_LOOP(i, cnt) { const int l = s.lab2[i]; s.id[i] = l >= 0 ? s.rootid[l] : 0; }
-  if (ls != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
-    ls_rec z = {};
-    ls[0] = z;
-    s.segaux[0] = -1; s.segaux[1] = 0x7fffffff;
-    for (int k = 2; k < 24; k++) s.ctr[k] = 0;
-    s.ctr[25] = 0;
   }
 }
 
@@ -1005,13 +1010,12 @@ void polyline(hipStream_t st, PolyScratch *ps, void *lslist, int lslist_bytes, i
 
   // compaction of the chain pixels in raster order
   const int nblk = cdiv(N, CP_PER_BLOCK);
-  hipLaunchKernelGGL(k_compact1, dim3(nblk), dim3(256), 0, st, s.pos, s.cidx, (int *)nullptr, (const int *)s.planeC, N, (const int *)nullptr, s.ctr, s.cstate, (const int *)s.csync);
+  hipLaunchKernelGGL(k_compact1<0>, dim3(nblk), dim3(256), 0, st, s.pos, s.cidx, (int *)nullptr, (const int *)s.planeC, N, (const int *)nullptr, s.ctr, s.cstate, (const int *)s.csync, s, 0, (ls_rec *)nullptr);
 
   // chains, loops, ends (oclpolyline.c:237-266)
   hipLaunchKernelGGL(k_build_nbr, sg, sb, 0, st, s, iw);
   hipLaunchKernelGGL(k_chain_union, sg, sb, 0, st, s);
   hipLaunchKernelGGL(k_flatten, sg, sb, 0, st, s.lab, (const int *)s.ctr, s.ends, (const int *)s.flag2, (int *)nullptr);      // + ends per chain
-  hipLaunchKernelGGL(k_break_loops, sg, sb, 0, st, s);
   hipLaunchKernelGGL(k_find_ends0, sg, sb, 0, st, s);
   hipLaunchKernelGGL(k_find_ends0_flags, sg, sb, 0, st, s);
   for (int r = 0; r < 4; r++) hipLaunchKernelGGL(k_find_ends1, sg, sb, 0, st, s, r & 1, r == 3 ? 1 : 0);      // (the last one also links and numbers: pl:269-285)
@@ -1023,10 +1027,8 @@ void polyline(hipStream_t st, PolyScratch *ps, void *lslist, int lslist_bytes, i
   hipLaunchKernelGGL(k_sub_union, sg, sb, 0, st, s, number);
   hipLaunchKernelGGL(k_flatten, sg, sb, 0, st, s.lab2, (const int *)s.ctr, (int *)nullptr, (const int *)nullptr, s.size);     // + sub-chain sizes
   // (the chain-pixel count lives on the device: launch for the worst case, blocks beyond it exit at once)
-  hipLaunchKernelGGL(k_root_flags, sg, sb, 0, st, s, sizeThre);
-  hipLaunchKernelGGL(k_compact1, dim3(nblk), dim3(256), 0, st, (int *)nullptr, (int *)nullptr, s.rootid, (const int *)s.flag2, N, (const int *)s.ctr, s.ctr + 1, s.cstate + (size_t)nblk, (const int *)s.csync);
-  hipLaunchKernelGGL(k_assign_ids, sg, sb, 0, st, s, mode == 1 ? ls : (ls_rec *)nullptr);
-  hipLaunchKernelGGL(k_compact1, dim3(nblk), dim3(256), 0, st, s.live, (int *)nullptr, (int *)nullptr, (const int *)s.id, N, (const int *)s.ctr, s.ctr + 24, s.cstate + 2 * (size_t)nblk, (const int *)s.csync);
+  hipLaunchKernelGGL(k_compact1<1>, dim3(nblk), dim3(256), 0, st, (int *)nullptr, (int *)nullptr, s.rootid, (const int *)nullptr, N, (const int *)s.ctr, s.ctr + 1, s.cstate + (size_t)nblk, (const int *)s.csync, s, sizeThre, (ls_rec *)nullptr);
+  hipLaunchKernelGGL(k_compact1<2>, dim3(nblk), dim3(256), 0, st, s.live, (int *)nullptr, (int *)nullptr, (const int *)nullptr, N, (const int *)s.ctr, s.ctr + 24, s.cstate + 2 * (size_t)nblk, (const int *)s.csync, s, 0, mode == 1 ? ls : (ls_rec *)nullptr);
 
   if (mode == 1) {
     // fast path: initial segments, 15 subdivision rounds and the refinement in one persistent launch (overflow -> ctr[25])
