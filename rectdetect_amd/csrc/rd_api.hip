@@ -431,10 +431,9 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   rdk::thinthres(st, s->nms, s->strength, s->vxy, iw, ih);
 
   // mask of positive responses and the rect-path tidy (oclrect.c:262-272)
-  rdk::rect_tidy(st, s->mask0, s->tidy, s->nms, iw, ih, s->strsum);     // (also clears the strength sums for the H1 segment)
-
-  // components (background included)
-  rdk::label8(st, s->label1, s->tidy, -1, iw, ih, 1);      // (the walk to the roots happens in the first kernel of the next segment)
+  // components (background included) of the tidied mask; the tidy itself runs inside the labelling's tile kernel (and clears the
+  // strength sums for the H1 segment); the walk to the roots happens in the first kernel of the next segment
+  rdk::label8_tidy(st, s->label1, s->mask0, s->tidy, s->nms, s->strsum, iw, ih, 1);
   return;
   }
   if (seg == 1) {

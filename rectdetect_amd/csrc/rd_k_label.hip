@@ -6,6 +6,7 @@
 // 8-connected component of equal pixel value, -1 for pixels equal to the background value.
 #include "rd_device.h"
 #include "rd_kernels.h"
+#include "rd_tidy_tile.h"
 
 namespace {
 
@@ -44,8 +45,12 @@ __device__ __forceinline__ void lt_union(int *lab, int a, int b) {
 // every other pixel -1; evaluated separably like this: hu = "the five cells x-2..x+2 of a row equal the one at x", window uniform
 // iff the five cells of the centre column equal the centre and their rows are uniform) and also written to `pix_out` for the
 // border kernel - one launch and one pass over the plane less than marking first and labelling then.
-template <bool BOUNDARY>
-__global__ __launch_bounds__(256) void k_label_tile(int *__restrict__ label, const int *__restrict__ pix, int bgc, int iw, int ih, int *__restrict__ pix_out) {
+// SRC == 2: the pixel values are the rect-variant edge tidy of the NMS response `nms` (rd_tidy_tile.h), computed here and written to
+// mask0 / pix_out (and zero_plane cleared) as k_rect_tidy would.
+template <int SRC>
+__global__ __launch_bounds__(256) void k_label_tile(int *__restrict__ label, const int *__restrict__ pix, int bgc, int iw, int ih, int *__restrict__ pix_out,
+                                                    const float *__restrict__ nms, int *__restrict__ mask0, int *__restrict__ zero_plane) {
+  constexpr bool BOUNDARY = SRC == 1;
   __shared__ int lab[LT_W * LT_H];
   __shared__ int pv[LT_W * LT_H];
   const int tx = threadIdx.x, x = blockIdx.x * LT_W + tx, y0 = blockIdx.y * LT_H;
@@ -53,7 +58,14 @@ __global__ __launch_bounds__(256) void k_label_tile(int *__restrict__ label, con
   int v00;
   bool uniform = true;
   int pv8[LT_H / LT_TY];            // this thread's pixels, requested together (one wait for memory instead of one per row)
-  if (!BOUNDARY) {
+  if (SRC == 2) {
+    __shared__ uint8_t A[(LT_H + 2 * TD_M) * TD_P], B[(LT_H + 2 * TD_M) * TD_P];
+    rect_tidy_tile<LT_H>(A, B, blockIdx.x * LT_W, y0, threadIdx.y * 64 + tx, nms, mask0, pix_out, zero_plane, iw, ih, pv8);
+    __shared__ int s_t00;            // the value of the tile's first pixel, for the uniform-tile test below
+    if (threadIdx.y == 0 && tx == 0) s_t00 = pv8[0];
+    __syncthreads();
+    v00 = s_t00;
+  } else if (!BOUNDARY) {
     v00 = pix[(size_t)y0 * iw + blockIdx.x * LT_W];   // the tile's first pixel is always inside the frame
 #pragma unroll
     for (int k = 0; k < LT_H / LT_TY; k++) {
@@ -352,7 +364,7 @@ __global__ __launch_bounds__(256) void k_strength_masks(int *__restrict__ strong
 namespace rdk {
 
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, int skip_flatten) {
-  hipLaunchKernelGGL(k_label_tile<false>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, pix, bgc, iw, ih, (int *)nullptr);
+  hipLaunchKernelGGL(k_label_tile<0>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, pix, bgc, iw, ih, (int *)nullptr, (const float *)nullptr, (int *)nullptr, (int *)nullptr);
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
   if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb), dim3(256), 0, s, label, pix, bgc, iw, ih, hb);
@@ -362,9 +374,21 @@ void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, 
   hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n, (int *)nullptr, (int *)nullptr, (int *)nullptr);
 }
 
+// rect_tidy(mask0, tidy, nms, zero_plane) + label8(label, tidy, background -1, skip_flatten) with the tidy computed inside the tile kernel
+void label8_tidy(hipStream_t s, int *label, int *mask0, int *tidy, const float *nms, int *zero_plane, int iw, int ih, int skip_flatten) {
+  hipLaunchKernelGGL(k_label_tile<2>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, (const int *)nullptr, -1, iw, ih, tidy, nms, mask0, zero_plane);
+  const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
+  const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
+  if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb), dim3(256), 0, s, label, (const int *)tidy, -1, iw, ih, hb);
+  if (skip_flatten) return;
+  const int n = iw * ih;
+  int g = cdiv(n, 256 * 4);
+  hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n, (int *)nullptr, (int *)nullptr, (int *)nullptr);
+}
+
 // region boundaries (oclrect.cl:373-390) marked into `marks` and their 8-connected components labelled into `label`
 void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih, int *vt_table, int *vt_claim, int *vt_list) {
-  hipLaunchKernelGGL(k_label_tile<true>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, region, -1, iw, ih, marks);
+  hipLaunchKernelGGL(k_label_tile<1>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, region, -1, iw, ih, marks, (const float *)nullptr, (int *)nullptr, (int *)nullptr);
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
   if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb), dim3(256), 0, s, label, (const int *)marks, -1, iw, ih, hb);

@@ -39,6 +39,7 @@ void rand_i(hipStream_t s, int *out, uint64_t seed, int n);
 // ---- rd_k_label.hip: connected components and per-label reductions
 // 8-connected components of equal `pix` value, pixels equal to bgc -> -1, label = smallest pixel index
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, int skip_flatten = 0);   // label = smallest index of the 8-connected component of equal value, -1 for bgc; skip_flatten: the final walk to the roots is left to calc_strength(flatten = 1)
+void label8_tidy(hipStream_t s, int *label, int *mask0, int *tidy, const float *nms, int *zero_plane, int iw, int ih, int skip_flatten = 0);   // rect_tidy + label8(tidy, background -1) in the same tile kernel
 void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih, int *vt_table = nullptr, int *vt_claim = nullptr, int *vt_list = nullptr);   // mark_boundary + label8(marks, background -1) with the marking fused into the tile kernel
 // add (optional): a plane whose non-zero elements are added to out element by element in the same launch (out = zeros + add + sums)
 void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int iw, int ih, const int *add = nullptr, int flatten = 0);
