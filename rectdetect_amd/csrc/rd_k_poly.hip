@@ -225,39 +225,27 @@ __global__ __launch_bounds__(256) void k_compact1(int *__restrict__ pos, int *__
     const unsigned long long m = __ballot(o);
     if (i >= n) continue;
     const int rank = excl + wcount[k * 4 + w] + __popcll(m & ((1ull << lane) - 1ull));
-    if (o) { if (pos) pos[rank] = i; if (rank1) rank1[i] = rank + 1; }
+    if (o) { if (pos) pos[rank] = i; if (rank1) rank1[i] = rank + 1; if (MODE == 0 && s.lab != nullptr) { s.lab[rank] = rank; s.ends[rank] = 0; } }
     if (cidx) cidx[i] = o ? rank : -1;
   }
 }
 
 // ------------------------------------------------------------------------------------------------ chain graph
-__global__ void k_build_nbr(PolyScratch s, int iw) {
+// The 8 neighbour compact indices of every chain pixel (E,NE,N,NW,W,SW,S,SE; -1 = none), its degree, and - in the same launch -
+// the 8-connected components of the chain mask (pl:811-854 to convergence): union with every neighbour of smaller index.
+// (lab[i] = i and ends[i] = 0 were set for all chain pixels by the compaction that produced them: k_compact1<0>)
+__global__ void k_chain_union(PolyScratch s, int iw) {
   const int cnt = s.ctr[0];
   SPARSE_LOOP(i, cnt) {
     const int p = s.pos[i];
-    int deg = 0;
+    int nb[8], deg = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int j = s.cidx[p + nbr_dx(k) + nbr_dy(k) * iw];   // chain pixels are interior: no bounds check needed
-      s.nbr[i * 8 + k] = j;
-      deg += j >= 0;
-    }
-    s.lab[i] = i;
-    s.alive[i] = 1;
-    s.ends[i] = 0;
+    for (int k = 0; k < 8; k++) nb[k] = s.cidx[p + nbr_dx(k) + nbr_dy(k) * iw];   // chain pixels are interior: no bounds check needed
+#pragma unroll
+    for (int k = 0; k < 8; k++) { s.nbr[i * 8 + k] = nb[k]; deg += nb[k] >= 0; }
     s.flag2[i] = deg;     // degree, used for the end-point count
-  }
-}
-
-// 8-connected components of the chain mask (pl:811-854 to convergence): union with every neighbour of smaller index
-__global__ void k_chain_union(PolyScratch s) {
-  const int cnt = s.ctr[0];
-  SPARSE_LOOP(i, cnt) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int j = s.nbr[i * 8 + k];
-      if (j >= 0 && j < i) uf_union(s.lab, i, j);
-    }
+    for (int k = 0; k < 8; k++) if (nb[k] >= 0 && nb[k] < i) uf_union(s.lab, i, nb[k]);
   }
 }
 
@@ -1013,8 +1001,7 @@ void polyline(hipStream_t st, PolyScratch *ps, void *lslist, int lslist_bytes, i
   hipLaunchKernelGGL(k_compact1<0>, dim3(nblk), dim3(256), 0, st, s.pos, s.cidx, (int *)nullptr, (const int *)s.planeC, N, (const int *)nullptr, s.ctr, s.cstate, (const int *)s.csync, s, 0, (ls_rec *)nullptr);
 
   // chains, loops, ends (oclpolyline.c:237-266)
-  hipLaunchKernelGGL(k_build_nbr, sg, sb, 0, st, s, iw);
-  hipLaunchKernelGGL(k_chain_union, sg, sb, 0, st, s);
+  hipLaunchKernelGGL(k_chain_union, sg, sb, 0, st, s, iw);
   hipLaunchKernelGGL(k_flatten, sg, sb, 0, st, s.lab, (const int *)s.ctr, s.ends, (const int *)s.flag2, (int *)nullptr);      // + ends per chain
   hipLaunchKernelGGL(k_find_ends0, sg, sb, 0, st, s);
   hipLaunchKernelGGL(k_find_ends0_flags, sg, sb, 0, st, s);
