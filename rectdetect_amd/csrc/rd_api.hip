@@ -275,7 +275,7 @@ struct Slot {
   // host side
   void *h_bgr;            // pinned staging for host frames
   void *h_segs; int *h_probes; int *h_ctr;   // views into h_pack
-  int *pack, *h_pack;                      // everything the host needs from a frame, assembled on the device, one copy
+  int *h_pack, *h_pack_dev;                // everything the host needs from a frame, assembled by the device in pinned host memory (host / device address)
   long seq;
   int ws;
   // captured launch sequences (three segments, see enqueue_frame) and the stride they were captured for
@@ -346,8 +346,8 @@ static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
   s->ps = rdk::poly_scratch_create(d->iw, d->ih);
   RD_HIP(hipHostMalloc(&s->h_bgr, N * 4, hipHostMallocDefault));
   const size_t pack_ints = 64 + (size_t)RD_MAXREC * (14 + 15 * 6);
-  s->pack = dnew<int>(pack_ints);
   RD_HIP(hipHostMalloc((void **)&s->h_pack, pack_ints * sizeof(int), hipHostMallocDefault)); memset(s->h_pack, 0, pack_ints * sizeof(int));
+  RD_HIP(hipHostGetDevicePointer((void **)&s->h_pack_dev, s->h_pack, 0));
   s->h_ctr = s->h_pack; s->h_segs = s->h_pack + 64; s->h_probes = s->h_pack + 64 + (size_t)RD_MAXREC * 14;
   s->rounds = 20;
   s->seq = -1;
@@ -360,7 +360,7 @@ static void slot_free(Slot *s) {
   for (void *p : all) dfree(p);
   for (int k = 0; k < 3; k++) { dfree(s->tr[k]); dfree(s->fw[k]); dfree(s->bw[k]); dfree(s->hz[k]); dfree(s->bl[k]); }
   rdk::poly_scratch_destroy(s->ps);
-  RD_HIP(hipHostFree(s->h_bgr)); RD_HIP(hipHostFree(s->h_pack)); dfree(s->pack);
+  RD_HIP(hipHostFree(s->h_bgr)); RD_HIP(hipHostFree(s->h_pack));
   RD_HIP(hipEventDestroy(s->ev_begin)); RD_HIP(hipEventDestroy(s->ev_done)); RD_HIP(hipEventDestroy(s->ev_strong));
   RD_HIP(hipEventDestroy(s->ev_fork)); RD_HIP(hipEventDestroy(s->ev_mm)); RD_HIP(hipEventDestroy(s->ev_join));
   if (!s->shares_streams) {
@@ -387,11 +387,11 @@ static void frame_votes(rd_detector *d, Slot *s, int tables_are_clean) {
   // segment / boundary votes (oclrect.c:365-367) and the probes the host needs (oclrect.c:1066-1098)
   const int nentry = N * 4 / 5;
   rdk::reduce_ls(st, s->table, s->claim, s->tlist, s->boundary, s->ps, iw, ih, nentry, tables_are_clean);
-  const int ncopy = d->maxrec_dev < RD_MAXREC ? d->maxrec_dev : RD_MAXREC;
+  // The block the host needs - counters + round flags, the first RD_MAXREC segment records, their probes - is assembled by the
+  // sampling kernel directly in pinned host memory (0.2 MB of posted writes; frames with more records fetch the rest on demand):
+  // no copy launch at the end of the frame.
   rdk::sample_segments(st, s->probes, s->lslist, d->maxrec_dev, s->boundary, s->table, iw, ih, nentry,
-                       s->pack, RD_MAXREC, rdk::poly_scratch_counters(s->ps), s->scratch2 + (size_t)N);
-  // one transfer: counters + round flags, the first ncopy segment records, their probes (frames with more records fetch the rest on demand)
-  RD_HIP(hipMemcpyAsync(s->h_pack, s->pack, (64 + (size_t)RD_MAXREC * 14 + (size_t)ncopy * 15 * 6) * sizeof(int), hipMemcpyDeviceToHost, st));
+                       s->h_pack_dev, RD_MAXREC, rdk::poly_scratch_counters(s->ps), s->scratch2 + (size_t)N);
 }
 
 static void frame_tail(rd_detector *d, Slot *s, int mode) {   // both, in order, on the slot's main stream (overflow redo)
