@@ -164,12 +164,13 @@ __global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ e
 #define BP_ROWS 64
 #define BP_SW 73              // row pitch of the staged input (72 used)
 // floor(s / w) for 0 <= s <= 40950, 1 <= w <= 10 (exhaustively checked: tools/check_div_small.py)
-__device__ __forceinline__ unsigned div_small_f(unsigned s, float rw) { return (unsigned)(((float)s + 0.5f) * rw); }
+// (one fused multiply-add: float(s) * (1/w) + 0.5 * (1/w), rounded once - the explicit fma is part of the checked formula, not a contraction)
+__device__ __forceinline__ unsigned div_small_f(unsigned s, float2 rw) { return (unsigned)__fmaf_rn((float)s, rw.x, rw.y); }
 
 __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih) {
   __shared__ uint2 src[(BP_ROWS + 8) * BP_SW + 1];
   __shared__ uint2 hz[(BP_ROWS + 8) * 64 + 1];
-  __shared__ float rwt[16];                                      // 1 / w, correctly rounded
+  __shared__ float2 rwt[16];                                     // (1 / w correctly rounded, half of it)
   const int ZS = (BP_ROWS + 8) * BP_SW, ZH = (BP_ROWS + 8) * 64;   // zero slots
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BP_ROWS;
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
     q[i] = in[okq[i] ? yy * iw + xx : 0];
   }
   if (tid == 0) { src[ZS] = make_uint2(0, 0); hz[ZH] = make_uint2(0, 0); }
-  if (tid < 16) rwt[tid] = tid >= 1 && tid <= 10 ? 1.0f / (float)tid : 0.0f;      // 1 / w, correctly rounded
+  if (tid < 16) { const float r = tid >= 1 && tid <= 10 ? 1.0f / (float)tid : 0.0f; rwt[tid] = make_float2(r, 0.5f * r); }
 #pragma unroll
   for (int i = 0; i < NQ; i++) {
     const int t = tid + 1024 * i;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
     const int w = nl + nr;
     uint2 o = src[c];
     if (w > 0) {
-      const float rw = rwt[w];
+      const float2 rw = rwt[w];
       o = make_uint2(div_small_f(lo & 0xffffu, rw) | (div_small_f(lo >> 16, rw) << 16), div_small_f(hi, rw));   // fields cannot exceed their range: no clamp needed
     }
     hz[r * 64 + tx] = o;
@@ -264,7 +265,7 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
     const int w = nl + nr;
     uint2 o = hz[c];
     if (w > 0) {
-      const float rw = rwt[w];
+      const float2 rw = rwt[w];
       o = make_uint2(div_small_f(lo & 0xffffu, rw) | (div_small_f(lo >> 16, rw) << 16), div_small_f(hi, rw));
     }
     out[y * iw + x] = (o.x & 0xffffu) | ((o.x >> 16) << 12) | (o.y << 22);
