@@ -4,6 +4,7 @@
 // (oclimgutil.cl:495-538, oclimgutil.c:227-246: 1 + 10 launches, converged only by luck - SURVEY.md H4).
 // Here the labelling is a run-based union-find that always converges: label = smallest pixel index of the
 // 8-connected component of equal pixel value, -1 for pixels equal to the background value.
+#include <stdlib.h>
 #include "rd_device.h"
 #include "rd_kernels.h"
 #include "rd_tidy_tile.h"
@@ -379,7 +380,10 @@ void label8_tidy(hipStream_t s, int *label, int *mask0, int *tidy, const float *
   hipLaunchKernelGGL(k_label_tile<2>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, (const int *)nullptr, -1, iw, ih, tidy, nms, mask0, zero_plane);
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
-  if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb), dim3(256), 0, s, label, (const int *)tidy, -1, iw, ih, hb);
+  // (this plane is labelled with its background, one component that spans the frame: uniting the tiles of a row first and the rows
+  //  afterwards keeps the trees that the concurrent unions walk shorter than doing both at once - measured 49 against 56 us)
+  if (vb > 0) hipLaunchKernelGGL(k_label_border, dim3(vb), dim3(256), 0, s, label, (const int *)tidy, -1, iw, ih, 0);
+  if (hb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb), dim3(256), 0, s, label, (const int *)tidy, -1, iw, ih, hb);
   if (skip_flatten) return;
   const int n = iw * ih;
   int g = cdiv(n, 256 * 4);
