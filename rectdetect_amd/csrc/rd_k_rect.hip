@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
 // its pixel's own label), which is what the next round and the host test.
 // Memory-latency bound: every thread handles RR_PX pixels (64 columns apart, so each load instruction stays coalesced) and
 // issues all of their label / proposal loads before using any, then the first pointer jumps together.
-#define RR_PX 4
+#define RR_PX 2
 #define RR_VBITS 25
 #define RR_NONE 0x7fffffff
 // (the set a round reads holds only words of that round's predecessor - tag `tag` - or of earlier rounds / the initial fill, whose
