@@ -464,7 +464,7 @@ __device__ __forceinline__ float bicubic(const float *__restrict__ p, float x, f
 // (64+8) x (TT_ROWS+7) tile of the strength plane in LDS with the mirrored border already applied, so a bicubic is one
 // address computation and 16 ds_reads at constant offsets instead of 8 mirror clamps and 16 global gathers.  The outer
 // two samples are only evaluated for local maxima (they do not influence the comparison).
-#define TT_ROWS 16
+#define TT_ROWS 8
 #define TT_PITCH 72
 __device__ __forceinline__ float bicubic_lds(const float *t, float x, float y, int x0, int y0) {
   const int ix = (int)x, iy = (int)y;

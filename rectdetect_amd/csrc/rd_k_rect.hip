@@ -384,7 +384,7 @@ __device__ __forceinline__ unsigned dxmask(int dy, int lo, int hi) {
 
 // block: 64 columns x MM_ROWS rows; the (MM_ROWS + 16) x 3 words x 2 classes of bit rows it needs are staged in LDS with one
 // load per thread (the row loop was a chain of dependent global loads before: latency-bound)
-#define MM_ROWS 16
+#define MM_ROWS 8
 __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const unsigned long long *__restrict__ bits, int iw, int ih, int wpr) {
   __shared__ unsigned long long sb[(MM_ROWS + 16) * 6];
   const int k = blockIdx.x;                 // word holding this block's own 64 columns
