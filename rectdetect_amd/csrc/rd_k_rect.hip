@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_rect_tidy(int *__restrict__ mask0, int 
 //       c > n-1, or (centre on an edge ? !E[c] : !E[c] & E[c+1]).
 // Cells outside the frame are staged as zero, which makes the reference's `c < n-1` and `has side cell` tests redundant.
 // A pixel then reads its five relevant stop bits per direction and counts the leading clear ones.
-#define BE_ROWS 32
+#define BE_ROWS 16
 #define BE_NR (BE_ROWS + 11)          // rows y0-5 .. y0+BE_ROWS+5
 __global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ ext, const int8_t *__restrict__ edge, int iw, int ih) {
   typedef unsigned long long u64;
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const 
 // One block per 64 x RI_ROWS tile: the links that stay inside the tile are followed to their end in LDS (pointer doubling),
 // so every pixel leaves pointing either at the root of its initial tree (if that root lies in the tile) or at the first
 // pixel outside the tile on its way up/left; the few remaining tile-to-tile hops are left to k_region_flatten.
-#define RI_ROWS 32
+#define RI_ROWS 16
 __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, int *__restrict__ prop, int *__restrict__ selfp, int *__restrict__ prop1, int *__restrict__ selfp1, const int *__restrict__ pix, const int *__restrict__ mask,
                                                      const int *__restrict__ edge, int iw, int ih, int *__restrict__ flags, int *__restrict__ size_out, const int *__restrict__ size_init) {
   __shared__ int par[64 * RI_ROWS];     // >= 0: tile-local index of the parent; < 0: -(global index) - 1 of a parent outside the tile
