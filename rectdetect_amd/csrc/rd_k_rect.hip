@@ -1279,7 +1279,7 @@ void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int 
     const bool last = r == DOUBLE_ROUNDS - 1;
     // (the work lists shrink by an order of magnitude per launch: later launches need few blocks, and dispatching blocks that
     //  find nothing to do is what an almost empty launch costs)
-    hipLaunchKernelGGL(k_despeckle2_active, dim3(r < 2 ? 512 : (r < 4 ? 128 : 32)), dim3(256), 0, s, nxt, cur, (const int *)(lists + (size_t)li * n), (const int *)(count + li),
+    hipLaunchKernelGGL(k_despeckle2_active, dim3(r < 2 ? 512 : 128), dim3(256), 0, s, nxt, cur, (const int *)(lists + (size_t)li * n), (const int *)(count + li),
                        last ? (int *)nullptr : lists + (size_t)lo * n, count + lo, count + lz, count + 3 + r, stamp, r + 1, in, size, thre, iw, ih);
     cur = nxt;
   }
