@@ -93,7 +93,13 @@ def test_product_does_not_reference_the_oracle():
 
 def test_example_programs_build_against_the_headers():
     """examples/rdrect.c and rdvid.c are written against include/*.h only (the reference's API) and link with the library"""
-    import subprocess
     subprocess.check_call(["make", "-C", os.path.join(helpers.ROOT, "examples")], stdout=subprocess.DEVNULL)
     for exe in ("rdrect", "rdvid", "rdpoly"):
         assert os.access(os.path.join(helpers.ROOT, "examples", exe), os.X_OK)
+
+
+def test_blur_division_formula_is_exact():
+    """the edge-stopped blur replaces floor(s / w) by trunc(fma(float(s), 1/w, 0.5/w)) (rd_k_rect.hip: div_small_f); the formula is
+    checked for every operand pair the kernel can produce"""
+    out = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tools", "check_div_small.py")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "exact" in out.stdout, out.stdout + out.stderr
