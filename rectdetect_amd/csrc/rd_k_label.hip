@@ -257,11 +257,16 @@ __global__ __launch_bounds__(256) void k_label_border(int *label, const int *__r
 // (vt_*, optional: block 0 also undoes the previous frame's entries of the vote tables - what k_reduce_clean does - so that the
 //  vote kernels that follow the boundary labelling find them clean without a launch of their own)
 __global__ __launch_bounds__(256) void k_label_flatten(int *label, int n, int *vt_table, int *vt_claim, int *vt_list) {
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int l = label[i];
-    if (l >= 0) {
-      const int r = uf_find(label, l);
-      if (r != l) label[i] = r;
+  const int stride = gridDim.x * blockDim.x;
+  for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * 4) {      // four pixels per step: their first loads are in flight together
+    int l[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int i = i0 + k * stride; l[k] = i < n ? label[i] : -1; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (l[k] < 0) continue;
+      const int r = uf_find(label, l[k]);
+      if (r != l[k]) label[i0 + k * stride] = r;
     }
   }
   if (vt_list != nullptr && blockIdx.x == 0) {

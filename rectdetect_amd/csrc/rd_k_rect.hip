@@ -655,12 +655,20 @@ __global__ void k_region_finish(int *label, const int *__restrict__ propP, const
 __global__ void k_region_flatten(int *label, int n, int *flags, int round) {
   if (round > 0 && flags[round - 1] == 0) return;
   bool changed = false;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int l = label[i];
-    int a = label[l];
-    if (a != l) {
-      for (int j = 0; j < 14; j++) { const int b = label[a]; if (b == a) break; a = b; }   // (most chains end after a jump or two)
-      label[i] = a;
+  const int stride = gridDim.x * blockDim.x;
+  for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * 4) {     // four pixels per step: their first two jumps are in flight together
+    int l[4], a[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { const int i = i0 + k * stride; l[k] = label[i < n ? i : 0]; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) a[k] = label[l[k]];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int i = i0 + k * stride;
+      if (i >= n || a[k] == l[k]) continue;
+      int r = a[k];
+      for (int j = 0; j < 14; j++) { const int b = label[r]; if (b == r) break; r = b; }   // (most chains end after a jump or two)
+      label[i] = r;
       changed = true;
     }
   }
