@@ -770,14 +770,25 @@ __global__ __launch_bounds__(256) void k_despeckle2_first(int *__restrict__ nxt,
   }
   __syncthreads();
   const int x = blockIdx.x * 64 + threadIdx.x;
-  for (int r = threadIdx.y; r < D2_ROWS; r += 4) {
+  // the labels and region sizes of this thread's D2_ROWS / 4 pixels: two levels of loads, each issued for all of them together
+  int l0s[D2_ROWS / 4], szs[D2_ROWS / 4];
+#pragma unroll
+  for (int k = 0; k < D2_ROWS / 4; k++) {
+    const int y = blockIdx.y * D2_ROWS + threadIdx.y + 4 * k;
+    l0s[k] = old[(x < iw && y < ih) ? y * iw + x : 0];
+  }
+#pragma unroll
+  for (int k = 0; k < D2_ROWS / 4; k++) szs[k] = size[l0s[k]];
+#pragma unroll
+  for (int k = 0; k < D2_ROWS / 4; k++) {
+    const int r = threadIdx.y + 4 * k;
     const int y = blockIdx.y * D2_ROWS + r;
     const bool inside = x < iw && y < ih;
     const int p0 = y * iw + x;
     bool small = false;
     if (inside) {
-      const int l0 = old[p0];
-      small = size[l0] <= thre;
+      const int l0 = l0s[k];
+      small = szs[k] <= thre;
       nxt[p0] = small ? despeckle2_pick(old, old, size, l0, x, y, iw, ih) : l0;
       other[p0] = l0;
       stamp[p0] = small ? 0 : 0x7fffffff;      // work-list stamps (k_despeckle2_active): other pixels never enter a list
