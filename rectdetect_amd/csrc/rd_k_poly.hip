@@ -281,14 +281,24 @@ __global__ void k_flatten(int *lab, const int *ctr, int *ends, const int *deg, i
 __global__ void k_find_ends0(PolyScratch s) {
   const int cnt = s.ctr[0];
   SPARSE_LOOP(i, cnt) {
-    auto living = [&](int j) { return !(s.lab[j] == j && s.ends[j] == 0); };
+    // (the eight neighbours, then their labels and end counts: two levels of loads, each issued together)
+    int nb[8], lb[8], eb[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) nb[k] = s.nbr[i * 8 + k];
+    const int li = s.lab[i], ei = s.ends[i];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const int j = nb[k] >= 0 ? nb[k] : i; lb[k] = s.lab[j]; eb[k] = s.ends[j]; }
     int a = i, b = i;
-    const bool me = living(i);
+    const bool me = !(li == i && ei == 0);
     s.alive[i] = me ? 1 : 0;
     if (me) {
-      int k = 0;
-      for (; k < 8; k++) { const int j = s.nbr[i * 8 + k]; if (j >= 0 && living(j)) { a = j; break; } }
-      for (k++; k < 8; k++) { const int j = s.nbr[i * 8 + k]; if (j >= 0 && living(j)) { b = j; break; } }
+      int found = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const bool living = nb[k] >= 0 && !(lb[k] == nb[k] && eb[k] == 0);
+        if (living && found == 0) { a = nb[k]; found = 1; }
+        else if (living && found == 1) { b = nb[k]; found = 2; }
+      }
     }
     s.nx[0][i] = a; s.pv[0][i] = b;
   }
@@ -337,9 +347,18 @@ __global__ void k_find_ends1(PolyScratch s, int page, int final) {
     else { f &= (3 << 2); f |= revn ? 1 : 0; f |= revp ? 2 : 0; }
     fout[i] = f;
     if (final) {
-      int a = i, b = i, k = 0;
-      for (; k < 8; k++) { const int j = s.nbr[i * 8 + k]; if (j >= 0 && s.alive[j]) { a = j; break; } }
-      for (k++; k < 8; k++) { const int j = s.nbr[i * 8 + k]; if (j >= 0 && s.alive[j]) { b = j; break; } }
+      int nb[8], al[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) nb[k] = s.nbr[i * 8 + k];
+#pragma unroll
+      for (int k = 0; k < 8; k++) al[k] = s.alive[nb[k] >= 0 ? nb[k] : i];
+      int a = i, b = i, found = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const bool living = nb[k] >= 0 && al[k] != 0;
+        if (living && found == 0) { a = nb[k]; found = 1; }
+        else if (living && found == 1) { b = nb[k]; found = 2; }
+      }
       const int lk = nn < pp ? a : b;
       s.num[0][i] = lk == i ? 0 : 1; s.link[0][i] = lk;
     }
