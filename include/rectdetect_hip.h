@@ -56,7 +56,7 @@ long rd_detector_counter(rd_detector *d, int which);
 
 /* Test hook: copy an internal plane of the most recently completed frame to host memory.  Returns bytes written,
  * 0 for an unknown name.  Names: plab0 plab1 lblur vxy strength nms mask0 tidy label1 strsum edge500 smooth quant
- * strong junction mergemask region rsize boundarysrc boundary lsid */
+ * strong junction mergemask region0 (merged regions) rsize region (after absorbing small ones) boundarysrc boundary lsid table */
 size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size_t max_bytes);
 
 /* timing of the device stages of the last drained batch, microseconds per named stage (NULL-terminated names) */

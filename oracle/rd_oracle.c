@@ -642,6 +642,9 @@ void *rdo_rect_plane(rdo_rect_t *c, const char *name) {
   return NULL;
 }
 
+void rdo_rect_set_region_mode(rdo_rect_t *c, int mode) { c->region_mode = mode; }
+int rdo_rect_info(const rdo_rect_t *c, int which) { return which == 0 ? c->region_mode : which == 1 ? c->region_rounds : which == 2 ? c->absorb_rounds : -1; }
+
 void rdo_rect_frame(rdo_rect_t *c, const uint8_t *bgr, int ws) {
   const int iw = c->iw, ih = c->ih, N = iw * ih;
   float *fa = (float *)malloc(sizeof(float) * N), *fb = (float *)malloc(sizeof(float) * N);
@@ -690,11 +693,14 @@ void rdo_rect_frame(rdo_rect_t *c, const uint8_t *bgr, int ws) {
   rdo_merge_mask(c->mergemask, c->junction, iw, ih);
 
   /* rh:325-336 regions */
-  rdo_region_label_init(c->region, (const int *)c->quant, iw, ih);
-  for (int i = 0; i < 8; i++) rdo_region_merge_pass(c->region, (const int *)c->quant, c->mergemask, c->label1, iw, ih);
+  if (c->region_mode == 0) {                               /* the reference in serial raster order */
+    rdo_region_label_init(c->region, (const int *)c->quant, iw, ih);
+    for (int i = 0; i < 8; i++) rdo_region_merge_pass(c->region, (const int *)c->quant, c->mergemask, c->label1, iw, ih);
+  } else c->region_rounds = rdo_region_sync(c->region, (const int *)c->quant, c->mergemask, c->label1, iw, ih, RDO_REGION_SYNC_MAX_ROUNDS);
   memcpy(c->rsize, c->junction, sizeof(int) * N);          /* H2: size plane still holds the junction counts */
   rdo_region_size(c->rsize, c->region, N);
-  rdo_despeckle2(c->region, c->rsize, 16, iw, ih);
+  if (c->region_mode == 0) rdo_despeckle2(c->region, c->rsize, 16, iw, ih);
+  else c->absorb_rounds = rdo_despeckle2_jacobi_k(c->region, c->rsize, 16, iw, ih, NULL, RDO_DESPECKLE2_JACOBI_ROUNDS);
 
   /* rh:340-342 region boundaries and their components */
   rdo_mark_boundary(c->boundary_src, c->region, iw, ih);
@@ -710,93 +716,71 @@ void rdo_rect_frame(rdo_rect_t *c, const uint8_t *bgr, int ws) {
   free(fa); free(fb); free(ba); free(bb); free(t0); free(t1); free(e8);
 }
 
-/* ------------------------------------------------------------------ experiments for the GPU formulation */
+/* ------------------------------------------------------------------ SPEC of the order-free region schedule
+ *
+ * The reference's labelMergeMain (rc:300-334, 8 in-place launches) and despeckle2 (rc:348-371, in place) give results that
+ * depend on the order in which work-items run: a device is free to pick any order, the serial raster
+ * order of rdo_region_merge_pass / rdo_despeckle2 above is only one of them, and no parallel schedule reproduces it.
+ * The HIP path therefore evaluates the SAME per-pixel rules in a schedule that has no order in it, and this section is
+ * the normative definition of that schedule ("region mode 1" of rdo_rect_frame).  GPU tests compare the region, rsize,
+ * boundary_src, boundary and table planes bit for bit against it (tests/test_gpu_parity.py). */
 
-/* Candidate closed form of the 8 rc:300-334 passes: components of the graph that has an (undirected) edge
- * p0 - p1 whenever the kernel would let p0 adopt p1's label (4-neighbours, interior p0), label = smallest index. */
-void rdo_region_cc(int *label, const int *pix, const int *mask, const int *edge, int iw, int ih) {
+/* rc:289-334 evaluated in SYNCHRONOUS rounds.
+ *   start:  every pixel points at the root of its tree of initial links (rc:289-298; links go to smaller indices, so one
+ *           ascending sweep resolves them);
+ *   round:  every interior pixel evaluates rc:308-333 on the labels of the PREVIOUS round - the smallest label among itself
+ *           and the neighbours it may adopt from, followed by the kernel's 8 pointer jumps - and, when that differs from its
+ *           label, proposes it for itself and for its old label's pixel; all proposals of a round take effect together
+ *           (minimum per target), which is what atomic_min does to concurrent work-items;
+ *   end:    the first round without a proposal, or max_rounds rounds (the HIP path launches at most 20).
+ * Returns the number of rounds evaluated (the last one of which made no proposal unless max_rounds was hit). */
+int rdo_region_sync(int *label, const int *pix, const int *mask, const int *edge, int iw, int ih, int max_rounds) {
   const int N = iw * ih;
   rdo_region_label_init(label, pix, iw, ih);
-  /* the initialisation links are unions too */
-  int *lab = (int *)malloc(sizeof(int) * N);
-  for (int p = 0; p < N; p++) lab[p] = p;
-  for (int p = 0; p < N; p++) if (label[p] != p) uf_union(lab, p, label[p]);
-  for (int y = 1; y < ih - 1; y++)
-    for (int x = 1; x < iw - 1; x++) {
-      const int p0 = y * iw + x;
-      const int any = mask[p0] != 0;
-      int p1;
-      p1 = p0 - iw; if ((pix[p0] == pix[p1] || any) && edge[p0] <= 0) uf_union(lab, p0, p1);
-      p1 = p0 - 1;  if ((pix[p0] == pix[p1] || any) && edge[p0] <= 0) uf_union(lab, p0, p1);
-      p1 = p0 + 1;  if ((pix[p0] == pix[p1] || any) && edge[p1] <= 0) uf_union(lab, p0, p1);
-      p1 = p0 + iw; if ((pix[p0] == pix[p1] || any) && edge[p1] <= 0) uf_union(lab, p0, p1);
-    }
-  for (int p = 0; p < N; p++) label[p] = uf_find(lab, p);
-  free(lab);
-}
-
-/* same per-pixel rule as rdo_region_merge_pass, but (a) any visiting order, (b) optional synchronous
- * (double-buffered) update, (c) full root search instead of 8 jumps.  Returns number of changed pixels. */
-int rdo_region_merge_pass_x(int *label, const int *pix, const int *mask, const int *edge, int iw, int ih, int mode) {
-  const int N = iw * ih;
-  int *src = label, *snap = NULL;
-  if (mode == 2) { snap = (int *)malloc(sizeof(int) * N); memcpy(snap, label, sizeof(int) * N); src = snap; }
-  int changed = 0;
-  for (int k = 0; k < N; k++) {
-    const int p0 = mode == 1 ? N - 1 - k : k;
-    const int x = p0 % iw, y = p0 / iw;
-    if (x <= 0 || y <= 0 || x >= iw - 1 || y >= ih - 1) continue;
-    int g = src[p0];
-    const int og = g;
-    const int any = mask[p0] != 0;
-    int p1, s;
-    p1 = p0 - iw; s = src[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p0] <= 0) g = s;
-    p1 = p0 - 1;  s = src[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p0] <= 0) g = s;
-    p1 = p0 + 1;  s = src[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p1] <= 0) g = s;
-    p1 = p0 + iw; s = src[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p1] <= 0) g = s;
-    while (src[g] != g) g = src[g];
-    if (g != og) {
-      if (g < label[og]) { label[og] = g; changed++; }
-      if (g < label[p0]) { label[p0] = g; changed++; }
-    }
+  for (int p = 0; p < N; p++) label[p] = label[label[p]];      /* label[p] <= p, and label[label[p]] is final already */
+  int *nxt = (int *)malloc(sizeof(int) * N);
+  int rounds = 0;
+  while (rounds < max_rounds) {
+    int changed = 0;
+    memcpy(nxt, label, sizeof(int) * N);
+    for (int y = 1; y < ih - 1; y++)
+      for (int x = 1; x < iw - 1; x++) {
+        const int p0 = y * iw + x;
+        const int og = label[p0];
+        int g = og;
+        const int any = mask[p0] != 0;
+        int p1, s;
+        p1 = p0 - iw; s = label[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p0] <= 0) g = s;
+        p1 = p0 - 1;  s = label[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p0] <= 0) g = s;
+        p1 = p0 + 1;  s = label[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p1] <= 0) g = s;
+        p1 = p0 + iw; s = label[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p1] <= 0) g = s;
+        for (int j = 0; j < 8; j++) g = label[g];
+        if (g != og) {
+          if (g < nxt[og]) nxt[og] = g;
+          if (g < nxt[p0]) nxt[p0] = g;
+          changed = 1;
+        }
+      }
+    memcpy(label, nxt, sizeof(int) * N);
+    rounds++;
+    if (!changed) break;
   }
-  free(snap);
-  return changed;
+  free(nxt);
+  return rounds;
 }
 
-/* experiment: pure min-label propagation (no hooking of the old parent), alternating sweep directions */
-int rdo_region_propagate_pass(int *label, const int *pix, const int *mask, const int *edge, int iw, int ih, int reverse) {
-  const int N = iw * ih;
-  int changed = 0;
-  for (int k = 0; k < N; k++) {
-    const int p0 = reverse ? N - 1 - k : k;
-    const int x = p0 % iw, y = p0 / iw;
-    if (x <= 0 || y <= 0 || x >= iw - 1 || y >= ih - 1) continue;
-    int g = label[p0];
-    const int any = mask[p0] != 0;
-    int p1, s;
-    p1 = p0 - iw; s = label[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p0] <= 0) g = s;
-    p1 = p0 - 1;  s = label[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p0] <= 0) g = s;
-    p1 = p0 + 1;  s = label[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p1] <= 0) g = s;
-    p1 = p0 + iw; s = label[p1]; if (s < g && (pix[p0] == pix[p1] || any) && edge[p1] <= 0) g = s;
-    if (g != label[p0]) { label[p0] = g; changed++; }
-  }
-  return changed;
-}
-
-/* experiment: Jacobi evaluation of rdo_despeckle2's raster-order recurrence; returns rounds until fixpoint */
-int rdo_despeckle2_jacobi_k(int *label, const int *size, int thre, int iw, int ih, int *nsmall, int max_rounds);
-int rdo_despeckle2_jacobi(int *label, const int *size, int thre, int iw, int ih, int *nsmall) { return rdo_despeckle2_jacobi_k(label, size, thre, iw, ih, nsmall, 1 << 30); }
-
-/* the same with a bound on the rounds (the HIP path runs 8) */
+/* rc:348-371 as `max_rounds` JACOBI rounds of the raster-order recurrence: in round r+1 a small-region pixel picks the
+ * largest region among its 3x3 neighbourhood, reading the round-r labels of the four neighbours that precede it in raster
+ * order (NW, N, NE, W) and the input labels of the others.  The fixed point of this iteration IS the serial raster result
+ * (rdo_despeckle2); the HIP path evaluates 27 rounds.  Returns the rounds evaluated, *nsmall = pixels of small regions. */
 int rdo_despeckle2_jacobi_k(int *label, const int *size, int thre, int iw, int ih, int *nsmall, int max_rounds) {
   const int N = iw * ih;
   int *old = (int *)malloc(sizeof(int) * N), *cur = (int *)malloc(sizeof(int) * N), *nxt = (int *)malloc(sizeof(int) * N);
   memcpy(old, label, sizeof(int) * N); memcpy(cur, label, sizeof(int) * N);
   int rounds = 0, ns = 0;
   for (int p = 0; p < N; p++) if (size[old[p]] <= thre) ns++;
-  *nsmall = ns;
-  for (;;) {
+  if (nsmall) *nsmall = ns;
+  while (rounds < max_rounds) {
     int changed = 0;
     memcpy(nxt, cur, sizeof(int) * N);
     for (int y = 0; y < ih; y++)
@@ -815,58 +799,10 @@ int rdo_despeckle2_jacobi_k(int *label, const int *size, int thre, int iw, int i
       }
     memcpy(cur, nxt, sizeof(int) * N);
     rounds++;
-    if (!changed || rounds >= max_rounds) break;
+    if (!changed) break;
   }
   memcpy(label, cur, sizeof(int) * N);
   free(old); free(cur); free(nxt);
-  return rounds;
-}
-
-/* experiment "S": (1) union-find over the initial links and the symmetric allowed pairs, (2) synchronous rounds of
- * root-level adoption over the asymmetric pairs (masked pixel may adopt a differently coloured neighbour's tree). */
-int rdo_region_S(int *label, const int *pix, const int *mask, const int *edge, int iw, int ih) {
-  const int N = iw * ih;
-  int *lab = (int *)malloc(sizeof(int) * N), *nxt = (int *)malloc(sizeof(int) * N);
-  rdo_region_label_init(label, pix, iw, ih);
-  for (int p = 0; p < N; p++) lab[p] = p;
-  for (int p = 0; p < N; p++) if (label[p] != p) uf_union(lab, p, label[p]);
-  for (int y = 1; y < ih - 1; y++)
-    for (int x = 1; x < iw - 1; x++) {
-      const int p0 = y * iw + x;
-      const int nb[4] = { p0 - iw, p0 - 1, p0 + 1, p0 + iw };
-      for (int k = 0; k < 4; k++) {
-        const int p1 = nb[k];
-        const int eok = k < 2 ? edge[p0] <= 0 : edge[p1] <= 0;
-        if (!eok) continue;
-        const int x1 = p1 % iw, y1 = p1 / iw;
-        const int p1_interior = x1 > 0 && y1 > 0 && x1 < iw - 1 && y1 < ih - 1;
-        if (pix[p0] == pix[p1] || (mask[p0] != 0 && mask[p1] != 0 && p1_interior)) uf_union(lab, p0, p1);
-      }
-    }
-  int rounds = 0;
-  for (;;) {
-    for (int p = 0; p < N; p++) lab[p] = uf_find(lab, p);
-    for (int p = 0; p < N; p++) nxt[p] = lab[p];
-    int changed = 0;
-    for (int y = 1; y < ih - 1; y++)
-      for (int x = 1; x < iw - 1; x++) {
-        const int p0 = y * iw + x;
-        if (mask[p0] == 0) continue;
-        const int nb[4] = { p0 - iw, p0 - 1, p0 + 1, p0 + iw };
-        for (int k = 0; k < 4; k++) {
-          const int p1 = nb[k];
-          const int eok = k < 2 ? edge[p0] <= 0 : edge[p1] <= 0;
-          if (!eok || pix[p0] == pix[p1]) continue;
-          const int ra = lab[p0], rb = lab[p1];
-          if (rb < ra && rb < nxt[ra]) { nxt[ra] = rb; changed = 1; }
-        }
-      }
-    rounds++;
-    if (!changed) break;
-    for (int p = 0; p < N; p++) if (lab[p] == p && nxt[p] < p) lab[p] = nxt[p];
-  }
-  for (int p = 0; p < N; p++) label[p] = lab[p];
-  free(lab); free(nxt);
   return rounds;
 }
 

@@ -52,6 +52,11 @@ void rdo_region_merge_pass(int *label, const int *pix, const int *mask, const in
 void rdo_region_size(int *out, const int *label, int n);
 void rdo_despeckle2(int *label, const int *size, int thre, int iw, int ih);
 void rdo_mark_boundary(int *out, const int *in, int iw, int ih);
+/* SPEC of the order-free schedule the HIP path uses for the region stages (see rd_oracle.c) */
+#define RDO_REGION_SYNC_MAX_ROUNDS 20
+#define RDO_DESPECKLE2_JACOBI_ROUNDS 27
+int rdo_region_sync(int *label, const int *pix, const int *mask, const int *edge, int iw, int ih, int max_rounds);
+int rdo_despeckle2_jacobi_k(int *label, const int *size, int thre, int iw, int ih, int *nsmall, int max_rounds);
 void rdo_reduce_ls(int *table, const int *boundary, const int *lsid, int iw, int ih, int nentry);
 
 /* oclpolyline_execute (oclpolyline.c:218-309).  lslist: lslist_bytes bytes, record 0 = header.
@@ -69,12 +74,16 @@ typedef struct {
   int *strong, *junction, *mergemask, *region, *rsize, *boundary_src, *boundary, *lsid;
   void *lslist;
   int *table;
+  int region_mode;      /* 0: the reference's in-place kernels in serial raster order; 1: the order-free SPEC schedule (rdo_region_sync + 27 Jacobi rounds) */
+  int region_rounds, absorb_rounds;   /* mode 1: rounds the last frame's merge / absorption evaluated */
 } rdo_rect_t;
 
 rdo_rect_t *rdo_rect_new(int iw, int ih);
 void rdo_rect_free(rdo_rect_t *c);
 void *rdo_rect_plane(rdo_rect_t *c, const char *name);
 void rdo_rect_frame(rdo_rect_t *c, const uint8_t *bgr, int ws);
+void rdo_rect_set_region_mode(rdo_rect_t *c, int mode);
+int rdo_rect_info(const rdo_rect_t *c, int which);   /* 0: region_mode, 1: region_rounds, 2: absorb_rounds */
 
 /* poly.cpp:104-123 device part: ids (N ints) and lslist (16N bytes) */
 void rdo_poly_frame(void *lslist, int *ids, const uint8_t *bgr, int iw, int ih, int ws, int strengthThre, float minerror, int sizeThre);

@@ -260,6 +260,32 @@ cl_int clSetKernelArg(cl_kernel k, cl_uint idx, size_t size, const void *val) {
   return CL_SUCCESS;
 }
 
+/* ---------------------------------------------------------------- work-item order (default: raster, dimension 0 fastest)
+ * OpenCL leaves the order in which work-items run to the device.  rdcl_set_order(filter, gw, gh, group_order, seed) makes the
+ * launches of the kernels named in `filter` ("prog:kernel,prog:kernel,..."; NULL or "" = every kernel) run in another LEGAL
+ * order, so that tests can see which of the reference's results depend on it: the NDRange is cut into
+ * work-groups of gw x gh items (0 x 0: one group = the whole range), items inside a group run in raster order, and the
+ * groups are visited in group_order 0 = raster, 1 = reversed raster, 2 = column-major, 3 = scrambled (a stride walk that
+ * depends on `seed`).  group_order 4 = the whole range in reversed raster order (items too). */
+static int order_on = 0, order_gw = 0, order_gh = 0, order_go = 0, order_seed = 0;
+static char order_filter[512] = "";
+void rdcl_set_order(const char *filter, int gw, int gh, int group_order, int seed) {
+  order_on = !(gw == 0 && gh == 0 && group_order == 0);
+  order_gw = gw; order_gh = gh; order_go = group_order; order_seed = seed;
+  snprintf(order_filter, sizeof(order_filter), "%s", filter ? filter : "");
+}
+static size_t gcd_sz(size_t a, size_t b) { while (b) { size_t t = a % b; a = b; b = t; } return a; }
+static int order_applies(const struct _cl_kernel *k) {
+  if (!order_on) return 0;
+  if (order_filter[0] == '\0') return 1;
+  char full[96];
+  snprintf(full, sizeof(full), "%s:%s", prog_tag[k->prog.which], k->name);
+  const size_t n = strlen(full);
+  for (const char *p = order_filter; (p = strstr(p, full)) != NULL; p += n)
+    if ((p == order_filter || p[-1] == ',') && (p[n] == '\0' || p[n] == ',')) return 1;
+  return 0;
+}
+
 typedef void (*generic_fn)(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
                            int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
                            float, float, float, float);
@@ -294,14 +320,31 @@ cl_int clEnqueueNDRangeKernel(cl_command_queue q, cl_kernel k, cl_uint dim, cons
   size_t *gid = k->prog.gid;
   size_t g0 = gws[0], g1 = dim == 2 ? gws[1] : 1;
   gid[2] = 0;
-  for (size_t y = 0; y < g1; y++) {
-    gid[1] = y;
-    for (size_t x = 0; x < g0; x++) {
-      gid[0] = x;
-      fn(ia[0], ia[1], ia[2], ia[3], ia[4], ia[5], ia[6], ia[7], ia[8], ia[9], ia[10], ia[11], ia[12], ia[13], ia[14], ia[15],
-         fa[0], fa[1], fa[2], fa[3]);
+#define RUN_ITEM(X, Y) do { gid[0] = (X); gid[1] = (Y); \
+      fn(ia[0], ia[1], ia[2], ia[3], ia[4], ia[5], ia[6], ia[7], ia[8], ia[9], ia[10], ia[11], ia[12], ia[13], ia[14], ia[15], \
+         fa[0], fa[1], fa[2], fa[3]); } while (0)
+  if (!order_applies(k)) {
+    for (size_t y = 0; y < g1; y++) for (size_t x = 0; x < g0; x++) RUN_ITEM(x, y);
+  } else if (order_go == 4) {
+    for (size_t y = g1; y-- > 0;) for (size_t x = g0; x-- > 0;) RUN_ITEM(x, y);
+  } else {
+    const size_t tw = order_gw > 0 ? (size_t)order_gw : g0, th = order_gh > 0 ? (size_t)order_gh : g1;
+    const size_t nx = (g0 + tw - 1) / tw, ny = (g1 + th - 1) / th, nt = nx * ny;
+    size_t step = 1, start = 0;
+    if (order_go == 3 && nt > 1) {
+      step = (7919u + 104729u * (size_t)order_seed) % nt; if (step == 0) step = 1;
+      while (gcd_sz(step, nt) != 1) step++;
+      start = (nt / 3 + 31u * (size_t)order_seed) % nt;
+    }
+    for (size_t i = 0, t = start; i < nt; i++, t = (t + step) % nt) {
+      size_t g = order_go == 3 ? t : i;
+      if (order_go == 1) g = nt - 1 - i;
+      const size_t gx = order_go == 2 ? g / ny : g % nx, gy = order_go == 2 ? g % ny : g / nx;
+      const size_t tx = gx * tw, ty = gy * th;
+      for (size_t y = ty; y < ty + th && y < g1; y++) for (size_t x = tx; x < tx + tw && x < g0; x++) RUN_ITEM(x, y);
     }
   }
+#undef RUN_ITEM
 
   if (trace_on) {
     char full[96];

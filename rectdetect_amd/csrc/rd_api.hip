@@ -762,7 +762,7 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
     { "plab0", s->plab0, N * 4 }, { "plab1", s->plab1, N * 4 }, { "lblur", s->bl[0], N * 4 }, { "vxy", s->vxy, N * 8 }, { "strength", s->strength, N * 4 },
     { "nms", s->nms, N * 4 }, { "mask0", s->mask0, N * 4 }, { "tidy", s->tidy, N * 4 }, { "label1", s->label1, N * 4 }, { "strsum", s->strsum, N * 4 },
     { "edge500", s->edge500, N * 4 }, { "smooth", s->smooth, N * 4 }, { "quant", s->quant, N * 4 }, { "strong", s->strong, N * 4 }, { "junction", s->junction, N * 4 },
-    { "mergemask", s->mergemask, N * 4 }, { "region", s->region, N * 4 }, { "rsize", s->rsize, N * 4 }, { "boundarysrc", s->boundarysrc, N * 4 },
+    { "mergemask", s->mergemask, N * 4 }, { "region", s->region, N * 4 }, { "region0", s->region0, N * 4 }, { "rsize", s->rsize, N * 4 }, { "boundarysrc", s->boundarysrc, N * 4 },
     { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 }, { "polyctr", rdk::poly_scratch_counters(s->ps), 64 * 4 }, { "iirflags", s->flags, 16 * 4 }, { "d2work", s->d2s + N, 16 * 4 },
   };
   for (size_t i = 0; i < sizeof(tab) / sizeof(tab[0]); i++)

@@ -76,170 +76,224 @@ static vec2 line_intersection(seg2 u, seg2 v) {
   return cvec2(v.e0.a[0] + q * (v.e1.a[0] - v.e0.a[0]), v.e0.a[1] + q * (v.e1.a[1] - v.e0.a[1]));
 }
 
-static vec3 cross3v(vec3 v, vec3 w) {
-  return cvec3(v.a[1] * w.a[2] - v.a[2] * w.a[1], v.a[2] * w.a[0] - v.a[0] * w.a[2], v.a[0] * w.a[1] - v.a[1] * w.a[0]);
+/* ------------------------------------------------------------------ pose of a quadrilateral (behaviour of rh:427-656)
+ *
+ * Four image corners define four unit viewing rays r_i; wanted are depths t_i such that the points P_i = t_i r_i form a planar
+ * rectangle.  The reference minimises a 12-term residual twice - once for each way of pairing the sides with the unit
+ * length ("pairing" 0 and 1) - by a diagonally preconditioned non-linear conjugate-gradient descent with finite-difference
+ * derivatives, and keeps the better one.  The two descents do not depend on each other, so they are carried through the
+ * iteration side by side here (index m; structure of arrays): on the host that is a loop of two, in a device port it is the
+ * lane index.  What is fixed by the reference is the arithmetic - every sum below is evaluated in the
+ * reference's operand order, because the rect_t doubles must match bit for bit - not the decomposition, which is ours.
+ */
+#define PAIRINGS 2
+#define FD_STEP (1e-6)        /* finite-difference step (rh:430) */
+#define CG_STEPS 12           /* rh:611,618 */
+#define WALK_STEPS 10         /* Newton steps per line search (rh:611,618) */
+#define CG_RESTART 10         /* steepest-descent restart period (rh:575) */
+
+typedef struct { double r[4][3]; } rays4;
+
+enum { S01, S12, S23, S03, S02, S13, NSIDES };                       /* squared distances between P_a and P_b */
+static const int side_a[NSIDES] = { 0, 1, 2, 0, 0, 1 }, side_b[NSIDES] = { 1, 2, 3, 3, 2, 3 };
+/* per pairing: the two sides that must have length 1, the side that scales the relative terms, and the corner that
+ * takes part first in the two parallelogram defects (the other one is its opposite, 2 - first) */
+static const int unit_p[PAIRINGS] = { S03, S23 }, unit_q[PAIRINGS] = { S12, S01 }, scale_s[PAIRINGS] = { S01, S12 }, first_c[PAIRINGS] = { 2, 0 };
+
+static inline double sum_sq3(const double w[3]) { return w[0] * w[0] + w[1] * w[1] + w[2] * w[2]; }
+static inline double inner3(const double u[3], const double w[3]) { return u[0] * w[0] + u[1] * w[1] + u[2] * w[2]; }
+static inline void normal_of(const double P[4][3], int apex, int i, int j, double n[3]) {      /* (P_i - P_apex) x (P_j - P_apex) */
+  double u[3], w[3];
+  for (int c = 0; c < 3; c++) { u[c] = P[i][c] - P[apex][c]; w[c] = P[j][c] - P[apex][c]; }
+  n[0] = u[1] * w[2] - u[2] * w[1]; n[1] = u[2] * w[0] - u[0] * w[2]; n[2] = u[0] * w[1] - u[1] * w[0];
 }
 
-/* ------------------------------------------------------------------ pose estimation (rh:427-634) */
-/* Unknowns: the depths of the four corner rays.  The residual asks for a planar rectangle with unit sides in one of two
- * pairings (mode).  Minimised by a diagonally preconditioned non-linear CG with numerical derivatives. */
-
-typedef struct { const vec3 *ray; int mode; } pose_arg;
-
-#define POSE_EPS (1e-6)
-
-static double pose_residual(vec4 v, const pose_arg *arg) {
-  const vec3 *ray = arg->ray;
-  const int mode = arg->mode;
-  vec3 q[4];
-  for (int i = 0; i < 4; i++) q[i] = dot3(ray[i], v.a[i]);
-
-  double score = 0;
-  const double l01 = distanceSqu3(q[0], q[1]), l12 = distanceSqu3(q[1], q[2]), l23 = distanceSqu3(q[2], q[3]);
-  const double l03 = distanceSqu3(q[0], q[3]), l02 = distanceSqu3(q[0], q[2]), l13 = distanceSqu3(q[1], q[3]);
-
-  score += sq((mode ? l23 : l03) - 1);
-  score += sq((mode ? l01 : l12) - 1);
-  const double comp = 1.0 / (mode ? l12 : l01);
-
-  score += lengthSqu3(plus3(minus3(mode ? q[0] : q[2], q[1]), minus3(mode ? q[2] : q[0], q[3])));
-  score += comp * lengthSqu3(plus3(minus3(q[1], mode ? q[2] : q[0]), minus3(q[3], mode ? q[0] : q[2])));
-
-  score += sq(l01 + l12 - l02);
-  score += sq(l03 + l23 - l02);
-  score += sq(l01 + l03 - l13);
-  score += sq(l12 + l23 - l13);
-
-  const vec3 n013 = cross3v(minus3(q[1], q[0]), minus3(q[3], q[0]));
-  score += comp * sq(vdot3(n013, q[2]) - vdot3(n013, q[0])) / vdot3(n013, n013);
-  const vec3 n102 = cross3v(minus3(q[0], q[1]), minus3(q[2], q[1]));
-  score += comp * sq(vdot3(n102, q[3]) - vdot3(n102, q[1])) / vdot3(n102, n102);
-  return score;
+/* the residual of pairing m at depths t (rh:442-477: two unit sides, two parallelogram defects, four right angles by
+ * Pythagoras, two planarity terms; the relative terms are divided by the squared length of the free side) */
+static double rect_defect(const rays4 *R, int m, const double t[4]) {
+  double P[4][3], L[NSIDES];
+  for (int i = 0; i < 4; i++) for (int c = 0; c < 3; c++) P[i][c] = R->r[i][c] * t[i];
+  for (int k = 0; k < NSIDES; k++) {
+    double d[3];
+    for (int c = 0; c < 3; c++) d[c] = P[side_a[k]][c] - P[side_b[k]][c];
+    L[k] = sum_sq3(d);
+  }
+  const int f = first_c[m], o = 2 - f;
+  const double rel = 1.0 / L[scale_s[m]];
+  double e[3], acc = 0;
+  acc += sq(L[unit_p[m]] - 1);
+  acc += sq(L[unit_q[m]] - 1);
+  for (int c = 0; c < 3; c++) e[c] = (P[f][c] - P[1][c]) + (P[o][c] - P[3][c]);
+  acc += sum_sq3(e);
+  for (int c = 0; c < 3; c++) e[c] = (P[1][c] - P[o][c]) + (P[3][c] - P[f][c]);
+  acc += rel * sum_sq3(e);
+  acc += sq(L[S01] + L[S12] - L[S02]);
+  acc += sq(L[S03] + L[S23] - L[S02]);
+  acc += sq(L[S01] + L[S03] - L[S13]);
+  acc += sq(L[S12] + L[S23] - L[S13]);
+  double n[3];
+  normal_of(P, 0, 1, 3, n);
+  acc += rel * sq(inner3(n, P[2]) - inner3(n, P[0])) / inner3(n, n);
+  normal_of(P, 1, 0, 2, n);
+  acc += rel * sq(inner3(n, P[3]) - inner3(n, P[1])) / inner3(n, n);
+  return acc;
 }
 
-/* value, first and second directional derivative along dir (rh:479-490) */
-static vec3 directional(vec4 v, vec4 dir, const pose_arg *arg) {
-  const double h = POSE_EPS;
-  const double f0 = pose_residual(v, arg);
-  const double fp = pose_residual(plus4(v, dot4(dir, h)), arg);
-  const double fm = pose_residual(plus4(v, dot4(dir, -h)), arg);
-  return cvec3(f0, (fp - fm) * (1.0 / (2 * h)), (fp + fm - 2 * f0) * (1.0 / (h * h)));
+/* descent state of the two pairings, side by side */
+typedef struct {
+  double t[PAIRINGS][4];        /* current depths */
+  double res[PAIRINGS][4];      /* negative gradient */
+  double pre[PAIRINGS][4];      /* preconditioned residual */
+  double dir[PAIRINGS][4];      /* search direction */
+  double rp[PAIRINGS];          /* res . pre of the current point */
+  int since_restart[PAIRINGS];
+} descent2;
+
+static inline double inner4(const double u[4], const double w[4]) { return u[0] * w[0] + u[1] * w[1] + u[2] * w[2] + u[3] * w[3]; }
+
+/* central differences along the four axes (rh:492-512) -> res = -gradient; pre = res / curvature per axis when every
+ * curvature is positive, else res (rh:538-555) */
+static void probe_axes(const rays4 *R, descent2 *D) {
+  for (int m = 0; m < PAIRINGS; m++) {
+    const double f0 = rect_defect(R, m, D->t[m]);
+    double curv[4];
+    int convex = 1;
+    for (int i = 0; i < 4; i++) {
+      double lo[4], hi[4];
+      for (int j = 0; j < 4; j++) { const double h = j == i ? FD_STEP : 0; lo[j] = D->t[m][j] - h; hi[j] = D->t[m][j] + h; }
+      const double fl = rect_defect(R, m, lo), fh = rect_defect(R, m, hi);
+      D->res[m][i] = (fh - fl) / (2 * FD_STEP) * -1;
+      curv[i] = (fl - 2 * f0 + fh) / (FD_STEP * FD_STEP);
+      if (curv[i] <= 0) convex = 0;
+    }
+    for (int i = 0; i < 4; i++) {
+      if (convex) { D->pre[m][i] = 1.0 / curv[i]; D->pre[m][i] *= D->res[m][i]; }
+      else D->pre[m][i] = D->res[m][i];
+    }
+  }
 }
 
-/* per-coordinate first and second derivatives (rh:492-512) */
-static void coordinate_derivs(vec4 v, const pose_arg *arg, vec4 *g, vec4 *g2) {
-  const double fx = pose_residual(v, arg);
+/* WALK_STEPS damped Newton steps along dir (rh:514-536): slope and curvature from a three-point stencil, the step is halved
+ * whenever it does not lower the residual, a pairing stops once its step falls below 1e-10 */
+static void walk_along(const rays4 *R, descent2 *D) {
+  double u[PAIRINGS][4], damp[PAIRINGS];
+  int done[PAIRINGS];
+  for (int m = 0; m < PAIRINGS; m++) {
+    const double k = 1.0 / (sqrt(D->dir[m][0] * D->dir[m][0] + D->dir[m][1] * D->dir[m][1] + D->dir[m][2] * D->dir[m][2] + D->dir[m][3] * D->dir[m][3]) + 1e-20);
+    for (int i = 0; i < 4; i++) u[m][i] = D->dir[m][i] * k;
+    damp[m] = 1.0; done[m] = 0;
+  }
+  for (int step = 0; step < WALK_STEPS; step++)
+    for (int m = 0; m < PAIRINGS; m++) {
+      if (done[m]) continue;
+      double fwd[4], bwd[4], cand[4];
+      for (int i = 0; i < 4; i++) { fwd[i] = D->t[m][i] + u[m][i] * FD_STEP; bwd[i] = D->t[m][i] + u[m][i] * -FD_STEP; }
+      const double f0 = rect_defect(R, m, D->t[m]), ff = rect_defect(R, m, fwd), fb = rect_defect(R, m, bwd);
+      const double slope = (ff - fb) * (1.0 / (2 * FD_STEP));
+      double curv = (ff + fb - 2 * f0) * (1.0 / (FD_STEP * FD_STEP));
+      if (curv * curv < 1e-10) curv = 1;
+      const double len = fabs(slope / curv);
+      if (len < 1e-10) { done[m] = 1; continue; }
+      for (int i = 0; i < 4; i++) cand[i] = D->t[m][i] + u[m][i] * (len * damp[m]);
+      if (f0 < rect_defect(R, m, cand)) { damp[m] *= 0.5; continue; }
+      for (int i = 0; i < 4; i++) D->t[m][i] = cand[i];
+    }
+}
+
+/* rh:557-588: Polak-Ribiere conjugate gradients on the preconditioned residual, restarted every CG_RESTART steps and whenever
+ * beta is not positive.  On return D->t holds the depths of both pairings. */
+static void descend(const rays4 *R, descent2 *D) {
+  probe_axes(R, D);
+  for (int m = 0; m < PAIRINGS; m++) {
+    memcpy(D->dir[m], D->pre[m], sizeof(D->dir[m]));
+    D->rp[m] = inner4(D->res[m], D->dir[m]);
+    D->since_restart[m] = 0;
+  }
+  for (int it = 0; it < CG_STEPS; it++) {
+    walk_along(R, D);
+    double old_pre[PAIRINGS][4];
+    memcpy(old_pre, D->pre, sizeof(old_pre));
+    probe_axes(R, D);
+    for (int m = 0; m < PAIRINGS; m++) {
+      const double before = D->rp[m];
+      const double cross = inner4(D->res[m], old_pre[m]);
+      D->rp[m] = inner4(D->res[m], D->pre[m]);
+      const double beta = (D->rp[m] - cross) / before;
+      if (D->since_restart[m] == CG_RESTART || beta <= 0 || before == 0) {
+        memcpy(D->dir[m], D->pre[m], sizeof(D->dir[m]));
+        D->since_restart[m] = 0;
+      } else
+        for (int i = 0; i < 4; i++) D->dir[m][i] = D->pre[m][i] + D->dir[m][i] * beta;
+      D->since_restart[m]++;
+    }
+  }
+}
+
+static inline double gap3(const double a[3], const double b[3]) {
+  const double d[3] = { a[0] - b[0], a[1] - b[1], a[2] - b[2] };
+  return sqrt(sum_sq3(d));
+}
+
+/* rh:590-634: sides = the four sides in angular order (side i starts at corner i), centre = their length-weighted centroid.
+ * The corner order of the result starts at the side whose outward normal points most upwards in the image. */
+static rect_t estimate_pose(const seg2 *sides, vec2 centre, int iw, int ih, double tanAOV) {
+  int first = 0;
+  double lowest = 1e+100;
   for (int i = 0; i < 4; i++) {
-    vec4 d = cvec4(0, 0, 0, 0);
-    d.a[i] = POSE_EPS;
-    const double fm = pose_residual(minus4(v, d), arg);
-    const double fp = pose_residual(plus4(v, d), arg);
-    g->a[i] = (fp - fm) / (2 * POSE_EPS);
-    g2->a[i] = (fm - 2 * fx + fp) / (POSE_EPS * POSE_EPS);
+    const vec2 along = normalize2(minus2(sides[i].e1, sides[i].e0));
+    vec2 out = cvec2(-along.a[1], along.a[0]);
+    if (vdot2(minus2(sides[i].e0, centre), out) < 0) out = dot2(out, -1);
+    if (out.a[1] < lowest) { lowest = out.a[1]; first = i; }
   }
-}
-
-/* Newton steps along dir with step halving (rh:514-536) */
-static vec4 line_search(vec4 iv, vec4 dir, int iters, const pose_arg *arg) {
-  dir = normalize4(dir);
-  double scale = 1.0;
-  for (int i = 0; i < iters; i++) {
-    vec3 gd = directional(iv, dir, arg);
-    const double ep = gd.a[0];
-    if (gd.a[2] * gd.a[2] < 1e-10) gd.a[2] = 1;
-    const double delta = fabs(gd.a[1] / gd.a[2]);
-    if (delta < 1e-10) return iv;
-    const vec4 v = plus4(iv, dot4(dir, delta * scale));
-    const double e1 = pose_residual(v, arg);
-    if (ep < e1) { scale *= 0.5; continue; }
-    iv = v;
-  }
-  return iv;
-}
-
-/* r / m per coordinate when every m is positive, else r (rh:538-555) */
-static vec4 precondition(vec4 m, vec4 r) {
-  for (int i = 0; i < 4; i++) if (m.a[i] <= 0) return r;
-  vec4 a;
-  for (int i = 0; i < 4; i++) { a.a[i] = 1.0 / m.a[i]; a.a[i] *= r.a[i]; }
-  return a;
-}
-
-/* rh:557-588 */
-static vec4 conjugate_gradient(vec4 x, int loops, int ls_iters, const pose_arg *arg) {
-  vec4 g, g2;
-  coordinate_derivs(x, arg, &g, &g2);
-  vec4 r = dot4(g, -1), m = g2;
-  vec4 s = precondition(m, r), d = s;
-  double deltanew = vdot4(r, d);
-  int k = 0;
-  for (int i = 0; i < loops; i++) {
-    x = line_search(x, d, ls_iters, arg);
-    coordinate_derivs(x, arg, &g, &g2);
-    r = dot4(g, -1); m = g2;
-    const double deltaold = deltanew;
-    const double deltamid = vdot4(r, s);
-    s = precondition(m, r);
-    deltanew = vdot4(r, s);
-    const double beta = (deltanew - deltamid) / deltaold;
-    if (k == 10 || beta <= 0 || deltaold == 0) { d = s; k = 0; }
-    else d = plus4(s, dot4(d, beta));
-    k++;
-  }
-  return x;
-}
-
-/* rh:590-634: als = the four sides in angular order, centre = their length-weighted centroid */
-static rect_t estimate_pose(const seg2 *als, vec2 centre, int iw, int ih, double tanAOV) {
-  vec3 p[4];
-  int tl = 0;
-  double min = 1e+100;
+  rays4 R;
+  const double focal = iw / 2 / tanAOV;                        /* (integer half width, like the reference) */
   for (int i = 0; i < 4; i++) {
-    vec2 v = normalize2(minus2(als[i].e1, als[i].e0));
-    v = cvec2(-v.a[1], v.a[0]);
-    if (vdot2(minus2(als[i].e0, centre), v) < 0) v = dot2(v, -1);
-    if (v.a[1] < min) { min = v.a[1]; tl = i; }
+    const vec2 c = sides[(i + first) & 3].e0;
+    const vec3 v = normalize3(cvec3(c.a[0] - (iw / 2), -(c.a[1] - ih / 2), focal));
+    for (int k = 0; k < 3; k++) R.r[i][k] = v.a[k];
   }
-  for (int i = 0; i < 4; i++) {
-    const seg2 *s = &als[(i + tl) & 3];
-    p[i] = normalize3(cvec3((s->e0.a[0] - (iw / 2)), (-(s->e0.a[1] - ih / 2)), iw / 2 / tanAOV));
-  }
-  const double d01 = 1.0 / distance3(p[0], p[1]), d23 = 1.0 / distance3(p[2], p[3]);
-  pose_arg a0 = { p, 1 };
-  const vec4 x0 = conjugate_gradient(cvec4(d01, d01, d23, d23), 12, 10, &a0);
-  const double v0 = pose_residual(x0, &a0);
-  const double d12 = 1.0 / distance3(p[1], p[2]), d03 = 1.0 / distance3(p[0], p[3]);
-  pose_arg a1 = { p, 0 };
-  const vec4 x1 = conjugate_gradient(cvec4(d03, d12, d12, d03), 12, 10, &a1);
-  const double v1 = pose_residual(x1, &a1);
+  /* starting depths: both ends of a unit side at the depth where that side subtends unit length (rh:607-617) */
+  const double a01 = 1.0 / gap3(R.r[0], R.r[1]), a23 = 1.0 / gap3(R.r[2], R.r[3]);
+  const double a12 = 1.0 / gap3(R.r[1], R.r[2]), a03 = 1.0 / gap3(R.r[0], R.r[3]);
+  descent2 D;
+  memset(&D, 0, sizeof(D));
+  D.t[1][0] = a01; D.t[1][1] = a01; D.t[1][2] = a23; D.t[1][3] = a23;
+  D.t[0][0] = a03; D.t[0][1] = a12; D.t[0][2] = a12; D.t[0][3] = a03;
+  descend(&R, &D);
+  const double f1 = rect_defect(&R, 1, D.t[1]), f0 = rect_defect(&R, 0, D.t[0]);
+  const int best = f1 < f0 ? 1 : 0;
 
   rect_t ret;
   memset(&ret, 0, sizeof(ret));
-  ret.value = v0 < v1 ? v0 : v1;
-  vec4 x = v0 < v1 ? x0 : x1;
-  if (x.a[0] < 0) x = dot4(x, -1);
+  ret.value = best ? f1 : f0;
+  const double flip = D.t[best][0] < 0 ? -1 : 1;               /* a mirrored solution behind the camera is turned round */
   for (int i = 0; i < 4; i++) {
-    ret.c3[i] = dot3(p[i], x.a[i]);
-    ret.c2[i] = als[(i + tl) & 3].e0;
+    const double depth = flip < 0 ? D.t[best][i] * -1 : D.t[best][i];
+    for (int k = 0; k < 3; k++) ret.c3[i].a[k] = R.r[i][k] * depth;
+    ret.c2[i] = sides[(i + first) & 3].e0;
   }
   return ret;
 }
 
-/* rh:636-656 */
+/* rh:636-656: small residual, in front of the camera, aspect ratio within 1:12, and no corner much closer to a side's
+ * segment than the farthest one is (ratio of squared distances <= 100) */
 static int looks_like_a_screen(const rect_t *r) {
   if (r->value > 0.05) return 0;
   for (int i = 0; i < 4; i++) if (r->c3[i].a[2] < 0) return 0;
-  const double asp = distance3(r->c3[0], r->c3[1]) / distance3(r->c3[1], r->c3[2]);
-  if (asp < 1.0 / 12 || 12 < asp) return 0;
-  double maxs = 0, mins = 1e+100;
+  const double aspect = distance3(r->c3[0], r->c3[1]) / distance3(r->c3[1], r->c3[2]);
+  if (aspect < 1.0 / 12 || 12 < aspect) return 0;
+  double widest = 0, narrowest = 1e+100;
   for (int i = 0; i < 4; i++) {
-    const vec2 a = r->c2[i], b = r->c2[(i + 1) % 4], c = r->c2[(i + 2) % 4], d = r->c2[(i + 3) % 4];
-    const double s0 = distanceSqu2(c, closest_on_seg(a, b, c));
-    const double s1 = distanceSqu2(d, closest_on_seg(a, b, d));
-    maxs = fmax(maxs, fmax(s0, s1));
-    mins = fmin(mins, fmax(s0, s1));
+    double reach[2];
+    for (int k = 0; k < 2; k++) {
+      const vec2 far = r->c2[(i + 2 + k) % 4];
+      reach[k] = distanceSqu2(far, closest_on_seg(r->c2[i], r->c2[(i + 1) % 4], far));
+    }
+    const double m = fmax(reach[0], reach[1]);
+    widest = fmax(widest, m);
+    narrowest = fmin(narrowest, m);
   }
-  return maxs / mins > 100 ? 0 : 1;
+  return widest / narrowest > 100 ? 0 : 1;
 }
 
 /* ------------------------------------------------------------------ convex hull (rh:658-734) */

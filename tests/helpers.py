@@ -38,6 +38,14 @@ def oracle():
         O.rdo_rect_plane.restype = ctypes.c_void_p
         O.rdo_rect_plane.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
         O.rdo_rect_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        O.rdo_rect_set_region_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        O.rdo_rect_info.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        O.rdo_region_sync.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3
+        O.rdo_despeckle2_jacobi_k.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+        O.rdo_region_size.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        O.rdo_mark_boundary.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+        O.rdo_label8.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        O.rdo_reduce_ls.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         O.rdo_poly_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]
         O.rdo_polyline.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         O.rdo_lut.restype = ctypes.POINTER(ctypes.c_uint16)
@@ -45,12 +53,22 @@ def oracle():
     return _oracle
 
 
-class OracleRect:
-    """All device stages of the rect path on the CPU (oracle/rd_oracle.c), every plane inspectable."""
+REGION_REFERENCE_RASTER = 0   # the reference's in-place region kernels, work-items in serial raster order (what oracle/_ref runs)
+REGION_SPEC = 1               # the order-free schedule of the same rules that the HIP path implements (oracle/rd_oracle.c: rdo_region_sync, 27 Jacobi rounds)
 
-    def __init__(self, iw, ih):
+
+class OracleRect:
+    """All device stages of the rect path on the CPU (oracle/rd_oracle.c), every plane inspectable.
+    region_mode selects how the two order-dependent region kernels of the reference are evaluated."""
+
+    def __init__(self, iw, ih, region_mode=REGION_REFERENCE_RASTER):
         self.iw, self.ih, self.N = iw, ih, iw * ih
         self.h = oracle().rdo_rect_new(iw, ih)
+        oracle().rdo_rect_set_region_mode(self.h, region_mode)
+
+    def rounds(self):
+        """(merge rounds, absorption rounds) the last frame took in REGION_SPEC mode"""
+        return oracle().rdo_rect_info(self.h, 1), oracle().rdo_rect_info(self.h, 2)
 
     def frame(self, bgr):
         a = np.ascontiguousarray(bgr)

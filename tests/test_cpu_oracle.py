@@ -188,3 +188,64 @@ def test_oracle_operators_against_reference_golden(name):
     l2 = lab.copy()
     O.rdo_filter_strength(P(l2), P(acc), 5000, iw, ih)
     assert np.array_equal(l2.ravel(), g["filterStrength"])
+
+
+def test_region_spec_against_the_references_own_order_dependence():
+    """The order-free region schedule (oracle REGION_SPEC mode = what the HIP path implements) against the reference's own
+    rectangle lists under 26 legal work-item orders of its two in-place region kernels (tests/golden/hard_rect_orders.npz,
+    order 0 = serial raster): on a busy frame the reference returns 32..36 rectangles depending on the order; the spec must
+    contain every rectangle common to all orders and nothing that no order produces.  (All 14 frames: GPU test
+    test_busy_inputs_final_outputs_vs_reference; here the first tile frame and one order-independent frame, to bound the time.)"""
+    g, go = golden("hard_rect"), golden("hard_rect_orders")
+    key = lambda r: r["c2"].tobytes() + r["c3"].tobytes() + r["value"].tobytes() + r["status"].tobytes()
+    tan = float(np.tan(36.0 / 180.0 * np.pi))
+    for hi in (0, 9):
+        kind = g["kinds"].tolist()[hi]
+        seed, iw, ih = g["params"].tolist()[hi]
+        union, member = go["h%d_union" % hi], go["h%d_member" % hi]
+        ukeys = [key(r) for r in union]
+        assert set(k for k, m in zip(ukeys, member[0]) if m) == set(key(r) for r in g["h%d_rects" % hi])      # order 0 is the raster fixture
+        orc = helpers.OracleRect(iw, ih, helpers.REGION_SPEC)
+        orc.frame(synth.hard_frame(kind, seed, iw, ih))
+        assert helpers.segments_equal(orc.segments(), g["h%d_segments" % hi])
+        assert orc.rounds()[0] < 20
+        rects = ra.postprocess_planes(orc.segments(), orc.plane("boundary"), orc.plane("table"), iw, ih, tan)
+        here = set(key(r) for r in rects)
+        stable = set(k for k, m in zip(ukeys, member.all(0)) if m)
+        assert stable <= here <= set(ukeys)
+        if hi == 0:
+            assert member.sum(1).min() < member.sum(1).max() and len(stable) < len(here)     # the reference does depend on the order here
+        orc.close()
+
+
+@pytest.mark.parametrize("iw,ih,seed", [(333, 217, 2), (640, 480, 5)])
+def test_region_spec_stage_relations(iw, ih, seed):
+    """REGION_SPEC mode: the synchronous merge settles well inside 20 rounds; a fixed point of the Jacobi absorption IS the serial
+    raster result of the reference's kernel (same inputs); the planes downstream follow from it by the order-independent stages"""
+    O, P = helpers.oracle(), helpers.P
+    N = iw * ih
+    img = synth.frame(synth.SEED0 + seed, iw, ih, 0)
+    orc = helpers.OracleRect(iw, ih, helpers.REGION_SPEC)
+    orc.frame(img)
+    merge_rounds, absorb_rounds = orc.rounds()
+    assert 1 <= merge_rounds < 20 and 1 <= absorb_rounds <= 27
+    quant, mask, edge, junction = (orc.plane(n).view(np.int32) for n in ("quant", "mergemask", "label1", "junction"))
+    lab = np.zeros(N, np.int32)
+    r = O.rdo_region_sync(P(lab), P(quant), P(mask), P(edge), iw, ih, 1000)
+    assert r == merge_rounds        # 20 was not the limit
+    again = lab.copy()
+    size = junction.copy()
+    O.rdo_region_size(P(size), P(lab), N)
+    assert np.array_equal(size, orc.plane("rsize"))
+    serial, jac = lab.copy(), lab.copy()
+    O.rdo_despeckle2.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_void_p] + [__import__("ctypes").c_int] * 3
+    O.rdo_despeckle2(P(serial), P(size), 16, iw, ih)
+    rounds = O.rdo_despeckle2_jacobi_k(P(jac), P(size), 16, iw, ih, None, 1 << 30)
+    assert np.array_equal(serial, jac), "the fixed point of the Jacobi rounds must be the raster-order result"
+    if rounds <= 27:
+        assert np.array_equal(jac, orc.plane("region"))
+    marks = np.zeros(N, np.int32)
+    O.rdo_mark_boundary(P(marks), P(orc.plane("region")), iw, ih)
+    assert np.array_equal(marks, orc.plane("boundary_src"))
+    assert np.array_equal(again, lab)
+    orc.close()

@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Longer streams from THE REFERENCE (oracle/_ref), consecutive frames of one detector instance, so that the state the
+reference carries from frame to frame takes part well beyond the 2-3 frames of the other fixtures:
+  stream_1920x1080_s0.npz  16 frames of the benchmark workload (BASELINE.json configs[4]: 1920x1080, stream seed 0)
+  stream_1280x720_s1.npz   30 frames of configs[2] (1280x720, AOV 72 like vidrect's default)
+Per frame: the rect_t list and the line-segment list.  Only runs where /root/reference exists."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import rectdetect_amd as ra  # noqa: E402
+from rectdetect_amd import synth  # noqa: E402
+from tests import helpers  # noqa: E402
+
+CASES = {"stream_1920x1080_s0": (1920, 1080, 0, 16, 36.0), "stream_1280x720_s1": (1280, 720, 1, 30, 36.0)}
+
+
+def main():
+    for name in sys.argv[1:] or sorted(CASES):
+        iw, ih, seed, nframes, half_aov = CASES[name]
+        tan = float(np.tan(half_aov / 180.0 * np.pi))
+        r = helpers.RefRect(iw, ih)
+        out = {"iw": iw, "ih": ih, "seed": synth.SEED0 + seed, "nframes": nframes, "tan_aov": tan}
+        for t in range(nframes):
+            rects, snaps = r.execute_once(synth.frame(synth.SEED0 + seed, iw, ih, t), tan, snapshots=["lslist"])
+            n = int(snaps["lslist"][0])
+            out[f"f{t}_rects"] = rects
+            out[f"f{t}_segments"] = snaps["lslist"][: 14 * (n + 1)].view(ra.LS_DTYPE)
+            print(name, "frame", t, "rects", len(rects), "segments", n, flush=True)
+        r.close()
+        np.savez_compressed(os.path.join(helpers.GOLDEN, name + ".npz"), **out)
+
+
+if __name__ == "__main__":
+    main()
