@@ -25,9 +25,11 @@ static int load_ppm(FILE *f, const char *path, rdimage *img) {
   int w, h, maxv;
   if (ppm_token(f, &w) || ppm_token(f, &h) || ppm_token(f, &maxv)) return fail(path, "truncated PPM header");
   if (w < 1 || h < 1 || maxv != 255) return fail(path, "only 8-bit P6 images are supported");
+  if (w > 32768 || h > 32768 || (long long)w * h >= (1 << 25)) return fail(path, "PPM dimensions out of range (frames must be below 2^25 pixels)");
   img->iw = w; img->ih = h; img->ws = w * 3;
   img->bgr = (uint8_t *)malloc((size_t)img->ws * h);
   uint8_t *row = (uint8_t *)malloc((size_t)w * 3);
+  if (!img->bgr || !row) { free(img->bgr); img->bgr = NULL; free(row); return fail(path, "out of memory"); }
   for (int y = 0; y < h; y++) {
     if (fread(row, 3, (size_t)w, f) != (size_t)w) { free(row); return fail(path, "truncated PPM data"); }
     uint8_t *o = img->bgr + (size_t)y * img->ws;
@@ -51,14 +53,24 @@ static int load_png(FILE *f, const char *path, rdimage *img) {
   for (;;) {
     if (fread(hd, 1, 8, f) != 8) { free(z); return fail(path, "truncated PNG"); }
     const uint32_t len = be32(hd);
+    if (len > (1u << 28)) { free(z); return fail(path, "PNG chunk too large"); }      /* (the detector takes frames below 2^25 pixels) */
     uint8_t *data = (uint8_t *)malloc(len ? len : 1);
+    if (!data) { free(z); return fail(path, "out of memory"); }
     if (fread(data, 1, len, f) != len || fread(hd + 0, 1, 4, f) != 4 /* CRC, not checked */) { free(data); free(z); return fail(path, "truncated PNG chunk"); }
     if (!memcmp(hd + 4, "IHDR", 4)) {
-      w = (int)be32(data); h = (int)be32(data + 4);
+      if (len < 13) { free(data); free(z); return fail(path, "PNG header chunk too short"); }
+      const uint32_t uw = be32(data), uh = be32(data + 4);
+      if (uw < 1 || uh < 1 || uw > 32768 || uh > 32768 || (uint64_t)uw * uh >= (1u << 25)) { free(data); free(z); return fail(path, "PNG dimensions out of range (frames must be below 2^25 pixels)"); }
+      w = (int)uw; h = (int)uh;
       if (data[8] != 8 || (data[9] != 2 && data[9] != 6) || data[12] != 0) { free(data); free(z); return fail(path, "only 8-bit RGB / RGBA non-interlaced PNG is supported"); }
       bpp = data[9] == 2 ? 3 : 4;
     } else if (!memcmp(hd + 4, "IDAT", 4)) {
-      if (zn + len > zcap) { zcap = (zn + len) * 2; z = (uint8_t *)realloc(z, zcap); }
+      if (zn + len > zcap) {
+        zcap = (zn + len) * 2;
+        uint8_t *nz = (uint8_t *)realloc(z, zcap);
+        if (!nz) { free(data); free(z); return fail(path, "out of memory"); }
+        z = nz;
+      }
       memcpy(z + zn, data, len); zn += len;
     } else if (!memcmp(hd + 4, "IEND", 4)) { free(data); break; }
     free(data);
@@ -67,11 +79,13 @@ static int load_png(FILE *f, const char *path, rdimage *img) {
   const size_t stride = (size_t)w * bpp + 1;
   uLongf rawn = (uLongf)(stride * h);
   uint8_t *raw = (uint8_t *)malloc(rawn);
+  if (!raw) { free(z); return fail(path, "out of memory"); }
   if (uncompress(raw, &rawn, z, (uLong)zn) != Z_OK || rawn != stride * h) { free(raw); free(z); return fail(path, "PNG data does not inflate"); }
   free(z);
   img->iw = w; img->ih = h; img->ws = w * 3;
   img->bgr = (uint8_t *)malloc((size_t)img->ws * h);
   uint8_t *prev = (uint8_t *)calloc(stride, 1);
+  if (!img->bgr || !prev) { free(img->bgr); img->bgr = NULL; free(prev); free(raw); return fail(path, "out of memory"); }
   for (int y = 0; y < h; y++) {
     uint8_t *line = raw + (size_t)y * stride + 1;
     const int ft = line[-1];

@@ -26,7 +26,8 @@ void rd_download(void *host, const void *dptr, size_t bytes);
 /* ---- one detector instance = one stream of frames (state carried between frames) */
 typedef struct rd_detector rd_detector;
 
-/* nslots frames in flight (>= 1), nworkers host threads for the post-process (0 = run it on the polling thread).
+/* nslots frames in flight (>= 1); nworkers != 0: the host post-process runs on worker threads, ONE PER SLOT (the value itself is
+ * not a thread count), 0: on the polling thread.
  * 1-2 frames in flight: a frame spreads over two HIP streams (shortest latency); from 3 on: one stream per frame, and frames
  * beyond the fourth queue up on the same four streams (the device runs four hardware queues side by side) - 8 gives the highest
  * rate ("Execution"). */
@@ -51,16 +52,15 @@ int rd_detector_last_segments(rd_detector *d, void *dst, int max_records);
  * was repeated with the multi-launch path (same results, slower); 1 = device microseconds summed over the polled frames
  * (HIP events on the frame's stream: first kernel start to last copy end, so concurrent frames overlap); 2 = frames in that sum; 3 = host microseconds spent inside rd_detector_enqueue;
  * 4 = frames whose region merge had not settled within the launched round budget and were repeated with all 20 rounds;
- * 5 = the current round budget (8, 12, 16 or 20) */
+ * 5 = the current round budget (8, 12, 16 or 20); 6..9 = frames launched with a budget of 8 / 12 / 16 / 20 rounds;
+ * 10 = frames with more line segments than the probe buffer holds (65535): the rest took no part in the rectangle search (a
+ * message goes to stderr the first time) */
 long rd_detector_counter(rd_detector *d, int which);
 
 /* Test hook: copy an internal plane of the most recently completed frame to host memory.  Returns bytes written,
  * 0 for an unknown name.  Names: plab0 plab1 lblur vxy strength nms mask0 tidy label1 strsum edge500 smooth quant
  * strong junction mergemask region0 (merged regions) rsize region (after absorbing small ones) boundarysrc boundary lsid table */
 size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size_t max_bytes);
-
-/* timing of the device stages of the last drained batch, microseconds per named stage (NULL-terminated names) */
-int rd_detector_stage_times(rd_detector *d, const char **names, float *usec, int max);
 
 /* ---- host post-process alone (oclrect.c:1049-1226 restated): segments + samples -> rectangles.  Used by tests to
  * check the post-process against the reference with identical inputs.  `boundary` is the boundary-label plane,

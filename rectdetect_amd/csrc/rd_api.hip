@@ -263,6 +263,7 @@ struct Slot {
   int shares_streams;                     // st / st2 belong to another slot (see rd_detector_create)
   hipEvent_t ev_fork, ev_mm, ev_join;
   hipEvent_t ev_begin, ev_done, ev_strong;   // ev_begin/ev_done carry timestamps: device time of the frame (rd_detector_counter)
+  hipEvent_t ev_redo;                        // end of a repeated part of the frame (slot_finish_device)
   uint8_t *bgr;
   uint32_t *plab0, *plab1, *smooth, *quant;
   float *tr[3], *fw[3], *bw[3], *hz[3], *bl[3], *vxy, *strength, *nms;
@@ -308,6 +309,12 @@ struct rd_detector {
   long dev_us, dev_frames;   // sum over polled frames of (last kernel end - first kernel start) on the frame's stream, HIP events
   double tan_aov; int have_tan;    // what the workers use ahead of the poll that asks for the result
   pthread_mutex_t tan_mu; pthread_cond_t tan_cv;
+  // Slots share streams (slot i uses the streams of slot i mod 4) and a worker thread may repeat part of its slot's frame on such a
+  // stream while the enqueueing thread captures another slot's launch sequence on it: a capture would record the foreign launches, and
+  // a stream that is capturing must not be synchronised.  launch_mu serialises captures against the launches of a repeat; repeats wait
+  // on an event of their own (ev_redo), never on the stream.
+  pthread_mutex_t launch_mu;
+  long n_truncated;          // frames with more segment records than the probe buffer holds (maxrec_dev)
 };
 
 // share: the slot whose streams this one uses as well (NULL: own streams)
@@ -325,6 +332,7 @@ static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
   RD_HIP(hipEventCreate(&s->ev_begin));
   RD_HIP(hipEventCreate(&s->ev_done));
   RD_HIP(hipEventCreateWithFlags(&s->ev_strong, hipEventDisableTiming));
+  RD_HIP(hipEventCreateWithFlags(&s->ev_redo, hipEventDisableTiming));
   s->bgr = dnew<uint8_t>(N * 4);
   s->plab0 = dnew<uint32_t>(N); s->plab1 = dnew<uint32_t>(N); s->smooth = dnew<uint32_t>(N); s->quant = dnew<uint32_t>(N);
   for (int k = 0; k < 3; k++) { s->tr[k] = dnew<float>(N); s->fw[k] = dnew<float>(N); s->bw[k] = dnew<float>(N); s->hz[k] = dnew<float>(N); s->bl[k] = dnew<float>(N); }
@@ -362,7 +370,7 @@ static void slot_free(Slot *s) {
   rdk::poly_scratch_destroy(s->ps);
   RD_HIP(hipHostFree(s->h_bgr)); RD_HIP(hipHostFree(s->h_pack));
   RD_HIP(hipEventDestroy(s->ev_begin)); RD_HIP(hipEventDestroy(s->ev_done)); RD_HIP(hipEventDestroy(s->ev_strong));
-  RD_HIP(hipEventDestroy(s->ev_fork)); RD_HIP(hipEventDestroy(s->ev_mm)); RD_HIP(hipEventDestroy(s->ev_join));
+  RD_HIP(hipEventDestroy(s->ev_fork)); RD_HIP(hipEventDestroy(s->ev_mm)); RD_HIP(hipEventDestroy(s->ev_join)); RD_HIP(hipEventDestroy(s->ev_redo));
   if (!s->shares_streams) {
     RD_HIP(hipStreamDestroy(s->st2));
     RD_HIP(hipStreamDestroy(s->st));
@@ -493,9 +501,11 @@ static void run_segment(rd_detector *d, Slot *s, int ws, int seg) {
   if (seg == 2) for (int k = 0; k < 4; k++) if (kRoundBudgets[k] == s->rounds) ge = &s->gexec2[k * 2 + (s->poly_mode ? 1 : 0)];
   if (!*ge) {
     hipGraph_t g = NULL;
+    pthread_mutex_lock(&d->launch_mu);
     RD_HIP(hipStreamBeginCapture(s->st, hipStreamCaptureModeThreadLocal));
     frame_segment(d, s, ws, seg);
     RD_HIP(hipStreamEndCapture(s->st, &g));
+    pthread_mutex_unlock(&d->launch_mu);
     RD_HIP(hipGraphInstantiate(ge, g, NULL, NULL, 0));
     RD_HIP(hipGraphDestroy(g));
   }
@@ -522,13 +532,17 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   rdrt::check_launch("rect frame");
 }
 
-// host post-process of one finished slot (on the polling thread or on the slot's worker)
-static void *slot_postprocess(rd_detector *d, Slot *s, double tanAOV, void **segs_out, int *nsegs_out) {
+// What remains to be done on the device for a finished slot, once per frame (on the polling thread or on the slot's worker): the two
+// rare repeats and the bookkeeping of the round budget.
+static void slot_finish_device(rd_detector *d, Slot *s) {
   if (s->rounds < 20 && s->h_ctr[32 + s->rounds - 1] != 0) {   // the region merge was still changing in its last launched round: repeat with the full budget
     s->rounds = 20;
+    pthread_mutex_lock(&d->launch_mu);
     frame_regions(d, s);
     frame_votes(d, s, 1);
-    RD_HIP(hipStreamSynchronize(s->st));
+    RD_HIP(hipEventRecord(s->ev_redo, s->st));
+    pthread_mutex_unlock(&d->launch_mu);
+    RD_HIP(hipEventSynchronize(s->ev_redo));
     __atomic_add_fetch(&d->n_redo_rounds, 1, __ATOMIC_RELAXED);
   }
   {   // budget for the frames to come: what the last 64 frames needed (first round without a change, + 1 to see that) + 1.
@@ -547,16 +561,29 @@ static void *slot_postprocess(rd_detector *d, Slot *s, double tanAOV, void **seg
   if (s->poly_mode && s->h_ctr[25] != 0 && ++s->overflow_streak >= 2) __atomic_store_n(&d->poly_overflows, 1, __ATOMIC_RELAXED);   // this stream's frames do not fit the single-launch kernel (e.g. 4K): stop trying
   if (s->poly_mode && s->h_ctr[25] == 0) s->overflow_streak = 0;
   if ((s->poly_mode && s->h_ctr[25] != 0) || d->force_redo) {   // the single-launch polyline stage overflowed: repeat the tail the long way
+    pthread_mutex_lock(&d->launch_mu);
     frame_tail(d, s, 0);
-    RD_HIP(hipStreamSynchronize(s->st));
+    RD_HIP(hipEventRecord(s->ev_redo, s->st));
+    pthread_mutex_unlock(&d->launch_mu);
+    RD_HIP(hipEventSynchronize(s->ev_redo));
     __atomic_add_fetch(&d->n_redo, 1, __ATOMIC_RELAXED);
   }
+}
+
+// host post-process of a slot whose device work is complete: rectangles for the given aperture + a copy of the segment list
+// (can run again for another aperture: touches nothing on the device but, for frames with very many segments, two copies)
+static void *slot_rectangles(rd_detector *d, Slot *s, double tanAOV, void **segs_out, int *nsegs_out) {
   int n = ((int *)s->h_segs)[0];
   const void *segs = s->h_segs; const int *probes = s->h_probes;
   void *big_segs = NULL; int *big_probes = NULL;
   int maxrec = d->maxrec_dev < RD_MAXREC ? d->maxrec_dev : RD_MAXREC;
   if (n + 1 > maxrec) {   // rare: more segments than the fixed-size transfer covers
-    if (n + 1 > d->maxrec_dev) n = d->maxrec_dev - 1;
+    if (n + 1 > d->maxrec_dev) {
+      // The list itself holds up to N*16/56 records like the reference's, the probe buffer RD_MAXREC_DEV of them: the rest is dropped, loudly
+      if (__atomic_add_fetch(&d->n_truncated, 1, __ATOMIC_RELAXED) == 1)
+        fprintf(stderr, "rectdetect: a frame has %d line segments; only the first %d take part in the rectangle search (rd_detector_counter 10 counts such frames)\n", n, d->maxrec_dev - 1);
+      n = d->maxrec_dev - 1;
+    }
     big_segs = malloc((size_t)(n + 1) * 56); big_probes = (int *)malloc((size_t)(n + 1) * 15 * 6 * sizeof(int));
     RD_HIP(hipMemcpy(big_segs, s->lslist, (size_t)(n + 1) * 56, hipMemcpyDeviceToHost));
     RD_HIP(hipMemcpy(big_probes, s->probes, (size_t)(n + 1) * 15 * 6 * sizeof(int), hipMemcpyDeviceToHost));
@@ -589,7 +616,8 @@ static void *slot_worker(void *arg) {
     if (s->quit) return NULL;
     RD_HIP(hipEventSynchronize(s->ev_done));
     void *segs = NULL; int ns = 0;
-    void *r = slot_postprocess(d, s, tan, &segs, &ns);
+    slot_finish_device(d, s);
+    void *r = slot_rectangles(d, s, tan, &segs, &ns);
     pthread_mutex_lock(&s->mu);
     s->result = r; s->result_tan = tan; s->res_segs = segs; s->res_nsegs = ns;
     s->state = 2;
@@ -630,6 +658,7 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->rounds_budget = 20;
   d->diag_skip = getenv("RD_DIAG_SKIP") ? atoi(getenv("RD_DIAG_SKIP")) : 0;   // timing diagnostics only: leaves stages out (wrong results)
   pthread_mutex_init(&d->tan_mu, NULL); pthread_cond_init(&d->tan_cv, NULL);
+  pthread_mutex_init(&d->launch_mu, NULL);
   d->slots = (Slot *)calloc((size_t)nslots, sizeof(Slot));
   // One stream per frame: the frames beyond the fourth queue up behind earlier ones on the same four streams (slot i uses the
   // streams of slot i mod 4) - a stream of its own would be time-sliced onto the same four hardware queues and stall frames
@@ -713,11 +742,12 @@ void *rd_detector_poll(rd_detector *d, double tanAOV) {
     pthread_mutex_unlock(&s->mu);
     if (used != tanAOV) {      // the worker ran ahead with another aperture: redo with the requested one
       free(r); free(segs);
-      r = slot_postprocess(d, s, tanAOV, &segs, &ns);
+      r = slot_rectangles(d, s, tanAOV, &segs, &ns);
     }
   } else {
     RD_HIP(hipEventSynchronize(s->ev_done));
-    r = slot_postprocess(d, s, tanAOV, &segs, &ns);
+    slot_finish_device(d, s);
+    r = slot_rectangles(d, s, tanAOV, &segs, &ns);
   }
   { float ms = 0.0f; if (hipEventElapsedTime(&ms, s->ev_begin, s->ev_done) == hipSuccess) { d->dev_us += (long)(ms * 1000.0f); d->dev_frames++; } }
   free(d->last_segs);
@@ -739,6 +769,7 @@ long rd_detector_counter(rd_detector *d, int which) {
   if (which == 4) return __atomic_load_n(&d->n_redo_rounds, __ATOMIC_RELAXED);
   if (which == 5) return __atomic_load_n(&d->rounds_budget, __ATOMIC_RELAXED);
   if (which >= 6 && which <= 9) return d->budget_count[which - 6];   // frames launched with a budget of 8 / 12 / 16 / 20 rounds
+  if (which == 10) return __atomic_load_n(&d->n_truncated, __ATOMIC_RELAXED);
   if (which == 1) return d->dev_us;
   if (which == 2) return d->dev_frames;
   return which == 0 ? __atomic_load_n(&d->n_redo, __ATOMIC_RELAXED) : -1;
@@ -775,8 +806,6 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
     }
   return 0;
 }
-
-int rd_detector_stage_times(rd_detector *d, const char **names, float *usec, int max) { (void)d; (void)names; (void)usec; (void)max; return 0; }
 
 // ================================================================================================ oclrect (reference API)
 struct oclrect_t { uint32_t magic; rd_detector *det; int iw, ih; };

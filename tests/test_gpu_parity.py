@@ -136,6 +136,81 @@ def test_rect_outputs_match_reference_golden(name):
     det.close()
 
 
+@pytest.mark.parametrize("name,nslots", [("stream_1920x1080_s0", 8), ("stream_1280x720_s1", 8), ("stream_1280x720_s1", 2)])
+def test_long_streams_in_the_benchmarked_configuration_vs_reference(name, nslots):
+    """16 consecutive 1920x1080 frames of the bench stream (BASELINE.json configs[4]) and 30 frames of the 1280x720 stream
+    (configs[2]) the way bench.py runs them - 8 frames in flight on four shared streams, captured graphs, post-process on worker
+    threads, frames resident in HBM, adaptive round budget - against what THE REFERENCE returned for the same stream
+    (tests/golden/stream_*.npz, tools/make_golden_streams.py): the state carried from frame to frame (H1) is exercised 16 / 30 frames
+    deep.  Segment lists bit-identical; rectangle lists: same count and status, integer pixel coordinates identical, float
+    parameters within 1e-4 (north_star tolerance; they are in fact bit-identical on these streams, which is reported)."""
+    g = golden(name)
+    iw, ih, nframes, tan = int(g["iw"]), int(g["ih"]), int(g["nframes"]), float(g["tan_aov"])
+    L = ra.lib()
+    dptrs = []
+    for t in range(nframes):
+        a = synth.frame(int(g["seed"]), iw, ih, t)
+        p = L.rd_device_alloc(a.nbytes)
+        L.rd_upload(p, a.ctypes.data, a.nbytes)
+        dptrs.append(p)
+    det = ra.Detector(iw, ih, nslots=nslots, nworkers=1)
+    got, inflight = [], 0
+    for p in dptrs:
+        if inflight == nslots:
+            got.append((det.poll(tan), det.last_segments()))
+            inflight -= 1
+        det.enqueue(p, ws=iw * 3, on_device=True)
+        inflight += 1
+    while inflight:
+        got.append((det.poll(tan), det.last_segments()))
+        inflight -= 1
+    exact = 0
+    for t, (rects, segs) in enumerate(got):
+        assert helpers.segments_equal(segs, g[f"f{t}_segments"]), f"{name} frame {t}: segments differ from the reference"
+        ref = g[f"f{t}_rects"]
+        assert len(rects) == len(ref), f"{name} frame {t}: {len(rects)} rectangles, reference {len(ref)}"
+        assert np.array_equal(rects["status"], ref["status"])
+        assert np.array_equal(np.rint(rects["c2"]), np.rint(ref["c2"]))
+        for f in ("c2", "c3", "value"):
+            assert np.abs(rects[f] - ref[f]).max(initial=0) <= 1e-4
+        exact += helpers.rects_equal(rects, ref)
+    print(name, "slots", nslots, ": rectangle lists bit-identical to the reference's on %d of %d frames; round budget, repeats:" % (exact, nframes), det.region_round_budget())
+    det.close()
+    for p in dptrs:
+        L.rd_device_free(p)
+
+
+def test_repeats_on_shared_streams_while_graphs_are_captured(monkeypatch):
+    """8 frames in flight share four streams; with the round budget pinned to 8 most 1080p frames have their region stage repeated
+    by their slot's worker thread on a stream that the enqueueing thread is using - and, for each slot's first frames, capturing
+    graphs on.  Results must equal the plain sequential run."""
+    iw, ih = 1920, 1080
+    frames = [synth.frame(synth.SEED0 + 3, iw, ih, t) for t in range(20)]
+    seq = ra.Detector(iw, ih, nslots=1, nworkers=0)
+    want = []
+    for f in frames:
+        seq.enqueue(f)
+        want.append((seq.poll(TAN36), seq.last_segments()))
+    seq.close()
+    monkeypatch.setenv("RD_REGION_ROUNDS_FIXED", "8")
+    par = ra.Detector(iw, ih, nslots=8, nworkers=1)
+    monkeypatch.delenv("RD_REGION_ROUNDS_FIXED")
+    got, inflight = [], 0
+    for f in frames:
+        if inflight == 8:
+            got.append((par.poll(TAN36), par.last_segments()))
+            inflight -= 1
+        par.enqueue(f)
+        inflight += 1
+    while inflight:
+        got.append((par.poll(TAN36), par.last_segments()))
+        inflight -= 1
+    assert par.region_round_budget()[1] > 0, "the repeat path must have run"
+    par.close()
+    for (r1, s1), (r2, s2) in zip(want, got):
+        assert helpers.rects_equal(r1, r2) and helpers.segments_equal(s1, s2)
+
+
 @pytest.mark.parametrize("name", ["poly_640x480_s0", "poly_333x217_s2", "poly_1280x720_s1_vid"])
 def test_poly_path_through_operator_api(ctx, name):
     """poly.cpp's operator sequence through the oclimgutil_* / oclpolyline_execute entry points"""
