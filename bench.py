@@ -25,38 +25,99 @@ HBM_PEAK = 8.0e12              # MI355X_MICROARCH.md: 8.0 TB/s spec
 TAN_AOV = float(np.tan(72.0 / 2 / 180.0 * np.pi))
 
 
-def cpu_baseline(frames):
-    """The reference itself (oracle/_ref: its kernels + host C on the serial OpenCL shim) when that build travelled
-    with the repo, else our C restatement + the product's host post-process, timed on a bounded sample."""
+def _cpu_baseline_worker(args):
+    """one process = one instance of the CPU path on `n` consecutive frames of stream `seed` (the first one untimed: page faults, LUTs)"""
+    seed, n, use_ref = args
     from tests import helpers
     import rectdetect_amd as ra
-    sample = frames[:4]     # ~13 s of the reference on one core
-    t0 = time.time()
-    if helpers.have_ref():
+    from rectdetect_amd import synth
+    frames = [synth.frame(synth.SEED0 + seed, IW, IH, t) for t in range(n + 1)]
+    if use_ref:
         r = helpers.RefRect(IW, IH)
-        for f in sample:
-            r.execute_once(f, TAN_AOV)
-        r.close()
-        kind = "reference"
+        run = lambda f: r.execute_once(f, TAN_AOV)
     else:
         o = helpers.OracleRect(IW, IH)
-        for f in sample:
+
+        def run(f):
             o.frame(f)
             ra.postprocess_planes(o.segments(), o.plane("boundary"), o.plane("table"), IW, IH, TAN_AOV)
-        o.close()
-        kind = "port"
-    dt = time.time() - t0
-    return {"value": round(len(sample) / dt, 4), "unit": "frames/s", "cores": 1, "kind": kind,
-            "sample": "%d consecutive 1920x1080 frames of the bench stream, single thread, %.1f s" % (len(sample), dt)}
+    run(frames[0])
+    t0 = time.time()
+    for f in frames[1:]:
+        run(f)
+    return time.time() - t0
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline():
+    """The reference itself (oracle/_ref: its kernels + host C on the serial OpenCL shim) when that build travelled with the repo, else
+    our C restatement + the product's host post-process, on the GPU box's host cores: one thread (4 frames), and all streams a
+    host would run side by side - one single-threaded instance per core on up to 64 cores, 2 frames each (frames of different
+    streams are independent, SURVEY.md 8e: this is what `nproc` threads buy the CPU path).  A bounded sample, ~25 s."""
+    import multiprocessing as mp
+    from tests import helpers
+    use_ref = helpers.have_ref()
+    ncpu = len(os.sched_getaffinity(0))
+    t1 = _cpu_baseline_worker((0, 4, use_ref))
+    P = max(1, min(ncpu, 64))
+    ctx = mp.get_context("spawn")
+    t0 = time.time()
+    with ctx.Pool(P) as pool:
+        per = pool.map(_cpu_baseline_worker, [(100 + k, 2, use_ref) for k in range(P)])
+    wall = time.time() - t0
+    many = sum(2 / t for t in per)        # aggregate rate while all P instances were running (start-up of the workers excluded)
+    return {"value": round(many, 3), "unit": "frames/s", "cores": P, "kind": "reference" if use_ref else "port", "cpu_model": cpu_model(), "host_cores": ncpu,
+            "single_thread": {"value": round(4 / t1, 4), "cores": 1, "sample": "4 consecutive 1920x1080 frames after one untimed, %.1f s" % t1},
+            "sample": "%d single-threaded instances side by side, one per core, 2 consecutive 1920x1080 frames each after one untimed (%.1f s wall incl. start-up); "
+                      "the reference's kernels run one work-item at a time on the serial OpenCL shim" % (P, wall)}
+
+
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic.json")
 
 
 def traffic_per_frame():
-    """HBM-side bytes per frame from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE cannot be
-    collected in the same pass, nor from inside this process); null when that file is absent."""
+    """HBM-side bytes per frame from rocprofv3 PMC passes OF THIS COMMAND LINE's configuration (tools/gpu_pmc.sh: FETCH_SIZE and
+    WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes; they cannot be collected from inside this process),
+    committed under profiles/; null when that file is absent.  Returns (bytes, provenance)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
-            return int(json.load(f)["hbm_bytes_per_frame"])
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
+            j = json.load(f)
+        return int(j["hbm_bytes_per_frame"]), {"file": TRAFFIC_FILE, "measured_at_commit": j.get("commit"), "command": j.get("command")}
     except (OSError, KeyError, ValueError):
+        return None, None
+
+
+def pin_to_gpu_cores(L, dev):
+    """One process per GPU runs the enqueue / poll loop plus one post-process worker thread per frame slot (9 threads); on the
+    8-GPU node (256 host cores, several NUMA nodes) keep them on the cores next to this rank's GPU.  Best effort: returns the
+    cpulist used, or None when the topology is not visible."""
+    try:
+        import ctypes
+        buf = ctypes.create_string_buffer(64)
+        if L.rd_device_pci_bus_id(dev, buf, 64) != 0:
+            return None
+        bus = buf.value.decode().lower()
+        with open("/sys/bus/pci/devices/%s/local_cpulist" % bus) as f:
+            spec = f.read().strip()
+        cpus = set()
+        for part in spec.split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if len(cpus) < 2:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return spec
+    except (OSError, ValueError, AttributeError):
         return None
 
 
@@ -69,6 +130,7 @@ def main():
     ap.add_argument("--slots", type=int, default=8, help="frames in flight per GPU (from three on: one stream per frame on four shared streams)")
     ap.add_argument("--host-frames", action="store_true", help="hand over host buffers (PCIe upload inside the timed region); not the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="profiling runs only: skip the sequential verification pass and the host-frames pass (the line then says outputs_verified: null)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercises sharding/aggregation only (CPU tests)")
     ap.add_argument("--backend", default=None)
     args = ap.parse_args()
@@ -104,6 +166,7 @@ def main():
             L.rd_synth_frame(a.ctypes.data, IW, IH, IW * 3, synth.SEED0 + seed_stream, t, 1)
             frames.append(a)
         dev = local % L.rd_device_count()     # identity on a full node; lets two ranks share the only GPU of a test box (gloo)
+        pinned = pin_to_gpu_cores(L, dev) if world > 1 else None
         det = ra.Detector(IW, IH, device=dev, nslots=args.slots, nworkers=1)
         dframes = []
         for a in frames:
@@ -111,37 +174,49 @@ def main():
             L.rd_upload(p, a.ctypes.data, a.nbytes)
             dframes.append(p)
 
-    nrect = 0
+    import zlib
+    results = []                 # rectangle lists in stream order (numpy arrays returned by poll)
     inflight = 0
+    use_host = [args.host_frames]
 
-    def step():
+    def step(d=None, slots=None):
         """one pass over the batch of F frames: every frame is handed to the detector; it is a stream, so the results of the
         last frames in flight are collected at the beginning of the next step (or by sync() at the end of the timed region)"""
-        nonlocal nrect, inflight
+        nonlocal inflight
         if args.dry_run:
             time.sleep(0.01 * (1 + rank))
             return
+        d = d or det
+        slots = slots or args.slots
         for i in range(F):
-            if inflight == args.slots:
-                nrect += len(det.poll(TAN_AOV))
+            if inflight == slots:
+                results.append(d.poll(TAN_AOV))
                 inflight -= 1
-            if args.host_frames:
-                det.enqueue(frames[i])
+            if use_host[0]:
+                d.enqueue(frames[i])
             else:
-                det.enqueue(dframes[i], ws=IW * 3, on_device=True)
+                d.enqueue(dframes[i], ws=IW * 3, on_device=True)
             inflight += 1
 
-    def sync():
+    def sync(d=None):
         """all frames handed over so far are finished, post-processed and their rectangles collected"""
-        nonlocal nrect, inflight
+        nonlocal inflight
         if not args.dry_run:
+            d = d or det
             while inflight:
-                nrect += len(det.poll(TAN_AOV))
+                results.append(d.poll(TAN_AOV))
                 inflight -= 1
-            det.drain()
+            d.drain()
             if dist is not None and dist.get_backend() == "nccl":
                 import torch
                 torch.cuda.synchronize()
+
+    def timed(nsteps, d=None, slots=None):
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            step(d, slots)
+        sync(d)
+        return time.perf_counter() - t0
 
     for _ in range(args.warmup):
         step()
@@ -150,11 +225,8 @@ def main():
         dist.barrier()
     dev0 = det.device_time() if det is not None else (0, 0)
     enq0 = ra.lib().rd_detector_counter(det.h, 3) if det is not None else 0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(args.steps)
+    own_elapsed = elapsed
     dev1 = det.device_time() if det is not None else (0, 0)
     enq1 = ra.lib().rd_detector_counter(det.h, 3) if det is not None else 0
     if dist is not None:
@@ -166,20 +238,66 @@ def main():
         elapsed = float(t.item())
         dist.barrier()
 
+    # who did what: every rank reports its device, stream seed, frames and time (host-side gather of a few bytes, not a data-path collective)
+    mine = {"rank": rank, "device": None if args.dry_run else dev, "stream_seed": seed_stream, "frames": args.steps * F,
+            "rectangles": int(sum(len(r) for r in results[args.warmup * F:])), "own_elapsed_s": round(own_elapsed, 4), "pinned_cpus": None if args.dry_run else pinned}
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+
     if rank == 0:
         total_frames = world * args.steps * F
         fps = total_frames / elapsed
         N = IW * IH
         achieved = fps / world * B_ALG_PER_PIXEL * N      # bytes/s per GPU
+        digest = lambda lists: zlib.crc32(b"".join(np.ascontiguousarray(r).tobytes() for r in lists)) & 0xFFFFFFFF
+        verify = None
+        host_rate = None
+        rho = None
+        if det is not None and not args.no_verify:
+            # (1) the timed run's outputs against a plain sequential pass over the same stream (one frame in flight, no worker threads,
+            #     post-process inline), outside the timed region: a run that returned garbage cannot print a valid line
+            timed_lists = results[args.warmup * F:]
+            nrect = int(sum(len(r) for r in timed_lists))
+            chk = ra.Detector(IW, IH, device=dev, nslots=1, nworkers=0)
+            seq = []
+            for k in range((args.warmup + args.steps) * F):
+                chk.enqueue(dframes[k % F], ws=IW * 3, on_device=True)
+                seq.append(chk.poll(TAN_AOV))
+            ctr = chk.plane("polyctr", np.int32, 64)
+            rho = {"chain_pixels": int(ctr[0]), "chains": int(ctr[1]), "live_pixels": int(ctr[24]), "edge_density": round(float(ctr[0]) / N, 5)}
+            chk.close()
+            verify = {"outputs_verified": bool(len(timed_lists) == args.steps * F and digest(timed_lists) == digest(seq[args.warmup * F:])),
+                      "rectangles_in_timed_frames": nrect, "rect_list_crc32": "%08x" % digest(timed_lists),
+                      "against": "sequential pass of the same %d-frame stream, 1 frame in flight, no worker threads, outside the timed region" % len(seq)}
+            # (2) the same work with host buffers handed over (memcpy into pinned memory + PCIe upload inside the timed region):
+            #     SURVEY.md 8(d)'s "upload -> ... -> post-process" unit; reported beside the HBM-resident headline, never as `value`
+            if world == 1 and not args.host_frames:
+                results.clear()
+                use_host[0] = True
+                timed(1)
+                th = timed(args.steps)
+                use_host[0] = False
+                host_rate = round(args.steps * F / th, 2)
+        traffic, traffic_src = traffic_per_frame()
         out = {
             "metric": "1920x1080 frames/sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i32/f32 (bit-exact integer + IEEE f32 stencil path)", "data": "synthetic",
             "config": {"workload": "vidrect 1920x1080 synthetic stream per GPU (BASELINE.json configs[4]; configs[1] is one frame of it)",
                        "frames_per_step": F, "frames_in_flight": args.slots, "input": "BGR u8 host buffers (PCIe upload timed)" if args.host_frames else "BGR u8 frames resident in HBM", "parallelism": "independent streams, one per GPU, no collective"},
+            "ranks": per_rank,
+            "value_host_frames": host_rate,     # frames/s with host BGR buffers handed over (upload inside the timed region), same run, N=1 only
             "roofline": {"bound": "hbm", "kernel": "whole per-frame device pipeline (all stages, one stream per frame slot)",
                          "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
-                         "algorithmic_bytes_per_frame": B_ALG_PER_PIXEL * N, "traffic": traffic_per_frame(), "traffic_unit": "bytes/frame",
+                         "algorithmic_bytes_per_frame": B_ALG_PER_PIXEL * N,
+                         # how to read `frac`: SURVEY.md 8(d) prices the polyline stages S12-S18 as dense sweeps (697 of the 829 B/px); this
+                         # implementation runs them on compacted chain pixels (edge density below), so the 132 B/px of the stages it does run
+                         # densely are the part of the contract figure that costs HBM time here
+                         "algorithmic_bytes_dense_stages": 132 * N, "algorithmic_bytes_polyline_stages_priced_dense": 697 * N,
+                         "frac_dense_stages_only": round(fps / world * 132 * N / HBM_PEAK, 4), "stream_statistics": rho,
+                         "traffic": traffic, "traffic_unit": "bytes/frame", "traffic_source": traffic_src,
                          # HIP events on each frame's own stream over the timed region (rank 0): first kernel start -> last copy end.
                          # With several frames in flight these intervals overlap, which is why `achieved` is taken from the aggregate rate.
                          "frame_device_us_avg": round((dev1[0] - dev0[0]) / max(1, dev1[1] - dev0[1]), 1), "frames_in_flight": args.slots,
@@ -188,12 +306,17 @@ def main():
                          "frames_per_budget_8_12_16_20": [ra.lib().rd_detector_counter(det.h, 6 + k) for k in range(4)] if det is not None else None,
                          "frames_repeated": {"round_budget": det.region_round_budget()[1], "polyline_overflow": det.redone_frames()} if det is not None else None},
         }
+        out.update(verify or {"outputs_verified": None})
         if not args.dry_run and not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(frames)
+            out["cpu_baseline"] = cpu_baseline()
         if args.dry_run:
             out["dry_run"] = True
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
+        if verify and not verify["outputs_verified"]:
+            raise SystemExit("bench.py: the timed run's rectangle lists differ from the sequential pass - the line above is INVALID")
 
+    if dist is not None:
+        dist.barrier()       # (rank 0 verifies its outputs while the others wait)
     if det is not None:
         det.close()
     if dist is not None:

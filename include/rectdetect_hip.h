@@ -16,6 +16,7 @@ extern "C" {
 const char *rd_version(void);
 int rd_device_count(void);                  /* number of HIP devices visible to this process */
 void rd_select_device(int ordinal);         /* device used by simpleGetDevice(0) and new detectors (default 0) */
+int rd_device_pci_bus_id(int ordinal, char *buf, int len);   /* "0000:c1:00.0" into buf (len >= 16); 0 on success: for pinning a per-GPU host process to the GPU's NUMA cores */
 
 /* device memory helpers for callers without a HIP binding of their own (tests, bench) */
 void *rd_device_alloc(size_t bytes);

@@ -49,6 +49,7 @@ def _declare(L):
         "rd_version": (ctypes.c_char_p, []),
         "rd_device_count": (ci, []),
         "rd_select_device": (None, [ci]),
+        "rd_device_pci_bus_id": (ci, [ci, ctypes.c_char_p, ci]),
         "rd_device_alloc": (vp, [cz]),
         "rd_device_free": (None, [vp]),
         "rd_upload": (None, [vp, vp, cz]),

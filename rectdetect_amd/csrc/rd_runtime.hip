@@ -53,6 +53,13 @@ extern "C" {
 
 const char *rd_version(void) { return "rectdetect-mi355x 0.1 (gfx950)"; }
 int rd_device_count(void) { enumerate(); return g_ndev; }
+// PCI bus id ("0000:c1:00.0") of a HIP device: lets a per-GPU host process pin itself to the cores next to its GPU
+// (/sys/bus/pci/devices/<id>/local_cpulist).  Returns 0 on success.
+int rd_device_pci_bus_id(int ordinal, char *buf, int len) {
+  enumerate();
+  if (ordinal < 0 || ordinal >= g_ndev || !buf || len < 16) return -1;
+  return hipDeviceGetPCIBusId(buf, len, ordinal) == hipSuccess ? 0 : -1;
+}
 void rd_select_device(int ordinal) { enumerate(); if (ordinal < 0 || ordinal >= g_ndev) exitf(-1, "rd_select_device: no HIP device %d\n", ordinal); g_selected = ordinal; RD_HIP(hipSetDevice(ordinal)); }
 void *rd_device_alloc(size_t bytes) { void *p = NULL; RD_HIP(hipMalloc(&p, bytes ? bytes : 1)); return p; }
 void rd_device_free(void *dptr) { if (dptr) RD_HIP(hipFree(dptr)); }

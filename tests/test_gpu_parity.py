@@ -726,3 +726,33 @@ def test_busy_inputs_final_outputs_vs_reference():
         orc.close()
     for r in report:
         print(r)
+
+
+def test_two_real_detector_processes_share_the_gpu():
+    """bench.py --gpus 2 as the driver launches it, but with gloo and both ranks on this box's only GPU (dev = local_rank mod device
+    count): two real per-GPU processes - own detector, own stream seed, own worker threads - a barrier and the MAX-reduced time;
+    rank 0 verifies its outputs against a sequential pass.  What can be proven about the N > 1 path without the 8-GPU node."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(helpers.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--frames-per-step", "24", "--backend", "gloo"]
+    p = subprocess.run(cmd, cwd=helpers.ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["outputs_verified"] is True
+    ranks = sorted(out["ranks"], key=lambda r: r["rank"])
+    assert [r["rank"] for r in ranks] == [0, 1] and ranks[0]["stream_seed"] != ranks[1]["stream_seed"]
+    assert all(r["frames"] == 48 and r["rectangles"] > 0 for r in ranks)
+    assert ranks[0]["rectangles"] != ranks[1]["rectangles"] or ranks[0]["stream_seed"] != ranks[1]["stream_seed"]
+    assert abs(out["ms_per_step"] * 2 / 1e3 - max(r["own_elapsed_s"] for r in ranks)) < 5e-3      # MAX over ranks
+    assert abs(out["value"] - 96 / (out["ms_per_step"] * 2 / 1e3)) / out["value"] < 0.01             # whole-job frames / that time
+    print("two ranks on one GPU:", out["value"], "frames/s;", ranks)

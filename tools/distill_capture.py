@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn what tools/gpu_capture.sh <tag> brought back (gpurun_out/cap<tag>/) into the files committed under profiles/.
-usage: distill_capture.py <tag> <round prefix, e.g. r01_g>"""
+usage: distill_capture.py <tag> <round prefix, e.g. r02_a>"""
 import sys, os, json, shutil, sqlite3, subprocess, collections
 
 tag, pre = sys.argv[1], sys.argv[2]
@@ -13,8 +13,7 @@ def run(*a):
     return subprocess.run([sys.executable] + list(a), capture_output=True, text=True, check=True).stdout
 
 
-for src, dst in (("bench_default.json", "bench_default_slots8.json"), ("bench_hostframes.json", "bench_hostframes_slots8.json"),
-                 ("bench_slots1.json", "bench_slots1.json"), ("bench_slots2.json", "bench_slots2.json")):
+for src, dst in (("bench_default.json", "bench_default_slots8.json"), ("bench_slots1.json", "bench_slots1.json"), ("bench_slots2.json", "bench_slots2.json")):
     shutil.copy(os.path.join(C, src), os.path.join(P, pre + "_" + dst))
 with open(os.path.join(P, pre + "_size_sweep.txt"), "w") as f:
     f.write("# tools/size_sweep.py, SLOTS=8\n" + open(os.path.join(C, "size_sweep.txt")).read())
@@ -25,7 +24,7 @@ for name, out in (("trace_default", "kernel_stats_1080p_default.txt"), ("trace_s
     con = sqlite3.connect(db)
     frames = con.execute("select total_calls from top_kernels where name like '%k_bgr2plab_t%'").fetchone()[0]
     head = "# rocprofv3 --kernel-trace --stats -- python bench.py %s (%d frames)\n" % (
-        "--steps 2 --warmup 1 --no-cpu-baseline" if name == "trace_default" else "--steps 1 --warmup 1 --slots 1 --frames-per-step 8 --no-cpu-baseline", frames)
+        "--steps 2 --warmup 1 --no-cpu-baseline --no-verify" if name == "trace_default" else "--steps 1 --warmup 1 --slots 1 --frames-per-step 8 --no-cpu-baseline --no-verify", frames)
     with open(os.path.join(P, pre + "_" + out), "w") as f:
         f.write(head + run(os.path.join(R, "tools", "prof_summary.py"), db, str(frames)))
 
@@ -44,22 +43,30 @@ def total(db, counter, like=None):
     return con.execute(q, a).fetchone()[0] or 0.0
 
 
-rd = total(os.path.join(C, "pmc_rd", "results.db"), "FETCH_SIZE") / 8
-wr = total(os.path.join(C, "pmc_wr", "results.db"), "WRITE_SIZE") / 8
+def frames_in(db):
+    return sqlite3.connect(db).execute("select count(*) from counters_collection where kernel_name like '%k_bgr2plab_t%'").fetchone()[0]
+
+
+TRAFFIC_CMD = "python bench.py --steps 2 --warmup 1 --frames-per-step 16 --no-cpu-baseline --no-verify"
+nf_rd, nf_wr = frames_in(os.path.join(C, "pmc_rd", "results.db")), frames_in(os.path.join(C, "pmc_wr", "results.db"))
+rd = total(os.path.join(C, "pmc_rd", "results.db"), "FETCH_SIZE") / nf_rd
+wr = total(os.path.join(C, "pmc_wr", "results.db"), "WRITE_SIZE") / nf_wr
 cal_rd = total(os.path.join(C, "pmc_calrd", "results.db"), "FETCH_SIZE", "%k_copy_i%") / 3
 cal_wr = total(os.path.join(C, "pmc_calwr", "results.db"), "WRITE_SIZE", "%k_copy_i%") / 3
 gib_kib = (1 << 30) / 1024
 corr_rd = round(gib_kib / cal_rd, 3)
 corr_wr = round(gib_kib / cal_wr, 3)
 with open(os.path.join(P, pre + "_pmc_traffic_1080p.txt"), "w") as f:
-    f.write("# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KiB per frame; RD_NO_GRAPH=1, bench.py --steps 1 --warmup 1 --slots 1 --frames-per-step 4)\n")
-    f.write(run(os.path.join(R, "tools", "pmc_summary.py"), os.path.join(C, "pmc_rd", "results.db"), "8", "40"))
-    f.write(run(os.path.join(R, "tools", "pmc_summary.py"), os.path.join(C, "pmc_wr", "results.db"), "8", "40"))
+    f.write("# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KiB per frame; the benchmarked configuration: %s; %d frames)\n" % (TRAFFIC_CMD, nf_rd))
+    f.write(run(os.path.join(R, "tools", "pmc_summary.py"), os.path.join(C, "pmc_rd", "results.db"), str(nf_rd), "40"))
+    f.write(run(os.path.join(R, "tools", "pmc_summary.py"), os.path.join(C, "pmc_wr", "results.db"), str(nf_wr), "40"))
     f.write("# calibration (tools/pmc_calibrate.py: k_copy_i moves 1 GiB = %d KiB each way per call): FETCH_SIZE reports %.0f KiB, WRITE_SIZE %.0f KiB per call\n" % (gib_kib, cal_rd, cal_wr))
     f.write("# corrections: fetch x %.3f, write x %.3f\n" % (corr_rd, corr_wr))
 hbm = int((rd * corr_rd + wr * corr_wr) * 1024)
-with open(os.path.join(P, "r01_traffic.json"), "w") as f:
-    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over bench.py --slots 1 --frames-per-step 4 (profiles/%s_pmc_traffic_1080p.txt); "
+commit = subprocess.run(["git", "-C", R, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+with open(os.path.join(P, "r02_traffic.json"), "w") as f:
+    json.dump({"commit": commit + " (HEAD when the capture was distilled; the capture ran on the working tree)", "command": TRAFFIC_CMD, "frames": nf_rd,
+               "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over the benchmarked configuration (default slots, graphs on; profiles/%s_pmc_traffic_1080p.txt); "
                "each corrected by the factor the calibration copy of 3 x 1 GiB (4 B/lane coalesced, tools/pmc_calibrate.py) yields in the same capture "
                "(FETCH_SIZE reports half of the bytes read on gfx950, as MI355X_MICROARCH.md describes)" % pre,
                "fetch_size_kib_per_frame": int(rd), "write_size_kib_per_frame": int(wr), "fetch_correction": corr_rd, "write_correction": corr_wr,
