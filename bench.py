@@ -61,14 +61,14 @@ def cpu_model():
 def cpu_baseline():
     """The reference itself (oracle/_ref: its kernels + host C on the serial OpenCL shim) when that build travelled with the repo, else
     our C restatement + the product's host post-process, on the GPU box's host cores: one thread (4 frames), and all streams a
-    host would run side by side - one single-threaded instance per core on up to 64 cores, 2 frames each (frames of different
+    host would run side by side - one single-threaded instance per core on up to 32 cores, 2 frames each (frames of different
     streams are independent, SURVEY.md 8e: this is what `nproc` threads buy the CPU path).  A bounded sample, ~25 s."""
     import multiprocessing as mp
     from tests import helpers
     use_ref = helpers.have_ref()
     ncpu = len(os.sched_getaffinity(0))
     t1 = _cpu_baseline_worker((0, 4, use_ref))
-    P = max(1, min(ncpu, 64))
+    P = max(1, min(ncpu, 32))
     ctx = mp.get_context("spawn")
     t0 = time.time()
     with ctx.Pool(P) as pool:

@@ -164,17 +164,22 @@ def test_long_streams_in_the_benchmarked_configuration_vs_reference(name, nslots
     while inflight:
         got.append((det.poll(tan), det.last_segments()))
         inflight -= 1
-    exact = 0
+    exact = same_order = 0
+    canon = lambda rs: rs[np.lexsort(np.rint(rs["c2"]).reshape(len(rs), 8).T[::-1])] if len(rs) else rs     # by rounded corner coordinates
     for t, (rects, segs) in enumerate(got):
         assert helpers.segments_equal(segs, g[f"f{t}_segments"]), f"{name} frame {t}: segments differ from the reference"
         ref = g[f"f{t}_rects"]
         assert len(rects) == len(ref), f"{name} frame {t}: {len(rects)} rectangles, reference {len(ref)}"
+        same_order += helpers.rects_equal(rects, ref)
+        # The ORDER of the list is the iteration order of the reference's hash map over boundary-component ids (oclrect.c:1103); the ids
+        # come out of the region planes, whose values depend on the work-item order in the reference (H5/H6): compare as sets
+        rects, ref = canon(rects), canon(ref)
         assert np.array_equal(rects["status"], ref["status"])
         assert np.array_equal(np.rint(rects["c2"]), np.rint(ref["c2"]))
         for f in ("c2", "c3", "value"):
             assert np.abs(rects[f] - ref[f]).max(initial=0) <= 1e-4
         exact += helpers.rects_equal(rects, ref)
-    print(name, "slots", nslots, ": rectangle lists bit-identical to the reference's on %d of %d frames; round budget, repeats:" % (exact, nframes), det.region_round_budget())
+    print(name, "slots", nslots, ": rectangle sets bit-identical to the reference's on %d of %d frames (%d in the same list order); round budget, repeats:" % (exact, nframes, same_order), det.region_round_budget())
     det.close()
     for p in dptrs:
         L.rd_device_free(p)
