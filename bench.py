@@ -127,7 +127,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-step", type=int, default=64)
-    ap.add_argument("--slots", type=int, default=8, help="frames in flight per GPU (from three on: one stream per frame on four shared streams)")
+    ap.add_argument("--slots", type=int, default=16, help="frames in flight per GPU (from three on: one stream per frame on four shared streams; from twelve on: sparse stages in batches of four)")
     ap.add_argument("--host-frames", action="store_true", help="hand over host buffers (PCIe upload inside the timed region); not the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="profiling runs only: skip the sequential verification pass and the host-frames pass (the line then says outputs_verified: null)")

@@ -15,6 +15,9 @@ namespace {
 
 using namespace rd;
 using rdk::PolyScratch;
+using rdk::PolyFrame;
+// the frame a block works on (see PolyFrame): its descriptor lives in the kernel-argument segment (uniform scalar loads, indexable)
+#define RD_FRAME const PolyFrame &FRM = FRS.f[blockIdx.z]; const PolyScratch &s = FRM.ps
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 const dim3 block2(64, 4);
@@ -39,7 +42,12 @@ struct lsx_rec { long long mx00, mx01, mx11, my0, my1; short dx, dy, vx, vy; int
 #define PT_ROWS 16
 #define PT_M 6
 #define PT_P (64 + 2 * PT_M)
-__global__ __launch_bounds__(256) void k_poly_tidy(int *__restrict__ out, const int *__restrict__ in, const int *__restrict__ ring_src, int ring_const, int iw, int ih, int *gen) {
+__global__ __launch_bounds__(256) void k_poly_tidy(const rdk::PolyFrames FRS, int ring_const, int iw, int ih) {
+  RD_FRAME;
+  int *__restrict__ out = s.planeC;
+  const int *__restrict__ in = FRM.in;
+  const int *__restrict__ ring_src = FRM.ring_src;
+  int *gen = s.csync;
   __shared__ uint8_t A[(PT_ROWS + 2 * PT_M) * PT_P], B[(PT_ROWS + 2 * PT_M) * PT_P];
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * PT_ROWS;
   const int tid = threadIdx.y * 64 + threadIdx.x;
@@ -134,8 +142,18 @@ __device__ __forceinline__ unsigned long long cp_word(unsigned gen, unsigned sta
 // sub-chain (0 = dropped), computed and stored on the way; block 0 also resets what the single-launch stage expects cleared
 // (header record, counters ctr[2..23], ctr[25]) when ls != nullptr.
 template <int MODE>
-__global__ __launch_bounds__(256) void k_compact1(int *__restrict__ pos, int *__restrict__ cidx, int *__restrict__ rank1, const int *__restrict__ plane, int n, const int *nptr,
-                                                  int *cnt, unsigned long long *state, const int *genp, PolyScratch s, int size_thre, ls_rec *ls) {
+__global__ __launch_bounds__(256) void k_compact1(const rdk::PolyFrames FRS, int n, int nblk, int size_thre, int init_ls) {
+  RD_FRAME;
+  // what the three call sites compact, and where the results go (each has its own state words)
+  int *__restrict__ pos = MODE == 0 ? s.pos : (MODE == 2 ? s.live : nullptr);
+  int *__restrict__ cidx = MODE == 0 ? s.cidx : nullptr;
+  int *__restrict__ rank1 = MODE == 1 ? s.rootid : nullptr;
+  const int *__restrict__ plane = MODE == 0 ? s.planeC : nullptr;
+  const int *nptr = MODE == 0 ? nullptr : s.ctr;
+  int *cnt = MODE == 0 ? s.ctr : (MODE == 1 ? s.ctr + 1 : s.ctr + 24);
+  unsigned long long *state = s.cstate + (size_t)MODE * nblk;
+  const int *genp = s.csync;
+  ls_rec *ls = (MODE == 2 && init_ls) ? (ls_rec *)FRM.lslist : nullptr;
   if (MODE == 2 && ls != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
     ls_rec z = {};
     ls[0] = z;
@@ -234,7 +252,8 @@ __global__ __launch_bounds__(256) void k_compact1(int *__restrict__ pos, int *__
 // The 8 neighbour compact indices of every chain pixel (E,NE,N,NW,W,SW,S,SE; -1 = none), its degree, and - in the same launch -
 // the 8-connected components of the chain mask (pl:811-854 to convergence): union with every neighbour of smaller index.
 // (lab[i] = i and ends[i] = 0 were set for all chain pixels by the compaction that produced them: k_compact1<0>)
-__global__ void k_chain_union(PolyScratch s, int iw) {
+__global__ void k_chain_union(const rdk::PolyFrames FRS, int iw) {
+  RD_FRAME;
   const int cnt = s.ctr[0];
   SPARSE_LOOP(i, cnt) {
     const int p = s.pos[i];
@@ -254,8 +273,14 @@ __global__ void k_chain_union(PolyScratch s, int iw) {
 //   size: pl:357-378 - pixels per sub-chain.  The lanes of a wave are consecutive chain pixels in raster order: a run of equal roots
 //         (a horizontal stretch of one chain) is counted by its first lane - same-address atomics are served one after the other,
 //         a long chain was thousands of them.
-__global__ void k_flatten(int *lab, const int *ctr, int *ends, const int *deg, int *size) {
-  const int cnt = ctr[0];
+// which 0: chain labels (+ ends per chain); 1: sub-chain labels (+ sizes)
+__global__ void k_flatten(const rdk::PolyFrames FRS, int which) {
+  RD_FRAME;
+  int *lab = which == 0 ? s.lab : s.lab2;
+  int *ends = which == 0 ? s.ends : nullptr;
+  const int *deg = s.flag2;
+  int *size = which == 0 ? nullptr : s.size;
+  const int cnt = s.ctr[0];
   for (int i0 = (blockIdx.x * blockDim.x + threadIdx.x) & ~63; i0 < cnt; i0 += gridDim.x * blockDim.x) {     // whole waves together
     const int lane = threadIdx.x & 63, i = i0 + lane;
     int r = -1;
@@ -278,7 +303,8 @@ __global__ void k_flatten(int *lab, const int *ctr, int *ends, const int *deg, i
 // pl:169-220: the first two living neighbours (order E,NE,N,NW,W,SW,S,SE) become next / prev; self if missing.
 // (one launch: whether a pixel is such a root is read off the labels and end counts directly; the pixel's own verdict is stored
 //  in alive[] for the launches that follow)
-__global__ void k_find_ends0(PolyScratch s) {
+__global__ void k_find_ends0(const rdk::PolyFrames FRS) {
+  RD_FRAME;
   const int cnt = s.ctr[0];
   SPARSE_LOOP(i, cnt) {
     // (the eight neighbours, then their labels and end counts: two levels of loads, each issued together)
@@ -304,7 +330,8 @@ __global__ void k_find_ends0(PolyScratch s) {
   }
 }
 
-__global__ void k_find_ends0_flags(PolyScratch s) {
+__global__ void k_find_ends0_flags(const rdk::PolyFrames FRS) {
+  RD_FRAME;
   const int cnt = s.ctr[0];
   SPARSE_LOOP(i, cnt) {
     int f = 0;
@@ -320,7 +347,8 @@ __global__ void k_find_ends0_flags(PolyScratch s) {
 // pl:222-267: eight hops towards both chain ends with orientation-reversal tracking; page selects the flag bit pair
 // (final: the last of the four launches also does pl:269-285 for its pixel - link towards the end with the smaller index, the
 //  end itself gets number 0 - with the two ends it has just found)
-__global__ void k_find_ends1(PolyScratch s, int page, int final) {
+__global__ void k_find_ends1(const rdk::PolyFrames FRS, int page, int final) {
+  RD_FRAME;
   const int cnt = s.ctr[0];
   const int *ni = s.nx[page], *pi = s.pv[page];
   int *no = s.nx[page ^ 1], *po = s.pv[page ^ 1];
@@ -367,7 +395,8 @@ __global__ void k_find_ends1(PolyScratch s, int page, int final) {
 
 // pl:287-310: 32-hop pointer-jumping prefix sum of the hop counts
 // (init_sub: the last round also sets up the sub-chain labelling that follows - pl:312-355 - from the final numbers)
-__global__ void k_number(PolyScratch s, int src, int init_sub) {
+__global__ void k_number(const rdk::PolyFrames FRS, int src, int init_sub) {
+  RD_FRAME;
   const int cnt = s.ctr[0];
   const int *ni = s.num[src], *li = s.link[src];
   int *no = s.num[src ^ 1], *lo_ = s.link[src ^ 1];
@@ -390,7 +419,9 @@ __global__ void k_number(PolyScratch s, int src, int init_sub) {
 }
 
 // pl:312-355 to convergence: split chains where the numbering jumps by more than one (set up by the last k_number launch)
-__global__ void k_sub_union(PolyScratch s, const int *number) {
+__global__ void k_sub_union(const rdk::PolyFrames FRS) {
+  RD_FRAME;
+  const int *__restrict__ number = s.num[1];
   const int cnt = s.ctr[0];
   SPARSE_LOOP(i, cnt) {
     const int a = number[i];
@@ -410,7 +441,9 @@ __global__ void k_sub_union(PolyScratch s, const int *number) {
 // ------------------------------------------------------------------------------------------------ initial segments (pl:439-506)
 #define FITS(g, bytes) ((g) >= 0 && (long long)(bytes) > (long long)((g) + 1) * 56ll)
 
-__global__ void k_seg_clear(PolyScratch s, ls_rec *ls, int lsbytes) {
+__global__ void k_seg_clear(const rdk::PolyFrames FRS, int lsbytes) {
+  RD_FRAME;
+  ls_rec *ls = (ls_rec *)FRM.lslist;
   const int K = s.ctr[1];
   const int maxrec = lsbytes / 56;
   SPARSE_LOOP(g, K + 1) {
@@ -423,7 +456,10 @@ __global__ void k_seg_clear(PolyScratch s, ls_rec *ls, int lsbytes) {
   if (blockIdx.x == 0 && threadIdx.x == 0) { for (int k = 2; k < 24; k++) s.ctr[k] = 0; s.ctr[25] = 0; }
 }
 
-__global__ void k_seg_pass0a(PolyScratch s, ls_rec *ls, int lsbytes, const int *number) {
+__global__ void k_seg_pass0a(const rdk::PolyFrames FRS, int lsbytes) {
+  RD_FRAME;
+  ls_rec *ls = (ls_rec *)FRM.lslist;
+  const int *__restrict__ number = s.num[1];
   const int nlive = s.ctr[24];
   SPARSE_LOOP(j, nlive) {
     const int i = s.live[j];
@@ -436,7 +472,10 @@ __global__ void k_seg_pass0a(PolyScratch s, ls_rec *ls, int lsbytes, const int *
   }
 }
 
-__global__ void k_seg_pass0b(PolyScratch s, ls_rec *ls, int lsbytes, const int *number) {
+__global__ void k_seg_pass0b(const rdk::PolyFrames FRS, int lsbytes) {
+  RD_FRAME;
+  ls_rec *ls = (ls_rec *)FRM.lslist;
+  const int *__restrict__ number = s.num[1];
   const int nlive = s.ctr[24];
   SPARSE_LOOP(j, nlive) {
     const int i = s.live[j];
@@ -447,7 +486,9 @@ __global__ void k_seg_pass0b(PolyScratch s, ls_rec *ls, int lsbytes, const int *
   }
 }
 
-__global__ void k_seg_finish(PolyScratch s, ls_rec *ls, int lsbytes, int iw) {
+__global__ void k_seg_finish(const rdk::PolyFrames FRS, int lsbytes, int iw) {
+  RD_FRAME;
+  ls_rec *ls = (ls_rec *)FRM.lslist;
   const int K = s.ctr[1];
   SPARSE_LOOP(g0, K) {
     const int g = g0 + 1;
@@ -468,7 +509,10 @@ __device__ __forceinline__ float dist2f(float vx, float vy, float wx, float wy) 
 
 // pass 3 of the previous round (pixels beyond the new end move right) fused with pass 1 of this round (distance to
 // the chord with integer-truncated end points, tie-breaking hash, per-segment maximum)
-__global__ void k_split_move_dist(PolyScratch s, ls_rec *ls, int lsbytes, const int *number, int iw, int do_dist) {
+__global__ void k_split_move_dist(const rdk::PolyFrames FRS, int lsbytes, int iw, int do_dist) {
+  RD_FRAME;
+  ls_rec *ls = (ls_rec *)FRM.lslist;
+  const int *__restrict__ number = s.num[1];
   const int nlive = s.ctr[24];
   SPARSE_LOOP(j, nlive) {
     const int i = s.live[j];
@@ -499,7 +543,10 @@ __global__ void k_split_move_dist(PolyScratch s, ls_rec *ls, int lsbytes, const 
 // pass 2, detection: the pixel that realises its segment's maximum distance and passes the split tests becomes a
 // candidate; everything pass 2 needs from the OLD list is stored with the candidate (the reference reads a snapshot).
 // cand record: {i, g, n, maxDist, oldEndIndex, oldRight, x1 bits, y1 bits}
-__global__ void k_split_detect(PolyScratch s, const ls_rec *ls, int lsbytes, const int *number, float minerror, int iw, int round) {
+__global__ void k_split_detect(const rdk::PolyFrames FRS, int lsbytes, float minerror, int iw, int round) {
+  RD_FRAME;
+  const ls_rec *ls = (const ls_rec *)FRM.lslist;
+  const int *__restrict__ number = s.num[1];
   const int nlive = s.ctr[24];
   SPARSE_LOOP(j, nlive) {
     const int i = s.live[j];
@@ -525,7 +572,9 @@ __global__ void k_split_detect(PolyScratch s, const ls_rec *ls, int lsbytes, con
 
 // pass 2, application: new ids follow the raster order of the candidates (rank by pixel index); when several
 // candidates share a segment the one latest in raster order decides the shared fields, as a serial execution would.
-__global__ void k_split_apply(PolyScratch s, ls_rec *ls, int lsbytes, int iw, int round) {
+__global__ void k_split_apply(const rdk::PolyFrames FRS, int lsbytes, int iw, int round) {
+  RD_FRAME;
+  ls_rec *ls = (ls_rec *)FRM.lslist;
   const int C = s.ctr[2 + round];
   const int base = *(const int *)ls;
   SPARSE_LOOP(c, C) {
@@ -554,12 +603,16 @@ __global__ void k_split_apply(PolyScratch s, ls_rec *ls, int lsbytes, int iw, in
   }
 }
 
-__global__ void k_split_commit(PolyScratch s, ls_rec *ls, int round) {
+__global__ void k_split_commit(const rdk::PolyFrames FRS, int round) {
+  RD_FRAME;
+  ls_rec *ls = (ls_rec *)FRM.lslist;
   if (blockIdx.x == 0 && threadIdx.x == 0) *(int *)ls += s.ctr[2 + round];
 }
 
 // ------------------------------------------------------------------------------------------------ refinement (pl:680-809)
-__global__ void k_refine0(PolyScratch s, const ls_rec *ls, int maxrec) {
+__global__ void k_refine0(const rdk::PolyFrames FRS, int maxrec) {
+  RD_FRAME;
+  const ls_rec *ls = (const ls_rec *)FRM.lslist;
   const int n = *(const int *)ls;
   lsx_rec *sx = (lsx_rec *)s.lsx;
   SPARSE_LOOP(g0, n) {
@@ -575,7 +628,9 @@ __global__ void k_refine0(PolyScratch s, const ls_rec *ls, int maxrec) {
   }
 }
 
-__global__ void k_refine1(PolyScratch s, const ls_rec *ls, int maxrec, int iw) {
+__global__ void k_refine1(const rdk::PolyFrames FRS, int maxrec, int iw) {
+  RD_FRAME;
+  const ls_rec *ls = (const ls_rec *)FRM.lslist;
   const int nlive = s.ctr[24];
   const int n = *(const int *)ls;
   lsx_rec *sx = (lsx_rec *)s.lsx;
@@ -596,7 +651,9 @@ __global__ void k_refine1(PolyScratch s, const ls_rec *ls, int maxrec, int iw) {
   }
 }
 
-__global__ void k_refine2(PolyScratch s, ls_rec *ls, int maxrec) {
+__global__ void k_refine2(const rdk::PolyFrames FRS, int maxrec) {
+  RD_FRAME;
+  ls_rec *ls = (ls_rec *)FRM.lslist;
   const int n = *(const int *)ls;
   const lsx_rec *sx = (const lsx_rec *)s.lsx;
   SPARSE_LOOP(g0, n) {
@@ -617,7 +674,9 @@ __global__ void k_refine2(PolyScratch s, ls_rec *ls, int maxrec) {
 // Steps of non-adjacent segments commute, hence the serial result is obtained by letting a segment run as soon as every
 // neighbour with a smaller id has run and keeping neighbours with larger ids waiting: one block, rounds separated by
 // barriers; `done` lives in global scratch.
-__global__ __launch_bounds__(1024) void k_refine3(PolyScratch s, ls_rec *ls, int maxrec) {
+__global__ __launch_bounds__(1024) void k_refine3(const rdk::PolyFrames FRS, int maxrec) {
+  RD_FRAME;
+  ls_rec *ls = (ls_rec *)FRM.lslist;
   __shared__ int progress;
   const int n0 = *(const int *)ls;
   const int n = n0 < maxrec - 1 ? n0 : maxrec - 1;
@@ -748,7 +807,10 @@ __device__ __noinline__ void pp_moments(pp_lds &L, int pk, int xyv, int n) {
   atomicAdd((unsigned long long *)&L.sx[g].my1, (unsigned long long)(long long)rintf((float)ax1 * (float)ay));
 }
 
-__global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec *ls, int lsbytes, const int *__restrict__ number, float minerror, int iw) {
+__global__ __launch_bounds__(PP_T) void k_poly_persistent(const rdk::PolyFrames FRS, int lsbytes, float minerror, int iw) {
+  RD_FRAME;
+  ls_rec *ls = (ls_rec *)FRM.lslist;
+  const int *__restrict__ number = s.num[1];
   extern __shared__ __attribute__((aligned(16))) char pp_raw[];
   pp_lds &L = *(pp_lds *)pp_raw;
   const int tid = threadIdx.x;
@@ -959,7 +1021,9 @@ __global__ __launch_bounds__(PP_T) void k_poly_persistent(PolyScratch s, ls_rec 
   if (tid == 0) s.ctr[45] = (int)wall_clock64();
 }
 
-__global__ void k_scatter_ids(PolyScratch s, int *ids) {
+__global__ void k_scatter_ids(const rdk::PolyFrames FRS) {
+  RD_FRAME;
+  int *ids = FRM.ids;
   const int nlive = s.ctr[24];
   SPARSE_LOOP(j, nlive) { const int i = s.live[j]; ids[s.pos[i]] = s.id[i]; }
 }
@@ -1004,76 +1068,72 @@ void poly_scratch_destroy(PolyScratch *ps) {
   delete ps;
 }
 
-void polyline(hipStream_t st, PolyScratch *ps, void *lslist, int lslist_bytes, int *ids, const int *in, const int *ring_src, int ring_const,
-              float minerror, int sizeThre, int iw, int ih, int mode) {
+// frames_host: nb <= RD_MAXB descriptors (frame z of every launch = frames_host[z]); all frames share the scalar parameters
+void polyline(hipStream_t st, const PolyFrame *frames_host, int nb, int lslist_bytes, int ring_const, float minerror, int sizeThre, int iw, int ih, int mode) {
+  const PolyFrames frames = pack_frames(frames_host, nb);
   const int N = iw * ih;
-  PolyScratch s = *ps;
-  ls_rec *ls = (ls_rec *)lslist;
   const int maxrec = lslist_bytes / 56;
-  const dim3 sg(SPARSE_GRID), sb(256);
+  const dim3 sg(SPARSE_GRID, 1, nb), sb(256);
 
   // tidy (oclpolyline.c:222-235)
-  hipLaunchKernelGGL(k_poly_tidy, dim3(cdiv(iw, 64), cdiv(ih, PT_ROWS)), dim3(64, 4), 0, st, s.planeC, in, ring_src, ring_const, iw, ih, s.csync);
+  hipLaunchKernelGGL(k_poly_tidy, dim3(cdiv(iw, 64), cdiv(ih, PT_ROWS), nb), dim3(64, 4), 0, st, frames, ring_const, iw, ih);
 
   // compaction of the chain pixels in raster order
   const int nblk = cdiv(N, CP_PER_BLOCK);
-  hipLaunchKernelGGL(k_compact1<0>, dim3(nblk), dim3(256), 0, st, s.pos, s.cidx, (int *)nullptr, (const int *)s.planeC, N, (const int *)nullptr, s.ctr, s.cstate, (const int *)s.csync, s, 0, (ls_rec *)nullptr);
+  const dim3 cg(nblk, 1, nb);
+  hipLaunchKernelGGL(k_compact1<0>, cg, dim3(256), 0, st, frames, N, nblk, 0, 0);
 
   // chains, loops, ends (oclpolyline.c:237-266)
-  hipLaunchKernelGGL(k_chain_union, sg, sb, 0, st, s, iw);
-  hipLaunchKernelGGL(k_flatten, sg, sb, 0, st, s.lab, (const int *)s.ctr, s.ends, (const int *)s.flag2, (int *)nullptr);      // + ends per chain
-  hipLaunchKernelGGL(k_find_ends0, sg, sb, 0, st, s);
-  hipLaunchKernelGGL(k_find_ends0_flags, sg, sb, 0, st, s);
-  for (int r = 0; r < 4; r++) hipLaunchKernelGGL(k_find_ends1, sg, sb, 0, st, s, r & 1, r == 3 ? 1 : 0);      // (the last one also links and numbers: pl:269-285)
-  // numbering (oclpolyline.c:268-275): three rounds 0->1->0->1
-  for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k_number, sg, sb, 0, st, s, r & 1, r == 2 ? 1 : 0);
-  const int *number = s.num[1];
+  hipLaunchKernelGGL(k_chain_union, sg, sb, 0, st, frames, iw);
+  hipLaunchKernelGGL(k_flatten, sg, sb, 0, st, frames, 0);      // + ends per chain
+  hipLaunchKernelGGL(k_find_ends0, sg, sb, 0, st, frames);
+  hipLaunchKernelGGL(k_find_ends0_flags, sg, sb, 0, st, frames);
+  for (int r = 0; r < 4; r++) hipLaunchKernelGGL(k_find_ends1, sg, sb, 0, st, frames, r & 1, r == 3 ? 1 : 0);      // (the last one also links and numbers: pl:269-285)
+  // numbering (oclpolyline.c:268-275): three rounds 0->1->0->1 (the result is num[1])
+  for (int r = 0; r < 3; r++) hipLaunchKernelGGL(k_number, sg, sb, 0, st, frames, r & 1, r == 2 ? 1 : 0);
 
   // split at numbering jumps, size filter, compact ids (oclpolyline.c:277-295)
-  hipLaunchKernelGGL(k_sub_union, sg, sb, 0, st, s, number);
-  hipLaunchKernelGGL(k_flatten, sg, sb, 0, st, s.lab2, (const int *)s.ctr, (int *)nullptr, (const int *)nullptr, s.size);     // + sub-chain sizes
+  hipLaunchKernelGGL(k_sub_union, sg, sb, 0, st, frames);
+  hipLaunchKernelGGL(k_flatten, sg, sb, 0, st, frames, 1);     // + sub-chain sizes
   // (the chain-pixel count lives on the device: launch for the worst case, blocks beyond it exit at once)
-  hipLaunchKernelGGL(k_compact1<1>, dim3(nblk), dim3(256), 0, st, (int *)nullptr, (int *)nullptr, s.rootid, (const int *)nullptr, N, (const int *)s.ctr, s.ctr + 1, s.cstate + (size_t)nblk, (const int *)s.csync, s, sizeThre, (ls_rec *)nullptr);
-  hipLaunchKernelGGL(k_compact1<2>, dim3(nblk), dim3(256), 0, st, s.live, (int *)nullptr, (int *)nullptr, (const int *)nullptr, N, (const int *)s.ctr, s.ctr + 24, s.cstate + 2 * (size_t)nblk, (const int *)s.csync, s, 0, mode == 1 ? ls : (ls_rec *)nullptr);
+  hipLaunchKernelGGL(k_compact1<1>, cg, dim3(256), 0, st, frames, N, nblk, sizeThre, 0);
+  hipLaunchKernelGGL(k_compact1<2>, cg, dim3(256), 0, st, frames, N, nblk, 0, mode == 1 ? 1 : 0);
 
   if (mode == 1) {
-    // fast path: initial segments, 15 subdivision rounds and the refinement in one persistent launch (overflow -> ctr[25])
+    // fast path: initial segments, 15 subdivision rounds and the refinement in one persistent launch, one block per frame (overflow -> ctr[25])
     static bool attr_set = false;
     if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_poly_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pp_lds)); attr_set = true; }
-    hipLaunchKernelGGL(k_poly_persistent, dim3(1), dim3(PP_T), sizeof(pp_lds), st, s, ls, lslist_bytes, number, minerror, iw);
-    if (ids) polyline_ids(st, ps, ids, N);
+    hipLaunchKernelGGL(k_poly_persistent, dim3(1, 1, nb), dim3(PP_T), sizeof(pp_lds), st, frames, lslist_bytes, minerror, iw);
     return;
   }
 
   // initial segments (oclpolyline.c:191-197)
-  (void)hipMemsetAsync(lslist, 0, 56, st);
-  hipLaunchKernelGGL(k_seg_clear, sg, sb, 0, st, s, ls, lslist_bytes);
-  hipLaunchKernelGGL(k_seg_pass0a, sg, sb, 0, st, s, ls, lslist_bytes, number);
-  hipLaunchKernelGGL(k_seg_pass0b, sg, sb, 0, st, s, ls, lslist_bytes, number);
-  hipLaunchKernelGGL(k_seg_finish, sg, sb, 0, st, s, ls, lslist_bytes, iw);
+  hipLaunchKernelGGL(k_seg_clear, sg, sb, 0, st, frames, lslist_bytes);
+  hipLaunchKernelGGL(k_seg_pass0a, sg, sb, 0, st, frames, lslist_bytes);
+  hipLaunchKernelGGL(k_seg_pass0b, sg, sb, 0, st, frames, lslist_bytes);
+  hipLaunchKernelGGL(k_seg_finish, sg, sb, 0, st, frames, lslist_bytes, iw);
 
   // 15 subdivision rounds (oclpolyline.c:202-213)
   for (int r = 0; r < 15; r++) {
-    hipLaunchKernelGGL(k_split_move_dist, sg, sb, 0, st, s, ls, lslist_bytes, number, iw, 1);
-    hipLaunchKernelGGL(k_split_detect, sg, sb, 0, st, s, (const ls_rec *)ls, lslist_bytes, number, minerror, iw, r);
-    hipLaunchKernelGGL(k_split_apply, sg, sb, 0, st, s, ls, lslist_bytes, iw, r);
-    hipLaunchKernelGGL(k_split_commit, dim3(1), dim3(64), 0, st, s, ls, r);
+    hipLaunchKernelGGL(k_split_move_dist, sg, sb, 0, st, frames, lslist_bytes, iw, 1);
+    hipLaunchKernelGGL(k_split_detect, sg, sb, 0, st, frames, lslist_bytes, minerror, iw, r);
+    hipLaunchKernelGGL(k_split_apply, sg, sb, 0, st, frames, lslist_bytes, iw, r);
+    hipLaunchKernelGGL(k_split_commit, dim3(1, 1, nb), dim3(64), 0, st, frames, r);
   }
-  hipLaunchKernelGGL(k_split_move_dist, sg, sb, 0, st, s, ls, lslist_bytes, number, iw, 0);
+  hipLaunchKernelGGL(k_split_move_dist, sg, sb, 0, st, frames, lslist_bytes, iw, 0);
 
   // refinement (oclpolyline.c:299-306)
-  hipLaunchKernelGGL(k_refine0, sg, sb, 0, st, s, (const ls_rec *)ls, maxrec);
-  hipLaunchKernelGGL(k_refine1, sg, sb, 0, st, s, (const ls_rec *)ls, maxrec, iw);
-  hipLaunchKernelGGL(k_refine2, sg, sb, 0, st, s, ls, maxrec);
-  hipLaunchKernelGGL(k_refine3, dim3(1), dim3(1024), 0, st, s, ls, maxrec);
-
-  // per-pixel segment ids as a dense plane (lsIdOut)
-  if (ids) polyline_ids(st, ps, ids, N);
+  hipLaunchKernelGGL(k_refine0, sg, sb, 0, st, frames, maxrec);
+  hipLaunchKernelGGL(k_refine1, sg, sb, 0, st, frames, maxrec, iw);
+  hipLaunchKernelGGL(k_refine2, sg, sb, 0, st, frames, maxrec);
+  hipLaunchKernelGGL(k_refine3, dim3(1, 1, nb), dim3(1024), 0, st, frames, maxrec);
 }
 
-void polyline_ids(hipStream_t st, PolyScratch *ps, int *ids, int n) {
-  (void)hipMemsetAsync(ids, 0, sizeof(int) * (size_t)n, st);
-  hipLaunchKernelGGL(k_scatter_ids, dim3(SPARSE_GRID), dim3(256), 0, st, *ps, ids);
+// per-pixel segment ids as a dense plane (lsIdOut = frames[z].ids) from the compact state
+void polyline_ids(hipStream_t st, const PolyFrame *frames_host, int nb, int n) {
+  const PolyFrames frames = pack_frames(frames_host, nb);
+  for (int z = 0; z < nb; z++) (void)hipMemsetAsync(frames_host[z].ids, 0, sizeof(int) * (size_t)n, st);
+  hipLaunchKernelGGL(k_scatter_ids, dim3(SPARSE_GRID, 1, nb), dim3(256), 0, st, frames);
 }
 
 }  // namespace rdk

@@ -272,6 +272,116 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
   }
 }
 
+// TWO (horizontal, vertical) pairs in a single launch: the tile is staged with a halo of 8 cells, and the four passes run through
+// two LDS planes that are reused (input -> H -> V -> H -> V -> output), each pass over a region that shrinks by the 4 cells its
+// samples can reach: 80x72, 72x72, 72x64 cells and the 64x64 tile.  A halo pixel's intermediate value is exactly the value the
+// full-plane pass gives it, because a run never extends beyond 4 cells from its pixel and never leaves the frame (the extents
+// say so), so everything it reads lies inside the staged region.  Half the launches and about half the HBM traffic of two
+// k_blblur_pair launches (27 against 61 MB per two pairs at 1920x1080) for 13 % more cell evaluations.
+#define BQ_ROWS 64
+#define BQ_AW 81              // pitch of plane A (80 columns used: x0-8 .. x0+71)
+#define BQ_BW 73              // pitch of plane B (72 columns used: x0-4 .. x0+67)
+#define BQ_NT 1024
+struct bq_lds {
+  uint2 A[(BQ_ROWS + 16) * BQ_AW + 1];      // staged input, later the first vertical pass's output (72 x 72 at the same pitch)
+  uint2 B[(BQ_ROWS + 16) * BQ_BW + 1];      // first horizontal pass's output, later the second one's (72 rows x 64, pitch 64)
+  float2 rwt[16];
+};
+// one pass over `ncell` cells of a region `cw` cells wide: cell t = (row t / cw, column t % cw) reads its run from `src` at
+// (row + dr0, column + dc0) +- d steps of `step` cells and writes `dst` at row * dpitch + column.  e[] = this thread's extents
+// for its cells of this pass (3-bit fields at bit `sh`: samples towards smaller / larger coordinates, each including the centre).
+template <int NCELL, int CW, int SPITCH, int DR0, int DC0, int STEP, int DPITCH, int SH, bool FINAL>
+__device__ __forceinline__ void bq_pass(const uint2 *src, int zslot, uint2 *dst, const float2 *rwt, const unsigned *e, int tid,
+                                        uint32_t *__restrict__ out, int x0, int y0, int iw, int ih) {
+  constexpr int IT = (NCELL + BQ_NT - 1) / BQ_NT;
+#pragma unroll
+  for (int i = 0; i < IT; i++) {
+    const int t = tid + BQ_NT * i;
+    if (IT * BQ_NT != NCELL && t >= NCELL) break;
+    const int r = t / CW, cc = t % CW;
+    const unsigned ee = e[i] >> SH;
+    const int nl = ee & 7, nr = (ee >> 3) & 7;
+    const int c = (r + DR0) * SPITCH + cc + DC0;
+    const unsigned cb = (unsigned)c * 8u, zb = (unsigned)zslot * 8u;
+    constexpr unsigned SB = 8u * STEP;
+    uint2 v[10];
+#pragma unroll
+    for (int d = 0; d < 5; d++) {
+      v[d] = *(const uint2 *)((const char *)src + ((d < nl ? cb - 4u * SB : zb - (4u * SB - SB * d)) + (4u * SB - SB * d)));
+      v[5 + d] = *(const uint2 *)((const char *)src + ((d < nr ? cb : zb - SB * d) + SB * d));
+    }
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int d = 0; d < 10; d++) { lo += v[d].x; hi += v[d].y; }
+    const int w = nl + nr;
+    uint2 o = src[c];
+    if (w > 0) {
+      const float2 rw = rwt[w];
+      o = make_uint2(div_small_f(lo & 0xffffu, rw) | (div_small_f(lo >> 16, rw) << 16), div_small_f(hi, rw));
+    }
+    if (FINAL) {
+      const int x = x0 + cc, y = y0 + r;
+      if (x < iw && y < ih) out[y * iw + x] = (o.x & 0xffffu) | ((o.x >> 16) << 12) | (o.y << 22);
+    } else dst[r * DPITCH + cc] = o;
+  }
+}
+
+__global__ __launch_bounds__(BQ_NT) void k_blblur_quad(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih) {
+  extern __shared__ __align__(16) unsigned char bq_raw[];
+  bq_lds &S = *reinterpret_cast<bq_lds *>(bq_raw);
+  constexpr int R16 = BQ_ROWS + 16, R8 = BQ_ROWS + 8;
+  constexpr int ZA = R16 * BQ_AW, ZB = R16 * BQ_BW;      // zero slots (behind the planes; the second use of B, 72 x 64, stays below ZB too)
+  constexpr int N1 = R16 * 72, N2 = R8 * 72, N3 = R8 * 64, N4 = BQ_ROWS * 64, NQ = R16 * 80;
+  constexpr int I1 = (N1 + BQ_NT - 1) / BQ_NT, I2 = (N2 + BQ_NT - 1) / BQ_NT, I3 = (N3 + BQ_NT - 1) / BQ_NT, I4 = (N4 + BQ_NT - 1) / BQ_NT, IQ = (NQ + BQ_NT - 1) / BQ_NT;
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BQ_ROWS;
+  // every global load of the block is issued here, unconditionally (clamped address, value dropped where the cell lies outside the
+  // frame), so that they are all in flight together: the extents of the thread's cells in the four passes and its share of the tile
+  unsigned e1[I1], e2[I2], e3[I3], e4[I4];
+  uint32_t q[IQ];
+  bool okq[IQ];
+#define BQ_EXT(E, I, N, CW, XOFF, YOFF)                                                       \
+  _Pragma("unroll") for (int i = 0; i < I; i++) {                                             \
+    const int t = tid + BQ_NT * i;                                                            \
+    const int xx = x0 + (XOFF) + t % (CW), yy = y0 + (YOFF) + t / (CW);                       \
+    const bool ok = t < (N) && xx >= 0 && xx < iw && yy >= 0 && yy < ih;                      \
+    const unsigned v = ext[ok ? yy * iw + xx : 0];                                            \
+    E[i] = ok ? v : 0u;                                                                       \
+  }
+  BQ_EXT(e1, I1, N1, 72, -4, -8)
+  BQ_EXT(e2, I2, N2, 72, -4, -4)
+  BQ_EXT(e3, I3, N3, 64, 0, -4)
+  BQ_EXT(e4, I4, N4, 64, 0, 0)
+#undef BQ_EXT
+#pragma unroll
+  for (int i = 0; i < IQ; i++) {
+    const int t = tid + BQ_NT * i;
+    const int xx = x0 - 8 + t % 80, yy = y0 - 8 + t / 80;
+    okq[i] = t < NQ && xx >= 0 && xx < iw && yy >= 0 && yy < ih;
+    q[i] = in[okq[i] ? yy * iw + xx : 0];
+  }
+  if (tid == 0) { S.A[ZA] = make_uint2(0, 0); S.B[ZB] = make_uint2(0, 0); }
+  if (tid < 16) { const float r = tid >= 1 && tid <= 10 ? 1.0f / (float)tid : 0.0f; S.rwt[tid] = make_float2(r, 0.5f * r); }
+#pragma unroll
+  for (int i = 0; i < IQ; i++) {
+    const int t = tid + BQ_NT * i;
+    const uint32_t v = okq[i] ? q[i] : 0u;
+    if (t < NQ) S.A[(t / 80) * BQ_AW + t % 80] = make_uint2((v & 4095u) | ((v << 4) & 0x3ff0000u), v >> 22);
+  }
+  __syncthreads();
+  // H: cells (row 0..79, column 0..71) <-> A(row, column + 4)
+  bq_pass<N1, 72, BQ_AW, 0, 4, 1, BQ_BW, 0, false>(S.A, ZA, S.B, S.rwt, e1, tid, nullptr, x0, y0, iw, ih);
+  __syncthreads();
+  // V: cells (row 0..71, column 0..71) <-> B(row + 4, column); result into A (its contents are no longer needed)
+  bq_pass<N2, 72, BQ_BW, 4, 0, BQ_BW, BQ_AW, 6, false>(S.B, ZB, S.A, S.rwt, e2, tid, nullptr, x0, y0, iw, ih);
+  __syncthreads();
+  // H: cells (row 0..71, column 0..63) <-> A(row, column + 4); result into B at pitch 64
+  bq_pass<N3, 64, BQ_AW, 0, 4, 1, 64, 0, false>(S.A, ZA, S.B, S.rwt, e3, tid, nullptr, x0, y0, iw, ih);
+  __syncthreads();
+  // V: the tile <-> B(row + 4, column)
+  bq_pass<N4, 64, 64, 4, 0, 64, 0, 6, true>(S.B, ZB, nullptr, S.rwt, e4, tid, out, x0, y0, iw, ih);
+}
+
 // rc:207-216: each Lab field rounded to n levels
 __device__ __forceinline__ uint32_t quantize_plab(uint32_t v, int n0, int n1, int n2) {
   float L, a, b;
@@ -831,20 +941,19 @@ __device__ __forceinline__ void d2_flush(int *__restrict__ list_out, int *count_
   if (tid == 0) nloc = 0;
   __syncthreads();
 }
-__global__ __launch_bounds__(256) void k_despeckle2_active(int *__restrict__ nxt, const int *__restrict__ cur, const int *__restrict__ list, const int *__restrict__ count,
-                                                            int *__restrict__ list_out, int *count_out, int *count_zero, int *work_trace, int *__restrict__ stamp, int tag,
-                                                            const int *__restrict__ old, const int *__restrict__ size, int thre, int iw, int ih) {
-  __shared__ int loc[D2A_CAP];
-  __shared__ int nloc, base;
+// (blk of nblk blocks of 256 threads; loc / nloc / base: the block's LDS)
+__device__ __forceinline__ void d2_active_rounds(int *__restrict__ nxt, const int *__restrict__ cur, const int *__restrict__ list, const int *__restrict__ count,
+                                                 int *__restrict__ list_out, int *count_out, int *count_zero, int *work_trace, int *__restrict__ stamp, int tag,
+                                                 const int *__restrict__ old, const int *__restrict__ size, int thre, int iw, int ih, int blk, int nblk, int *loc, int &nloc, int &base) {
   const int tid = threadIdx.x;
   if (tid == 0) {
     nloc = 0;
-    if (blockIdx.x == 0) *count_zero = 0;        // the list after next: nobody reads or appends to it during this launch
+    if (blk == 0) *count_zero = 0;        // the list after next: nobody reads or appends to it during this launch
   }
   __syncthreads();
   const int n = *count;
-  if (blockIdx.x == 0 && tid == 0) *work_trace = n;   // (diagnostic: the work list length of each launch)
-  for (int j0 = blockIdx.x * 256; j0 < n; j0 += gridDim.x * 256) {
+  if (blk == 0 && tid == 0) *work_trace = n;   // (diagnostic: the work list length of each launch)
+  for (int j0 = blk * 256; j0 < n; j0 += nblk * 256) {
     const int j = j0 + tid;
     bool changed = false;
     int p0 = 0, x = 0, y = 0;
@@ -918,6 +1027,33 @@ __global__ __launch_bounds__(256) void k_despeckle2_active(int *__restrict__ nxt
   if (list_out != nullptr) d2_flush(list_out, count_out, loc, nloc, base, tid);
 }
 
+__global__ __launch_bounds__(256) void k_despeckle2_active(int *__restrict__ nxt, const int *__restrict__ cur, const int *__restrict__ list, const int *__restrict__ count,
+                                                            int *__restrict__ list_out, int *count_out, int *count_zero, int *work_trace, int *__restrict__ stamp, int tag,
+                                                            const int *__restrict__ old, const int *__restrict__ size, int thre, int iw, int ih) {
+  __shared__ int loc[D2A_CAP];
+  __shared__ int nloc, base;
+  d2_active_rounds(nxt, cur, list, count, list_out, count_out, count_zero, work_trace, stamp, tag, old, size, thre, iw, ih, blockIdx.x, gridDim.x, loc, nloc, base);
+}
+
+// The launches r0 .. r1-1 of despeckle2()'s loop in ONE single-block launch: from the fourth launch on the work lists hold a few
+// hundred pixels at most (measured on the bench stream: 74 k, 4.3 k, 300, 100, 45, 20, < 10 ...), so a launch is all latency; one
+// block walks through them with a barrier in between (whatever the list lengths are, the result is the same - only slower).
+// pa / pb: the two planes the launches alternate between (launch r writes pb if r is odd, else pa; reads the other one);
+// lists: the three rotating work lists (n ints each), counts: their counters (+ the per-launch trace behind them)
+__global__ __launch_bounds__(256) void k_despeckle2_tail(int *pa, int *pb, int *lists, int *counts, int *__restrict__ stamp, int r0, int r1, int n,
+                                                          const int *__restrict__ old, const int *__restrict__ size, int thre, int iw, int ih) {
+  __shared__ int loc[D2A_CAP];
+  __shared__ int nloc, base;
+  for (int r = r0; r < r1; r++) {
+    int *nx = (r & 1) ? pb : pa;
+    const int *cu = (r & 1) ? pa : pb;
+    const int li = r % 3, lo = (r + 1) % 3, lz = (r + 2) % 3;
+    d2_active_rounds(nx, cu, lists + (size_t)li * n, counts + li, r == r1 - 1 ? (int *)nullptr : lists + (size_t)lo * n, counts + lo, counts + lz, counts + 3 + r, stamp, r + 1,
+                     old, size, thre, iw, ih, 0, 1, loc, nloc, base);
+    __syncthreads();
+  }
+}
+
 // (rc:373-390, the region-boundary marks, are computed inside the labelling kernel: rd_k_label.hip, k_label_tile<true>)
 
 // ------------------------------------------------------------------------------------------------ voting
@@ -985,7 +1121,11 @@ __device__ __forceinline__ void tlist_append(int *tlist, bool first, unsigned sl
   }
 }
 
-__global__ __launch_bounds__(1024) void k_reduce_clean(int *table, int *claim, int *tlist) {
+// (the three vote kernels and the sampling kernel work on frame blockIdx.z of a batch: see rdk::PolyFrame)
+#define RD_VFRAME const rdk::PolyFrame &FRM = FRS.f[blockIdx.z]; const rdk::PolyScratch &s = FRM.ps; (void)s
+__global__ __launch_bounds__(1024) void k_reduce_clean(const rdk::PolyFrames FRS) {
+  RD_VFRAME;
+  int *table = FRM.table, *claim = FRM.claim, *tlist = FRM.tlist;
   const int n = tlist[0];
   for (int j = threadIdx.x; j < n; j += blockDim.x) {
     const int slot = tlist[1 + j];
@@ -1000,7 +1140,10 @@ __global__ __launch_bounds__(1024) void k_reduce_clean(int *table, int *claim, i
 // (claims are aggregated per block like the box updates below: slot -> smallest claiming pixel in an LDS hash, one atomicMin per
 //  slot and block at the end; the one that finds the slot unclaimed appends it to tlist)
 #define CA_T 1024
-__global__ __launch_bounds__(256) void k_reduce_claim(int *claim, int *tlist, const int *__restrict__ boundary, rdk::PolyScratch s, int iw, int ih, int nentry) {
+__global__ __launch_bounds__(256) void k_reduce_claim(const rdk::PolyFrames FRS, int iw, int ih, int nentry) {
+  RD_VFRAME;
+  int *claim = FRM.claim, *tlist = FRM.tlist;
+  const int *__restrict__ boundary = FRM.boundary;
   __shared__ int keys[CA_T], vals[CA_T];
   const int nlive = s.ctr[24];
   if ((int)(blockIdx.x * blockDim.x) >= nlive) return;       // (whole block without pixels)
@@ -1111,7 +1254,11 @@ __device__ __forceinline__ void box_vote(BoxAgg &A, int *table, const int *__res
   }
 }
 
-__global__ __launch_bounds__(256) void k_reduce_box(int *table, const int *__restrict__ claim, const int *__restrict__ boundary, rdk::PolyScratch s, int iw, int ih, int nentry) {
+__global__ __launch_bounds__(256) void k_reduce_box(const rdk::PolyFrames FRS, int iw, int ih, int nentry) {
+  RD_VFRAME;
+  int *table = FRM.table;
+  const int *__restrict__ claim = FRM.claim;
+  const int *__restrict__ boundary = FRM.boundary;
   __shared__ BoxAgg A;
   const int nlive = s.ctr[24];
   if ((int)(blockIdx.x * blockDim.x) >= nlive) return;       // (whole block without pixels)
@@ -1181,8 +1328,15 @@ struct ls_rec { float x0, y0, x1, y1; int startIndex, endIndex, leftPtr, rightPt
 
 // The kernel also assembles the block that travels to the host in ONE copy (pack): [0,32) polyline counters, [32,52) region
 // round flags, [64, 64 + 14 * pack_records) segment records 0.., then 90 ints of probes per record.
-__global__ void k_sample_segments(int *__restrict__ out, const ls_rec *__restrict__ ls, int max_records, const int *__restrict__ boundary, const int *__restrict__ table,
-                                  int iw, int ih, int nentry, int *__restrict__ pack, int pack_records, const int *__restrict__ polyctr, const int *__restrict__ rflags) {
+__global__ void k_sample_segments(const rdk::PolyFrames FRS, int max_records, int iw, int ih, int nentry, int pack_records) {
+  RD_VFRAME;
+  int *__restrict__ out = FRM.probes;
+  const ls_rec *__restrict__ ls = (const ls_rec *)FRM.lslist;
+  const int *__restrict__ boundary = FRM.boundary;
+  const int *__restrict__ table = FRM.table;
+  int *__restrict__ pack = FRM.pack;
+  const int *__restrict__ polyctr = s.ctr;
+  const int *__restrict__ rflags = FRM.rflags;
   const int n = *(const int *)ls;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (pack) {
@@ -1240,6 +1394,12 @@ void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, in
 void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih) {
   hipLaunchKernelGGL(k_blblur_pair, dim3(cdiv(iw, 64), cdiv(ih, BP_ROWS)), dim3(64, 16), 0, s, out, ext, in, iw, ih);
 }
+// two pairs per launch (out = pair(pair(in))); out must not alias in
+void blblur_quad(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih) {
+  static bool attr_set = false;
+  if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_blblur_quad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(bq_lds)); attr_set = true; }
+  hipLaunchKernelGGL(k_blblur_quad, dim3(cdiv(iw, 64), cdiv(ih, BQ_ROWS)), dim3(64, 16), sizeof(bq_lds), s, out, ext, in, iw, ih);
+}
 void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih, int quantize24) {
   if (quantize24) hipLaunchKernelGGL(k_despeckle<24>, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS)), dim3(64, 4), 0, s, out, in, edge, iw, ih);
   else hipLaunchKernelGGL(k_despeckle<0>, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS)), dim3(64, 4), 0, s, out, in, edge, iw, ih);
@@ -1292,16 +1452,18 @@ void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int 
   // first round: tmp <- result, out <- input (both planes then agree on every pixel that is not in the list)
   hipLaunchKernelGGL(k_despeckle2_first, dim3(cdiv(iw, 64), cdiv(ih, D2_ROWS)), dim3(64, 4), 0, s, tmp, out, stamp, lists, count, in, size, thre, iw, ih);
   const int *cur = tmp;
-  for (int r = 0; r < DOUBLE_ROUNDS; r++) {
+  const int HEAD = 4;       // launches with lists long enough to be worth more than one block
+  for (int r = 0; r < HEAD; r++) {
     int *nxt = (r & 1) ? tmp : out;
     const int li = r % 3, lo = (r + 1) % 3, lz = (r + 2) % 3;
-    const bool last = r == DOUBLE_ROUNDS - 1;
     // (the work lists shrink by an order of magnitude per launch: later launches need few blocks, and dispatching blocks that
     //  find nothing to do is what an almost empty launch costs)
     hipLaunchKernelGGL(k_despeckle2_active, dim3(r < 2 ? 512 : 128), dim3(256), 0, s, nxt, cur, (const int *)(lists + (size_t)li * n), (const int *)(count + li),
-                       last ? (int *)nullptr : lists + (size_t)lo * n, count + lo, count + lz, count + 3 + r, stamp, r + 1, in, size, thre, iw, ih);
+                       lists + (size_t)lo * n, count + lo, count + lz, count + 3 + r, stamp, r + 1, in, size, thre, iw, ih);
     cur = nxt;
   }
+  // launches HEAD .. 12 in one (launch r writes `tmp` if r is odd, else `out`; DOUBLE_ROUNDS is odd: the last one writes `out`)
+  hipLaunchKernelGGL(k_despeckle2_tail, dim3(1), dim3(256), 0, s, out, tmp, lists, count, stamp, HEAD, DOUBLE_ROUNDS, n, in, size, thre, iw, ih);
 }
 
 // table: nentry*5 ints, claim: nentry ints, tlist: nentry+1 ints; all three are set up once by reduce_ls_init and kept
@@ -1312,17 +1474,17 @@ void reduce_ls_init(hipStream_t s, int *table, int *claim, int *tlist, int nentr
   (void)hipMemsetAsync(tlist, 0, sizeof(int), s);
 }
 
-void reduce_ls(hipStream_t s, int *table, int *claim, int *tlist, const int *boundary, const PolyScratch *ps, int iw, int ih, int nentry, int tables_are_clean) {
-  if (!tables_are_clean) hipLaunchKernelGGL(k_reduce_clean, dim3(1), dim3(1024), 0, s, table, claim, tlist);       // undo the previous use
-  hipLaunchKernelGGL(k_reduce_claim, dim3(512), dim3(256), 0, s, claim, tlist, boundary, *ps, iw, ih, nentry);
-  hipLaunchKernelGGL(k_reduce_box, dim3(512), dim3(256), 0, s, table, (const int *)claim, boundary, *ps, iw, ih, nentry);
+void reduce_ls(hipStream_t s, const PolyFrame *frames_host, int nb, int iw, int ih, int nentry, int tables_are_clean) {
+  const PolyFrames frames = pack_frames(frames_host, nb);
+  if (!tables_are_clean) hipLaunchKernelGGL(k_reduce_clean, dim3(1, 1, nb), dim3(1024), 0, s, frames);       // undo the previous use
+  hipLaunchKernelGGL(k_reduce_claim, dim3(512, 1, nb), dim3(256), 0, s, frames, iw, ih, nentry);
+  hipLaunchKernelGGL(k_reduce_box, dim3(512, 1, nb), dim3(256), 0, s, frames, iw, ih, nentry);
 }
 
-void sample_segments(hipStream_t s, int *out, const void *lslist, int max_records, const int *boundary, const int *table, int iw, int ih, int nentry,
-                     int *pack, int pack_records, const int *polyctr, const int *rflags) {
+void sample_segments(hipStream_t s, const PolyFrame *frames_host, int nb, int max_records, int iw, int ih, int nentry, int pack_records) {
+  const PolyFrames frames = pack_frames(frames_host, nb);
   const int threads = max_records * 15;
-  hipLaunchKernelGGL(k_sample_segments, dim3(cdiv(threads, 256)), dim3(256), 0, s, out, (const ls_rec *)lslist, max_records, boundary, table, iw, ih, nentry,
-                     pack, pack_records, polyctr, rflags);
+  hipLaunchKernelGGL(k_sample_segments, dim3(cdiv(threads, 256), 1, nb), dim3(256), 0, s, frames, max_records, iw, ih, nentry, pack_records);
 }
 
 }  // namespace rdk

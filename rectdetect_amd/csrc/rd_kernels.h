@@ -55,6 +55,8 @@ void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, i
 void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih);
 // one horizontal + vertical pass pair; out must not alias in
 void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih);
+// two pairs in one launch through LDS (halo of 8 cells): half the launches and HBM traffic of two blblur_pair calls
+void blblur_quad(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih);
 void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih, int quantize24);   // quantize24: `in` is quantised to 24 levels per field on the fly
 void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih);   // scratch: >= ih*ceil(iw/64)*4 ints
 // proposals of the last launched round of region_merge that have not taken effect yet (see k_region_round)
@@ -65,22 +67,21 @@ void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, const
 #define RD_D2_SCRATCH_INTS(N) (5 * (size_t)(N) + 64)
 void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih, int count_is_zero);   // out != in; scratch: RD_D2_SCRATCH_INTS(N) ints (scratch[N] = 0 already if count_is_zero)
 struct PolyScratch;
-// votes of the chain pixels left in `ps` by the last polyline() call on this stream (their final segment ids)
+struct PolyFrame;      // rd_poly_scratch.h: per-frame descriptor of the sparse stages; launches cover nb <= RD_MAXB frames (frame = blockIdx.z), descriptors in HOST memory
 void reduce_ls_init(hipStream_t s, int *table, int *claim, int *tlist, int nentry);   // once per allocation
-void reduce_ls(hipStream_t s, int *table, int *claim, int *tlist, const int *boundary, const PolyScratch *ps, int iw, int ih, int nentry, int tables_are_clean = 0);   // tables_are_clean: label8_boundary(vt_*) has undone the previous use already
+// votes of the chain pixels left in each frame's scratch by the last polyline() call (their final segment ids) into frames[z].table
+void reduce_ls(hipStream_t s, const PolyFrame *frames, int nb, int iw, int ih, int nentry, int tables_are_clean = 0);   // tables_are_clean: label8_boundary(vt_*) has undone the previous use already
 // per segment, 15 probe points: {boundary id, table slot owner, 4 box values} -> out[(seg*15 + k)*6 ..]
 // pack (may be null): the block for the host in one piece - 64 ints of counters / flags, pack_records records of 14 ints, then their probes
-void sample_segments(hipStream_t s, int *out, const void *lslist, int max_records, const int *boundary, const int *table, int iw, int ih, int nentry,
-                     int *pack, int pack_records, const int *polyctr, const int *rflags);
+void sample_segments(hipStream_t s, const PolyFrame *frames, int nb, int max_records, int iw, int ih, int nentry, int pack_records);
 
 // ---- rd_k_poly.hip: polyline stage on compacted chain pixels
 PolyScratch *poly_scratch_create(int iw, int ih);
 void poly_scratch_destroy(PolyScratch *ps);
 const int *poly_scratch_counters(const PolyScratch *ps);   // device pointer: [0] chain pixels, [1] chains, [2+r] split candidates of round r
-// ring_src: plane whose 2-px frame ring supplies the stale ring values (may be null -> ring_const is used)
-void polyline(hipStream_t s, PolyScratch *ps, void *lslist, int lslist_bytes, int *ids, const int *in, const int *ring_src, int ring_const,
-              float minerror, int sizeThre, int iw, int ih, int mode);
-// ids may be null (the dense id plane is then not produced); polyline_ids() materialises it later from the compact state
-void polyline_ids(hipStream_t s, PolyScratch *ps, int *ids, int n);
+// frames: nb descriptors (host memory); frames[z].ring_src: plane whose 2-px frame ring supplies the stale ring values (null -> ring_const)
+void polyline(hipStream_t s, const PolyFrame *frames, int nb, int lslist_bytes, int ring_const, float minerror, int sizeThre, int iw, int ih, int mode);
+// materialises the dense id planes frames[z].ids from the compact state
+void polyline_ids(hipStream_t s, const PolyFrame *frames, int nb, int n);
 
 }  // namespace rdk

@@ -22,4 +22,30 @@ struct PolyScratch {
   int *live;          // compact indices of the chain pixels that survived the size filter (ascending); count in ctr[24]
 };
 
+// Everything the sparse stages (polylines, votes, probes) of ONE frame work on.  A launch of these stages covers gridDim.z frames:
+// the kernels take the descriptors BY VALUE (PolyFrames, in the kernel-argument segment: uniform scalar loads, indexable) and work on
+// element blockIdx.z - frames of one stream, batched, so that the 20-odd latency-bound launches of these stages are paid once per
+// batch instead of once per frame.
+struct PolyFrame {
+  PolyScratch ps;
+  const int *in;           // the mask whose curves are traced (dense int plane)
+  const int *ring_src;     // plane supplying the stale 2-px ring of the bridging step; null: a constant is used
+  void *lslist;            // linesegment_t list, record 0 = header
+  int *ids;                // dense per-pixel segment ids (only written by polyline_ids)
+  // votes and probes (rect path only)
+  const int *boundary;     // boundary-component labels
+  int *table, *claim, *tlist;
+  int *probes;             // 15 probes x 6 ints per segment
+  int *pack;               // the block that travels to the host (pinned host memory, device address); may be null
+  const int *rflags;       // round flags of the region merge (travel with the block)
+};
+
+#define RD_MAXB 4        // frames per launch of the sparse stages (4 descriptors = 1.4 KB of kernel arguments)
+struct PolyFrames { PolyFrame f[RD_MAXB]; };
+inline PolyFrames pack_frames(const PolyFrame *frames, int nb) {
+  PolyFrames r;
+  for (int z = 0; z < RD_MAXB; z++) r.f[z] = frames[z < nb ? z : 0];
+  return r;
+}
+
 }  // namespace rdk

@@ -431,6 +431,52 @@ def test_pipelined_workers_equal_sequential(nslots):
         assert helpers.rects_equal(r1, r2) and helpers.segments_equal(s1, s2)
 
 
+def test_blur_two_pairs_per_launch_equals_single_pairs():
+    """the edge-stopped blur as five launches of two fused pairs (default) and as ten launches of one pair: same plane"""
+    iw, ih = 333, 217
+    img = synth.frame(synth.SEED0 + 12, iw, ih, 0)
+    planes = []
+    for env in ({}, {"RD_BLUR_SINGLE_PAIRS": "1"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        det = ra.Detector(iw, ih, nslots=1)
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        det.enqueue(img)
+        det.poll(TAN36)
+        planes.append(det.plane("smooth", np.uint32))
+        det.close()
+    assert np.array_equal(planes[0], planes[1])
+
+
+@pytest.mark.parametrize("nslots,pattern", [(8, [1, 3, 8, 5, 2, 8, 8, 1]), (4, [4, 1, 2, 3]), (6, [6, 5, 6]), (5, [2, 5])])
+def test_batched_sparse_stages_any_polling_pattern(nslots, pattern):
+    """From four frame slots on, the sparse stages (polylines, votes, probes) of up to four consecutive slots run as one set of
+    launches (frame = blockIdx.z).  Whatever the caller's rhythm - groups filled completely, polled when partly filled, slot
+    counts that are no multiple of four - the results must equal one frame at a time on a single-slot detector."""
+    iw, ih = 640, 480
+    frames = [synth.frame(synth.SEED0 + 21, iw, ih, t) for t in range(sum(pattern))]
+    seq = ra.Detector(iw, ih, nslots=1, nworkers=0)
+    want = []
+    for f in frames:
+        seq.enqueue(f)
+        want.append((seq.poll(TAN36), seq.last_segments()))
+    seq.close()
+    for workers in (0, 1):
+        det = ra.Detector(iw, ih, nslots=nslots, nworkers=workers)
+        got, k = [], 0
+        for burst in pattern:          # hand over `burst` frames, then collect all of them
+            for _ in range(burst):
+                det.enqueue(frames[k])
+                k += 1
+            for _ in range(burst):
+                got.append((det.poll(TAN36), det.last_segments()))
+        det.close()
+        assert len(got) == len(want)
+        for t, ((r1, s1), (r2, s2)) in enumerate(zip(want, got)):
+            assert helpers.rects_equal(r1, r2) and helpers.segments_equal(s1, s2), (workers, t)
+
+
 def _run_with_env(env, iw, ih, frames):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)

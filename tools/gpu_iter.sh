@@ -1,15 +1,17 @@
 #!/bin/bash
-# one optimisation-loop iteration on the GPU box: parity tests, bench points, one kernel trace, one SQ counter pass
-# usage (from the repo root, on the box): bash tools/gpu_iter.sh <tag>
+# one optimisation-loop iteration on the GPU box: parity tests, bench points, one kernel trace
+# usage (from the repo root, on the box): bash tools/gpu_iter.sh <tag> [pytest -k expression]
 tag=${1:-x}
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests -m gpu -x -q -s 2>&1 | tail -15 > gpurun_out/pytest_gpu.log
-tail -4 gpurun_out/pytest_gpu.log
+if [ -n "$2" ]; then K=(-k "$2"); else K=(); fi
+timeout 1200 python -m pytest tests -m gpu -x -q "${K[@]}" 2>&1 | tail -15 > gpurun_out/pytest_$tag.log
+tail -6 gpurun_out/pytest_$tag.log
 for s in 1 4 8; do
-  timeout 300 python bench.py --steps 3 --warmup 1 --slots $s --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_s$s.log | cut -c1-100
+  timeout 300 python bench.py --steps 3 --warmup 1 --slots $s --no-cpu-baseline 2>&1 | tail -1 | tee gpurun_out/bench_${tag}_s$s.log | cut -c1-120
 done
 export TMPDIR=/tmp
 R=$PWD
-cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof$tag -o r$tag -- python $R/bench.py --steps 1 --warmup 1 --slots 1 --frames-per-step 8 --no-cpu-baseline > $R/gpurun_out/prof$tag.log 2>&1
-RD_NO_GRAPH=1 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace -d $R/gpurun_out/sq$tag -o sq -- python $R/bench.py --steps 1 --warmup 1 --slots 1 --frames-per-step 4 --no-cpu-baseline > $R/gpurun_out/sq$tag.log 2>&1
+cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof$tag -o r$tag -- python $R/bench.py --steps 1 --warmup 1 --slots 1 --frames-per-step 8 --no-cpu-baseline --no-verify > $R/gpurun_out/prof$tag.log 2>&1
 cd $R
+python tools/prof_summary.py $(find gpurun_out/prof$tag -name "*results.db" | head -1) 16 > gpurun_out/kstats_$tag.txt 2>&1
+head -30 gpurun_out/kstats_$tag.txt
