@@ -293,7 +293,6 @@ struct Slot {
   hipGraphExec_t gexec2[8];                // [round budget index][polyline mode]
   int poly_mode;                           // polyline mode of the frame in flight (1 = single launch, 0 = multi-launch)
   int rounds;                             // region-merge round budget of the frame in flight
-  int overflow_streak;
   // post-process worker
   pthread_t th; pthread_mutex_t mu; pthread_cond_t cv;
   int state;              // 0 idle, 1 submitted to the GPU, 2 result ready
@@ -318,7 +317,8 @@ struct rd_detector {
   long next_enqueue, next_poll;
   int last_polled_slot;
   void *last_segs; int last_nsegs;
-  int use_graph, poly_mode, force_redo, diag_no_post, diag_skip, fork_poly, fixed_rounds, blur_single_pairs; long n_redo, n_redo_rounds;
+  int use_graph, poly_mode, force_redo, diag_no_post, diag_skip, fork_poly, fixed_rounds; long n_redo, n_redo_rounds;
+  int overflow_streak;
   int poly_overflows;                     // set once two frames in a row overflowed the single-launch polyline kernel: later frames go multi-launch
   int rounds_budget, need_hist[64]; unsigned need_pos; long budget_count[4];
   long host_enqueue_ns;      // wall time the caller spent inside rd_detector_enqueue
@@ -492,9 +492,11 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
 
   // edge-preserving smoothing x10, quantise, despeckle (oclrect.c:286-303)
   rdk::blblur_extents(st, s->ext, s->e8, iw, ih);
-  { const uint32_t *src = s->plab0;     // ten pairs, two per launch, ping-pong between smooth and i0; the last one lands in smooth
-    if (d->blur_single_pairs) for (int i = 0; i < 10; i++) { uint32_t *dst = (i & 1) ? s->smooth : (uint32_t *)s->i0; rdk::blblur_pair(st, dst, s->ext, src, iw, ih); src = dst; }
-    else for (int i = 0; i < ((d->diag_skip & 1) ? 1 : 5); i++) { uint32_t *dst = (i & 1) ? (uint32_t *)s->i0 : s->smooth; rdk::blblur_quad(st, dst, s->ext, src, iw, ih); src = dst; } }
+  // (Two pairs per launch - halo of 8 cells, four passes through two LDS planes, with and without running sums - halve the launches and
+  //  the HBM traffic of this stage and were measured 6 % SLOWER at full rate: 100 KB of LDS leave one 1024-thread block per CU and the
+  //  extra barriers cost more than the saved traffic; the stage is bound by vector instructions, not by memory.  DESIGN.md.)
+  { const uint32_t *src = s->plab0;     // ping-pong between i0 and smooth; the 10th pair lands in smooth
+    for (int i = 0; i < ((d->diag_skip & 1) ? 2 : 10); i++) { uint32_t *dst = (i & 1) ? s->smooth : (uint32_t *)s->i0; rdk::blblur_pair(st, dst, s->ext, src, iw, ih); src = dst; } }
   rdk::despeckle(st, s->quant, s->smooth, s->nms, iw, ih, 1);      // quantisation to 24 levels per field (oclrect.c:298) happens on the fly
 
   if (d->fork_poly) RD_HIP(hipStreamWaitEvent(st, s->ev_mm, 0));
@@ -624,8 +626,9 @@ static void slot_finish_device(rd_detector *d, Slot *s) {
     __atomic_store_n(&d->rounds_budget, b, __ATOMIC_RELAXED);
     pthread_mutex_unlock(&d->tan_mu);
   }
-  if (s->poly_mode && s->h_ctr[25] != 0 && ++s->overflow_streak >= 2) __atomic_store_n(&d->poly_overflows, 1, __ATOMIC_RELAXED);   // this stream's frames do not fit the single-launch kernel (e.g. 4K): stop trying
-  if (s->poly_mode && s->h_ctr[25] == 0) s->overflow_streak = 0;
+  // two overflows among the stream's recent frames (whichever slots they ran in): its frames do not fit the single-launch kernel (e.g. 4K) - stop trying
+  if (s->poly_mode && s->h_ctr[25] != 0 && __atomic_add_fetch(&d->overflow_streak, 1, __ATOMIC_RELAXED) >= 2) __atomic_store_n(&d->poly_overflows, 1, __ATOMIC_RELAXED);
+  if (s->poly_mode && s->h_ctr[25] == 0) __atomic_store_n(&d->overflow_streak, 0, __ATOMIC_RELAXED);
   if ((s->poly_mode && s->h_ctr[25] != 0) || d->force_redo) {   // the single-launch polyline stage overflowed: repeat the tail the long way
     pthread_mutex_lock(&d->launch_mu);
     frame_tail(d, s, 0);
@@ -710,7 +713,6 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : 1;
   d->force_redo = getenv("RD_POLY_FORCE_REDO") ? 1 : 0;
   d->diag_no_post = getenv("RD_DIAG_NO_POST") ? 1 : 0;
-  d->blur_single_pairs = getenv("RD_BLUR_SINGLE_PAIRS") ? 1 : 0;     // tests: the edge-stopped blur as ten launches of one pair instead of five of two
   // The device runs four hardware queues side by side (more are time-sliced: measured 2x slower per frame).  With one or two
   // frames in flight a frame spreads over two streams (polyline chain beside the blur chain: shortest latency); from three
   // frames on every frame keeps to one stream, so that four frames occupy the four queues (highest throughput).

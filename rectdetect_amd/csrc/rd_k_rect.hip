@@ -272,116 +272,6 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
   }
 }
 
-// TWO (horizontal, vertical) pairs in a single launch: the tile is staged with a halo of 8 cells, and the four passes run through
-// two LDS planes that are reused (input -> H -> V -> H -> V -> output), each pass over a region that shrinks by the 4 cells its
-// samples can reach: 80x72, 72x72, 72x64 cells and the 64x64 tile.  A halo pixel's intermediate value is exactly the value the
-// full-plane pass gives it, because a run never extends beyond 4 cells from its pixel and never leaves the frame (the extents
-// say so), so everything it reads lies inside the staged region.  Half the launches and about half the HBM traffic of two
-// k_blblur_pair launches (27 against 61 MB per two pairs at 1920x1080) for 13 % more cell evaluations.
-#define BQ_ROWS 64
-#define BQ_AW 81              // pitch of plane A (80 columns used: x0-8 .. x0+71)
-#define BQ_BW 73              // pitch of plane B (72 columns used: x0-4 .. x0+67)
-#define BQ_NT 1024
-struct bq_lds {
-  uint2 A[(BQ_ROWS + 16) * BQ_AW + 1];      // staged input, later the first vertical pass's output (72 x 72 at the same pitch)
-  uint2 B[(BQ_ROWS + 16) * BQ_BW + 1];      // first horizontal pass's output, later the second one's (72 rows x 64, pitch 64)
-  float2 rwt[16];
-};
-// one pass over `ncell` cells of a region `cw` cells wide: cell t = (row t / cw, column t % cw) reads its run from `src` at
-// (row + dr0, column + dc0) +- d steps of `step` cells and writes `dst` at row * dpitch + column.  e[] = this thread's extents
-// for its cells of this pass (3-bit fields at bit `sh`: samples towards smaller / larger coordinates, each including the centre).
-template <int NCELL, int CW, int SPITCH, int DR0, int DC0, int STEP, int DPITCH, int SH, bool FINAL>
-__device__ __forceinline__ void bq_pass(const uint2 *src, int zslot, uint2 *dst, const float2 *rwt, const unsigned *e, int tid,
-                                        uint32_t *__restrict__ out, int x0, int y0, int iw, int ih) {
-  constexpr int IT = (NCELL + BQ_NT - 1) / BQ_NT;
-#pragma unroll
-  for (int i = 0; i < IT; i++) {
-    const int t = tid + BQ_NT * i;
-    if (IT * BQ_NT != NCELL && t >= NCELL) break;
-    const int r = t / CW, cc = t % CW;
-    const unsigned ee = e[i] >> SH;
-    const int nl = ee & 7, nr = (ee >> 3) & 7;
-    const int c = (r + DR0) * SPITCH + cc + DC0;
-    const unsigned cb = (unsigned)c * 8u, zb = (unsigned)zslot * 8u;
-    constexpr unsigned SB = 8u * STEP;
-    uint2 v[10];
-#pragma unroll
-    for (int d = 0; d < 5; d++) {
-      v[d] = *(const uint2 *)((const char *)src + ((d < nl ? cb - 4u * SB : zb - (4u * SB - SB * d)) + (4u * SB - SB * d)));
-      v[5 + d] = *(const uint2 *)((const char *)src + ((d < nr ? cb : zb - SB * d) + SB * d));
-    }
-    unsigned lo = 0, hi = 0;
-#pragma unroll
-    for (int d = 0; d < 10; d++) { lo += v[d].x; hi += v[d].y; }
-    const int w = nl + nr;
-    uint2 o = src[c];
-    if (w > 0) {
-      const float2 rw = rwt[w];
-      o = make_uint2(div_small_f(lo & 0xffffu, rw) | (div_small_f(lo >> 16, rw) << 16), div_small_f(hi, rw));
-    }
-    if (FINAL) {
-      const int x = x0 + cc, y = y0 + r;
-      if (x < iw && y < ih) out[y * iw + x] = (o.x & 0xffffu) | ((o.x >> 16) << 12) | (o.y << 22);
-    } else dst[r * DPITCH + cc] = o;
-  }
-}
-
-__global__ __launch_bounds__(BQ_NT) void k_blblur_quad(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih) {
-  extern __shared__ __align__(16) unsigned char bq_raw[];
-  bq_lds &S = *reinterpret_cast<bq_lds *>(bq_raw);
-  constexpr int R16 = BQ_ROWS + 16, R8 = BQ_ROWS + 8;
-  constexpr int ZA = R16 * BQ_AW, ZB = R16 * BQ_BW;      // zero slots (behind the planes; the second use of B, 72 x 64, stays below ZB too)
-  constexpr int N1 = R16 * 72, N2 = R8 * 72, N3 = R8 * 64, N4 = BQ_ROWS * 64, NQ = R16 * 80;
-  constexpr int I1 = (N1 + BQ_NT - 1) / BQ_NT, I2 = (N2 + BQ_NT - 1) / BQ_NT, I3 = (N3 + BQ_NT - 1) / BQ_NT, I4 = (N4 + BQ_NT - 1) / BQ_NT, IQ = (NQ + BQ_NT - 1) / BQ_NT;
-  const int tid = threadIdx.y * 64 + threadIdx.x;
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BQ_ROWS;
-  // every global load of the block is issued here, unconditionally (clamped address, value dropped where the cell lies outside the
-  // frame), so that they are all in flight together: the extents of the thread's cells in the four passes and its share of the tile
-  unsigned e1[I1], e2[I2], e3[I3], e4[I4];
-  uint32_t q[IQ];
-  bool okq[IQ];
-#define BQ_EXT(E, I, N, CW, XOFF, YOFF)                                                       \
-  _Pragma("unroll") for (int i = 0; i < I; i++) {                                             \
-    const int t = tid + BQ_NT * i;                                                            \
-    const int xx = x0 + (XOFF) + t % (CW), yy = y0 + (YOFF) + t / (CW);                       \
-    const bool ok = t < (N) && xx >= 0 && xx < iw && yy >= 0 && yy < ih;                      \
-    const unsigned v = ext[ok ? yy * iw + xx : 0];                                            \
-    E[i] = ok ? v : 0u;                                                                       \
-  }
-  BQ_EXT(e1, I1, N1, 72, -4, -8)
-  BQ_EXT(e2, I2, N2, 72, -4, -4)
-  BQ_EXT(e3, I3, N3, 64, 0, -4)
-  BQ_EXT(e4, I4, N4, 64, 0, 0)
-#undef BQ_EXT
-#pragma unroll
-  for (int i = 0; i < IQ; i++) {
-    const int t = tid + BQ_NT * i;
-    const int xx = x0 - 8 + t % 80, yy = y0 - 8 + t / 80;
-    okq[i] = t < NQ && xx >= 0 && xx < iw && yy >= 0 && yy < ih;
-    q[i] = in[okq[i] ? yy * iw + xx : 0];
-  }
-  if (tid == 0) { S.A[ZA] = make_uint2(0, 0); S.B[ZB] = make_uint2(0, 0); }
-  if (tid < 16) { const float r = tid >= 1 && tid <= 10 ? 1.0f / (float)tid : 0.0f; S.rwt[tid] = make_float2(r, 0.5f * r); }
-#pragma unroll
-  for (int i = 0; i < IQ; i++) {
-    const int t = tid + BQ_NT * i;
-    const uint32_t v = okq[i] ? q[i] : 0u;
-    if (t < NQ) S.A[(t / 80) * BQ_AW + t % 80] = make_uint2((v & 4095u) | ((v << 4) & 0x3ff0000u), v >> 22);
-  }
-  __syncthreads();
-  // H: cells (row 0..79, column 0..71) <-> A(row, column + 4)
-  bq_pass<N1, 72, BQ_AW, 0, 4, 1, BQ_BW, 0, false>(S.A, ZA, S.B, S.rwt, e1, tid, nullptr, x0, y0, iw, ih);
-  __syncthreads();
-  // V: cells (row 0..71, column 0..71) <-> B(row + 4, column); result into A (its contents are no longer needed)
-  bq_pass<N2, 72, BQ_BW, 4, 0, BQ_BW, BQ_AW, 6, false>(S.B, ZB, S.A, S.rwt, e2, tid, nullptr, x0, y0, iw, ih);
-  __syncthreads();
-  // H: cells (row 0..71, column 0..63) <-> A(row, column + 4); result into B at pitch 64
-  bq_pass<N3, 64, BQ_AW, 0, 4, 1, 64, 0, false>(S.A, ZA, S.B, S.rwt, e3, tid, nullptr, x0, y0, iw, ih);
-  __syncthreads();
-  // V: the tile <-> B(row + 4, column)
-  bq_pass<N4, 64, 64, 4, 0, 64, 0, 6, true>(S.B, ZB, nullptr, S.rwt, e4, tid, out, x0, y0, iw, ih);
-}
-
 // rc:207-216: each Lab field rounded to n levels
 __device__ __forceinline__ uint32_t quantize_plab(uint32_t v, int n0, int n1, int n2) {
   float L, a, b;
@@ -1393,12 +1283,6 @@ void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, in
 }
 void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih) {
   hipLaunchKernelGGL(k_blblur_pair, dim3(cdiv(iw, 64), cdiv(ih, BP_ROWS)), dim3(64, 16), 0, s, out, ext, in, iw, ih);
-}
-// two pairs per launch (out = pair(pair(in))); out must not alias in
-void blblur_quad(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih) {
-  static bool attr_set = false;
-  if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_blblur_quad, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(bq_lds)); attr_set = true; }
-  hipLaunchKernelGGL(k_blblur_quad, dim3(cdiv(iw, 64), cdiv(ih, BQ_ROWS)), dim3(64, 16), sizeof(bq_lds), s, out, ext, in, iw, ih);
 }
 void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih, int quantize24) {
   if (quantize24) hipLaunchKernelGGL(k_despeckle<24>, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS)), dim3(64, 4), 0, s, out, in, edge, iw, ih);

@@ -431,24 +431,6 @@ def test_pipelined_workers_equal_sequential(nslots):
         assert helpers.rects_equal(r1, r2) and helpers.segments_equal(s1, s2)
 
 
-def test_blur_two_pairs_per_launch_equals_single_pairs():
-    """the edge-stopped blur as five launches of two fused pairs (default) and as ten launches of one pair: same plane"""
-    iw, ih = 333, 217
-    img = synth.frame(synth.SEED0 + 12, iw, ih, 0)
-    planes = []
-    for env in ({}, {"RD_BLUR_SINGLE_PAIRS": "1"}):
-        old = {k: os.environ.get(k) for k in env}
-        os.environ.update(env)
-        det = ra.Detector(iw, ih, nslots=1)
-        for k, v in old.items():
-            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
-        det.enqueue(img)
-        det.poll(TAN36)
-        planes.append(det.plane("smooth", np.uint32))
-        det.close()
-    assert np.array_equal(planes[0], planes[1])
-
-
 @pytest.mark.parametrize("nslots,pattern", [(8, [1, 3, 8, 5, 2, 8, 8, 1]), (4, [4, 1, 2, 3]), (6, [6, 5, 6]), (5, [2, 5])])
 def test_batched_sparse_stages_any_polling_pattern(nslots, pattern):
     """From four frame slots on, the sparse stages (polylines, votes, probes) of up to four consecutive slots run as one set of

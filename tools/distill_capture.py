@@ -13,7 +13,7 @@ def run(*a):
     return subprocess.run([sys.executable] + list(a), capture_output=True, text=True, check=True).stdout
 
 
-for src, dst in (("bench_default.json", "bench_default_slots8.json"), ("bench_slots1.json", "bench_slots1.json"), ("bench_slots2.json", "bench_slots2.json")):
+for src, dst in (("bench_default.json", "bench_default.json"), ("bench_slots1.json", "bench_slots1.json"), ("bench_slots2.json", "bench_slots2.json")):
     shutil.copy(os.path.join(C, src), os.path.join(P, pre + "_" + dst))
 with open(os.path.join(P, pre + "_size_sweep.txt"), "w") as f:
     f.write("# tools/size_sweep.py, SLOTS=8\n" + open(os.path.join(C, "size_sweep.txt")).read())

@@ -7,7 +7,7 @@ mkdir -p $O
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --slots 1 --no-cpu-baseline > $O/bench_slots1.json 2>> $O/bench_default.err
 python bench.py --slots 2 --no-cpu-baseline > $O/bench_slots2.json 2>> $O/bench_default.err
-SLOTS=8 python tools/size_sweep.py > $O/size_sweep.txt 2>&1
+SLOTS=16 python tools/size_sweep.py > $O/size_sweep.txt 2>&1
 export TMPDIR=/tmp
 cd /tmp
 # kernel trace of the default command (fewer steps) and of one frame slot alone
