@@ -225,7 +225,9 @@ def main():
         dist.barrier()
     dev0 = det.device_time() if det is not None else (0, 0)
     enq0 = ra.lib().rd_detector_counter(det.h, 3) if det is not None else 0
+    post0 = [ra.lib().rd_detector_counter(det.h, k) for k in (11, 12, 13)] if det is not None else [0, 0, 0]
     elapsed = timed(args.steps)
+    post1 = [ra.lib().rd_detector_counter(det.h, k) for k in (11, 12, 13)] if det is not None else [0, 0, 0]
     own_elapsed = elapsed
     dev1 = det.device_time() if det is not None else (0, 0)
     enq1 = ra.lib().rd_detector_counter(det.h, 3) if det is not None else 0
@@ -302,6 +304,9 @@ def main():
                          # With several frames in flight these intervals overlap, which is why `achieved` is taken from the aggregate rate.
                          "frame_device_us_avg": round((dev1[0] - dev0[0]) / max(1, dev1[1] - dev0[1]), 1), "frames_in_flight": args.slots,
                          "host_enqueue_us_avg": round((enq1 - enq0) / max(1, dev1[1] - dev0[1]), 1),
+                         # rectangles from segments + probes: on the host's worker threads (one per frame slot, CPU time per frame) or - RD_DEVICE_POST=1 - on the device
+                         "postprocess": {"frames_on_device": post1[0] - post0[0], "frames_on_host": post1[1] - post0[1],
+                                         "host_cpu_us_per_frame": round((post1[2] - post0[2]) / max(1, post1[1] - post0[1]), 1)},
                          "region_round_budget": det.region_round_budget()[0] if det is not None else None,
                          "frames_per_budget_8_12_16_20": [ra.lib().rd_detector_counter(det.h, 6 + k) for k in range(4)] if det is not None else None,
                          "frames_repeated": {"round_budget": det.region_round_budget()[1], "polyline_overflow": det.redone_frames()} if det is not None else None},

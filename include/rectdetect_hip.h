@@ -55,7 +55,9 @@ int rd_detector_last_segments(rd_detector *d, void *dst, int max_records);
  * 4 = frames whose region merge had not settled within the launched round budget and were repeated with all 20 rounds;
  * 5 = the current round budget (8, 12, 16 or 20); 6..9 = frames launched with a budget of 8 / 12 / 16 / 20 rounds;
  * 10 = frames with more line segments than the probe buffer holds (65535): the rest took no part in the rectangle search (a
- * message goes to stderr the first time) */
+ * message goes to stderr the first time); 11 / 12 = frames whose rectangles came from the device post-process (RD_DEVICE_POST=1:
+ * candidate funnel + pose estimation in rd_k_post.hip) / from the host post-process; 13 = microseconds the worker threads spent in the
+ * host post-process (sum over frames) */
 long rd_detector_counter(rd_detector *d, int which);
 
 /* Test hook: copy an internal plane of the most recently completed frame to host memory.  Returns bytes written,

@@ -282,6 +282,9 @@ struct Slot {
   rdk::PolyFrame *frame;                  // this slot's descriptor for the sparse stages (element `slot index` of the detector's array)
   hipEvent_t ev_dense;                    // batched mode: the frame's dense stages are done (the batch's sparse stages wait for it)
   int pending_sparse;                     // batched mode: dense stages enqueued, sparse stages not launched yet
+  // rectangles on the device (RD_DEVICE_POST): scratch, result block in pinned host memory, whether this frame's block is valid and for which aperture
+  int *post_scratch, *h_post, *h_post_dev;
+  int post_mode; double post_tan;
   // host side
   void *h_bgr;            // pinned staging for host frames
   void *h_segs; int *h_probes; int *h_ctr;   // views into h_pack
@@ -309,6 +312,8 @@ struct rd_detector {
   // batch instead of per frame.  Slots [g * batch, (g + 1) * batch) form group g; 1 = every frame on its own (shortest latency).
   int batch; unsigned sparse_rot;
   hipStream_t sparse_st;                  // (experiment RD_SPARSE_STREAM: the batched sparse stages on a stream of their own)
+  int device_post;                        // candidate funnel + pose estimation on the device (rd_k_post.hip) instead of the host worker threads
+  long n_post_device, n_post_host, host_post_ns;
   int defer, deferred_slot;               // batched mode: a complete group's sparse stages are launched only once the NEXT group's dense stages are enqueued (deferred_slot: a slot of the waiting group or -1)
   rdk::PolyFrame *frames;                 // nslots descriptors (host memory; they travel as kernel arguments), slot order
   Slot *slots;
@@ -376,12 +381,18 @@ static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
   s->h_ctr = s->h_pack; s->h_segs = s->h_pack + 64; s->h_probes = s->h_pack + 64 + (size_t)RD_MAXREC * 14;
   s->rounds = 20;
   s->seq = -1;
+  if (d->device_post) {
+    s->post_scratch = dnew<int>(rdk::post_scratch_ints());
+    RD_HIP(hipHostMalloc((void **)&s->h_post, rdk::post_out_ints() * sizeof(int), hipHostMallocDefault)); memset(s->h_post, 0, rdk::post_out_ints() * sizeof(int));
+    RD_HIP(hipHostGetDevicePointer((void **)&s->h_post_dev, s->h_post, 0));
+  }
   // descriptor of the sparse stages
   s->frame = d->frames + (s - d->slots);
   rdk::PolyFrame &f = *s->frame;
   memset(&f, 0, sizeof(f));
   f.ps = *s->ps; f.in = s->strong; f.ring_src = NULL; f.lslist = s->lslist; f.ids = s->lsid;
   f.boundary = s->boundary; f.table = s->table; f.claim = s->claim; f.tlist = s->tlist; f.probes = s->probes; f.pack = s->h_pack_dev; f.rflags = s->scratch2 + N;
+  f.post_scratch = s->post_scratch; f.post_out = s->h_post_dev;
 }
 
 static void slot_free(Slot *s) {
@@ -392,6 +403,7 @@ static void slot_free(Slot *s) {
   for (int k = 0; k < 3; k++) { dfree(s->tr[k]); dfree(s->fw[k]); dfree(s->bw[k]); dfree(s->hz[k]); dfree(s->bl[k]); }
   rdk::poly_scratch_destroy(s->ps);
   RD_HIP(hipHostFree(s->h_bgr)); RD_HIP(hipHostFree(s->h_pack));
+  dfree(s->post_scratch); if (s->h_post) RD_HIP(hipHostFree(s->h_post));
   RD_HIP(hipEventDestroy(s->ev_begin)); RD_HIP(hipEventDestroy(s->ev_done)); RD_HIP(hipEventDestroy(s->ev_strong));
   RD_HIP(hipEventDestroy(s->ev_fork)); RD_HIP(hipEventDestroy(s->ev_mm)); RD_HIP(hipEventDestroy(s->ev_join)); RD_HIP(hipEventDestroy(s->ev_redo)); RD_HIP(hipEventDestroy(s->ev_dense));
   if (!s->shares_streams) {
@@ -416,12 +428,15 @@ static void frame_polyline(rd_detector *d, Slot *s, hipStream_t st, int mode) {
 // sampling kernel directly in pinned host memory (0.2 MB of posted writes; frames with more records fetch the rest on demand):
 // no copy launch at the end of the frame.
 // tables_are_clean: frame_regions() ran just before (its last kernel undoes the previous entries of the vote tables)
-static void frames_votes(rd_detector *d, const rdk::PolyFrame *frames, int nb, hipStream_t st, int tables_are_clean) {
+// with_post: also the rectangles on the device, for the aperture the caller polled with last (the reference hands the aperture over with
+// the poll, after the frame: a frame polled with another one, or the first frames of a stream, are post-processed on the host)
+static void frames_votes(rd_detector *d, const rdk::PolyFrame *frames, int nb, hipStream_t st, int tables_are_clean, int with_post) {
   const int nentry = d->N * 4 / 5;
   rdk::reduce_ls(st, frames, nb, d->iw, d->ih, nentry, tables_are_clean);
   rdk::sample_segments(st, frames, nb, d->maxrec_dev, d->iw, d->ih, nentry, RD_MAXREC);
+  if (with_post) rdk::post_device(st, frames, nb, d->maxrec_dev, d->iw, d->ih, d->tan_aov);
 }
-static void frame_votes(rd_detector *d, Slot *s, int tables_are_clean) { frames_votes(d, s->frame, 1, s->st, tables_are_clean); }
+static void frame_votes(rd_detector *d, Slot *s, int tables_are_clean) { frames_votes(d, s->frame, 1, s->st, tables_are_clean, 0); }
 
 static void frame_tail(rd_detector *d, Slot *s, int mode) {   // both, in order, on the slot's main stream (overflow redo)
   frame_polyline(d, s, s->st, mode);
@@ -551,10 +566,14 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   d->last_strong = s->ev_strong; d->have_last_strong = 1;
   s->rounds = d->fixed_rounds ? d->fixed_rounds : __atomic_load_n(&d->rounds_budget, __ATOMIC_RELAXED);
   s->poly_mode = (d->poly_mode && !__atomic_load_n(&d->poly_overflows, __ATOMIC_RELAXED)) ? 1 : 0;
+  if (d->batch == 1) { s->post_mode = d->device_post && d->have_tan; s->post_tan = d->tan_aov; }
   for (int k = 0; k < 4; k++) if (kRoundBudgets[k] == s->rounds) d->budget_count[k]++;
   run_segment(d, s, ws, 2);
   if (d->batch > 1) { RD_HIP(hipEventRecord(s->ev_dense, s->st)); s->pending_sparse = 1; }
-  else RD_HIP(hipEventRecord(s->ev_done, s->st));
+  else {
+    if (s->post_mode) rdk::post_device(s->st, s->frame, 1, d->maxrec_dev, d->iw, d->ih, d->tan_aov);      // (outside the captured graphs: the aperture is a launch argument)
+    RD_HIP(hipEventRecord(s->ev_done, s->st));
+  }
   rdrt::check_launch("rect frame");
 }
 
@@ -580,9 +599,11 @@ static void sparse_launch(rd_detector *d, int a, int b) {
   const int pm = (d->poly_mode && !__atomic_load_n(&d->poly_overflows, __ATOMIC_RELAXED)) ? 1 : 0;
   const rdk::PolyFrame *frames = d->frames + a;
   if (!(d->diag_skip & 4)) rdk::polyline(st, frames, nb, d->N * 16, 1, 4.0f, 20, d->iw, d->ih, pm);
-  frames_votes(d, frames, nb, st, 1);
+  const int with_post = d->device_post && d->have_tan;
+  frames_votes(d, frames, nb, st, 1, with_post);
   for (int i = a; i <= b; i++) {
     Slot *s = &d->slots[i];
+    s->post_mode = with_post; s->post_tan = d->tan_aov;
     s->poly_mode = pm;
     RD_HIP(hipEventRecord(s->ev_done, st));
     s->pending_sparse = 0;
@@ -605,6 +626,7 @@ static void sparse_flush(rd_detector *d, int si) {
 static void slot_finish_device(rd_detector *d, Slot *s) {
   if (s->rounds < 20 && s->h_ctr[32 + s->rounds - 1] != 0) {   // the region merge was still changing in its last launched round: repeat with the full budget
     s->rounds = 20;
+    s->post_mode = 0;                            // (the rectangles computed on the device belong to the discarded regions: the host path takes this frame)
     pthread_mutex_lock(&d->launch_mu);
     frame_regions(d, s);
     frame_votes(d, s, 1);
@@ -630,6 +652,7 @@ static void slot_finish_device(rd_detector *d, Slot *s) {
   if (s->poly_mode && s->h_ctr[25] != 0 && __atomic_add_fetch(&d->overflow_streak, 1, __ATOMIC_RELAXED) >= 2) __atomic_store_n(&d->poly_overflows, 1, __ATOMIC_RELAXED);
   if (s->poly_mode && s->h_ctr[25] == 0) __atomic_store_n(&d->overflow_streak, 0, __ATOMIC_RELAXED);
   if ((s->poly_mode && s->h_ctr[25] != 0) || d->force_redo) {   // the single-launch polyline stage overflowed: repeat the tail the long way
+    s->post_mode = 0;
     pthread_mutex_lock(&d->launch_mu);
     frame_tail(d, s, 0);
     RD_HIP(hipEventRecord(s->ev_redo, s->st));
@@ -643,6 +666,26 @@ static void slot_finish_device(rd_detector *d, Slot *s) {
 // (can run again for another aperture: touches nothing on the device but, for frames with very many segments, two copies)
 static void *slot_rectangles(rd_detector *d, Slot *s, double tanAOV, void **segs_out, int *nsegs_out) {
   int n = ((int *)s->h_segs)[0];
+  // the rectangles the device computed (rd_k_post.hip), if this frame has them for this aperture and nothing overflowed there:
+  // the valid candidates' records in candidate order (= the reference's list order)
+  if (s->post_mode && s->post_tan == tanAOV && s->h_post[1] == 0 && n + 1 <= d->maxrec_dev && !d->diag_no_post) {
+    const int nc = s->h_post[0];
+    const char *recs = (const char *)(s->h_post + 8 + RD_POST_MAXC);
+    int nv = 0;
+    for (int c = 0; c < nc; c++) nv += s->h_post[8 + c] != 0;
+    rect_t *ret = (rect_t *)calloc((size_t)nv + 1, sizeof(rect_t));
+    int at = 1;
+    for (int c = 0; c < nc; c++) if (s->h_post[8 + c] != 0) memcpy(&ret[at++], recs + (size_t)c * sizeof(rect_t), sizeof(rect_t));
+    ret[0].nItems = nv + 1;
+    const int maxrec0 = d->maxrec_dev < RD_MAXREC ? d->maxrec_dev : RD_MAXREC;
+    const int ns0 = n < maxrec0 ? n : maxrec0 - 1;
+    void *copy0 = malloc((size_t)(ns0 + 1) * 56);
+    memcpy(copy0, s->h_segs, (size_t)(ns0 + 1) * 56);
+    *segs_out = copy0; *nsegs_out = ns0;
+    __atomic_add_fetch(&d->n_post_device, 1, __ATOMIC_RELAXED);
+    return ret;
+  }
+  __atomic_add_fetch(&d->n_post_host, 1, __ATOMIC_RELAXED);
   const void *segs = s->h_segs; const int *probes = s->h_probes;
   void *big_segs = NULL; int *big_probes = NULL;
   int maxrec = d->maxrec_dev < RD_MAXREC ? d->maxrec_dev : RD_MAXREC;
@@ -659,7 +702,11 @@ static void *slot_rectangles(rd_detector *d, Slot *s, double tanAOV, void **segs
     segs = big_segs; probes = big_probes; maxrec = n + 1;
   }
   // RD_DIAG_NO_POST (diagnostics only): an empty rectangle list instead of the host post-process, to see whether a run is host-bound
+  struct timespec tp0, tp1;
+  clock_gettime(CLOCK_MONOTONIC, &tp0);
   void *r = d->diag_no_post ? calloc(1, 176) : rd_post_run(segs, maxrec, probes, d->iw, d->ih, tanAOV);
+  clock_gettime(CLOCK_MONOTONIC, &tp1);
+  __atomic_add_fetch(&d->host_post_ns, (tp1.tv_sec - tp0.tv_sec) * 1000000000L + (tp1.tv_nsec - tp0.tv_nsec), __ATOMIC_RELAXED);
   const int ns = n < maxrec ? n : maxrec - 1;
   void *copy = malloc((size_t)(ns + 1) * 56);
   memcpy(copy, segs, (size_t)(ns + 1) * 56);
@@ -713,6 +760,7 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : 1;
   d->force_redo = getenv("RD_POLY_FORCE_REDO") ? 1 : 0;
   d->diag_no_post = getenv("RD_DIAG_NO_POST") ? 1 : 0;
+  d->device_post = getenv("RD_DEVICE_POST") ? atoi(getenv("RD_DEVICE_POST")) != 0 : 0;    // candidate funnel + pose estimation on the device (rd_k_post.hip)
   // The device runs four hardware queues side by side (more are time-sliced: measured 2x slower per frame).  With one or two
   // frames in flight a frame spreads over two streams (polyline chain beside the blur chain: shortest latency); from three
   // frames on every frame keeps to one stream, so that four frames occupy the four queues (highest throughput).
@@ -818,11 +866,11 @@ void *rd_detector_poll(rd_detector *d, double tanAOV) {
   Slot *s = &d->slots[si];
   void *r = NULL, *segs = NULL; int ns = 0;
   if (s->pending_sparse) sparse_flush(d, si);       // (an incomplete group: the caller wants a result before handing over more frames)
+  pthread_mutex_lock(&d->tan_mu);
+  d->tan_aov = tanAOV; d->have_tan = 1;            // what workers and the device post-process of later frames run ahead with
+  pthread_cond_broadcast(&d->tan_cv);
+  pthread_mutex_unlock(&d->tan_mu);
   if (d->nworkers > 0) {
-    pthread_mutex_lock(&d->tan_mu);
-    d->tan_aov = tanAOV; d->have_tan = 1;
-    pthread_cond_broadcast(&d->tan_cv);
-    pthread_mutex_unlock(&d->tan_mu);
     pthread_mutex_lock(&s->mu);
     while (s->state != 2) pthread_cond_wait(&s->cv, &s->mu);
     r = s->result; segs = s->res_segs; ns = s->res_nsegs;
@@ -861,6 +909,9 @@ long rd_detector_counter(rd_detector *d, int which) {
   if (which == 5) return __atomic_load_n(&d->rounds_budget, __ATOMIC_RELAXED);
   if (which >= 6 && which <= 9) return d->budget_count[which - 6];   // frames launched with a budget of 8 / 12 / 16 / 20 rounds
   if (which == 10) return __atomic_load_n(&d->n_truncated, __ATOMIC_RELAXED);
+  if (which == 11) return __atomic_load_n(&d->n_post_device, __ATOMIC_RELAXED);
+  if (which == 12) return __atomic_load_n(&d->n_post_host, __ATOMIC_RELAXED);
+  if (which == 13) return __atomic_load_n(&d->host_post_ns, __ATOMIC_RELAXED) / 1000;
   if (which == 1) return d->dev_us;
   if (which == 2) return d->dev_frames;
   return which == 0 ? __atomic_load_n(&d->n_redo, __ATOMIC_RELAXED) : -1;

@@ -73,6 +73,11 @@ void reduce_ls(hipStream_t s, const PolyFrame *frames, int nb, int iw, int ih, i
 // pack (may be null): the block for the host in one piece - 64 ints of counters / flags, pack_records records of 14 ints, then their probes
 void sample_segments(hipStream_t s, const PolyFrame *frames, int nb, int max_records, int iw, int ih, int nentry, int pack_records);
 
+// ---- rd_k_post.hip: segments + probes -> rectangles on the device (candidate funnel + pose estimation, one wave per candidate)
+size_t post_scratch_ints();      // ints of PolyFrame::post_scratch
+size_t post_out_ints();          // ints of PolyFrame::post_out
+void post_device(hipStream_t s, const PolyFrame *frames, int nb, int max_records, int iw, int ih, double tanAOV);
+
 // ---- rd_k_poly.hip: polyline stage on compacted chain pixels
 PolyScratch *poly_scratch_create(int iw, int ih);
 void poly_scratch_destroy(PolyScratch *ps);

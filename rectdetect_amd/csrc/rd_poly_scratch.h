@@ -38,7 +38,11 @@ struct PolyFrame {
   int *probes;             // 15 probes x 6 ints per segment
   int *pack;               // the block that travels to the host (pinned host memory, device address); may be null
   const int *rflags;       // round flags of the region merge (travel with the block)
+  // rectangles on the device (rd_k_post.hip; optional): scratch in device memory, result block in pinned host memory (device address)
+  int *post_scratch;
+  int *post_out;           // [0] candidates, [1] overflow, [2..3] tanAOV (double), [8 + c] validity of candidate c, then RD_POST_MAXC rect_t records
 };
+#define RD_POST_MAXC 1024  // candidates per frame the device post-process holds (more: the host path takes the frame)
 
 #define RD_MAXB 4        // frames per launch of the sparse stages (4 descriptors = 1.4 KB of kernel arguments)
 struct PolyFrames { PolyFrame f[RD_MAXB]; };

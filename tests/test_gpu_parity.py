@@ -459,6 +459,47 @@ def test_batched_sparse_stages_any_polling_pattern(nslots, pattern):
             assert helpers.rects_equal(r1, r2) and helpers.segments_equal(s1, s2), (workers, t)
 
 
+@pytest.mark.parametrize("nslots", [1, 2, 8])
+def test_device_postprocess_equals_host_postprocess(nslots):
+    """RD_DEVICE_POST=1: candidate funnel + pose estimation on the device (rd_k_post.hip: one wave per candidate, double precision,
+    same source for the arithmetic as the host path) - rectangle lists bit-identical to the host post-process, on stream frames,
+    on the busy frames (up to 66 rectangles, 1500 segments) and with the sparse stages batched; frames the device cannot take
+    (no aperture known yet: the reference passes it with the poll; capacity overflow) fall back to the host path and are counted."""
+    g = golden("hard_rect")
+    jobs = [(640, 480, [synth.frame(synth.SEED0 + 31, 640, 480, t) for t in range(9)])]
+    jobs.append((640, 480, [synth.hard_frame(k, sd, iw, ih) for k, (sd, iw, ih) in zip(g["kinds"].tolist(), g["params"].tolist()) if iw == 640]))
+    jobs.append((1280, 720, [synth.hard_frame(k, sd, iw, ih) for k, (sd, iw, ih) in zip(g["kinds"].tolist(), g["params"].tolist()) if iw == 1280]))
+    jobs.append((1920, 1080, [synth.frame(synth.SEED0, 1920, 1080, t) for t in range(6)]))
+    for iw, ih, frames in jobs:
+        outs = []
+        for env in ({}, {"RD_DEVICE_POST": "1"}):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            det = ra.Detector(iw, ih, nslots=nslots, nworkers=1 if nslots > 1 else 0)
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+            res, infl = [], 0
+            det.enqueue(frames[0])              # (the first poll tells the detector the aperture)
+            res.append(det.poll(TAN36))
+            for f in frames[1:]:
+                if infl == nslots:
+                    res.append(det.poll(TAN36))
+                    infl -= 1
+                det.enqueue(f)
+                infl += 1
+            while infl:
+                res.append(det.poll(TAN36))
+                infl -= 1
+            on_device = ra.lib().rd_detector_counter(det.h, 11)
+            det.close()
+            outs.append((res, on_device))
+        (host, n0), (dev, n1) = outs
+        assert n0 == 0 and n1 >= len(frames) - 2, (iw, ih, n1)
+        for t, (a, b) in enumerate(zip(host, dev)):
+            assert helpers.rects_equal(a, b), (iw, ih, t, len(a), len(b))
+        print("%dx%d: %d frames, %d post-processed on the device, rectangles %s" % (iw, ih, len(frames), n1, [len(r) for r in dev]))
+
+
 def _run_with_env(env, iw, ih, frames):
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
