@@ -397,13 +397,28 @@ __global__ __launch_bounds__(256) void k_edgevec(float2 *__restrict__ dst, const
   if (x >= iw || y >= ih) return;
   if (pack_out != nullptr) { const int p = y * iw + x; pack_out[p] = pack_lab(in[p], pa[p], pb[p]); }
   float vx = 0, vy = 0;
+  // (blocks whose 5x5 windows stay inside the frame address the 25 samples by constant offsets from five row pointers; same sums in the same order)
+  const bool interior = blockIdx.x > 0 && blockIdx.y > 0 && (int)(blockIdx.x * 64 + 66) <= iw && (int)(blockIdx.y * 4 + 6) <= ih;
+  if (interior) {
 #pragma unroll
-  for (int yy = -2; yy <= 2; yy++) {
+    for (int yy = -2; yy <= 2; yy++) {
+      const float *row = in + (size_t)(y + yy) * iw + x;
 #pragma unroll
-    for (int xx = -2; xx <= 2; xx++) {
-      const float s = in[mirror2(x + xx, y + yy, iw, ih)];
-      vx += v5c((xx + 2) + (yy + 2) * 5) * s;
-      vy += v5c((yy + 2) + (xx + 2) * 5) * s;
+      for (int xx = -2; xx <= 2; xx++) {
+        const float s = row[xx];
+        vx += v5c((xx + 2) + (yy + 2) * 5) * s;
+        vy += v5c((yy + 2) + (xx + 2) * 5) * s;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int yy = -2; yy <= 2; yy++) {
+#pragma unroll
+      for (int xx = -2; xx <= 2; xx++) {
+        const float s = in[mirror2(x + xx, y + yy, iw, ih)];
+        vx += v5c((xx + 2) + (yy + 2) * 5) * s;
+        vy += v5c((yy + 2) + (xx + 2) * 5) * s;
+      }
     }
   }
   float len = vx * vx + vy * vy;
@@ -418,18 +433,33 @@ __global__ __launch_bounds__(256) void k_edgevec(float2 *__restrict__ dst, const
 
 // ------------------------------------------------------------------------------------------------ edge strength
 // iu:422-437 on the blurred packed Lab: per channel (NW-SE)(N+W-S-E) + (NE-SW)(N-W+E-S), clamped at 0, summed, sqrt
+// (blocks whose 3x3 windows stay inside the frame - all but the frame's rim - address their neighbours by constant offsets: the
+//  mirrored-index arithmetic of the general form costs as many instructions as the gradient itself)
 __global__ __launch_bounds__(256) void k_edge_plab(float *__restrict__ out, const uint32_t *__restrict__ in, int iw, int ih) {
   const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
   if (x >= iw || y >= ih) return;
   float n[3], s[3], w[3], e[3], nw[3], ne[3], sw[3], se[3];
-  unpack_lab(in[mirror2(x, y - 1, iw, ih)], n[0], n[1], n[2]);
-  unpack_lab(in[mirror2(x, y + 1, iw, ih)], s[0], s[1], s[2]);
-  unpack_lab(in[mirror2(x - 1, y, iw, ih)], w[0], w[1], w[2]);
-  unpack_lab(in[mirror2(x + 1, y, iw, ih)], e[0], e[1], e[2]);
-  unpack_lab(in[mirror2(x - 1, y - 1, iw, ih)], nw[0], nw[1], nw[2]);
-  unpack_lab(in[mirror2(x + 1, y - 1, iw, ih)], ne[0], ne[1], ne[2]);
-  unpack_lab(in[mirror2(x - 1, y + 1, iw, ih)], sw[0], sw[1], sw[2]);
-  unpack_lab(in[mirror2(x + 1, y + 1, iw, ih)], se[0], se[1], se[2]);
+  const bool interior = blockIdx.x > 0 && blockIdx.y > 0 && (int)(blockIdx.x * 64 + 64) < iw && (int)(blockIdx.y * 4 + 4) < ih;
+  if (interior) {
+    const uint32_t *c = in + (size_t)y * iw + x;
+    unpack_lab(c[-iw], n[0], n[1], n[2]);
+    unpack_lab(c[iw], s[0], s[1], s[2]);
+    unpack_lab(c[-1], w[0], w[1], w[2]);
+    unpack_lab(c[1], e[0], e[1], e[2]);
+    unpack_lab(c[-iw - 1], nw[0], nw[1], nw[2]);
+    unpack_lab(c[-iw + 1], ne[0], ne[1], ne[2]);
+    unpack_lab(c[iw - 1], sw[0], sw[1], sw[2]);
+    unpack_lab(c[iw + 1], se[0], se[1], se[2]);
+  } else {
+    unpack_lab(in[mirror2(x, y - 1, iw, ih)], n[0], n[1], n[2]);
+    unpack_lab(in[mirror2(x, y + 1, iw, ih)], s[0], s[1], s[2]);
+    unpack_lab(in[mirror2(x - 1, y, iw, ih)], w[0], w[1], w[2]);
+    unpack_lab(in[mirror2(x + 1, y, iw, ih)], e[0], e[1], e[2]);
+    unpack_lab(in[mirror2(x - 1, y - 1, iw, ih)], nw[0], nw[1], nw[2]);
+    unpack_lab(in[mirror2(x + 1, y - 1, iw, ih)], ne[0], ne[1], ne[2]);
+    unpack_lab(in[mirror2(x - 1, y + 1, iw, ih)], sw[0], sw[1], sw[2]);
+    unpack_lab(in[mirror2(x + 1, y + 1, iw, ih)], se[0], se[1], se[2]);
+  }
   float sum[3];
 #pragma unroll
   for (int c = 0; c < 3; c++) {

@@ -282,13 +282,18 @@ __global__ __launch_bounds__(256) void k_label_flatten(int *label, int n, int *v
   }
 }
 
-// oclimgutil.cl:641-649: out[label] += (int)(e*e*10000) for interior pixels with label > 0.  Lanes of a wave that
-// share a label are summed with a ballot/shuffle loop first, so a big component costs one atomic per wave instead of
-// one per pixel; zero contributions (most pixels) are skipped.  Integer addition: order independent.
+// oclimgutil.cl:641-649: out[label] += (int)(e*e*10000) for interior pixels with label > 0.  A third of the pixels of a noisy frame
+// contribute, to hundreds of different components per block: the block sums per label in an LDS hash (one LDS atomic per
+// contributing pixel, no loop over the distinct labels of a wave) and touches each of its labels once in global memory at the end;
+// zero contributions (most pixels) are skipped.  Integer addition: order independent.
 #define CS_ROWS 4      // rows per thread: their loads are in flight together
+#define CS_T 1024      // hash slots per block (64 x 16 pixels, a third of them contributing)
 // (flatten: the labels arrive as the trees the border kernel left - phase 3 of the labelling, k_label_flatten, is done here on the way:
 //  each pixel walks to its root and stores it; any interleaving only ever stores roots)
 __global__ __launch_bounds__(256) void k_calc_strength(int *out, const float *__restrict__ edge, int *label, int iw, int ih, const int *__restrict__ add, int flatten) {
+  __shared__ int keys[CS_T], vals[CS_T];
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  for (int t = tid; t < CS_T; t += 256) { keys[t] = -1; vals[t] = 0; }
   const int x = blockIdx.x * 64 + threadIdx.x, yb = blockIdx.y * (4 * CS_ROWS) + threadIdx.y;
   int ls[CS_ROWS], as[CS_ROWS];
   float es[CS_ROWS];
@@ -310,6 +315,7 @@ __global__ __launch_bounds__(256) void k_calc_strength(int *out, const float *__
       }
     }
   }
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < CS_ROWS; k++) {
     const int y = yb + 4 * k;
@@ -321,19 +327,19 @@ __global__ __launch_bounds__(256) void k_calc_strength(int *out, const float *__
       l = ls[k];
       if (l > 0) { const float e = es[k]; val = (int)(e * e * 10000.0f); }
     }
-    bool todo = l > 0 && val != 0;
-    while (__any(todo)) {
-      unsigned long long m = __ballot(todo);
-      const int leader = __ffsll((long long)m) - 1;
-      const int ll = __shfl(l, leader);
-      const bool mine = todo && l == ll;
-      int sum = mine ? val : 0;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-      if ((int)threadIdx.x == leader) atomicAdd(&out[ll], sum);
-      if (mine) todo = false;
+    if (l > 0 && val != 0) {
+      unsigned h = ((unsigned)l * 2654435761u) >> 22;
+      int probes = 0;
+      for (;;) {
+        const int kprev = atomicCAS(&keys[h], -1, l);
+        if (kprev == -1 || kprev == l) { atomicAdd(&vals[h], val); break; }
+        h = (h + 1) & (CS_T - 1);
+        if (++probes == 32) { atomicAdd(&out[l], val); break; }      // (table crowded around this slot: straight to memory)
+      }
     }
   }
+  __syncthreads();
+  for (int t = tid; t < CS_T; t += 256) if (keys[t] != -1 && vals[t] != 0) atomicAdd(&out[keys[t]], vals[t]);
 }
 
 // oclimgutil.cl:651-657
