@@ -799,6 +799,7 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
     if (nworkers > 0 && pthread_create(&s->th, NULL, slot_worker, s) != 0) exitf(-1, "rd_detector_create: cannot start worker thread\n");
   }
   d->last_polled_slot = -1;
+  rdk::quant_lut_init(d->slots[0].st);
   RD_HIP(hipDeviceSynchronize());
   return d;
 }

@@ -506,11 +506,19 @@ __device__ __forceinline__ float bicubic_lds(const float *t, float x, float y, i
   return cubic1(r[0], r[1], r[2], r[3], fy);
 }
 
+// Two bicubic samples (one step along the gradient direction either way) decide whether a pixel is a local maximum; only maxima -
+// a third of the pixels of a noisy frame, scattered over every wave - need the two outer samples.  Evaluated inside the same
+// loop, the outer samples would be computed by whole waves for the sake of a few lanes: the block collects its maxima in an LDS
+// list instead and works the list off with all lanes busy.
 __global__ __launch_bounds__(256) void k_thinthres(float *__restrict__ out, const float *__restrict__ in, const float2 *__restrict__ vxy, int iw, int ih) {
   __shared__ float tile[(TT_ROWS + 7) * TT_PITCH];
+  __shared__ float4 lst[64 * TT_ROWS];          // a maximum: {its inner samples am1, ap1, its direction}
+  __shared__ int lpix[64 * TT_ROWS];            // ... and its tile cell (row * 64 + column)
+  __shared__ int nlst;
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * TT_ROWS;
   const int tid = threadIdx.y * 64 + threadIdx.x;
   const int x = x0 + threadIdx.x;
+  if (tid == 0) nlst = 0;
   // the directions of this thread's pixels are requested together with the tile (one wait for memory per block)
   float2 dir[TT_ROWS / 4];
 #pragma unroll
@@ -522,24 +530,40 @@ __global__ __launch_bounds__(256) void k_thinthres(float *__restrict__ out, cons
     [&](int t, int &a) { a = mirror1(y0 - 3 + t / TT_PITCH, ih) * iw + mirror1(x0 - 3 + t % TT_PITCH, iw); return true; },
     [&](int t, bool, float v) { tile[t] = v; });
   __syncthreads();
-  if (x >= iw) return;
 #pragma unroll
   for (int k = 0; k < TT_ROWS / 4; k++) {
     const int r = threadIdx.y + 4 * k;
     const int y = y0 + r;
-    if (y >= ih) break;
-    const int p0 = y * iw + x;
+    const bool inside = x < iw && y < ih;
+    bool peak = false;
+    float am1 = 0, ap1 = 0;
     const float2 v = dir[k];
-    const float a0 = tile[(r + 3) * TT_PITCH + threadIdx.x + 3];
-    const float am1 = bicubic_lds(tile, x - 1 * v.x, y - 1 * v.y, x0, y0);
-    const float ap1 = bicubic_lds(tile, x + 1 * v.x, y + 1 * v.y, x0, y0);
-    float o = 0.0f;
-    if (am1 <= a0 && a0 >= ap1) {
-      const float am2 = bicubic_lds(tile, x - 2 * v.x, y - 2 * v.y, x0, y0);
-      const float ap2 = bicubic_lds(tile, x + 2 * v.x, y + 2 * v.y, x0, y0);
-      o = am2 + am1 + a0 + ap1 + ap2;
+    if (inside) {
+      const float a0 = tile[(r + 3) * TT_PITCH + threadIdx.x + 3];
+      am1 = bicubic_lds(tile, x - 1 * v.x, y - 1 * v.y, x0, y0);
+      ap1 = bicubic_lds(tile, x + 1 * v.x, y + 1 * v.y, x0, y0);
+      peak = am1 <= a0 && a0 >= ap1;
+      if (!peak) out[y * iw + x] = 0.0f;
     }
-    out[p0] = o;
+    const unsigned long long m = __ballot(peak);
+    if (m) {
+      const int lane = threadIdx.x, leader = __ffsll((long long)m) - 1;
+      int b = 0;
+      if (lane == leader) b = atomicAdd(&nlst, __popcll(m));
+      b = __shfl(b, leader);
+      if (peak) { const int i = b + __popcll(m & ((1ull << lane) - 1)); lst[i] = make_float4(am1, ap1, v.x, v.y); lpix[i] = r * 64 + threadIdx.x; }
+    }
+  }
+  __syncthreads();
+  const int n = nlst;
+  for (int i = tid; i < n; i += 256) {
+    const float4 e = lst[i];
+    const int c = lpix[i], r = c >> 6, tx = c & 63;
+    const int xx = x0 + tx, yy = y0 + r;
+    const float a0 = tile[(r + 3) * TT_PITCH + tx + 3];
+    const float am2 = bicubic_lds(tile, xx - 2 * e.z, yy - 2 * e.w, x0, y0);
+    const float ap2 = bicubic_lds(tile, xx + 2 * e.z, yy + 2 * e.w, x0, y0);
+    out[yy * iw + xx] = am2 + e.x + a0 + e.y + ap2;
   }
 }
 

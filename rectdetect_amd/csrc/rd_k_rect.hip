@@ -279,6 +279,16 @@ __device__ __forceinline__ uint32_t quantize_plab(uint32_t v, int n0, int n1, in
   return pack_lab(roundf(L * n0) / (float)n0, roundf(a * n1) / (float)n1, roundf(b * n2) / (float)n2);
 }
 
+// Quantising a packed Lab word field by field costs a rounding and an IEEE division per field; each result depends on nothing but
+// the field's 12 / 10 bits, so the 24-level tables are built once per device by the very function above (k_quant24_lut) and the
+// frame path looks them up: g_quant24[0..4095] = quantised L field, [4096..5119] = quantised a / b field.
+__device__ uint16_t g_quant24[4096 + 1024];
+__global__ void k_quant24_lut() {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < 4096) g_quant24[i] = (uint16_t)(quantize_plab((uint32_t)i, 24, 24, 24) & 4095u);
+  else if (i < 5120) g_quant24[i] = (uint16_t)((quantize_plab((uint32_t)(i - 4096) << 12, 24, 24, 24) >> 12) & 1023u);      // (a and b share the formula)
+}
+
 // rc:218-244: pixels with a non-zero NMS response take the colour of the Lab-nearest 3x3 neighbour without one.
 // One block per 64 x DS_ROWS tile: the tile and a 1-cell halo of both inputs are staged in LDS (colours already quantised,
 // the response reduced to flags) with all loads of a thread in flight together; the affected pixels - a few per cent, on thin
@@ -293,9 +303,18 @@ __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, c
   __shared__ uint8_t tf[NC];        // bit 0: replaced as a centre (!(e < 1e-6)), bit 1: skipped as a neighbour (e >= 1e-6), bit 2: outside the frame
   __shared__ int list[64 * DS_ROWS];
   __shared__ int nlist;
+  __shared__ uint32_t qlut[QN == 24 ? 2560 : 1];      // g_quant24, two entries per word
   const int tx = threadIdx.x, tid = threadIdx.y * 64 + tx;
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * DS_ROWS;
   if (tid == 0) nlist = 0;
+  if (QN == 24) {
+    uint32_t w[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) w[i] = ((const uint32_t *)g_quant24)[tid + 256 * i];
+#pragma unroll
+    for (int i = 0; i < 10; i++) qlut[tid + 256 * i] = w[i];
+    __syncthreads();
+  }
   {
     uint32_t v[IT];
     float e[IT];
@@ -313,7 +332,12 @@ __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, c
     for (int i = 0; i < IT; i++) {
       const int t = tid + 256 * i;
       if (t >= NC) break;
-      tq[t] = ok[i] ? (QN > 0 ? quantize_plab(v[i], QN, QN, QN) : v[i]) : 0u;
+      uint32_t qv = v[i];
+      if (QN == 24) {
+        const uint16_t *q16 = (const uint16_t *)qlut;
+        qv = (uint32_t)q16[qv & 4095u] | ((uint32_t)q16[4096 + ((qv >> 12) & 1023u)] << 12) | ((uint32_t)q16[4096 + (qv >> 22)] << 22);
+      } else if (QN > 0) qv = quantize_plab(qv, QN, QN, QN);
+      tq[t] = ok[i] ? qv : 0u;
       tf[t] = ok[i] ? (uint8_t)((!(e[i] < 1e-6f) ? 1 : 0) | (e[i] >= 1e-6f ? 2 : 0)) : (uint8_t)4;
     }
   }
@@ -1284,6 +1308,8 @@ void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, in
 void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih) {
   hipLaunchKernelGGL(k_blblur_pair, dim3(cdiv(iw, 64), cdiv(ih, BP_ROWS)), dim3(64, 16), 0, s, out, ext, in, iw, ih);
 }
+// fills the quantisation tables of the current device (once per device, before its first frame; the caller synchronises)
+void quant_lut_init(hipStream_t s) { hipLaunchKernelGGL(k_quant24_lut, dim3(20), dim3(256), 0, s); }
 void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih, int quantize24) {
   if (quantize24) hipLaunchKernelGGL(k_despeckle<24>, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS)), dim3(64, 4), 0, s, out, in, edge, iw, ih);
   else hipLaunchKernelGGL(k_despeckle<0>, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS)), dim3(64, 4), 0, s, out, in, edge, iw, ih);
