@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void k_label_tile(int *__restrict__ label, con
   bool uniform = true;
   int pv8[LT_H / LT_TY];            // this thread's pixels, requested together (one wait for memory instead of one per row)
   if (SRC == 2) {
-    __shared__ uint8_t A[(LT_H + 2 * TD_M) * TD_P], B[(LT_H + 2 * TD_M) * TD_P];
+    __shared__ __align__(16) uint8_t A[(LT_H + 2 * TD_M) * TD_P], B[(LT_H + 2 * TD_M) * TD_P];
     rect_tidy_tile<LT_H>(A, B, blockIdx.x * LT_W, y0, threadIdx.y * 64 + tx, nms, mask0, pix_out, zero_plane, iw, ih, pv8);
     __shared__ int s_t00;            // the value of the tile's first pixel, for the uniform-tile test below
     if (threadIdx.y == 0 && tx == 0) s_t00 = pv8[0];

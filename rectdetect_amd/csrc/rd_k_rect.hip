@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void k_junction(int *__restrict__ out, const i
 // the rect-variant edge tidy (rd_tidy_tile.h) as a kernel of its own; the frame path runs it inside the labelling tile kernel
 #define TD_ROWS 16
 __global__ __launch_bounds__(256) void k_rect_tidy(int *__restrict__ mask0, int *__restrict__ tidy, const float *__restrict__ nms, int iw, int ih, int *__restrict__ zero_plane) {
-  __shared__ uint8_t A[(TD_ROWS + 2 * TD_M) * TD_P], B[(TD_ROWS + 2 * TD_M) * TD_P];
+  __shared__ __align__(16) uint8_t A[(TD_ROWS + 2 * TD_M) * TD_P], B[(TD_ROWS + 2 * TD_M) * TD_P];
   int v[TD_ROWS / 4];
   rect_tidy_tile<TD_ROWS>(A, B, blockIdx.x * 64, blockIdx.y * TD_ROWS, threadIdx.y * 64 + threadIdx.x, nms, mask0, tidy, zero_plane, iw, ih, v);
 }
