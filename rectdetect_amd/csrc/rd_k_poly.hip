@@ -10,6 +10,7 @@
 #include "rd_kernels.h"
 
 #include "rd_poly_scratch.h"
+#include "rd_tidy_tile.h"
 
 namespace {
 
@@ -41,88 +42,106 @@ struct lsx_rec { long long mx00, mx01, mx11, my0, my1; short dx, dy, vx, vy; int
 // "zero / non-zero" matters, so every intermediate is a byte)
 #define PT_ROWS 16
 #define PT_M 6
-#define PT_P (64 + 2 * PT_M)
 __global__ __launch_bounds__(256) void k_poly_tidy(const rdk::PolyFrames FRS, int ring_const, int iw, int ih) {
   RD_FRAME;
   int *__restrict__ out = s.planeC;
   const int *__restrict__ in = FRM.in;
   const int *__restrict__ ring_src = FRM.ring_src;
   int *gen = s.csync;
-  __shared__ uint8_t A[(PT_ROWS + 2 * PT_M) * PT_P], B[(PT_ROWS + 2 * PT_M) * PT_P];
+  // On bit rows (rd_tidy_tile.h): a row of the tile with 6 cells of margin is 76 bits of a 128-bit word pair, bit b = column
+  // x0 - 6 + b; the five stencils are word operations on neighbouring rows, one thread per row.
+  constexpr int R = PT_ROWS + 2 * PT_M;
+  __shared__ bitrow M[R], NZ[R], E2[R], RG[R], O[R], T0[R], T1[R];
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * PT_ROWS;
   const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int lane = threadIdx.x, w = threadIdx.y;
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) gen[0] = gen[0] + 1;      // generation of this frame's compaction state words (k_compact1)
-#define PT_FOR(m) for (int t = tid; t < (PT_ROWS + 2 * (m)) * (64 + 2 * (m)); t += 256)
-#define PT_CELL(m) const int r = t / (64 + 2 * (m)) - (m), c = t % (64 + 2 * (m)) - (m); const int x = x0 + c, y = y0 + r; const int i = (r + PT_M) * PT_P + c + PT_M; const bool in_img = x >= 0 && x < iw && y >= 0 && y < ih
-  stage_cells<(PT_ROWS + 12) * (64 + 12), 256>(tid, in,
-    [&](int t, int &a) { PT_CELL(6); (void)i; a = y * iw + x; return in_img; },
-    [&](int t, bool ok, int v) { PT_CELL(6); (void)in_img; A[i] = (ok && v != 0) ? 1 : 0; });
-  __syncthreads();
-  PT_FOR(5) {   // pl:66-87
-    PT_CELL(5);
-    uint8_t v = 0;
-    if (in_img && x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && A[i] != 0) {
-      int count = 1;
+  {   // the mask (and, if the caller supplies one, the plane whose frame ring stands in for the bridging step's own) as bit rows:
+      // wave w takes rows w, w + 4, ...; lanes = columns -6..57, then lanes 0..11 = columns 58..69; all loads first
+    constexpr int RW = (R + 3) / 4;
+    int va[RW], vb[RW], ga[RW], gb[RW];
+    bool oka[RW], okb[RW];
 #pragma unroll
-      for (int k = 0; k < 8; k++) count += A[i + nbr_dx(k) + nbr_dy(k) * PT_P] != 0;
-      v = count == 1 ? 0 : count;
+    for (int k = 0; k < RW; k++) {
+      const int r = w + 4 * k, y = y0 - PT_M + r;
+      const int xa = x0 - PT_M + lane, xb = x0 - PT_M + 64 + lane;
+      const bool rowin = r < R && y >= 0 && y < ih;
+      oka[k] = rowin && xa >= 0 && xa < iw;
+      okb[k] = rowin && lane < 12 && xb < iw;
+      va[k] = in[oka[k] ? y * iw + xa : 0];
+      vb[k] = in[okb[k] ? y * iw + xb : 0];
+      // (the ring only: rows 0, 1, ih-2, ih-1 and columns 0, 1, iw-2, iw-1)
+      const bool yring = y <= 1 || y >= ih - 2;
+      const bool ra = ring_src != nullptr && oka[k] && (yring || xa <= 1 || xa >= iw - 2), rb = ring_src != nullptr && okb[k] && (yring || xb <= 1 || xb >= iw - 2);
+      ga[k] = ra ? ring_src[y * iw + xa] : 0;
+      gb[k] = rb ? ring_src[y * iw + xb] : 0;
     }
-    B[i] = v;
-  }
-  __syncthreads();
-  PT_FOR(3) {   // pl:89-110
-    PT_CELL(3);
-    uint8_t o = 0;
-    if (in_img) {
-      if (x <= 1 || y <= 1 || x >= iw - 2 || y >= ih - 2) o = (ring_src ? ring_src[y * iw + x] : ring_const) != 0;
-      else if (B[i] != 0) o = 1;
-      else {
-        const int W = PT_P;
-        if (B[i - 2] != 0 && B[i - 1] == 2 && B[i + 1] == 2 && B[i + 2] != 0) o = 1;
-        if (B[i - W * 2] != 0 && B[i - W] == 2 && B[i + W] == 2 && B[i + W * 2] != 0) o = 1;
-        if (B[i - W * 2 - 2] != 0 && B[i - W - 1] == 2 && B[i + W + 1] == 2 && B[i + W * 2 + 2] != 0) o = 1;
-        if (B[i - W * 2 + 2] != 0 && B[i - W + 1] == 2 && B[i + W - 1] == 2 && B[i + W * 2 - 2] != 0) o = 1;
-        if (B[i + 2] != 0 && B[i + 1] == 2 && B[i + W - 1] == 2 && B[i + W - 2] != 0) o = 1;
-        if (B[i - 2] != 0 && B[i - 1] == 2 && B[i + W + 1] == 2 && B[i + W + 2] != 0) o = 1;
-        if (B[i - W * 2 + 1] != 0 && B[i - W + 1] == 2 && B[i + W] == 2 && B[i + W * 2] != 0) o = 1;
-        if (B[i - W * 2 - 1] != 0 && B[i - W - 1] == 2 && B[i + W] == 2 && B[i + W * 2] != 0) o = 1;
-      }
-    }
-    A[i] = o;
-  }
-  __syncthreads();
-  PT_FOR(2) {   // pl:112-124, parity 0
-    PT_CELL(2);
-    uint8_t v = in_img ? A[i] : 0;
-    if (in_img && x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && ((x + y) & 1) == 0) {
-      if ((A[i - PT_P] != 0 || A[i + PT_P] != 0) && (A[i - 1] != 0 || A[i + 1] != 0)) v = 0;
-    }
-    B[i] = v;
-  }
-  __syncthreads();
-  PT_FOR(1) {   // parity 1
-    PT_CELL(1);
-    uint8_t v = in_img ? B[i] : 0;
-    if (in_img && x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && ((x + y) & 1) == 1) {
-      if ((B[i - PT_P] != 0 || B[i + PT_P] != 0) && (B[i - 1] != 0 || B[i + 1] != 0)) v = 0;
-    }
-    A[i] = v;
-  }
-  __syncthreads();
-  PT_FOR(0) {   // pl:126-147
-    PT_CELL(0);
-    if (!in_img) continue;
-    int v = 0;
-    if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && A[i] != 0) {
-      int count = 0;
 #pragma unroll
-      for (int k = 0; k < 8; k++) count += A[i + nbr_dx(k) + nbr_dy(k) * PT_P] != 0;
-      v = count <= 2 ? 1 : 0;
+    for (int k = 0; k < RW; k++) {
+      const int r = w + 4 * k;
+      const unsigned long long ma = __ballot(oka[k] && va[k] != 0), mb = __ballot(okb[k] && vb[k] != 0);
+      const unsigned long long qa = __ballot(ga[k] != 0), qb = __ballot(gb[k] != 0);
+      if (r < R && lane == 0) { M[r] = br(ma, mb); RG[r] = br(qa, qb); }
     }
-    out[y * iw + x] = v;
   }
-#undef PT_FOR
-#undef PT_CELL
+  __syncthreads();
+  const int r = tid;                                   // one thread per row for the stencils (R = 28 rows)
+  const int y = y0 - PT_M + r;
+  const int b0 = PT_M - x0;                            // bit of column 0
+  const bool yin = y >= 0 && y < ih;
+  const bitrow inimg = yin ? br_range(b0, iw - 1 + b0) : br(0, 0);
+  const bitrow in1 = (y >= 1 && y <= ih - 2) ? br_range(1 + b0, iw - 2 + b0) : br(0, 0);
+  const bitrow core = (y >= 2 && y <= ih - 3) ? br_range(2 + b0, iw - 3 + b0) : br(0, 0);      // the frame without its 2-px ring
+  const unsigned long long even = (((x0 - PT_M + y) & 1) == 0) ? 0x5555555555555555ull : 0xaaaaaaaaaaaaaaaaull;
+  if (r >= 1 && r < R - 1) {   // pl:66-87: on-pixels with at least one on-neighbour keep a count (!= 0); count 2 = exactly one neighbour
+    bitrow ge1, ge2;
+    br_count8(M[r - 1], M[r], M[r + 1], ge1, ge2);
+    const bitrow on = M[r] & in1;
+    NZ[r] = on & ge1;
+    E2[r] = on & ge1 & ~ge2;
+  } else if (r < R) { NZ[r] = br(0, 0); E2[r] = br(0, 0); }
+  __syncthreads();
+  if (r >= 3 && r < R - 3) {   // pl:89-110: on-pixels stay, 1-px gaps between two curve ends are bridged (8 strict patterns); the ring keeps stale values (H3)
+    const bitrow z2n = NZ[r - 2], zm = NZ[r], zs = NZ[r + 1], z2s = NZ[r + 2], en = E2[r - 1], em = E2[r], es = E2[r + 1];
+    const bitrow wem = br_west(em), eem = br_east(em), w2zm = br_west(br_west(zm)), e2zm = br_east(br_east(zm));
+    const bitrow pat = (w2zm & wem & eem & e2zm) |
+                       (z2n & en & es & z2s) |
+                       (br_west(br_west(z2n)) & br_west(en) & br_east(es) & br_east(br_east(z2s))) |
+                       (br_east(br_east(z2n)) & br_east(en) & br_west(es) & br_west(br_west(z2s))) |
+                       (e2zm & eem & br_west(es) & br_west(br_west(zs))) |
+                       (w2zm & wem & br_east(es) & br_east(br_east(zs))) |
+                       (br_east(z2n) & br_east(en) & es & z2s) |
+                       (br_west(z2n) & br_west(en) & es & z2s);
+    const bitrow ring = inimg & ~core;
+    const bitrow ringval = ring_src != nullptr ? RG[r] : (ring_const != 0 ? br(~0ull, ~0ull) : br(0, 0));
+    O[r] = (ring & ringval) | (core & (zm | pat));
+  } else if (r < R) O[r] = br(0, 0);
+  __syncthreads();
+  if (r >= 4 && r < R - 4) {   // pl:112-124, parity 0
+    const bitrow o = O[r];
+    T0[r] = o & ~(in1 & br(even, even) & (O[r - 1] | O[r + 1]) & (br_west(o) | br_east(o)));
+  } else if (r < R) T0[r] = br(0, 0);
+  __syncthreads();
+  if (r >= 5 && r < R - 5) {   // parity 1
+    const bitrow o = T0[r];
+    T1[r] = o & ~(in1 & br(~even, ~even) & (T0[r - 1] | T0[r + 1]) & (br_west(o) | br_east(o)));
+  } else if (r < R) T1[r] = br(0, 0);
+  __syncthreads();
+  if (r >= PT_M && r < R - PT_M) {   // pl:126-147: keep on-pixels with at most two on-neighbours (cuts the curves at junctions)
+    const bitrow u = T1[r - 1], m = T1[r], d = T1[r + 1];
+    const bitrow nb[8] = { br_west(u), u, br_east(u), br_west(m), br_east(m), br_west(d), d, br_east(d) };
+    bitrow ge1 = br(0, 0), ge2 = br(0, 0), ge3 = br(0, 0);
+#pragma unroll
+    for (int k = 0; k < 8; k++) { ge3 = ge3 | (ge2 & nb[k]); ge2 = ge2 | (ge1 & nb[k]); ge1 = ge1 | nb[k]; }
+    M[r] = m & in1 & ~ge3;       // (the mask rows are free by now)
+  }
+  __syncthreads();
+  const int x = x0 + lane;
+#pragma unroll
+  for (int j = 0; j < PT_ROWS / 4; j++) {
+    const int tr = w + 4 * j, yy = y0 + tr;
+    if (x < iw && yy < ih) out[yy * iw + x] = br_bit(M[tr + PT_M], lane + PT_M);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ raster-order compaction

@@ -398,59 +398,64 @@ __global__ __launch_bounds__(256) void k_mm_bits(unsigned long long *__restrict_
   }
 }
 
-// bit dx+8 of the result is set when dx^2 + dy^2 lies in [lo, hi)
-__device__ __forceinline__ unsigned dxmask(int dy, int lo, int hi) {
-  unsigned m = 0;
-#pragma unroll
-  for (int dx = -8; dx <= 8; dx++) { const int d2 = dx * dx + dy * dy; if (d2 >= lo && d2 < hi) m |= 1u << (dx + 8); }
-  return m;
+// The 64 cells of a word seeing the cell DX columns to their right (DX < 0: to their left): w0 w1 w2 = the words left of, at and
+// right of the output word in the source row.
+template <int DX>
+__device__ __forceinline__ unsigned long long mm_shift(unsigned long long w0, unsigned long long w1, unsigned long long w2) {
+  if (DX == 0) return w1;
+  if (DX > 0) return (w1 >> DX) | (w2 << (64 - DX));
+  return (w1 << -DX) | (w0 >> (64 + DX));
+}
+// OR over dx in [-8, 8] with dx^2 + DY^2 in [LO, HI) of the row shifted by dx (all of it resolved at compile time)
+template <int DY, int LO, int HI, int DX = -8>
+__device__ __forceinline__ unsigned long long mm_row(unsigned long long w0, unsigned long long w1, unsigned long long w2) {
+  unsigned long long r = 0;
+  if (DX * DX + DY * DY >= LO && DX * DX + DY * DY < HI) r = mm_shift<DX>(w0, w1, w2);
+  if constexpr (DX < 8) r |= mm_row<DY, LO, HI, DX + 1>(w0, w1, w2);
+  return r;
+}
+template <int DY>
+__device__ __forceinline__ void mm_rows(const unsigned long long *sb, int r, unsigned long long &A, unsigned long long &B, unsigned long long &C) {
+  const unsigned long long *row = sb + (r + 8 + DY) * 6;       // rows outside the frame hold zeros
+  const unsigned long long a0 = row[0], a1 = row[1], a2 = row[2], e0 = row[3], e1 = row[4], e2 = row[5];
+  constexpr int ADY = DY < 0 ? -DY : DY;
+  if (ADY * ADY < 36) A |= mm_row<ADY, 16, 36>(a0, a1, a2);
+  if (ADY * ADY < 64) B |= mm_row<ADY, 0, 64>(e0, e1, e2);
+  if (ADY * ADY < 16) C |= mm_row<ADY, 0, 16>(a0 & ~e0, a1 & ~e1, a2 & ~e2);
+  if constexpr (DY < 8) mm_rows<DY + 1>(sb, r, A, B, C);
 }
 
-// block: 64 columns x MM_ROWS rows; the (MM_ROWS + 16) x 3 words x 2 classes of bit rows it needs are staged in LDS with one
-// load per thread (the row loop was a chain of dependent global loads before: latency-bound)
-#define MM_ROWS 8
+// block: 64 columns x MM_ROWS rows.  The (MM_ROWS + 16) x 3 words x 2 classes of bit rows it needs are staged in LDS; ONE thread per
+// output row then evaluates the three tests for all 64 columns of its row at once - every (dy, dx) of a test is one shifted OR of
+// a 64-bit word instead of a 17-bit window test per pixel and row offset (262 -> 45 vector instructions per pixel) - and all
+// threads expand the result bits into the int plane.
+#define MM_ROWS 32
 __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const unsigned long long *__restrict__ bits, int iw, int ih, int wpr) {
   __shared__ unsigned long long sb[(MM_ROWS + 16) * 6];
+  __shared__ unsigned long long res[MM_ROWS];
   const int k = blockIdx.x;                 // word holding this block's own 64 columns
   const int y0 = blockIdx.y * MM_ROWS;
   const int tid = threadIdx.y * 64 + threadIdx.x;
-  if (tid < (MM_ROWS + 16) * 6) {
-    const int r = tid / 6, j = tid % 6;     // j: word k-1, k, k+1 of class any (0..2) / end (3..5)
+  for (int t = tid; t < (MM_ROWS + 16) * 6; t += 256) {
+    const int r = t / 6, j = t % 6;         // j: word k-1, k, k+1 of class any (0..2) / end (3..5)
     const int yy = y0 - 8 + r, kk = k - 1 + j % 3;
     unsigned long long v = 0ull;
     if (yy >= 0 && yy < ih && kk >= 0 && kk < wpr) v = bits[((size_t)yy * wpr + kk) * 2 + j / 3];
-    sb[tid] = v;
+    sb[t] = v;
+  }
+  __syncthreads();
+  if (tid < MM_ROWS) {
+    unsigned long long A = 0, B = 0, C = 0;
+    mm_rows<-8>(sb, tid, A, B, C);
+    res[tid] = A & ~B & ~C;
   }
   __syncthreads();
   const int x = k * 64 + threadIdx.x;
-  const int sh = threadIdx.x + 64 - 8;      // bit position of column x-8 inside the 192-bit window (words k-1, k, k+1)
+  if (x >= iw) return;
   for (int r = threadIdx.y; r < MM_ROWS; r += 4) {
     const int y = y0 + r;
     if (y >= ih) break;
-    unsigned A = 0, B = 0, C = 0;
-#pragma unroll
-    for (int dy = -8; dy <= 8; dy++) {
-      const unsigned long long *row = sb + (r + 8 + dy) * 6;   // rows outside the frame hold zeros
-      const unsigned long long a0 = row[0], a1 = row[1], a2 = row[2];
-      if ((a0 | a1 | a2) == 0ull) continue;   // wave-uniform: no counted pixel in this row of the window (ends are counted pixels too)
-      const unsigned long long e0 = row[3], e1 = row[4], e2 = row[5];
-      // 17 bits starting at window bit sh: take from (w0,w1) or (w1,w2)
-      unsigned wa, we;
-      if (sh < 64) {
-        wa = (unsigned)((a0 >> sh) | (sh ? (a1 << (64 - sh)) : 0ull));
-        we = (unsigned)((e0 >> sh) | (sh ? (e1 << (64 - sh)) : 0ull));
-      } else {
-        const int s2 = sh - 64;
-        wa = (unsigned)((a1 >> s2) | (s2 ? (a2 << (64 - s2)) : 0ull));
-        we = (unsigned)((e1 >> s2) | (s2 ? (e2 << (64 - s2)) : 0ull));
-      }
-      wa &= 0x1ffffu; we &= 0x1ffffu;
-      const int ady = dy < 0 ? -dy : dy;
-      A |= wa & dxmask(ady, 16, 36);
-      B |= we & dxmask(ady, 0, 64);
-      C |= (wa & ~we) & dxmask(ady, 0, 16);
-    }
-    if (x < iw) out[y * iw + x] = (A != 0 && B == 0 && C == 0) ? 1 : 0;
+    out[y * iw + x] = (int)((res[r] >> threadIdx.x) & 1ull);
   }
 }
 
