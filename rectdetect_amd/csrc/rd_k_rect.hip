@@ -183,6 +183,24 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
   unsigned eh[NH], ev[NV];
   uint32_t q[NQ];
   bool okh[NH], okv[NV], okq[NQ];
+  // (a block whose staged patch lies inside the frame - all but the frame's rim - needs no clamping and no validity flags: that
+  //  bookkeeping was an eighth of the kernel's vector instructions)
+  const bool interior = x0 >= 4 && y0 >= 4 && x0 + 68 <= iw && y0 + BP_ROWS + 4 <= ih;
+  if (interior) {
+    const uint16_t *eb = ext + (size_t)(y0 - 4 + ty) * iw + x;
+#pragma unroll
+    for (int k = 0; k < NH; k++) { okh[k] = ty + 16 * k < BP_ROWS + 8; eh[k] = okh[k] ? eb[(size_t)(16 * k) * iw] : (uint16_t)0; }
+#pragma unroll
+    for (int k = 0; k < NV; k++) { okv[k] = true; ev[k] = eb[(size_t)(16 * k + 4) * iw]; }
+    const uint32_t *ib = in + (size_t)(y0 - 4) * iw + x0 - 4;
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+      const int t = tid + 1024 * i;
+      const int r = t / 72, c = t % 72;
+      okq[i] = t < (BP_ROWS + 8) * 72;
+      q[i] = okq[i] ? ib[(size_t)r * iw + c] : 0u;
+    }
+  } else {
 #pragma unroll
   for (int k = 0; k < NH; k++) {
     const int y = y0 - 4 + ty + 16 * k;
@@ -202,6 +220,7 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
     const int xx = x0 - 4 + c, yy = y0 - 4 + r;
     okq[i] = t < (BP_ROWS + 8) * 72 && xx >= 0 && xx < iw && yy >= 0 && yy < ih;
     q[i] = in[okq[i] ? yy * iw + xx : 0];
+  }
   }
   if (tid == 0) { src[ZS] = make_uint2(0, 0); hz[ZH] = make_uint2(0, 0); }
   if (tid < 16) { const float r = tid >= 1 && tid <= 10 ? 1.0f / (float)tid : 0.0f; rwt[tid] = make_float2(r, 0.5f * r); }
