@@ -202,21 +202,27 @@ __host__ __device__ inline int if_nchunks(int H, int rows) {
   i7 = i6; i6 = i5; i5 = i4; i4 = i3; i3 = i2; i2 = i1; i1 = (i0v);                                                    \
   t6 = t5; t5 = t4; t4 = t3; t3 = t2; t2 = t1; t1 = t0; t0 = d;
 
+// TWO waves per block: wave 0 runs the causal sweep, wave 1 the anti-causal sweep of the same 64 columns AT THE SAME TIME.  Each parks
+// its raw outputs for the half of the block it reaches first in LDS; after one barrier in the middle each finishes the other half
+// with what the other wave parked there (anti-causal + causal - c0 * input: the sum commutes, so who adds does not matter).  The
+// recurrence is a chain of dependent operations - a wave's time is its step count - so the block takes rows + run-in steps instead
+// of twice that.
 template <int TOUT, int IF_ROWS>
-__global__ __launch_bounds__(64) void k_iir_fused(P3 dst, P3c src, float *__restrict__ tails, int W, int H, int nchunks, int *bad) {
+__global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__restrict__ tails, int W, int H, int nchunks, int *bad) {
   __shared__ float fwt[(IF_ROWS + 8) * IF_PITCH];
-  const int lane = threadIdx.x;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0) *bad = 0;      // diagnostics flag of the check that follows this launch
+  const int lane = threadIdx.x & 63, anti = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *bad = 0;      // diagnostics flag of the check that follows this launch
   const int x = blockIdx.x * 64 + lane;
   const int k = blockIdx.y, c = blockIdx.z;
   const bool xin = x < W;
   const float *__restrict__ in = src.p[k] + (xin ? x : W - 1);
   const int s0 = c * IF_ROWS, s1 = (c == nchunks - 1) ? H : s0 + IF_ROWS;
+  const int mid = s0 + (s1 - s0) / 2;             // rows [s0, mid) are finished by the anti-causal wave, [mid, s1) by the causal one
   // tails: [plane][chunk][set: 0 fwd warm, 1 fwd true, 2 bwd warm, 3 bwd true][7][W]
   float *__restrict__ tl = tails + ((size_t)(k * nchunks + c) * 4 * 7) * W + (xin ? x : W - 1);
   const int ylo = -IIR_WARM, yhi = H + IIR_WARM;
   float cur[IIR_CH], nxt[IIR_CH];
-  static_assert(IIR_CH == 16 && IF_WU % IIR_CH == 0 && IF_ROWS % IIR_CH == 0, "the interior path walks whole chunks");
+  static_assert(IIR_CH == 16 && IF_WU % IIR_CH == 0 && (IF_ROWS / 2) % IIR_CH == 0, "the interior path walks whole chunks, half a block per phase");
   if (s0 - IF_WU >= 0 && s1 + IF_WU <= H && s1 - s0 == IF_ROWS) {
     // Interior block (all but the first and last of a column): no mirrored rows, no clamping, a full block - the same steps
     // as below with every row test resolved at compile time (the scalar address and branch work of the general form costs
@@ -234,90 +240,100 @@ __global__ __launch_bounds__(64) void k_iir_fused(P3 dst, P3c src, float *__rest
       }                                                                                                                  \
       _Pragma("unroll") for (int j = 0; j < IIR_CH; j++) cur[j] = nxt[j];                                                \
     }
-    {   // causal: rows s0 - IF_WU .. s1 - 1
-      float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
-      float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+    constexpr int HALF = IF_ROWS / 2 / IIR_CH;     // chunks per phase
+    float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
+    float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+    if (!anti) {   // causal: rows s0 - IF_WU .. s1 - 1
       const float *p = in + (size_t)(s0 - IF_WU) * W;
 #pragma unroll
       for (int j = 0; j < IIR_CH; j++) cur[j] = p[(size_t)j * W];
-      for (int c = 0; c < IF_WU / IIR_CH - 1; c++) { IIR_CHUNK(p, 1, (void)0, -1, 0); p += (size_t)IIR_CH * W; }
+      for (int q = 0; q < IF_WU / IIR_CH - 1; q++) { IIR_CHUNK(p, 1, (void)0, -1, 0); p += (size_t)IIR_CH * W; }
       IIR_CHUNK(p, 1, (void)0, 0, j - (IIR_CH - 7)); p += (size_t)IIR_CH * W;                    // rows s0-16 .. s0-1: "warm" tails
       float *f = fwt + lane;
-      for (int c = 0; c < IF_ROWS / IIR_CH - 1; c++) { IIR_CHUNK(p, 1, f[j * IF_PITCH] = d, -1, 0); p += (size_t)IIR_CH * W; f += IIR_CH * IF_PITCH; }
-      IIR_CHUNK(p, 1, f[j * IF_PITCH] = d, 1, j - (IIR_CH - 7));                                  // rows s1-16 .. s1-1: "true" tails
-    }
-    {   // anti-causal: rows s1 - 1 + IF_WU .. s0, finishing the block's pixels
-      float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
-      float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+      for (int q = 0; q < HALF; q++) { IIR_CHUNK(p, 1, f[j * IF_PITCH] = d, -1, 0); p += (size_t)IIR_CH * W; f += IIR_CH * IF_PITCH; }
+      __syncthreads();
+      float *o = TOUT ? nullptr : dst.p[k] + (size_t)mid * W + (xin ? x : W - 1);
+#define IIR_FINISH_F { const float r = (f[j * IF_PITCH] + d) - cur[j] * IIR_C0; if (TOUT) f[j * IF_PITCH] = r; else if (xin) o[(long)j * W] = r; }
+      for (int q = 0; q < HALF - 1; q++) { IIR_CHUNK(p, 1, IIR_FINISH_F, -1, 0); p += (size_t)IIR_CH * W; f += IIR_CH * IF_PITCH; if (!TOUT) o += (size_t)IIR_CH * W; }
+      IIR_CHUNK(p, 1, IIR_FINISH_F, 1, j - (IIR_CH - 7));                                         // rows s1-16 .. s1-1: "true" tails
+#undef IIR_FINISH_F
+    } else {       // anti-causal: rows s1 - 1 + IF_WU .. s0
       const float *p = in + (size_t)(s1 - 1 + IF_WU) * W;
 #pragma unroll
       for (int j = 0; j < IIR_CH; j++) cur[j] = p[-(long)j * W];
-      for (int c = 0; c < IF_WU / IIR_CH - 1; c++) { IIR_CHUNK(p, -1, (void)0, -1, 0); p -= (size_t)IIR_CH * W; }
+      for (int q = 0; q < IF_WU / IIR_CH - 1; q++) { IIR_CHUNK(p, -1, (void)0, -1, 0); p -= (size_t)IIR_CH * W; }
       IIR_CHUNK(p, -1, (void)0, 2, (IIR_CH - 1) - j); p -= (size_t)IIR_CH * W;                   // rows s1+15 .. s1: "warm" tails (index = row - s1)
       float *f = fwt + (IF_ROWS - 1) * IF_PITCH + lane;
-      float *o = TOUT ? nullptr : dst.p[k] + (size_t)(s1 - 1) * W + (xin ? x : W - 1);
-#define IIR_FINISH { const float r = d + f[-j * IF_PITCH] - cur[j] * IIR_C0; if (TOUT) f[-j * IF_PITCH] = r; else if (xin) o[-(long)j * W] = r; }
-      for (int c = 0; c < IF_ROWS / IIR_CH - 1; c++) { IIR_CHUNK(p, -1, IIR_FINISH, -1, 0); p -= (size_t)IIR_CH * W; f -= IIR_CH * IF_PITCH; if (!TOUT) o -= (size_t)IIR_CH * W; }
-      IIR_CHUNK(p, -1, IIR_FINISH, 3, (IIR_CH - 1) - j);                                           // rows s0+15 .. s0: "true" tails (index = row - s0)
-#undef IIR_FINISH
+      for (int q = 0; q < HALF; q++) { IIR_CHUNK(p, -1, f[-j * IF_PITCH] = d, -1, 0); p -= (size_t)IIR_CH * W; f -= IIR_CH * IF_PITCH; }
+      __syncthreads();
+      float *o = TOUT ? nullptr : dst.p[k] + (size_t)(mid - 1) * W + (xin ? x : W - 1);
+#define IIR_FINISH_B { const float r = d + f[-j * IF_PITCH] - cur[j] * IIR_C0; if (TOUT) f[-j * IF_PITCH] = r; else if (xin) o[-(long)j * W] = r; }
+      for (int q = 0; q < HALF - 1; q++) { IIR_CHUNK(p, -1, IIR_FINISH_B, -1, 0); p -= (size_t)IIR_CH * W; f -= IIR_CH * IF_PITCH; if (!TOUT) o -= (size_t)IIR_CH * W; }
+      IIR_CHUNK(p, -1, IIR_FINISH_B, 3, (IIR_CH - 1) - j);                                         // rows s0+15 .. s0: "true" tails (index = row - s0)
+#undef IIR_FINISH_B
     }
 #undef IIR_CHUNK
   } else {
-  {   // ---------------- causal sweep: rows fb .. s1-1
-    const int fb = (s0 - IF_WU <= ylo) ? ylo : s0 - IF_WU;
-    const int total = s1 - fb;
     float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
     float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+    if (!anti) {   // ---------------- causal sweep: rows fb .. s1-1 (one barrier, before row `mid`)
+      const int fb = (s0 - IF_WU <= ylo) ? ylo : s0 - IF_WU;
+      const int total = s1 - fb;
 #pragma unroll
-    for (int j = 0; j < IIR_CH; j++) cur[j] = in[(size_t)mirror1(clampi(fb + j, ylo, yhi), H) * W];
-    for (int base = 0; base < total; base += IIR_CH) {
+      for (int j = 0; j < IIR_CH; j++) cur[j] = in[(size_t)mirror1(clampi(fb + j, ylo, yhi), H) * W];
+      for (int base = 0; base < total; base += IIR_CH) {
 #pragma unroll
-      for (int j = 0; j < IIR_CH; j++) nxt[j] = in[(size_t)mirror1(clampi(fb + base + IIR_CH + j, ylo, yhi), H) * W];
+        for (int j = 0; j < IIR_CH; j++) nxt[j] = in[(size_t)mirror1(clampi(fb + base + IIR_CH + j, ylo, yhi), H) * W];
 #pragma unroll
-      for (int j = 0; j < IIR_CH; j++) {
-        const int yy = fb + base + j;
-        IIR_STEP(cur[j]);
-        if (yy >= s0 && yy < s1) fwt[(yy - s0) * IF_PITCH + lane] = d;
-        if (xin && yy >= s0 - 7 && yy < s0) tl[(size_t)(0 * 7 + yy - (s0 - 7)) * W] = d;
-        if (xin && yy >= s1 - 7 && yy < s1) tl[(size_t)(1 * 7 + yy - (s1 - 7)) * W] = d;
-        IIR_SHIFT(cur[j]);
-      }
-#pragma unroll
-      for (int j = 0; j < IIR_CH; j++) cur[j] = nxt[j];
-    }
-  }
-  {   // ---------------- anti-causal sweep: rows bb .. s0 (descending), finishing the block's pixels
-    const int bb = (s1 - 1 + IF_WU >= yhi) ? yhi : s1 - 1 + IF_WU;
-    const int total = bb - s0 + 1;
-    float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
-    float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
-#pragma unroll
-    for (int j = 0; j < IIR_CH; j++) cur[j] = in[(size_t)mirror1(clampi(bb - j, ylo, yhi), H) * W];
-    for (int base = 0; base < total; base += IIR_CH) {
-#pragma unroll
-      for (int j = 0; j < IIR_CH; j++) nxt[j] = in[(size_t)mirror1(clampi(bb - (base + IIR_CH + j), ylo, yhi), H) * W];
-#pragma unroll
-      for (int j = 0; j < IIR_CH; j++) {
-        const int yy = bb - (base + j);
-        IIR_STEP(cur[j]);
-        if (yy >= s0 && yy < s1) {
-          const float o = d + fwt[(yy - s0) * IF_PITCH + lane] - cur[j] * IIR_C0;
-          if (TOUT) fwt[(yy - s0) * IF_PITCH + lane] = o;
-          else if (xin) dst.p[k][(size_t)yy * W + x] = o;
+        for (int j = 0; j < IIR_CH; j++) {
+          const int yy = fb + base + j;
+          if (yy == mid) __syncthreads();
+          IIR_STEP(cur[j]);
+          if (yy >= s0 && yy < mid) fwt[(yy - s0) * IF_PITCH + lane] = d;
+          else if (yy >= mid && yy < s1) {
+            const float o = (fwt[(yy - s0) * IF_PITCH + lane] + d) - cur[j] * IIR_C0;
+            if (TOUT) fwt[(yy - s0) * IF_PITCH + lane] = o;
+            else if (xin) dst.p[k][(size_t)yy * W + x] = o;
+          }
+          if (xin && yy >= s0 - 7 && yy < s0) tl[(size_t)(0 * 7 + yy - (s0 - 7)) * W] = d;
+          if (xin && yy >= s1 - 7 && yy < s1) tl[(size_t)(1 * 7 + yy - (s1 - 7)) * W] = d;
+          IIR_SHIFT(cur[j]);
         }
-        if (xin && yy >= s1 && yy < s1 + 7) tl[(size_t)(2 * 7 + yy - s1) * W] = d;
-        if (xin && yy >= s0 && yy < s0 + 7) tl[(size_t)(3 * 7 + yy - s0) * W] = d;
-        IIR_SHIFT(cur[j]);
-      }
 #pragma unroll
-      for (int j = 0; j < IIR_CH; j++) cur[j] = nxt[j];
+        for (int j = 0; j < IIR_CH; j++) cur[j] = nxt[j];
+      }
+    } else {       // ---------------- anti-causal sweep: rows bb .. s0, descending (one barrier, before row `mid - 1`)
+      const int bb = (s1 - 1 + IF_WU >= yhi) ? yhi : s1 - 1 + IF_WU;
+      const int total = bb - s0 + 1;
+#pragma unroll
+      for (int j = 0; j < IIR_CH; j++) cur[j] = in[(size_t)mirror1(clampi(bb - j, ylo, yhi), H) * W];
+      for (int base = 0; base < total; base += IIR_CH) {
+#pragma unroll
+        for (int j = 0; j < IIR_CH; j++) nxt[j] = in[(size_t)mirror1(clampi(bb - (base + IIR_CH + j), ylo, yhi), H) * W];
+#pragma unroll
+        for (int j = 0; j < IIR_CH; j++) {
+          const int yy = bb - (base + j);
+          if (yy == mid - 1) __syncthreads();
+          IIR_STEP(cur[j]);
+          if (yy >= mid && yy < s1) fwt[(yy - s0) * IF_PITCH + lane] = d;
+          else if (yy >= s0 && yy < mid) {
+            const float o = d + fwt[(yy - s0) * IF_PITCH + lane] - cur[j] * IIR_C0;
+            if (TOUT) fwt[(yy - s0) * IF_PITCH + lane] = o;
+            else if (xin) dst.p[k][(size_t)yy * W + x] = o;
+          }
+          if (xin && yy >= s1 && yy < s1 + 7) tl[(size_t)(2 * 7 + yy - s1) * W] = d;
+          if (xin && yy >= s0 && yy < s0 + 7) tl[(size_t)(3 * 7 + yy - s0) * W] = d;
+          IIR_SHIFT(cur[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < IIR_CH; j++) cur[j] = nxt[j];
+      }
     }
-  }
   }
   if (TOUT) {
     __syncthreads();
     const int rows = s1 - s0;
-    for (int col = 0; col < 64; col++) {
+    for (int col = anti; col < 64; col += 2) {
       const int xx = blockIdx.x * 64 + col;
       if (xx >= W) break;
       float *__restrict__ o = dst.p[k] + (size_t)xx * H + s0;
@@ -736,7 +752,7 @@ void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], 
 static int if_pick_rows(int np, int W, int H, int transpose_out) {
   (void)np; (void)W; (void)H;
   static const int forced = getenv("RD_IIR_ROWS") ? atoi(getenv("RD_IIR_ROWS")) : 0;
-  if (forced == 32 || forced == 48 || forced == 64 || forced == 96 || forced == 112 || forced == 128) return forced;
+  if (forced == 32 || forced == 64 || forced == 96 || forced == 128) return forced;
   (void)transpose_out;
   return 64;     // 32 rows of run-in per 64 rows of output: with several frames in flight the instruction count matters more than the wave count (48 / 32 rows ran 5 % slower there, though faster alone)
 }
@@ -752,14 +768,12 @@ void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3]
   const int rows = if_pick_rows(np, W, H, transpose_out);
   const int nchunks = if_nchunks(H, rows);
   const dim3 grid(cdiv(W, 64), np, nchunks);
-#define IF_LAUNCH(T, R) hipLaunchKernelGGL((k_iir_fused<T, R>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks, bad)
+#define IF_LAUNCH(T, R) hipLaunchKernelGGL((k_iir_fused<T, R>), grid, dim3(128), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks, bad)
 #define IF_LAUNCH_R(R) { if (transpose_out) IF_LAUNCH(1, R); else IF_LAUNCH(0, R); }
   switch (rows) {
     case 32: IF_LAUNCH_R(32); break;
-    case 48: IF_LAUNCH_R(48); break;
     case 64: IF_LAUNCH_R(64); break;
     case 96: IF_LAUNCH_R(96); break;
-    case 112: IF_LAUNCH_R(112); break;
     default: IF_LAUNCH_R(128); break;
   }
 #undef IF_LAUNCH_R

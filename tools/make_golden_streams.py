@@ -3,6 +3,7 @@
 reference carries from frame to frame takes part well beyond the 2-3 frames of the other fixtures:
   stream_1920x1080_s0.npz  16 frames of the benchmark workload (BASELINE.json configs[4]: 1920x1080, stream seed 0)
   stream_1280x720_s1.npz   30 frames of configs[2] (1280x720, AOV 72 like vidrect's default)
+  stream_3840x2160_s4.npz  3 frames of configs[3] (3840x2160)
 Per frame: the rect_t list and the line-segment list.  Only runs where /root/reference exists."""
 import os
 import sys
@@ -15,7 +16,8 @@ import rectdetect_amd as ra  # noqa: E402
 from rectdetect_amd import synth  # noqa: E402
 from tests import helpers  # noqa: E402
 
-CASES = {"stream_1920x1080_s0": (1920, 1080, 0, 16, 36.0), "stream_1280x720_s1": (1280, 720, 1, 30, 36.0)}
+CASES = {"stream_1920x1080_s0": (1920, 1080, 0, 16, 36.0), "stream_1280x720_s1": (1280, 720, 1, 30, 36.0),
+         "stream_3840x2160_s4": (3840, 2160, 4, 3, 36.0)}      # BASELINE.json configs[3]
 
 
 def main():
