@@ -136,11 +136,12 @@ def test_rect_outputs_match_reference_golden(name):
     det.close()
 
 
-@pytest.mark.parametrize("name,nslots", [("stream_1920x1080_s0", 8), ("stream_1280x720_s1", 8), ("stream_1280x720_s1", 2)])
+@pytest.mark.parametrize("name,nslots", [("stream_1920x1080_s0", 8), ("stream_1920x1080_s0", 16), ("stream_1280x720_s1", 8), ("stream_1280x720_s1", 2), ("stream_3840x2160_s4", 3)])
 def test_long_streams_in_the_benchmarked_configuration_vs_reference(name, nslots):
-    """16 consecutive 1920x1080 frames of the bench stream (BASELINE.json configs[4]) and 30 frames of the 1280x720 stream
-    (configs[2]) the way bench.py runs them - 8 frames in flight on four shared streams, captured graphs, post-process on worker
-    threads, frames resident in HBM, adaptive round budget - against what THE REFERENCE returned for the same stream
+    """16 consecutive 1920x1080 frames of the bench stream (BASELINE.json configs[4]), 30 frames of the 1280x720 stream
+    (configs[2]) and 3 frames of the 3840x2160 stream (configs[3]; its frames overflow the single-launch polyline kernel) the way
+    bench.py runs them - 8 or 16 frames in flight on four shared streams (16: sparse stages in deferred batches of four), captured
+    graphs, post-process on worker threads, frames resident in HBM, adaptive round budget - against what THE REFERENCE returned for the same stream
     (tests/golden/stream_*.npz, tools/make_golden_streams.py): the state carried from frame to frame (H1) is exercised 16 / 30 frames
     deep.  Segment lists bit-identical; rectangle lists: same count and status, integer pixel coordinates identical, float
     parameters within 1e-4 (north_star tolerance; they are in fact bit-identical on these streams, which is reported)."""
