@@ -10,12 +10,18 @@
 #include <stdlib.h>
 #include <string.h>
 
-static int g_selected = 0;
+#include <pthread.h>
+
+// State of this layer.  The reference keeps its plan, kernel ids and pinned-memory map in process-global variables and is not
+// re-entrant (oclhelper.c:329-334, 821, 835); here one process may drive several GPUs from several threads, so the
+// selected device is per thread and the shared tables are guarded.
+static thread_local int g_selected = 0;
 static struct _cl_device_id g_devices[16];
 static int g_ndev = -1;
+static pthread_once_t g_enum_once = PTHREAD_ONCE_INIT;
+static pthread_mutex_t g_state_mu = PTHREAD_MUTEX_INITIALIZER;     // pinned-memory map, plan table
 
-static void enumerate() {
-  if (g_ndev >= 0) return;
+static void enumerate_once() {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess) { n = 0; (void)hipGetLastError(); }
@@ -28,6 +34,7 @@ static void enumerate() {
   }
   g_ndev = n;
 }
+static void enumerate() { pthread_once(&g_enum_once, enumerate_once); }
 
 namespace rdrt {
 void wait_list(cl_command_queue q, const cl_event *events) {
@@ -242,13 +249,18 @@ void *allocatePinnedMemory(size_t z, cl_context context, cl_command_queue queue)
   (void)context; (void)queue;
   void *p = NULL;
   RD_HIP(hipHostMalloc(&p, z ? z : 1, hipHostMallocDefault));
+  pthread_mutex_lock(&g_state_mu);
   if (!g_pinned) g_pinned = initArrayMap();
   ArrayMap_put(g_pinned, (uint64_t)(uintptr_t)p, p);
+  pthread_mutex_unlock(&g_state_mu);
   return p;
 }
 void freePinnedMemory(void *p, cl_context context, cl_command_queue queue) {
   (void)context; (void)queue;
-  if (!g_pinned || ArrayMap_remove(g_pinned, (uint64_t)(uintptr_t)p) == NULL) exitf(-1, "freePinnedMemory: unknown pointer\n");
+  pthread_mutex_lock(&g_state_mu);
+  const bool known = g_pinned && ArrayMap_remove(g_pinned, (uint64_t)(uintptr_t)p) != NULL;
+  pthread_mutex_unlock(&g_state_mu);
+  if (!known) exitf(-1, "freePinnedMemory: unknown pointer\n");
   RD_HIP(hipHostFree(p));
 }
 
@@ -256,7 +268,7 @@ void freePinnedMemory(void *p, cl_context context, cl_command_queue queue) {
 // Work-group sizes are compile-time properties of the HIP kernels, so the plan has no effect on launches.  The functions
 // keep the reference's file format so that a plan.txt written by either implementation can be read by the other.
 static int g_next_kernel_id = 0;
-int getNextKernelID() { return g_next_kernel_id++; }
+int getNextKernelID() { return __atomic_fetch_add(&g_next_kernel_id, 1, __ATOMIC_RELAXED); }
 
 #define RD_KERNELIDMAX 1000
 static struct { int valid; long long ws[3], ns; } g_plan[RD_KERNELIDMAX];
