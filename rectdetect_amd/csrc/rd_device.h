@@ -97,6 +97,14 @@ __device__ __forceinline__ void stage_cells(int tid, const T *__restrict__ in, W
   }
 }
 
+// Element `idx` of a plane of 4-byte elements, addressed by a 32-bit BYTE offset (planes are below 2^25 elements): the access then
+// takes the plane's base from scalar registers plus a 32-bit vector offset, instead of a 64-bit address computed per lane with
+// sign extension, shift and 64-bit add (three vector instructions per access; a quarter of the region rounds' instruction count).
+template <typename T>
+__device__ __forceinline__ T &at32(T *base, unsigned idx) { return *(T *)((char *)base + (idx << 2)); }
+template <typename T>
+__device__ __forceinline__ const T &at32(const T *base, unsigned idx) { return *(const T *)((const char *)base + (idx << 2)); }
+
 // L2-coherent (device-scope) load: used to guard hot atomics so that later waves see an earlier wave's update instead of
 // a stale L1 line and skip the atomic
 __device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

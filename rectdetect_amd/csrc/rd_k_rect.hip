@@ -589,9 +589,9 @@ __device__ __forceinline__ int rr_min3(int l, int wp, int ws, int tag) {
   return l < v ? l : v;
 }
 template <bool FIRST>
-__device__ __forceinline__ int rr_eff(const int *label, const int *propP, const int *selfP, int q, int tag) {
-  if (FIRST) return label[q];
-  return rr_min3(label[q], propP[q], selfP[q], tag);
+__device__ __forceinline__ int rr_eff(const int *label, const int *propP, const int *selfP, unsigned q, int tag) {
+  if (FIRST) return at32(label, q);
+  return rr_min3(at32(label, q), at32(propP, q), at32(selfP, q), tag);
 }
 
 template <bool FIRST>
@@ -609,13 +609,14 @@ __global__ __launch_bounds__(256) void k_region_round(int *label, const int *__r
   unsigned a[RR_PX];
   bool valid[RR_PX], todo[RR_PX];
   {
-    int q[RR_PX][5], l[RR_PX][5], wp[RR_PX][5], ws[RR_PX][5];
+    unsigned q[RR_PX][5];       // (unsigned element indices: the loads then take the plane's base from scalar registers and a 32-bit offset, no 64-bit address arithmetic per access)
+    int l[RR_PX][5], wp[RR_PX][5], ws[RR_PX][5];
 #pragma unroll
     for (int k = 0; k < RR_PX; k++) {
       const int x = xb + k * 64;
       valid[k] = x < iw && y < ih;
       p0[k] = valid[k] ? y * iw + x : 0;
-      a[k] = valid[k] ? allow[p0[k]] : 0u;
+      a[k] = valid[k] ? allow[(unsigned)p0[k]] : 0u;
       // neighbour addresses clamped into the plane: the loads are unconditional, their use depends on the allow bits
       q[k][0] = p0[k];
       q[k][1] = (valid[k] && y > 0) ? p0[k] - iw : p0[k];
@@ -624,8 +625,8 @@ __global__ __launch_bounds__(256) void k_region_round(int *label, const int *__r
       q[k][4] = (valid[k] && y < ih - 1) ? p0[k] + iw : p0[k];
 #pragma unroll
       for (int c = 0; c < 5; c++) {
-        l[k][c] = label[q[k][c]];
-        if (!FIRST) { wp[k][c] = propP[q[k][c]]; ws[k][c] = selfP[q[k][c]]; }
+        l[k][c] = at32(label, q[k][c]);
+        if (!FIRST) { wp[k][c] = at32(propP, q[k][c]); ws[k][c] = at32(selfP, q[k][c]); }
       }
     }
 #pragma unroll
@@ -634,7 +635,7 @@ __global__ __launch_bounds__(256) void k_region_round(int *label, const int *__r
 #pragma unroll
       for (int c = 0; c < 5; c++) e[c] = FIRST ? l[k][c] : rr_min3(l[k][c], wp[k][c], ws[k][c], tagP);
       og[k] = e[0];
-      if (!FIRST && valid[k] && e[0] < l[k][0]) label[p0[k]] = e[0];     // what the apply pass would have stored
+      if (!FIRST && valid[k] && e[0] < l[k][0]) at32(label, (unsigned)p0[k]) = e[0];     // what the apply pass would have stored
       int m = e[0];
       if ((a[k] & 1) && e[1] < m) m = e[1];
       if ((a[k] & 2) && e[2] < m) m = e[2];
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(256) void k_region_round(int *label, const int *__r
   {
     int l[RR_PX], wp[RR_PX], ws[RR_PX];
 #pragma unroll
-    for (int k = 0; k < RR_PX; k++) { l[k] = label[g[k]]; if (!FIRST) { wp[k] = propP[g[k]]; ws[k] = selfP[g[k]]; } }     // rc:328: first of the eight pointer jumps (a root maps to itself)
+    for (int k = 0; k < RR_PX; k++) { l[k] = at32(label, (unsigned)g[k]); if (!FIRST) { wp[k] = at32(propP, (unsigned)g[k]); ws[k] = at32(selfP, (unsigned)g[k]); } }     // rc:328: first of the eight pointer jumps (a root maps to itself)
 #pragma unroll
     for (int k = 0; k < RR_PX; k++) nx[k] = FIRST ? l[k] : rr_min3(l[k], wp[k], ws[k], tagP);
   }
@@ -655,11 +656,11 @@ __global__ __launch_bounds__(256) void k_region_round(int *label, const int *__r
   for (int k = 0; k < RR_PX; k++) {
     if (a[k] & 16) {
       int n = nx[k];
-      for (int j = 1; j < 8 && n != g[k]; j++) { g[k] = n; n = rr_eff<FIRST>(label, propP, selfP, n, tagP); }
+      for (int j = 1; j < 8 && n != g[k]; j++) { g[k] = n; n = rr_eff<FIRST>(label, propP, selfP, (unsigned)n, tagP); }
       if (n != g[k]) g[k] = n;          // (the eighth jump)
     }
     todo[k] = (a[k] & 16) && g[k] != og[k];
-    if (todo[k]) selfW[p0[k]] = (tagW << RR_VBITS) | g[k];   // own update: nobody else writes this word
+    if (todo[k]) at32(selfW, (unsigned)p0[k]) = (tagW << RR_VBITS) | g[k];   // own update: nobody else writes this word
     any_todo = any_todo || todo[k];
   }
   // Hooking the old parent: after flattening, all pixels of a tree share one parent, so the block first reduces its
