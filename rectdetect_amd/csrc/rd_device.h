@@ -104,6 +104,11 @@ template <typename T>
 __device__ __forceinline__ T &at32(T *base, unsigned idx) { return *(T *)((char *)base + (idx << 2)); }
 template <typename T>
 __device__ __forceinline__ const T &at32(const T *base, unsigned idx) { return *(const T *)((const char *)base + (idx << 2)); }
+// the same for any element size: element `idx`, byte offset idx * sizeof(T) in 32 bits
+template <typename T>
+__device__ __forceinline__ T &atu(T *base, unsigned idx) { return *(T *)((char *)base + idx * (unsigned)sizeof(T)); }
+template <typename T>
+__device__ __forceinline__ const T &atu(const T *base, unsigned idx) { return *(const T *)((const char *)base + idx * (unsigned)sizeof(T)); }
 
 // L2-coherent (device-scope) load: used to guard hot atomics so that later waves see an earlier wave's update instead of
 // a stale L1 line and skip the atomic

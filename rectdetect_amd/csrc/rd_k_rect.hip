@@ -186,32 +186,33 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
   // (a block whose staged patch lies inside the frame - all but the frame's rim - needs no clamping and no validity flags: that
   //  bookkeeping was an eighth of the kernel's vector instructions)
   const bool interior = x0 >= 4 && y0 >= 4 && x0 + 68 <= iw && y0 + BP_ROWS + 4 <= ih;
+  // (element indices as unsigned 32-bit offsets from the planes' bases - atu() - keep the address arithmetic out of the vector unit)
   if (interior) {
-    const uint16_t *eb = ext + (size_t)(y0 - 4 + ty) * iw + x;
+    const unsigned eb = (unsigned)((y0 - 4 + ty) * iw + x);
 #pragma unroll
-    for (int k = 0; k < NH; k++) { okh[k] = ty + 16 * k < BP_ROWS + 8; eh[k] = okh[k] ? eb[(size_t)(16 * k) * iw] : (uint16_t)0; }
+    for (int k = 0; k < NH; k++) { okh[k] = ty + 16 * k < BP_ROWS + 8; eh[k] = okh[k] ? atu(ext, eb + (unsigned)(16 * k * iw)) : (uint16_t)0; }
 #pragma unroll
-    for (int k = 0; k < NV; k++) { okv[k] = true; ev[k] = eb[(size_t)(16 * k + 4) * iw]; }
-    const uint32_t *ib = in + (size_t)(y0 - 4) * iw + x0 - 4;
+    for (int k = 0; k < NV; k++) { okv[k] = true; ev[k] = atu(ext, eb + (unsigned)((16 * k + 4) * iw)); }
+    const unsigned ib = (unsigned)((y0 - 4) * iw + x0 - 4);
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
       const int t = tid + 1024 * i;
       const int r = t / 72, c = t % 72;
       okq[i] = t < (BP_ROWS + 8) * 72;
-      q[i] = okq[i] ? ib[(size_t)r * iw + c] : 0u;
+      q[i] = okq[i] ? atu(in, ib + (unsigned)(r * iw + c)) : 0u;
     }
   } else {
 #pragma unroll
   for (int k = 0; k < NH; k++) {
     const int y = y0 - 4 + ty + 16 * k;
     okh[k] = ty + 16 * k < BP_ROWS + 8 && x < iw && y >= 0 && y < ih;
-    eh[k] = ext[okh[k] ? y * iw + x : 0];
+    eh[k] = atu(ext, okh[k] ? (unsigned)(y * iw + x) : 0u);
   }
 #pragma unroll
   for (int k = 0; k < NV; k++) {
     const int y = y0 + ty + 16 * k;
     okv[k] = x < iw && y < ih;
-    ev[k] = ext[okv[k] ? y * iw + x : 0];
+    ev[k] = atu(ext, okv[k] ? (unsigned)(y * iw + x) : 0u);
   }
 #pragma unroll
   for (int i = 0; i < NQ; i++) {
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
     const int r = t / 72, c = t % 72;
     const int xx = x0 - 4 + c, yy = y0 - 4 + r;
     okq[i] = t < (BP_ROWS + 8) * 72 && xx >= 0 && xx < iw && yy >= 0 && yy < ih;
-    q[i] = in[okq[i] ? yy * iw + xx : 0];
+    q[i] = atu(in, okq[i] ? (unsigned)(yy * iw + xx) : 0u);
   }
   }
   if (tid == 0) { src[ZS] = make_uint2(0, 0); hz[ZH] = make_uint2(0, 0); }
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
       const float2 rw = rwt[w];
       o = make_uint2(div_small_f(lo & 0xffffu, rw) | (div_small_f(lo >> 16, rw) << 16), div_small_f(hi, rw));
     }
-    out[y * iw + x] = (o.x & 0xffffu) | ((o.x >> 16) << 12) | (o.y << 22);
+    atu(out, (unsigned)(y * iw + x)) = (o.x & 0xffffu) | ((o.x >> 16) << 12) | (o.y << 22);
   }
 }
 
