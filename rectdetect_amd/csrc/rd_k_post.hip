@@ -39,8 +39,7 @@ struct ls_rec { float x0, y0, x1, y1; int startIndex, endIndex, leftPtr, rightPt
 #define PS_MEM (PS_CAND + POST_MAXC * 4)          // POST_MEMBERS
 #define PS_FILL (PS_MEM + POST_MEMBERS)           // POST_MAXG fill counters
 #define PS_CTR (PS_FILL + POST_MAXG)              // [0] groups, [1] candidates, [2] overflow, [3] members
-#define PS_WORK (PS_CTR + 64)                     // POST_WAVES work spaces of RDP_WORK_BYTES(POST_CAP) bytes (8-byte aligned)
-#define PS_WORK_INTS ((int)((RDP_WORK_BYTES(POST_CAP) + 7) / 8 * 2))
+#define PS_END (PS_CTR + 64)
 
 __device__ __forceinline__ int am_bucket(unsigned k) { return (int)((k ^ (k >> 10) ^ (k >> 20) ^ (k >> 30)) & 1023u); }      // helper.c:127-134 on a 32-bit key
 __device__ __forceinline__ unsigned ht_hash(int key) { return ((unsigned)key * 2654435761u) >> 19; }      // 13 bits
@@ -198,8 +197,11 @@ __global__ __launch_bounds__(64) void k_post_solve(const PolyFrames FRS, int max
   __shared__ double t0[2][4];
   __shared__ int s_ok, s_first, s_over;
   __shared__ rdp_p2 s_centre;
+  // the funnel's work space (35 KB) lives in LDS: lane 0 walks through it one access after the other, a trip to global memory each
+  // time made the kernel three times as long
+  __shared__ __align__(16) unsigned char wmem[RDP_WORK_BYTES(POST_CAP)];
   rdp_work w;
-  rdp_work_place(&w, S + PS_WORK + (size_t)blockIdx.x * PS_WORK_INTS, POST_CAP);
+  rdp_work_place(&w, wmem, POST_CAP);
   if (lane == 0) s_over = 0;
   for (int c = blockIdx.x; c < ncand; c += gridDim.x) {
     const int type = cand[c * 4], key = cand[c * 4 + 1];
@@ -339,7 +341,7 @@ __global__ void k_post_header(const PolyFrames FRS, double tanAOV) {
 
 namespace rdk {
 
-size_t post_scratch_ints() { return (size_t)PS_WORK + (size_t)POST_WAVES * PS_WORK_INTS; }
+size_t post_scratch_ints() { return (size_t)PS_END; }
 size_t post_out_ints() { return 8 + (size_t)POST_MAXC + (size_t)POST_MAXC * (sizeof(rdp_rect) / sizeof(int)); }
 
 // rectangles of nb frames from their segment lists and probes (frames[z].probes / lslist as sample_segments left them) into frames[z].post_out

@@ -23,16 +23,22 @@ typedef struct { double x, y; } rdp_p2;
 typedef struct { rdp_p2 e0, e1; } rdp_seg;
 typedef struct { double c2[4][2]; double c3[4][3]; double value; uint32_t status, pad; } rdp_rect;      /* = rect_t (oclrect.h), 176 bytes */
 
-/* work space of one candidate: cap segments in `als` and `out`, 2*cap points, hull points and 16*cap pool ints */
+/* one pending call of the hull construction (see rdp_hull_side) */
+typedef struct { int s0, sn, l0, ln, mark, stage; rdp_p2 left, right, pf; } rdp_hull_frame;
+#define RDP_HULL_DEPTH 48
+
+/* work space of one candidate: cap segments in `als` and `out`, 2*cap points, hull points, 16*cap pool ints and the hull's call stack */
 typedef struct {
   rdp_seg *als, *out;
   rdp_p2 *pts, *hull;
   int *pool;
+  rdp_hull_frame *stack;
   int cap, overflow;
 } rdp_work;
-#define RDP_WORK_BYTES(cap) ((size_t)(cap) * (2 * sizeof(rdp_seg) + 4 * sizeof(rdp_p2) + 16 * sizeof(int)))
+#define RDP_WORK_BYTES(cap) ((size_t)(cap) * (2 * sizeof(rdp_seg) + 4 * sizeof(rdp_p2) + 16 * sizeof(int)) + RDP_HULL_DEPTH * sizeof(rdp_hull_frame))
 RD_HD void rdp_work_place(rdp_work *w, void *mem, int cap) {
   char *p = (char *)mem;
+  w->stack = (rdp_hull_frame *)p; p += sizeof(rdp_hull_frame) * RDP_HULL_DEPTH;
   w->als = (rdp_seg *)p; p += sizeof(rdp_seg) * (size_t)cap;
   w->out = (rdp_seg *)p; p += sizeof(rdp_seg) * (size_t)cap;
   w->pts = (rdp_p2 *)p; p += sizeof(rdp_p2) * (size_t)cap * 2;
@@ -198,11 +204,8 @@ RD_HD void rdp_pose_finish(const rdp_seg *sides, int first, const rdp_rays *R, c
 /* ------------------------------------------------------------------ convex hull (behaviour of rh:658-734, quick hull)
  * Same vertex order as the reference's recursion - right-most point, the points above the line left-right from right to left, left-most
  * point, the points below - with an explicit stack; subsets are index lists in w->pool, released in LIFO order. */
-typedef struct { int s0, sn, l0, ln, mark, stage; rdp_p2 left, right, pf; } rdp_hull_frame;
-#define RDP_HULL_DEPTH 48
-
 RD_HD int rdp_hull_side(rdp_work *w, int npts, int nh, int s0, int sn, rdp_p2 left, rdp_p2 right, int *pool_top) {
-  rdp_hull_frame st[RDP_HULL_DEPTH];
+  rdp_hull_frame *st = w->stack;
   int sp = 0;
   st[0].s0 = s0; st[0].sn = sn; st[0].left = left; st[0].right = right; st[0].stage = 0; st[0].mark = *pool_top; st[0].l0 = 0; st[0].ln = 0; st[0].pf = left;
   while (sp >= 0) {
