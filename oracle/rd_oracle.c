@@ -138,19 +138,20 @@ static const float IIR[15] = {
 };
 #define IIR_R 2
 #define IIR_WARM (IIR_R + 1 + 8)
+#include "rd_iircoef.h"     /* every radius (iu:900-1125), generated by tools/gen_iircoef.py; row 2 = IIR above */
 
 /* One causal sweep over a line of n samples with stride `st` (iu:542-559 and the three siblings):
  * positions start .. end in direction dir, warm-up samples mirrored, results written at wrapped
  * positions so that the final value at each in-range position is the true recurrence value. */
-static void iir_sweep(float *dst, const float *src, int n, int st, int dir) {
+static void iir_sweep(float *dst, const float *src, int n, int st, int dir, const float *C, int warm) {
   float iv[8] = { 0 }, tv[8] = { 0 };
-  int x = dir > 0 ? -IIR_WARM : n + IIR_WARM;
+  int x = dir > 0 ? -warm : n + warm;
   for (;;) {
     if (dir > 0 ? x >= n : x < 0) break;
     iv[0] = src[mirror1(x, n) * st];
-    float d = iv[0] * IIR[0];
-    d += IIR[1] * iv[1] + IIR[2] * iv[2] + IIR[3] * iv[3] + IIR[4] * iv[4] + IIR[5] * iv[5] + IIR[6] * iv[6] + IIR[7] * iv[7];
-    d += IIR[8] * tv[0] + IIR[9] * tv[1] + IIR[10] * tv[2] + IIR[11] * tv[3] + IIR[12] * tv[4] + IIR[13] * tv[5] + IIR[14] * tv[6];
+    float d = iv[0] * C[0];
+    d += C[1] * iv[1] + C[2] * iv[2] + C[3] * iv[3] + C[4] * iv[4] + C[5] * iv[5] + C[6] * iv[6] + C[7] * iv[7];
+    d += C[8] * tv[0] + C[9] * tv[1] + C[10] * tv[2] + C[11] * tv[3] + C[12] * tv[4] + C[13] * tv[5] + C[14] * tv[6];
     dst[wrap1(x, n) * st] = d;
     for (int k = 7; k > 0; k--) { iv[k] = iv[k - 1]; tv[k] = tv[k - 1]; }
     tv[0] = d;
@@ -159,21 +160,32 @@ static void iir_sweep(float *dst, const float *src, int n, int st, int dir) {
 }
 
 /* ih:248-273 + iu:542-637: out = vertical(horizontal(in)); each direction = causal + anti-causal - c0*in */
-void rdo_iirblur(float *out, const float *in, int iw, int ih) {
+static void iirblur_with(float *out, const float *in, int iw, int ih, const float *C, int warm) {
   const int N = iw * ih;
   float *t0 = (float *)malloc(sizeof(float) * N), *t1 = (float *)malloc(sizeof(float) * N);
   for (int y = 0; y < ih; y++) {
-    iir_sweep(t0 + y * iw, in + y * iw, iw, 1, +1);
-    iir_sweep(t1 + y * iw, in + y * iw, iw, 1, -1);
+    iir_sweep(t0 + y * iw, in + y * iw, iw, 1, +1, C, warm);
+    iir_sweep(t1 + y * iw, in + y * iw, iw, 1, -1, C, warm);
   }
-  for (int i = 0; i < N; i++) out[i] = t1[i] + t0[i] - in[i] * IIR[0];
+  for (int i = 0; i < N; i++) out[i] = t1[i] + t0[i] - in[i] * C[0];
   for (int x = 0; x < iw; x++) {
-    iir_sweep(t0 + x, out + x, ih, iw, +1);
-    iir_sweep(t1 + x, out + x, ih, iw, -1);
+    iir_sweep(t0 + x, out + x, ih, iw, +1, C, warm);
+    iir_sweep(t1 + x, out + x, ih, iw, -1, C, warm);
   }
-  for (int i = 0; i < N; i++) out[i] = t1[i] + t0[i] - out[i] * IIR[0];
+  for (int i = 0; i < N; i++) out[i] = t1[i] + t0[i] - out[i] * C[0];
   free(t0); free(t1);
 }
+
+void rdo_iirblur(float *out, const float *in, int iw, int ih) { iirblur_with(out, in, iw, ih, IIR, IIR_R + 1 + 8); }
+
+/* any radius r = 0..31 (sigma = (r + 1) / 3); lines must be at least r + 11 samples long (shorter ones make the reference's
+ * mirrored warm-up read outside the plane).  Returns 0, or -1 for arguments outside that domain. */
+int rdo_iirblur_r(float *out, const float *in, int iw, int ih, int r) {
+  if (r < 0 || r >= RD_IIRCOEF_NR || iw < r + 11 || ih < r + 11) return -1;
+  iirblur_with(out, in, iw, ih, rd_iircoef[r], r + 1 + 8);
+  return 0;
+}
+const float *rdo_iircoef(int r) { return r == -1 ? IIR : rd_iircoef[r]; }   /* (-1: the constants of the sigma = 1 path) */
 
 /* ------------------------------------------------------------------ gradient direction, strength, NMS */
 
@@ -813,7 +825,7 @@ int rdo_iir_chunk_test(const float *src, int n, int st, int dir, int C, int Wm, 
   float *full = (float *)malloc(sizeof(float) * (size_t)n * st + 64), *chk = (float *)malloc(sizeof(float) * (size_t)n * st + 64);
   memset(full, 0, sizeof(float) * (size_t)n * st);
   memset(chk, 0, sizeof(float) * (size_t)n * st);
-  iir_sweep(full, src, n, st, dir);
+  iir_sweep(full, src, n, st, dir, IIR, IIR_WARM);
   const int count = n + IIR_WARM + (dir > 0 ? 0 : 1);
   const int x0 = dir > 0 ? -IIR_WARM : n + IIR_WARM;
   int bad = 0, unv = 0;

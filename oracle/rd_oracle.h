@@ -24,7 +24,9 @@ const uint16_t *rdo_lut(int which, int *n);
 void rdo_bgr2plab(uint32_t *out, const uint8_t *bgr, int iw, int ih, int ws);
 void rdo_unpack_plab(float *L, float *a, float *b, const uint32_t *in, int n);
 void rdo_pack_plab(uint32_t *out, const float *L, const float *a, const float *b, int n);
-void rdo_iirblur(float *out, const float *in, int iw, int ih);
+void rdo_iirblur(float *out, const float *in, int iw, int ih);                 /* r = 2 (sigma 1): what every caller in the reference passes */
+int rdo_iirblur_r(float *out, const float *in, int iw, int ih, int r);         /* any radius 0..31; -1 if outside the reference's defined domain */
+const float *rdo_iircoef(int r);                                              /* the 15 coefficients of radius r (-1: the sigma = 1 path's own constants) */
 void rdo_edgevec(float *vxy, const float *in, int iw, int ih);
 void rdo_edge_plab(float *out, const uint32_t *in, int iw, int ih);
 void rdo_thinthres(float *out, const float *in, const float *vxy, int iw, int ih);

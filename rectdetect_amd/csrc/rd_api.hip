@@ -120,16 +120,27 @@ cl_event oclimgutil_pack_plab_f_f_f(oclimgutil_t *thiz, cl_mem out, cl_mem in0, 
   IU_END("oclimgutil_pack_plab_f_f_f");
 }
 
-// oclimgutil.c:248-273.  obuf = vertical(horizontal(ibuf)); tmp0 / tmp1 are scratch (only written when the blocked
-// evaluation fails its on-device check).  Only r = 2 (sigma 1) is implemented - the only radius any caller uses.
+// oclimgutil.c:248-273.  obuf = vertical(horizontal(ibuf)); tmp0 / tmp1 are scratch.  r = 2 (sigma 1, the only radius any
+// caller in the reference passes) takes the blocked evaluation of the frame path (scratch only written when that fails its
+// on-device check); every other radius of the table (0..31, sigma = (r + 1) / 3) the full-length sweeps.
 cl_event oclimgutil_iirblur_f_f(oclimgutil_t *thiz, cl_mem obuf, cl_mem ibuf, cl_mem tmp0, cl_mem tmp1, int r, int iw, int ih, cl_command_queue queue, const cl_event *events) {
   IU_BEGIN("oclimgutil_iirblur_f_f");
-  if (r != 2) exitf(-1, "oclimgutil_iirblur_f_f: only r = 2 (sigma = 1) is implemented in this build, got r = %d\n", r);
+  if (r < 0 || r > RD_IIR_MAX_R) exitf(-1, "oclimgutil_iirblur_f_f: r = %d is outside the coefficient table (0..%d; the reference reads beyond iircoef[] there)\n", r, RD_IIR_MAX_R);
   imgutil_scratch(thiz, iw, ih);
   ImgutilImpl *im = (ImgutilImpl *)thiz->impl;
   float *o = (float *)dptr(obuf), *t0 = (float *)dptr(tmp0), *t1 = (float *)dptr(tmp1);
   const float *in = (const float *)dptr(ibuf);
   float *d1[3] = { im->s[0], NULL, NULL }; const float *s1[3] = { in, NULL, NULL };
+  if (r != 2) {
+    // (the mirrored run-in of r + 9 samples must stay inside the line: iu:551 reads mirror1(x) unchecked)
+    if (iw < r + 11 || ih < r + 11) exitf(-1, "oclimgutil_iirblur_f_f: r = %d needs planes of at least %d x %d (the reference reads outside a smaller one), got %d x %d\n", r, r + 11, r + 11, iw, ih);
+    rdk::transpose_f(s, d1, s1, 1, iw, ih);                                 // s0 = in^T (ih wide)
+    rdk::iir_blur_lines(s, t0, im->s[0], t0, t1, ih, iw, r);                // along x; t0 = horizontal result, transposed
+    float *d2[3] = { im->s[1], NULL, NULL }; const float *s2[3] = { t0, NULL, NULL };
+    rdk::transpose_f(s, d2, s2, 1, ih, iw);                                 // s1 = horizontal result, original layout
+    rdk::iir_blur_lines(s, o, im->s[1], t0, t1, iw, ih, r);                 // along y
+    IU_END("oclimgutil_iirblur_f_f");
+  }
   rdk::transpose_f(s, d1, s1, 1, iw, ih);                                   // s0 = in^T (ih wide)
   float *fw[3] = { t0, NULL, NULL }, *bw[3] = { t1, NULL, NULL };
   { float *dst[3] = { im->s[1], NULL, NULL }; const float *src[3] = { im->s[0], NULL, NULL };

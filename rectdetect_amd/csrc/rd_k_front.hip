@@ -394,6 +394,48 @@ __global__ __launch_bounds__(64) void k_iir_check_fix(P3 dst, P3c src, P3 fwd, c
   }
 }
 
+// ------------------------------------------------------------------------------------------------ IIR Gaussian, any radius
+// oclimgutil_iirblur_f_f with r != 2 (no caller in the reference passes one; sigma = (r + 1) / 3, coefficients iu:900-1125).
+// The blocked evaluation above rests on the sigma = 1 filter forgetting its start within a few dozen samples, bit for bit; wider
+// filters do not, so these radii take the reference's own shape: every line swept over its full length (iu:542-627), the causal
+// sweep by one thread and the anti-causal sweep by its neighbour in threadIdx.y, each into its scratch plane, then combined.
+#define RD_IIRCOEF_ATTR __device__ __constant__
+#include "rd_iircoef.h"
+__global__ __launch_bounds__(128) void k_iir_line(float *dst, const float *__restrict__ src, float *fw, float *bw, int W, int H, int r) {
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  const bool xin = x < W;
+  float C[15];
+#pragma unroll
+  for (int k = 0; k < 15; k++) C[k] = rd_iircoef[r][k];
+  const int warm = r + 1 + 8;
+  if (xin) {
+    const float *in = src + x;
+    float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
+    float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+#define IIR_LINE_STEP                                                                                                    \
+    const float i0 = in[(size_t)mirror1(yy, H) * W];                                                                     \
+    float d = i0 * C[0];                                                                                                 \
+    d += C[1] * i1 + C[2] * i2 + C[3] * i3 + C[4] * i4 + C[5] * i5 + C[6] * i6 + C[7] * i7;                              \
+    d += C[8] * t0 + C[9] * t1 + C[10] * t2 + C[11] * t3 + C[12] * t4 + C[13] * t5 + C[14] * t6;                         \
+    i7 = i6; i6 = i5; i5 = i4; i4 = i3; i3 = i2; i2 = i1; i1 = i0;                                                       \
+    t6 = t5; t5 = t4; t4 = t3; t3 = t2; t2 = t1; t1 = t0; t0 = d;
+    if (threadIdx.y == 0) {
+      float *o = fw + x;
+      for (int yy = -warm; yy < H; yy++) { IIR_LINE_STEP; if (yy >= 0) o[(size_t)yy * W] = d; }
+    } else {
+      float *o = bw + x;
+      for (int yy = H + warm; yy >= 0; yy--) { IIR_LINE_STEP; if (yy < H) o[(size_t)yy * W] = d; }
+    }
+#undef IIR_LINE_STEP
+  }
+  __syncthreads();
+  if (!xin) return;
+  for (int yy = threadIdx.y; yy < H; yy += 2) {       // iu:580-589 / iu:629-637: tmp1 + tmp0 - in * c0
+    const size_t p = (size_t)yy * W + x;
+    dst[p] = bw[p] + fw[p] - src[p] * C[0];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ gradient direction
 // iu:346-352 (5x5 kernel; double literals narrowed to float) and iu:395-420
 __device__ __forceinline__ float v5c(int i) {
@@ -784,6 +826,11 @@ void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3]
     else hipLaunchKernelGGL(k_iir_check_fix<0>, grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force);
   }
   (void)bwd;
+}
+
+// one direction of the general-radius blur: lines run along y (W lines of H samples); dst may be fw or bw, not src
+void iir_blur_lines(hipStream_t s, float *dst, const float *src, float *fw, float *bw, int W, int H, int r) {
+  hipLaunchKernelGGL(k_iir_line, dim3(cdiv(W, 64)), dim3(64, 2), 0, s, dst, src, fw, bw, W, H, r);
 }
 
 void convert_bgr_lumaf(hipStream_t s, uint8_t *out, const float *in, float f, int iw, int ih, int ws) {

@@ -988,6 +988,11 @@ __global__ __launch_bounds__(256) void k_despeckle2_tail(int *pa, int *pb, int *
     int *nx = (r & 1) ? pb : pa;
     const int *cu = (r & 1) ? pa : pb;
     const int li = r % 3, lo = (r + 1) % 3, lz = (r + 2) % 3;
+    if (counts[li] == 0) {        // (same value for every thread: written before the last barrier)
+      // an empty list: nothing changes any more, and the two planes agree on every pixel that is in no list - on all of them
+      for (int q = r + threadIdx.x; q < r1; q += 256) counts[3 + q] = 0;
+      break;
+    }
     d2_active_rounds(nx, cu, lists + (size_t)li * n, counts + li, r == r1 - 1 ? (int *)nullptr : lists + (size_t)lo * n, counts + lo, counts + lz, counts + 3 + r, stamp, r + 1,
                      old, size, thre, iw, ih, 0, 1, loc, nloc, base);
     __syncthreads();

@@ -18,6 +18,8 @@ void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], 
 size_t iir_pass_scratch_floats(int np, int W, int H);
 void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3], float *const fwd[3], float *const bwd[3], int np, int W, int H,
                    int transpose_out, float *tails, int *bad);
+void iir_blur_lines(hipStream_t s, float *dst, const float *src, float *fw, float *bw, int W, int H, int r);   // any radius 0..31, full-length sweeps along y; dst may be fw or bw
+#define RD_IIR_MAX_R 31
 void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih, uint32_t *pack_out = nullptr, const float *a = nullptr, const float *b = nullptr);   // pack_out (optional): pack_plab(in, a, b) on the way
 // visualisers / operators no application calls (oclimgutil.h:84-98)
 void convert_bgr_lumaf(hipStream_t s, uint8_t *out, const float *in, float f, int iw, int ih, int ws);

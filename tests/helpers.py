@@ -49,6 +49,9 @@ def oracle():
         O.rdo_poly_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_float, ctypes.c_int]
         O.rdo_polyline.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         O.rdo_lut.restype = ctypes.POINTER(ctypes.c_uint16)
+        O.rdo_iirblur_r.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        O.rdo_iircoef.restype = ctypes.POINTER(ctypes.c_float)
+        O.rdo_iircoef.argtypes = [ctypes.c_int]
         _oracle = O
     return _oracle
 

@@ -190,6 +190,44 @@ def test_oracle_operators_against_reference_golden(name):
     assert np.array_equal(l2.ravel(), g["filterStrength"])
 
 
+@pytest.mark.parametrize("name", ["ops_iir_97x61", "ops_iir_160x131"])
+def test_oracle_iir_blur_every_radius_against_reference_golden(name):
+    """oclimgutil_iirblur_f_f with radii no application passes (sigma = (r + 1) / 3, r = 0 .. 31): the reference's own
+    kernels made the expected planes (tools/make_golden_ops.py); bit-exact"""
+    g = golden(name)
+    iw, ih = int(g["iw"]), int(g["ih"])
+    O, P = helpers.oracle(), helpers.P
+    f = np.ascontiguousarray(g["in_f"])
+    for r in [int(r) for r in g["radii"]]:
+        out = np.zeros(iw * ih, np.float32)
+        assert O.rdo_iirblur_r(P(out), P(f), iw, ih, r) == 0
+        assert np.array_equal(out.view(np.uint32), np.ascontiguousarray(g["r%d" % r]).view(np.uint32)), r
+    # r = 2 through the table == the sigma = 1 entry point every caller uses
+    a, b = np.zeros(iw * ih, np.float32), np.zeros(iw * ih, np.float32)
+    O.rdo_iirblur(P(a), P(f), iw, ih)
+    O.rdo_iirblur_r(P(b), P(f), iw, ih, 2)
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    # outside the domain the reference defines: unknown radius, lines shorter than the mirrored warm-up
+    for r, w, h in [(-1, iw, ih), (32, iw, ih), (5, 15, ih), (5, iw, 15)]:
+        assert O.rdo_iirblur_r(P(out), P(f), w, h, r) == -1
+
+
+def test_iir_table_row2_is_the_fast_paths():
+    """the generated table (tools/gen_iircoef.py) and the constants the sigma = 1 path was written with agree bit for bit"""
+    O = helpers.oracle()
+    row2 = np.array([O.rdo_iircoef(2)[k] for k in range(15)], np.float32)
+    own = np.array([O.rdo_iircoef(-1)[k] for k in range(15)], np.float32)
+    assert np.array_equal(row2.view(np.uint32), own.view(np.uint32))
+    # and the product's copy of the table is the oracle's (same generator, two outputs)
+    a = open(os.path.join(helpers.ROOT, "oracle", "rd_iircoef.h")).read()
+    b = open(os.path.join(helpers.ROOT, "rectdetect_amd", "csrc", "rd_iircoef.h")).read()
+    assert a == b
+    import re
+    src = open(os.path.join(helpers.ROOT, "rectdetect_amd", "csrc", "rd_k_front.hip")).read()
+    fast = [np.float32(re.search(r"#define IIR_C%d (-?[0-9.]+)f" % k, src).group(1)) for k in range(15)]
+    assert np.array_equal(np.array(fast, np.float32).view(np.uint32), own.view(np.uint32))
+
+
 def test_region_spec_against_the_references_own_order_dependence():
     """The order-free region schedule (oracle REGION_SPEC mode = what the HIP path implements) against the reference's own
     rectangle lists under 26 legal work-item orders of its two in-place region kernels (tests/golden/hard_rect_orders.npz,

@@ -332,6 +332,45 @@ def test_blur_operator_against_oracle(ctx):
     L.dispose_oclimgutil(iu)
 
 
+@pytest.mark.parametrize("name", ["ops_iir_97x61", "ops_iir_160x131"])
+def test_blur_operator_every_radius_against_reference_golden(ctx, name):
+    """oclimgutil_iirblur_f_f(r) for radii no application passes (sigma = (r + 1) / 3): expected planes made by the
+    reference's own kernels (tools/make_golden_ops.py); bit-exact.  r = 2 goes through the blocked path, the rest
+    through the full-length sweeps."""
+    g = np.load(os.path.join(helpers.GOLDEN, name + ".npz"))
+    iw, ih = int(g["iw"]), int(g["ih"])
+    L = ra.lib()
+    iu = L.init_oclimgutil(ctx.device, ctx.context)
+    x = np.ascontiguousarray(g["in_f"])
+    for r in [int(r) for r in g["radii"]]:
+        a, o, t0, t1 = ctx.buffer(x), ctx.buffer(iw * ih * 4), ctx.buffer(iw * ih * 4), ctx.buffer(iw * ih * 4)
+        L.oclimgutil_iirblur_f_f(iu, o, a, t0, t1, r, iw, ih, ctx.queue, None)
+        got = ctx.read(o, np.float32, iw * ih)
+        assert np.array_equal(got.view(np.uint32), np.ascontiguousarray(g["r%d" % r]).view(np.uint32)), r
+        ctx.release(a, o, t0, t1)
+    L.dispose_oclimgutil(iu)
+
+
+def test_blur_operator_every_radius_against_oracle(ctx):
+    """the same at sizes of its own (odd widths, a frame-sized plane), in place (obuf == ibuf) included"""
+    L = ra.lib()
+    iu = L.init_oclimgutil(ctx.device, ctx.context)
+    rng = np.random.default_rng(5)
+    O = helpers.oracle()
+    for iw, ih, radii in [(45, 43, [0, 31]), (333, 217, [1, 5, 9, 17, 31]), (1280, 720, [3, 24])]:
+        x = (rng.random((ih, iw), np.float32) * 2 - 0.5).astype(np.float32)
+        for r in radii:
+            want = np.zeros(iw * ih, np.float32)
+            assert O.rdo_iirblur_r(helpers.P(want), helpers.P(x), iw, ih, r) == 0
+            a, o, t0, t1 = ctx.buffer(x), ctx.buffer(iw * ih * 4), ctx.buffer(iw * ih * 4), ctx.buffer(iw * ih * 4)
+            L.oclimgutil_iirblur_f_f(iu, o, a, t0, t1, r, iw, ih, ctx.queue, None)
+            assert np.array_equal(ctx.read(o, np.float32, iw * ih).view(np.uint32), want.view(np.uint32)), (iw, ih, r)
+            L.oclimgutil_iirblur_f_f(iu, a, a, t0, t1, r, iw, ih, ctx.queue, None)
+            assert np.array_equal(ctx.read(a, np.float32, iw * ih).view(np.uint32), want.view(np.uint32)), (iw, ih, r, "in place")
+            ctx.release(a, o, t0, t1)
+    L.dispose_oclimgutil(iu)
+
+
 def test_full_size_properties_1080p():
     """size-independent properties at the benchmark size: determinism across detectors, id plane vs segment list
     consistency, chain links are mutual, every rectangle is a convex quad inside a generous frame margin"""

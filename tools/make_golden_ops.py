@@ -118,6 +118,23 @@ def run_all(o, iw, ih, seed):
     return res
 
 
+IIR_RADII = [0, 1, 2, 3, 4, 7, 12, 20, 31]
+
+
+def run_iir_radii(o, iw, ih, seed):
+    """oclimgutil_iirblur_f_f for radii no application passes (oclimgutil.c:243-273 with iircoef[r], oclimgutil.cl:900)"""
+    _, f, _, _ = inputs(iw, ih, seed)
+    N = iw * ih
+    res = {"in_f": f}
+    for r in IIR_RADII:
+        mf, t0, t1, m = o.buf(f), o.buf(N * 4), o.buf(N * 4), o.buf(N * 4)
+        o.call("iirblur_f_f", [vp, vp, vp, vp, ci, ci, ci], m, mf, t0, t1, r, iw, ih)
+        res["r%d" % r] = o.read(m, np.float32, N)
+        for b in (mf, t0, t1, m):
+            o.L.clReleaseMemObject(b)
+    return res
+
+
 def main():
     if not helpers.have_ref():
         raise SystemExit("oracle/_ref/librdref.so missing: run `make -C oracle ref` where /root/reference exists")
@@ -126,6 +143,10 @@ def main():
         res = run_all(o, iw, ih, seed)
         np.savez_compressed(os.path.join(helpers.GOLDEN, "ops_%dx%d.npz" % (iw, ih)), iw=iw, ih=ih, seed=seed, **res)
         print("ops_%dx%d.npz:" % (iw, ih), ", ".join(sorted(k for k in res if not k.startswith("in_"))))
+    for iw, ih, seed in [(97, 61, 3), (160, 131, 4)]:
+        res = run_iir_radii(o, iw, ih, seed)
+        np.savez_compressed(os.path.join(helpers.GOLDEN, "ops_iir_%dx%d.npz" % (iw, ih)), iw=iw, ih=ih, seed=seed, radii=np.array(IIR_RADII), **res)
+        print("ops_iir_%dx%d.npz:" % (iw, ih), ", ".join(k for k in res if k != "in_f"))
 
 
 if __name__ == "__main__":
