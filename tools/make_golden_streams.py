@@ -4,6 +4,10 @@ reference carries from frame to frame takes part well beyond the 
   stream_1920x1080_s0.npz  16 frames of the benchmark workload (BASELINE.json configs[4]: 1920x1080, stream seed 0)
   stream_1280x720_s1.npz   30 frames of configs[2] (1280x720, AOV 72 like vidrect's default)
   stream_3840x2160_s4.npz  3 frames of configs[3] (3840x2160)
+and the configurations at (or near) their full length (rect_t lists and segment lists only, a few hundred KB each):
+  stream_1280x720_s1_300.npz    all 300 frames of configs[2]
+  stream_1920x1080_s0_100.npz   100 frames of the benchmark stream
+  stream_3840x2160_s4_16.npz    16 frames of configs[3]
 Per frame: the rect_t list and the line-segment list.  Only runs where /root/reference exists."""
 import os
 import sys
@@ -17,11 +21,14 @@ from rectdetect_amd import synth  # noqa: E402
 from tests import helpers  # noqa: E402
 
 CASES = {"stream_1920x1080_s0": (1920, 1080, 0, 16, 36.0), "stream_1280x720_s1": (1280, 720, 1, 30, 36.0),
-         "stream_3840x2160_s4": (3840, 2160, 4, 3, 36.0)}      # BASELINE.json configs[3]
+         "stream_3840x2160_s4": (3840, 2160, 4, 3, 36.0),      # BASELINE.json configs[3]
+         "stream_1280x720_s1_300": (1280, 720, 1, 300, 36.0), "stream_1920x1080_s0_100": (1920, 1080, 0, 100, 36.0),
+         "stream_3840x2160_s4_16": (3840, 2160, 4, 16, 36.0)}
+DEFAULT = ["stream_1920x1080_s0", "stream_1280x720_s1", "stream_3840x2160_s4"]      # (the long ones by name: 6-10 minutes each)
 
 
 def main():
-    for name in sys.argv[1:] or sorted(CASES):
+    for name in sys.argv[1:] or DEFAULT:
         iw, ih, seed, nframes, half_aov = CASES[name]
         tan = float(np.tan(half_aov / 180.0 * np.pi))
         r = helpers.RefRect(iw, ih)
