@@ -17,6 +17,7 @@
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 typedef int int2 __attribute__((ext_vector_type(2)));
 typedef int int3 __attribute__((ext_vector_type(3)));
@@ -43,8 +44,29 @@ int b_atomic_inc(volatile int *p) { int o = *p; *p = o + 1; return o; }
 int b_atomic_max(volatile int *p, int v) __asm__("_Z10atomic_maxPU8CLglobalVii");
 int b_atomic_max(volatile int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
 
+/* "Concurrent" launches (rdcl_set_order group_order 5, rdcl_device.c): every work-item sees memory as it was when the launch
+ * began - a device gives no guarantee that one work-item sees another's update within a launch - and the atomic minima of all
+ * work-items take effect together when it ends.  rdcl_defer_atomic_min(1) starts logging, (0) applies the log. */
+static int defer_min_on = 0;
+static struct { volatile int *p; int v; } *defer_log = 0;
+static size_t defer_n = 0, defer_cap = 0;
+void rdcl_defer_atomic_min(int on) {
+  if (!on) {
+    for (size_t i = 0; i < defer_n; i++) if (defer_log[i].v < *defer_log[i].p) *defer_log[i].p = defer_log[i].v;
+    defer_n = 0;
+  }
+  defer_min_on = on;
+}
+
 int b_atomic_min(volatile int *p, int v) __asm__("_Z10atomic_minPU8CLglobalVii");
-int b_atomic_min(volatile int *p, int v) { int o = *p; if (v < o) *p = v; return o; }
+int b_atomic_min(volatile int *p, int v) {
+  int o = *p;
+  if (defer_min_on) {
+    if (defer_n == defer_cap) { defer_cap = defer_cap ? defer_cap * 2 : (1u << 20); defer_log = realloc(defer_log, defer_cap * sizeof(*defer_log)); }
+    defer_log[defer_n].p = p; defer_log[defer_n].v = v; defer_n++;
+  } else if (v < o) *p = v;
+  return o;
+}
 
 int b_atomic_cmpxchg(volatile int *p, int cmp, int v) __asm__("_Z14atomic_cmpxchgPU8CLglobalViii");
 int b_atomic_cmpxchg(volatile int *p, int cmp, int v) { int o = *p; if (o == cmp) *p = v; return o; }

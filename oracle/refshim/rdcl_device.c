@@ -35,7 +35,7 @@ struct _cl_device_id { int dummy; };
 struct _cl_context { int refs; };
 struct _cl_command_queue { int refs; };
 struct _cl_mem { uint32_t magic; void *data; size_t size; struct _cl_mem *next, *prev; };
-struct _cl_program { int which; void *dl; size_t *gid; };
+struct _cl_program { int which; void *dl; size_t *gid; void (*defer_min)(int); };
 struct _cl_kernel {
   struct _cl_program prog;
   char name[64];
@@ -217,6 +217,7 @@ cl_int clBuildProgram(cl_program p, cl_uint n, const cl_device_id *d, const char
   }
   p->dl = prog_dl[p->which];
   p->gid = (size_t *)dlsym(p->dl, "rdcl_gid");
+  p->defer_min = (void (*)(int))dlsym(p->dl, "rdcl_defer_atomic_min");
   return p->gid ? CL_SUCCESS : CL_BUILD_PROGRAM_FAILURE;
 }
 
@@ -266,7 +267,10 @@ cl_int clSetKernelArg(cl_kernel k, cl_uint idx, size_t size, const void *val) {
  * order, so that tests can see which of the reference's results depend on it: the NDRange is cut into
  * work-groups of gw x gh items (0 x 0: one group = the whole range), items inside a group run in raster order, and the
  * groups are visited in group_order 0 = raster, 1 = reversed raster, 2 = column-major, 3 = scrambled (a stride walk that
- * depends on `seed`).  group_order 4 = the whole range in reversed raster order (items too). */
+ * depends on `seed`).  group_order 4 = the whole range in reversed raster order (items too).  group_order 5 = CONCURRENT: no
+ * work-item sees another one's update - for kernels that update memory through atomic_min only (labelMergeMain): all of them
+ * read the state the launch began with and their minima take effect together at the end (rdcl_builtins.c); kernels that use
+ * plain stores run in raster order as before. */
 static int order_on = 0, order_gw = 0, order_gh = 0, order_go = 0, order_seed = 0;
 static char order_filter[512] = "";
 void rdcl_set_order(const char *filter, int gw, int gh, int group_order, int seed) {
@@ -325,6 +329,10 @@ cl_int clEnqueueNDRangeKernel(cl_command_queue q, cl_kernel k, cl_uint dim, cons
          fa[0], fa[1], fa[2], fa[3]); } while (0)
   if (!order_applies(k)) {
     for (size_t y = 0; y < g1; y++) for (size_t x = 0; x < g0; x++) RUN_ITEM(x, y);
+  } else if (order_go == 5) {
+    if (k->prog.defer_min) k->prog.defer_min(1);
+    for (size_t y = 0; y < g1; y++) for (size_t x = 0; x < g0; x++) RUN_ITEM(x, y);
+    if (k->prog.defer_min) k->prog.defer_min(0);
   } else if (order_go == 4) {
     for (size_t y = g1; y-- > 0;) for (size_t x = g0; x-- > 0;) RUN_ITEM(x, y);
   } else {

@@ -77,6 +77,12 @@ class OracleRect:
         a = np.ascontiguousarray(bgr)
         oracle().rdo_rect_frame(self.h, a.ctypes.data, a.strides[0])
 
+    def set_prev_strong(self, strong):
+        """the state the next frame inherits: the previous frame's strong-edge mask, e.g. taken from another implementation"""
+        a = np.ascontiguousarray(strong, dtype=np.int32)
+        assert a.size == self.N
+        ctypes.memmove(oracle().rdo_rect_plane(self.h, b"prev_strong"), a.ctypes.data, a.nbytes)
+
     def plane(self, name):
         dt, k = RECT_PLANES[name]
         p = oracle().rdo_rect_plane(self.h, name.encode())
