@@ -725,6 +725,34 @@ def test_smallest_frames(iw, ih):
     orc.close()
 
 
+ODD_SIZES = [(63, 64), (64, 63), (65, 65), (127, 33), (129, 31), (192, 95), (255, 129), (321, 97), (513, 66), (1027, 38), (2049, 20), (33, 300), (96, 1030)]
+
+
+@pytest.mark.parametrize("iw,ih", ODD_SIZES)
+def test_frame_sizes_around_every_tile_edge(iw, ih):
+    """frame sizes one short of, equal to and one beyond the tile sizes of the kernels (64-column tiles, 128-pixel region blocks, 32-row
+    labelling tiles, 64-row blur blocks, 16-row extent tiles), very wide and very tall ones: every plane of every stage, the segment
+    list and the rectangle list against the oracle (region stages in spec mode), on a busy tiled frame followed by a stream frame
+    (so the state carried between frames takes part)"""
+    N = iw * ih
+    det = ra.Detector(iw, ih, nslots=1)
+    orc = helpers.OracleRect(iw, ih, helpers.REGION_SPEC)
+    for t, img in enumerate([synth.hard_frame("tiles", 3, iw, ih), synth.frame(synth.SEED0 + 9, iw, ih, 1), synth.hard_frame("noise", 4, iw, ih)]):
+        det.enqueue(img)
+        rects = det.poll(TAN36)
+        orc.frame(img)
+        for g, o, k in EXACT:
+            a = det.plane(g, np.uint32, N * k)
+            b = orc.plane(o).view(np.uint32)[: N * k]
+            assert np.array_equal(a, b), f"{iw}x{ih} frame {t}: plane {g} differs in {int((a != b).sum())} elements"
+        assert helpers.segments_equal(det.last_segments(), orc.segments()), f"{iw}x{ih} frame {t}: polyline segments differ"
+        check_region_planes(det, orc, f"{iw}x{ih} frame {t}")
+        want = ra.postprocess_planes(orc.segments(), orc.plane("boundary"), orc.plane("table"), iw, ih, TAN36)
+        assert helpers.rects_equal(rects, want), f"{iw}x{ih} frame {t}"
+    det.close()
+    orc.close()
+
+
 @pytest.mark.parametrize("iw,ih,mode", [(640, 480, {}), (1920, 1080, {"RD_REGION_ROUNDS_FIXED": "8"})])
 def test_region_round_budget_does_not_change_results(iw, ih, mode):
     """fewer region-merge rounds are launched per frame than the full 20 (default: what recent frames needed + margin; fixed: 8)
