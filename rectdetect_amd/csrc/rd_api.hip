@@ -373,7 +373,7 @@ static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
   int **ip[] = { &s->i0, &s->i1, &s->mask0, &s->tidy, &s->label1, &s->strsum, &s->edge500, &s->strong, &s->junction, &s->mergemask, &s->region, &s->rsize,
                  &s->boundarysrc, &s->boundary, &s->lsid, &s->region0 };
   for (size_t i = 0; i < sizeof(ip) / sizeof(ip[0]); i++) *ip[i] = dnew<int>(N);
-  s->scratch2 = dnew<int>(N * 5 + 256);      // region_merge: two sets of proposal planes + flags + allow bytes
+  s->scratch2 = dnew<int>(N * 3 + 256);      // region_merge: two proposal planes + flags + allow bytes
   s->d2s = dnew<int>(RD_D2_SCRATCH_INTS(N));
   s->table = dnew<int>(N * 4); s->claim = dnew<int>(N); s->tlist = dnew<int>(N);
   rdk::reduce_ls_init(s->st, s->table, s->claim, s->tlist, (int)(N * 4 / 5));

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const 
 // so every pixel leaves pointing either at the root of its initial tree (if that root lies in the tile) or at the first
 // pixel outside the tile on its way up/left; the few remaining tile-to-tile hops are left to k_region_flatten.
 #define RI_ROWS 16
-__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, int *__restrict__ prop, int *__restrict__ selfp, int *__restrict__ prop1, int *__restrict__ selfp1, const int *__restrict__ pix, const int *__restrict__ mask,
+__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, int *__restrict__ prop, int *__restrict__ prop1, const int *__restrict__ pix, const int *__restrict__ mask,
                                                      const int *__restrict__ edge, int iw, int ih, int *__restrict__ flags, int *__restrict__ size_out, const int *__restrict__ size_init) {
   __shared__ int par[64 * RI_ROWS];     // >= 0: tile-local index of the parent; < 0: -(global index) - 1 of a parent outside the tile
   // (also: the round / flatten flags start at zero, and the size plane starts from size_init - quirk H2 - without extra launches)
@@ -536,9 +536,7 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
         }
         allow[p] = (uint8_t)a;
         prop[p] = 0x7f7f7f7f;      // no proposal (round tag 63: never current)
-        selfp[p] = 0x7f7f7f7f;
         prop1[p] = 0x7f7f7f7f;
-        selfp1[p] = 0x7f7f7f7f;
         if (size_out) size_out[p] = si[k];
       }
       par[r * 64 + tx] = l;
@@ -568,35 +566,35 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
 // reference applies the same rule in place for 8 launches, which makes its result depend on the work-item order
 // (SURVEY.md H5); synchronous rounds to convergence are the order-free reading of the same rule.
 //
-// One launch per round.  The proposals of a round are not applied by a launch of their own: they stay in their planes
-// (selfp: a pixel's own update, written by its thread; prop: updates for tree parents, atomicMin) and the next round reads every
-// label as  E(q) = min(label[q], prop[q], selfp[q])  - what an apply pass would have left in label[q].  The thread of pixel q
+// One launch per round.  The proposals of a round are not applied by a launch of their own: they stay in their plane
+// (`prop`: a pixel's own update and the updates for tree parents alike, atomicMin) and the next round reads every
+// label as  E(q) = min(label[q], prop[q])  - what an apply pass would have left in label[q].  The thread of pixel q
 // also stores E(q) back into label[q]; that store needs no ordering against the other threads' reads, because E(q) comes out
-// the same whether they see the old or the new label[q].  Two sets of proposal planes alternate (a round reads the previous
-// round's set while writing its own), and a proposal word carries the number of its round in its upper bits - (40 - round) <<
+// the same whether they see the old or the new label[q].  Two proposal planes alternate (a round reads the previous
+// round's while writing its own), and a proposal word carries the number of its round in its upper bits - (40 - round) <<
 // 25 | label - so that words left over from two rounds ago lose against every new proposal in the atomicMin and are ignored by
-// the readers: nothing is ever cleared between rounds.  flags[round] = "this round proposed something" (a proposal always lowers
+// the readers: nothing is ever cleared between rounds.  (A plane of its own for the pixels' own updates, written with plain
+// stores, was a third plane to read for every label: 8 MB per round and 3 % of the frame rate.)  flags[round] = "this round proposed something" (a proposal always lowers
 // its pixel's own label), which is what the next round and the host test.
 // Memory-latency bound: every thread handles RR_PX pixels (64 columns apart, so each load instruction stays coalesced) and
 // issues all of their label / proposal loads before using any, then the first pointer jumps together.
 #define RR_PX 2
 #define RR_VBITS 25
 #define RR_NONE 0x7fffffff
-// (the set a round reads holds only words of that round's predecessor - tag `tag` - or of earlier rounds / the initial fill, whose
-//  tags are larger: the smaller of the two words is the valid one if there is any)
-__device__ __forceinline__ int rr_min3(int l, int wp, int ws, int tag) {
-  const int m = wp < ws ? wp : ws;
-  const int v = m < ((tag + 1) << RR_VBITS) ? (m & ((1 << RR_VBITS) - 1)) : RR_NONE;
+// (the plane a round reads holds only words of that round's predecessor - tag `tag` - or of earlier rounds / the initial fill, whose
+//  tags are larger)
+__device__ __forceinline__ int rr_min2(int l, int wp, int tag) {
+  const int v = wp < ((tag + 1) << RR_VBITS) ? (wp & ((1 << RR_VBITS) - 1)) : RR_NONE;
   return l < v ? l : v;
 }
 template <bool FIRST>
-__device__ __forceinline__ int rr_eff(const int *label, const int *propP, const int *selfP, unsigned q, int tag) {
+__device__ __forceinline__ int rr_eff(const int *label, const int *propP, unsigned q, int tag) {
   if (FIRST) return at32(label, q);
-  return rr_min3(at32(label, q), at32(propP, q), at32(selfP, q), tag);
+  return rr_min2(at32(label, q), at32(propP, q), tag);
 }
 
 template <bool FIRST>
-__global__ __launch_bounds__(256) void k_region_round(int *label, const int *__restrict__ propP, const int *__restrict__ selfP, int *propW, int *__restrict__ selfW,
+__global__ __launch_bounds__(256) void k_region_round(int *label, const int *__restrict__ propP, int *propW,
                                                        const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round) {
   if (!FIRST && flags[round - 1] == 0) return;
   __shared__ int hk[512], hv[512];
@@ -611,7 +609,7 @@ __global__ __launch_bounds__(256) void k_region_round(int *label, const int *__r
   bool valid[RR_PX], todo[RR_PX];
   {
     unsigned q[RR_PX][5];       // (unsigned element indices: the loads then take the plane's base from scalar registers and a 32-bit offset, no 64-bit address arithmetic per access)
-    int l[RR_PX][5], wp[RR_PX][5], ws[RR_PX][5];
+    int l[RR_PX][5], wp[RR_PX][5];
 #pragma unroll
     for (int k = 0; k < RR_PX; k++) {
       const int x = xb + k * 64;
@@ -627,14 +625,14 @@ __global__ __launch_bounds__(256) void k_region_round(int *label, const int *__r
 #pragma unroll
       for (int c = 0; c < 5; c++) {
         l[k][c] = at32(label, q[k][c]);
-        if (!FIRST) { wp[k][c] = at32(propP, q[k][c]); ws[k][c] = at32(selfP, q[k][c]); }
+        if (!FIRST) wp[k][c] = at32(propP, q[k][c]);
       }
     }
 #pragma unroll
     for (int k = 0; k < RR_PX; k++) {
       int e[5];
 #pragma unroll
-      for (int c = 0; c < 5; c++) e[c] = FIRST ? l[k][c] : rr_min3(l[k][c], wp[k][c], ws[k][c], tagP);
+      for (int c = 0; c < 5; c++) e[c] = FIRST ? l[k][c] : rr_min2(l[k][c], wp[k][c], tagP);
       og[k] = e[0];
       if (!FIRST && valid[k] && e[0] < l[k][0]) at32(label, (unsigned)p0[k]) = e[0];     // what the apply pass would have stored
       int m = e[0];
@@ -646,22 +644,22 @@ __global__ __launch_bounds__(256) void k_region_round(int *label, const int *__r
     }
   }
   {
-    int l[RR_PX], wp[RR_PX], ws[RR_PX];
+    int l[RR_PX], wp[RR_PX];
 #pragma unroll
-    for (int k = 0; k < RR_PX; k++) { l[k] = at32(label, (unsigned)g[k]); if (!FIRST) { wp[k] = at32(propP, (unsigned)g[k]); ws[k] = at32(selfP, (unsigned)g[k]); } }     // rc:328: first of the eight pointer jumps (a root maps to itself)
+    for (int k = 0; k < RR_PX; k++) { l[k] = at32(label, (unsigned)g[k]); if (!FIRST) wp[k] = at32(propP, (unsigned)g[k]); }     // rc:328: first of the eight pointer jumps (a root maps to itself)
 #pragma unroll
-    for (int k = 0; k < RR_PX; k++) nx[k] = FIRST ? l[k] : rr_min3(l[k], wp[k], ws[k], tagP);
+    for (int k = 0; k < RR_PX; k++) nx[k] = FIRST ? l[k] : rr_min2(l[k], wp[k], tagP);
   }
   bool any_todo = false;
 #pragma unroll
   for (int k = 0; k < RR_PX; k++) {
     if (a[k] & 16) {
       int n = nx[k];
-      for (int j = 1; j < 8 && n != g[k]; j++) { g[k] = n; n = rr_eff<FIRST>(label, propP, selfP, (unsigned)n, tagP); }
+      for (int j = 1; j < 8 && n != g[k]; j++) { g[k] = n; n = rr_eff<FIRST>(label, propP, (unsigned)n, tagP); }
       if (n != g[k]) g[k] = n;          // (the eighth jump)
     }
     todo[k] = (a[k] & 16) && g[k] != og[k];
-    if (todo[k]) at32(selfW, (unsigned)p0[k]) = (tagW << RR_VBITS) | g[k];   // own update: nobody else writes this word
+    if (todo[k]) atomicMin(&propW[p0[k]], (tagW << RR_VBITS) | g[k]);   // own update (no value comes back: the thread does not wait for it)
     any_todo = any_todo || todo[k];
   }
   // Hooking the old parent: after flattening, all pixels of a tree share one parent, so the block first reduces its
@@ -689,12 +687,12 @@ __global__ __launch_bounds__(256) void k_region_round(int *label, const int *__r
 }
 
 // the proposals of the last launched round (if it made any) take effect
-__global__ void k_region_finish(int *label, const int *__restrict__ propP, const int *__restrict__ selfP, int n, const int *flags, int last_round) {
+__global__ void k_region_finish(int *label, const int *__restrict__ propP, int n, const int *flags, int last_round) {
   if (flags[last_round] == 0) return;
   const int tag = 40 - last_round;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int l = label[i];
-    const int e = rr_min3(l, propP[i], selfP[i], tag);
+    const int e = rr_min2(l, propP[i], tag);
     if (e < l) label[i] = e;
   }
 }
@@ -742,7 +740,7 @@ __device__ __forceinline__ void rs_accum(int *keys, int *vals, int *out, int lab
 }
 
 // (pend_*: the proposals of the region merge's last launched round, applied here on the way - see k_region_round / k_region_finish)
-__global__ __launch_bounds__(256) void k_region_size(int *out, int *__restrict__ label, int n, int *zero_me, const int *__restrict__ pend_prop, const int *__restrict__ pend_self,
+__global__ __launch_bounds__(256) void k_region_size(int *out, int *__restrict__ label, int n, int *zero_me, const int *__restrict__ pend_prop,
                                                       const int *__restrict__ pend_flags, int pend_round) {
   if (zero_me && blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;     // (a counter of the next stage: saves a fill launch)
   __shared__ int keys[RS_T], vals[RS_T];
@@ -760,7 +758,7 @@ __global__ __launch_bounds__(256) void k_region_size(int *out, int *__restrict__
 #pragma unroll
     for (int k = 0; k < RS_PER_THREAD; k++) {
       const int i = begin + k * 256 + threadIdx.x;
-      if (i < n) { const int e = rr_min3(lks[k], pend_prop[i], pend_self[i], tag); if (e < lks[k]) { label[i] = e; lks[k] = e; } }
+      if (i < n) { const int e = rr_min2(lks[k], pend_prop[i], tag); if (e < lks[k]) { label[i] = e; lks[k] = e; } }
     }
   }
 #pragma unroll
@@ -1352,7 +1350,7 @@ void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int 
   hipLaunchKernelGGL(k_mm_gather, dim3(wpr, cdiv(ih, MM_ROWS)), dim3(64, 4), 0, s, out, (const unsigned long long *)scratch, iw, ih, wpr);
 }
 
-// scratch: 5*N + 256 ints (hook proposals; round flags + allowed-direction bytes; self proposals; the second set of proposals)
+// scratch: 3*N + 256 ints (proposals; round flags + allowed-direction bytes; the second proposal plane)
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS, int *size_out, const int *size_init, RegionPending *pending) {
   const int n = iw * ih;
   // tile-to-tile hops left after k_region_init: at most ih/RI_ROWS + iw/64 + 2; each launch divides the depth by 16
@@ -1360,23 +1358,23 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
   for (long reach = 16; reach < ih / RI_ROWS + iw / 64 + 2; reach *= 16) FLAT++;
   int *flags = scratch + n, *fflags = flags + 32;
   uint8_t *allow = (uint8_t *)(flags + 64);
-  int *prop[2] = { scratch, scratch + 3 * (size_t)n }, *selfp[2] = { scratch + 2 * (size_t)n, scratch + 4 * (size_t)n };
-  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, label, allow, prop[0], selfp[0], prop[1], selfp[1], pix, mask, edge, iw, ih, flags, size_out, size_init);
+  int *prop[2] = { scratch, scratch + 2 * (size_t)n };
+  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, label, allow, prop[0], prop[1], pix, mask, edge, iw, ih, flags, size_out, size_init);
   // the initial links are flattened first; the synchronous rounds then start from trees of depth 1
   for (int r = 0; r < FLAT; r++) hipLaunchKernelGGL(k_region_flatten, dim3(ew_grid(n)), dim3(256), 0, s, label, n, fflags, r);
   const dim3 grid(cdiv(iw, 64 * RR_PX), cdiv(ih, 4));
   for (int r = 0; r < ROUNDS; r++) {
     const int w = r & 1, p = w ^ 1;
-    if (r == 0) hipLaunchKernelGGL(k_region_round<true>, grid, block2, 0, s, label, (const int *)prop[p], (const int *)selfp[p], prop[w], selfp[w], (const uint8_t *)allow, iw, ih, flags, r);
-    else hipLaunchKernelGGL(k_region_round<false>, grid, block2, 0, s, label, (const int *)prop[p], (const int *)selfp[p], prop[w], selfp[w], (const uint8_t *)allow, iw, ih, flags, r);
+    if (r == 0) hipLaunchKernelGGL(k_region_round<true>, grid, block2, 0, s, label, (const int *)prop[p], prop[w], (const uint8_t *)allow, iw, ih, flags, r);
+    else hipLaunchKernelGGL(k_region_round<false>, grid, block2, 0, s, label, (const int *)prop[p], prop[w], (const uint8_t *)allow, iw, ih, flags, r);
   }
-  if (pending) { pending->prop = ROUNDS > 0 ? prop[(ROUNDS - 1) & 1] : nullptr; pending->selfp = ROUNDS > 0 ? selfp[(ROUNDS - 1) & 1] : nullptr; pending->flags = ROUNDS > 0 ? flags : nullptr; pending->last_round = ROUNDS - 1; }
-  else if (ROUNDS > 0) hipLaunchKernelGGL(k_region_finish, dim3(ew_grid(n)), dim3(256), 0, s, label, (const int *)prop[(ROUNDS - 1) & 1], (const int *)selfp[(ROUNDS - 1) & 1], n, (const int *)flags, ROUNDS - 1);
+  if (pending) { pending->prop = ROUNDS > 0 ? prop[(ROUNDS - 1) & 1] : nullptr; pending->flags = ROUNDS > 0 ? flags : nullptr; pending->last_round = ROUNDS - 1; }
+  else if (ROUNDS > 0) hipLaunchKernelGGL(k_region_finish, dim3(ew_grid(n)), dim3(256), 0, s, label, (const int *)prop[(ROUNDS - 1) & 1], n, (const int *)flags, ROUNDS - 1);
 }
 
 void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, const RegionPending *pending) {
   hipLaunchKernelGGL(k_region_size, dim3(cdiv(n, 256 * RS_PER_THREAD)), dim3(256), 0, s, out, label, n, zero_me,
-                     pending ? pending->prop : (const int *)nullptr, pending ? pending->selfp : (const int *)nullptr, pending ? pending->flags : (const int *)nullptr, pending ? pending->last_round : 0);
+                     pending ? pending->prop : (const int *)nullptr, pending ? pending->flags : (const int *)nullptr, pending ? pending->last_round : 0);
 }
 
 // scratch: RD_D2_SCRATCH_INTS(N) ints, scratch[N] (the first list counter) zeroed by the caller when count_is_zero; out must not
