@@ -226,12 +226,13 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
   if (s0 - IF_WU >= 0 && s1 + IF_WU <= H && s1 - s0 == IF_ROWS) {
     // Interior block (all but the first and last of a column): no mirrored rows, no clamping, a full block - the same steps
     // as below with every row test resolved at compile time (the scalar address and branch work of the general form costs
-    // as many issue slots as the recurrence itself).  A chunk = IIR_CH rows; rows one chunk past either end are fetched
-    // and dropped (they exist: IF_WU >= IIR_CH).
+    // as many issue slots as the recurrence itself).  A chunk = IIR_CH rows; while one is evaluated the next one's rows are
+    // fetched (MORE = 0: there is no next one).
     // IIR_CHUNK(row pointer of the chunk's first row, row step, STORE: what to do with an output row, TAIL: tails set or -1)
-#define IIR_CHUNK(PTR, STEP, STORE, TAIL, TIDX)                                                                         \
+#define IIR_CHUNK(PTR, STEP, STORE, TAIL, TIDX) IIR_CHUNK_(PTR, STEP, STORE, TAIL, TIDX, 1)
+#define IIR_CHUNK_(PTR, STEP, STORE, TAIL, TIDX, MORE)                                                                  \
     {                                                                                                                    \
-      _Pragma("unroll") for (int j = 0; j < IIR_CH; j++) nxt[j] = (PTR)[((long)(IIR_CH + j) * (STEP)) * W];              \
+      if (MORE) { _Pragma("unroll") for (int j = 0; j < IIR_CH; j++) nxt[j] = (PTR)[((long)(IIR_CH + j) * (STEP)) * W]; } \
       _Pragma("unroll") for (int j = 0; j < IIR_CH; j++) {                                                               \
         IIR_STEP(cur[j]);                                                                                                \
         STORE;                                                                                                           \
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
       float *o = TOUT ? nullptr : dst.p[k] + (size_t)mid * W + (xin ? x : W - 1);
 #define IIR_FINISH_F { const float r = (f[j * IF_PITCH] + d) - cur[j] * IIR_C0; if (TOUT) f[j * IF_PITCH] = r; else if (xin) o[(long)j * W] = r; }
       for (int q = 0; q < HALF - 1; q++) { IIR_CHUNK(p, 1, IIR_FINISH_F, -1, 0); p += (size_t)IIR_CH * W; f += IIR_CH * IF_PITCH; if (!TOUT) o += (size_t)IIR_CH * W; }
-      IIR_CHUNK(p, 1, IIR_FINISH_F, 1, j - (IIR_CH - 7));                                         // rows s1-16 .. s1-1: "true" tails
+      IIR_CHUNK_(p, 1, IIR_FINISH_F, 1, j - (IIR_CH - 7), 0);                                     // rows s1-16 .. s1-1: "true" tails
 #undef IIR_FINISH_F
     } else {       // anti-causal: rows s1 - 1 + IF_WU .. s0
       const float *p = in + (size_t)(s1 - 1 + IF_WU) * W;
@@ -269,10 +270,11 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
       float *o = TOUT ? nullptr : dst.p[k] + (size_t)(mid - 1) * W + (xin ? x : W - 1);
 #define IIR_FINISH_B { const float r = d + f[-j * IF_PITCH] - cur[j] * IIR_C0; if (TOUT) f[-j * IF_PITCH] = r; else if (xin) o[-(long)j * W] = r; }
       for (int q = 0; q < HALF - 1; q++) { IIR_CHUNK(p, -1, IIR_FINISH_B, -1, 0); p -= (size_t)IIR_CH * W; f -= IIR_CH * IF_PITCH; if (!TOUT) o -= (size_t)IIR_CH * W; }
-      IIR_CHUNK(p, -1, IIR_FINISH_B, 3, (IIR_CH - 1) - j);                                         // rows s0+15 .. s0: "true" tails (index = row - s0)
+      IIR_CHUNK_(p, -1, IIR_FINISH_B, 3, (IIR_CH - 1) - j, 0);                                     // rows s0+15 .. s0: "true" tails (index = row - s0)
 #undef IIR_FINISH_B
     }
 #undef IIR_CHUNK
+#undef IIR_CHUNK_
   } else {
     float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
     float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
