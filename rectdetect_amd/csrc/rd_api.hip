@@ -478,7 +478,7 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
 
   // colour -> sigma=1 blur of L, a, b -> packed blurred Lab (oclrect.c:245-251)
   rdk::bgr2plab_transposed(st, s->plab0, s->tr, s->bgr, iw, ih, ws);
-  { const float *c[3] = { s->tr[0], s->tr[1], s->tr[2] }; rdk::iir_blur_pass(st, s->hz, c, s->fw, s->bw, 3, ih, iw, 1, s->tails, s->flags); }       // along x
+  { const float *c[3] = { s->tr[0], s->tr[1], s->tr[2] }; rdk::iir_blur_pass(st, s->hz, c, s->fw, s->bw, 3, ih, iw, 1, s->tails, s->flags, 1); }    // along x (source: 16-bit fields)
   { const float *c[3] = { s->hz[0], s->hz[1], s->hz[2] }; rdk::iir_blur_pass(st, s->bl, c, s->fw, s->bw, 3, iw, ih, 0, s->tails, s->flags + 1); }   // along y
   // gradient direction (+ the packing of the blurred Lab, oclrect.c:251, on the way), strength, non-max suppression (oclrect.c:253-258)
   rdk::edgevec(st, s->vxy, s->bl[0], iw, ih, s->plab1, s->bl[1], s->bl[2]);

@@ -57,11 +57,13 @@ __global__ __launch_bounds__(256) void k_bgr2plab(uint32_t *__restrict__ out, co
   }
 }
 
-// the same conversion for one 64x64 tile, which also leaves the unpacked L, a, b planes TRANSPOSED (input of the first
-// blur sweep) - saves re-reading the packed plane and one launch per frame
+// the same conversion for one 64x64 tile, which also leaves the L, a, b planes TRANSPOSED (input of the first blur sweep) -
+// saves re-reading the packed plane and one launch per frame.  The transposed planes hold the integer FIELDS (16 bits each; the
+// sweep turns them into the floats of iu:36-39 as it loads them, iir_field): the blocked sweep reads its source three times over,
+// and those reads come from HBM.
 __global__ __launch_bounds__(256) void k_bgr2plab_t(uint32_t *__restrict__ out, P3 dst, const uint8_t *__restrict__ bgr, int iw, int ih, int ws) {
   __shared__ unsigned short s_s2l[RD_LUT_S2L_N], s_cf[RD_LUT_CF_N], s_cf2[RD_LUT_CF_N];
-  __shared__ float tile[3][64][65];
+  __shared__ unsigned short tile[3][64][66];
   const int tid = threadIdx.y * 64 + threadIdx.x;
   for (int i = tid; i < RD_LUT_S2L_N; i += 256) s_s2l[i] = rd_lut_s2l[i];
   for (int i = tid; i < RD_LUT_CF_N; i += 256) { s_cf[i] = rd_lut_cfunc[i]; s_cf2[i] = rd_lut_cfunc2[i]; }
@@ -85,15 +87,13 @@ __global__ __launch_bounds__(256) void k_bgr2plab_t(uint32_t *__restrict__ out, 
     v = (v << 10) | clampu((uint32_t)ca, 0u, 1023u);
     v = (v << 12) | clampu((uint32_t)cl, 0u, 4095u);
     out[y * iw + x] = v;
-    float l, aa, bb;
-    unpack_lab(v, l, aa, bb);
-    tile[0][r][threadIdx.x] = l; tile[1][r][threadIdx.x] = aa; tile[2][r][threadIdx.x] = bb;
+    tile[0][r][threadIdx.x] = (unsigned short)(v & 4095u); tile[1][r][threadIdx.x] = (unsigned short)((v >> 12) & 1023u); tile[2][r][threadIdx.x] = (unsigned short)((v >> 22) & 1023u);
   }
   __syncthreads();
   for (int r = threadIdx.y; r < 64; r += 4) {
     const int ox = y0 + threadIdx.x, oy = x0 + r;   // output planes are ih wide, iw tall
     if (ox < ih && oy < iw)
-      for (int k = 0; k < 3; k++) dst.p[k][(size_t)oy * ih + ox] = tile[k][threadIdx.x][r];
+      for (int k = 0; k < 3; k++) ((unsigned short *)dst.p[k])[(size_t)oy * ih + ox] = tile[k][threadIdx.x][r];
   }
 }
 
@@ -207,7 +207,15 @@ __host__ __device__ inline int if_nchunks(int H, int rows) {
 // with what the other wave parked there (anti-causal + causal - c0 * input: the sum commutes, so who adds does not matter).  The
 // recurrence is a chain of dependent operations - a wave's time is its step count - so the block takes rows + run-in steps instead
 // of twice that.
-template <int TOUT, int IF_ROWS>
+// SRC16: the source planes hold 16-bit integer fields of a packed Lab value (k_bgr2plab_t); plane 0 = L (12 bits), 1 and 2 = a, b
+// (10 bits).  iir_field turns one into the float unpack_lab (iu:36-39) makes of it: a multiply and an add, not fused.
+template <int SRC16> struct iir_src { typedef float T; };
+template <> struct iir_src<1> { typedef unsigned short T; };
+template <int SRC16, typename T> __device__ __forceinline__ float iir_field(T v, float sc, float hf) {
+  if (SRC16) return (float)(int)v * sc + hf;
+  return (float)v;
+}
+template <int TOUT, int IF_ROWS, int SRC16>
 __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__restrict__ tails, int W, int H, int nchunks, int *bad) {
   __shared__ float fwt[(IF_ROWS + 8) * IF_PITCH];
   const int lane = threadIdx.x & 63, anti = threadIdx.x >> 6;
@@ -215,7 +223,10 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
   const int x = blockIdx.x * 64 + lane;
   const int k = blockIdx.y, c = blockIdx.z;
   const bool xin = x < W;
-  const float *__restrict__ in = src.p[k] + (xin ? x : W - 1);
+  typedef typename iir_src<SRC16>::T TS;
+  const TS *__restrict__ in = (const TS *)src.p[k] + (xin ? x : W - 1);
+  const float sc = k == 0 ? 1.0f / 4096 : 1.0f / 1024, hf = k == 0 ? 0.5f / 4096 : 0.5f / 1024;
+#define IIR_LD(v) iir_field<SRC16>(v, sc, hf)
   const int s0 = c * IF_ROWS, s1 = (c == nchunks - 1) ? H : s0 + IF_ROWS;
   const int mid = s0 + (s1 - s0) / 2;             // rows [s0, mid) are finished by the anti-causal wave, [mid, s1) by the causal one
   // tails: [plane][chunk][set: 0 fwd warm, 1 fwd true, 2 bwd warm, 3 bwd true][7][W]
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
 #define IIR_CHUNK(PTR, STEP, STORE, TAIL, TIDX) IIR_CHUNK_(PTR, STEP, STORE, TAIL, TIDX, 1)
 #define IIR_CHUNK_(PTR, STEP, STORE, TAIL, TIDX, MORE)                                                                  \
     {                                                                                                                    \
-      if (MORE) { _Pragma("unroll") for (int j = 0; j < IIR_CH; j++) nxt[j] = (PTR)[((long)(IIR_CH + j) * (STEP)) * W]; } \
+      if (MORE) { _Pragma("unroll") for (int j = 0; j < IIR_CH; j++) nxt[j] = IIR_LD((PTR)[((long)(IIR_CH + j) * (STEP)) * W]); } \
       _Pragma("unroll") for (int j = 0; j < IIR_CH; j++) {                                                               \
         IIR_STEP(cur[j]);                                                                                                \
         STORE;                                                                                                           \
@@ -245,9 +256,9 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
     float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
     float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
     if (!anti) {   // causal: rows s0 - IF_WU .. s1 - 1
-      const float *p = in + (size_t)(s0 - IF_WU) * W;
+      const TS *p = in + (size_t)(s0 - IF_WU) * W;
 #pragma unroll
-      for (int j = 0; j < IIR_CH; j++) cur[j] = p[(size_t)j * W];
+      for (int j = 0; j < IIR_CH; j++) cur[j] = IIR_LD(p[(size_t)j * W]);
       for (int q = 0; q < IF_WU / IIR_CH - 1; q++) { IIR_CHUNK(p, 1, (void)0, -1, 0); p += (size_t)IIR_CH * W; }
       IIR_CHUNK(p, 1, (void)0, 0, j - (IIR_CH - 7)); p += (size_t)IIR_CH * W;                    // rows s0-16 .. s0-1: "warm" tails
       float *f = fwt + lane;
@@ -259,9 +270,9 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
       IIR_CHUNK_(p, 1, IIR_FINISH_F, 1, j - (IIR_CH - 7), 0);                                     // rows s1-16 .. s1-1: "true" tails
 #undef IIR_FINISH_F
     } else {       // anti-causal: rows s1 - 1 + IF_WU .. s0
-      const float *p = in + (size_t)(s1 - 1 + IF_WU) * W;
+      const TS *p = in + (size_t)(s1 - 1 + IF_WU) * W;
 #pragma unroll
-      for (int j = 0; j < IIR_CH; j++) cur[j] = p[-(long)j * W];
+      for (int j = 0; j < IIR_CH; j++) cur[j] = IIR_LD(p[-(long)j * W]);
       for (int q = 0; q < IF_WU / IIR_CH - 1; q++) { IIR_CHUNK(p, -1, (void)0, -1, 0); p -= (size_t)IIR_CH * W; }
       IIR_CHUNK(p, -1, (void)0, 2, (IIR_CH - 1) - j); p -= (size_t)IIR_CH * W;                   // rows s1+15 .. s1: "warm" tails (index = row - s1)
       float *f = fwt + (IF_ROWS - 1) * IF_PITCH + lane;
@@ -282,10 +293,10 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
       const int fb = (s0 - IF_WU <= ylo) ? ylo : s0 - IF_WU;
       const int total = s1 - fb;
 #pragma unroll
-      for (int j = 0; j < IIR_CH; j++) cur[j] = in[(size_t)mirror1(clampi(fb + j, ylo, yhi), H) * W];
+      for (int j = 0; j < IIR_CH; j++) cur[j] = IIR_LD(in[(size_t)mirror1(clampi(fb + j, ylo, yhi), H) * W]);
       for (int base = 0; base < total; base += IIR_CH) {
 #pragma unroll
-        for (int j = 0; j < IIR_CH; j++) nxt[j] = in[(size_t)mirror1(clampi(fb + base + IIR_CH + j, ylo, yhi), H) * W];
+        for (int j = 0; j < IIR_CH; j++) nxt[j] = IIR_LD(in[(size_t)mirror1(clampi(fb + base + IIR_CH + j, ylo, yhi), H) * W]);
 #pragma unroll
         for (int j = 0; j < IIR_CH; j++) {
           const int yy = fb + base + j;
@@ -308,10 +319,10 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
       const int bb = (s1 - 1 + IF_WU >= yhi) ? yhi : s1 - 1 + IF_WU;
       const int total = bb - s0 + 1;
 #pragma unroll
-      for (int j = 0; j < IIR_CH; j++) cur[j] = in[(size_t)mirror1(clampi(bb - j, ylo, yhi), H) * W];
+      for (int j = 0; j < IIR_CH; j++) cur[j] = IIR_LD(in[(size_t)mirror1(clampi(bb - j, ylo, yhi), H) * W]);
       for (int base = 0; base < total; base += IIR_CH) {
 #pragma unroll
-        for (int j = 0; j < IIR_CH; j++) nxt[j] = in[(size_t)mirror1(clampi(bb - (base + IIR_CH + j), ylo, yhi), H) * W];
+        for (int j = 0; j < IIR_CH; j++) nxt[j] = IIR_LD(in[(size_t)mirror1(clampi(bb - (base + IIR_CH + j), ylo, yhi), H) * W]);
 #pragma unroll
         for (int j = 0; j < IIR_CH; j++) {
           const int yy = bb - (base + j);
@@ -344,12 +355,14 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
   }
 }
 
+#undef IIR_LD
+
 // The state a block reached after its warm-up must equal, bit for bit, what its neighbour computed for the same rows.  One
 // wave per (64 columns, plane, chunk) compares the chunk's two borders; a column with a difference - none has been seen, the
 // check is what guarantees the result - is evaluated again by the full-length sweeps (iu:580-589 / iu:629-637, mirrored ends,
 // IIR_WARM rows of run-in) by the lane that found it, through the `fwd` scratch plane (two chunks of one column may both do
 // that: they write the same values).  `force` (diagnostics) treats every column of chunk 0 as different.
-template <int TOUT>
+template <int TOUT, int SRC16>
 __global__ __launch_bounds__(64) void k_iir_check_fix(P3 dst, P3c src, P3 fwd, const float *__restrict__ tails, int *bad, int W, int H, int nchunks, int IF_ROWS, int force) {
   const int x = blockIdx.x * 64 + threadIdx.x;
   const int k = blockIdx.y, c = blockIdx.z;
@@ -369,13 +382,15 @@ __global__ __launch_bounds__(64) void k_iir_check_fix(P3 dst, P3c src, P3 fwd, c
   }
   if (!differ) return;
   atomicOr(bad, 1);
-  const float *__restrict__ in = src.p[k] + x;
+  typedef typename iir_src<SRC16>::T TS;
+  const TS *__restrict__ in = (const TS *)src.p[k] + x;
+  const float sc = k == 0 ? 1.0f / 4096 : 1.0f / 1024, hf = k == 0 ? 0.5f / 4096 : 0.5f / 1024;
   float *fw = fwd.p[k] + x;
   {
     float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
     float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
     for (int yy = -IIR_WARM; yy < H; yy++) {
-      const float i0 = in[(size_t)mirror1(yy, H) * W];
+      const float i0 = iir_field<SRC16>(in[(size_t)mirror1(yy, H) * W], sc, hf);
       IIR_STEP(i0);
       if (yy >= 0) fw[(size_t)yy * W] = d;
       IIR_SHIFT(i0);
@@ -385,7 +400,7 @@ __global__ __launch_bounds__(64) void k_iir_check_fix(P3 dst, P3c src, P3 fwd, c
     float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
     float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
     for (int yy = H + IIR_WARM; yy >= 0; yy--) {
-      const float i0 = in[(size_t)mirror1(yy, H) * W];
+      const float i0 = iir_field<SRC16>(in[(size_t)mirror1(yy, H) * W], sc, hf);
       IIR_STEP(i0);
       if (yy < H) {
         const float o = d + fw[(size_t)yy * W] - i0 * IIR_C0;
@@ -807,13 +822,14 @@ size_t iir_pass_scratch_floats(int np, int W, int H) { return (size_t)np * if_nc
 // are H wide, W tall.  fwd: scratch planes, only touched by columns whose blocked evaluation fails its on-device check and
 // which are then evaluated by full-length sweeps (*bad is set to 1: diagnostics; bwd is not used any more); tails:
 // iir_pass_scratch_floats() floats.
+// src16 (only with transpose_out): the source planes hold 16-bit Lab fields (bgr2plab_transposed), plane 0 = L
 void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3], float *const fwd[3], float *const bwd[3], int np, int W, int H,
-                   int transpose_out, float *tails, int *bad) {
+                   int transpose_out, float *tails, int *bad, int src16) {
   const int rows = if_pick_rows(np, W, H, transpose_out);
   const int nchunks = if_nchunks(H, rows);
   const dim3 grid(cdiv(W, 64), np, nchunks);
-#define IF_LAUNCH(T, R) hipLaunchKernelGGL((k_iir_fused<T, R>), grid, dim3(128), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks, bad)
-#define IF_LAUNCH_R(R) { if (transpose_out) IF_LAUNCH(1, R); else IF_LAUNCH(0, R); }
+#define IF_LAUNCH(T, R, S16) hipLaunchKernelGGL((k_iir_fused<T, R, S16>), grid, dim3(128), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks, bad)
+#define IF_LAUNCH_R(R) { if (transpose_out && src16) IF_LAUNCH(1, R, 1); else if (transpose_out) IF_LAUNCH(1, R, 0); else IF_LAUNCH(0, R, 0); }
   switch (rows) {
     case 32: IF_LAUNCH_R(32); break;
     case 64: IF_LAUNCH_R(64); break;
@@ -824,8 +840,9 @@ void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3]
 #undef IF_LAUNCH
   if (nchunks > 1) {
     const int force = getenv("RD_IIR_FORCE_FIX") ? 1 : 0;             // diagnostics: every column takes the full-length path
-    if (transpose_out) hipLaunchKernelGGL(k_iir_check_fix<1>, grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force);
-    else hipLaunchKernelGGL(k_iir_check_fix<0>, grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force);
+    if (transpose_out && src16) hipLaunchKernelGGL((k_iir_check_fix<1, 1>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force);
+    else if (transpose_out) hipLaunchKernelGGL((k_iir_check_fix<1, 0>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force);
+    else hipLaunchKernelGGL((k_iir_check_fix<0, 0>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force);
   }
   (void)bwd;
 }

@@ -9,7 +9,7 @@ namespace rdk {
 // ---- rd_k_front.hip: colour, blur, gradient, non-max suppression, element-wise ops
 void bgr2plab(hipStream_t s, uint32_t *out, const uint8_t *bgr, int iw, int ih, int ws);
 // colour conversion that also leaves the unpacked L, a, b planes transposed (ih wide, iw tall) for the first blur sweep
-void bgr2plab_transposed(hipStream_t s, uint32_t *out, float *const dst[3], const uint8_t *bgr, int iw, int ih, int ws);
+void bgr2plab_transposed(hipStream_t s, uint32_t *out, float *const dst[3], const uint8_t *bgr, int iw, int ih, int ws);   // dst: the three planes transposed, as 16-bit integer fields (iir_blur_pass src16)
 void unpack_plab(hipStream_t s, float *L, float *a, float *b, const uint32_t *in, int n);
 void pack_plab(hipStream_t s, uint32_t *out, const float *L, const float *a, const float *b, int n);
 // transposes of `np` float planes (src planes W x H row-major -> dst planes H x W); src may be packed Lab (np = 3)
@@ -17,7 +17,7 @@ void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], 
 // one complete blur pass (causal + anti-causal sweep + combination) in a single launch, see rd_k_front.hip
 size_t iir_pass_scratch_floats(int np, int W, int H);
 void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3], float *const fwd[3], float *const bwd[3], int np, int W, int H,
-                   int transpose_out, float *tails, int *bad);
+                   int transpose_out, float *tails, int *bad, int src16 = 0);
 void iir_blur_lines(hipStream_t s, float *dst, const float *src, float *fw, float *bw, int W, int H, int r);   // any radius 0..31, full-length sweeps along y; dst may be fw or bw
 #define RD_IIR_MAX_R 31
 void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih, uint32_t *pack_out = nullptr, const float *a = nullptr, const float *b = nullptr);   // pack_out (optional): pack_plab(in, a, b) on the way
