@@ -284,7 +284,7 @@ struct Slot {
   uint8_t *bgr;
   uint32_t *plab0, *plab1, *smooth, *quant;
   float *tr[3], *fw[3], *bw[3], *hz[3], *bl[3], *vxy, *strength, *nms;
-  int *i0, *i1, *mask0, *tidy, *label1, *strsum, *edge500, *strong, *junction, *mergemask, *region, *rsize, *scratch2, *d2s, *boundarysrc, *boundary, *lsid, *table, *claim, *probes, *region0, *tlist;
+  int *i0, *i1, *mask0, *tidy, *label1, *strsum, *strong, *junction, *mergemask, *region, *rsize, *scratch2, *d2s, *boundarysrc, *boundary, *lsid, *table, *claim, *probes, *region0, *tlist;
   int8_t *e8;
   uint16_t *ext;
   float *tails; int *flags; int iir_chunked;
@@ -328,7 +328,7 @@ struct rd_detector {
   int defer, deferred_slot;               // batched mode: a complete group's sparse stages are launched only once the NEXT group's dense stages are enqueued (deferred_slot: a slot of the waiting group or -1)
   rdk::PolyFrame *frames;                 // nslots descriptors (host memory; they travel as kernel arguments), slot order
   Slot *slots;
-  int *prev_strong;       // strong-edge mask of the previous frame (reference quirk H1)
+  int8_t *prev_strong;    // strong-edge mask of the previous frame (reference quirk H1), one byte per pixel
   hipEvent_t last_strong; int have_last_strong;
   long next_enqueue, next_poll;
   int last_polled_slot;
@@ -370,7 +370,7 @@ static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
   s->plab0 = dnew<uint32_t>(N); s->plab1 = dnew<uint32_t>(N); s->smooth = dnew<uint32_t>(N); s->quant = dnew<uint32_t>(N);
   for (int k = 0; k < 3; k++) { s->tr[k] = dnew<float>(N); s->fw[k] = dnew<float>(N); s->bw[k] = dnew<float>(N); s->hz[k] = dnew<float>(N); s->bl[k] = dnew<float>(N); }
   s->vxy = dnew<float>(N * 2); s->strength = dnew<float>(N); s->nms = dnew<float>(N);
-  int **ip[] = { &s->i0, &s->i1, &s->mask0, &s->tidy, &s->label1, &s->strsum, &s->edge500, &s->strong, &s->junction, &s->mergemask, &s->region, &s->rsize,
+  int **ip[] = { &s->i0, &s->i1, &s->mask0, &s->tidy, &s->label1, &s->strsum, &s->strong, &s->junction, &s->mergemask, &s->region, &s->rsize,
                  &s->boundarysrc, &s->boundary, &s->lsid, &s->region0 };
   for (size_t i = 0; i < sizeof(ip) / sizeof(ip[0]); i++) *ip[i] = dnew<int>(N);
   s->scratch2 = dnew<int>(N * 3 + 256);      // region_merge: two proposal planes + flags + allow bytes
@@ -408,7 +408,7 @@ static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
 
 static void slot_free(Slot *s) {
   RD_HIP(hipStreamSynchronize(s->st));
-  void *all[] = { s->bgr, s->plab0, s->plab1, s->smooth, s->quant, s->vxy, s->strength, s->nms, s->i0, s->i1, s->mask0, s->tidy, s->label1, s->strsum, s->edge500, s->strong,
+  void *all[] = { s->bgr, s->plab0, s->plab1, s->smooth, s->quant, s->vxy, s->strength, s->nms, s->i0, s->i1, s->mask0, s->tidy, s->label1, s->strsum, s->strong,
                   s->junction, s->mergemask, s->region, s->rsize, s->scratch2, s->d2s, s->boundarysrc, s->boundary, s->lsid, s->table, s->claim, s->tlist, s->region0, s->probes, s->e8, s->ext, s->tails, s->flags, s->lslist };
   for (void *p : all) dfree(p);
   for (int k = 0; k < 3; k++) { dfree(s->tr[k]); dfree(s->fw[k]); dfree(s->bw[k]); dfree(s->hz[k]); dfree(s->bl[k]); }
@@ -498,7 +498,7 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   rdk::calc_strength(st, s->strsum, s->nms, s->label1, iw, ih, d->prev_strong, 1);
   // (the same pass also yields the edge mask at 500 of oclrect.c:277-284 and filters the labels at 2500, oclrect.c:307-313:
   //  filtering once at 2500 equals filtering at 500 and then at 2500, and both masks come from the unfiltered labels)
-  rdk::strength_masks(st, s->strong, d->prev_strong, s->edge500, s->e8, s->label1, s->strsum, 500, 2500, iw, ih);
+  rdk::strength_masks(st, s->strong, d->prev_strong, NULL, s->e8, s->label1, s->strsum, 500, 2500, iw, ih);
   return;
   }
   // Three chains leave this point and meet again before the region stage / the votes:
@@ -765,8 +765,8 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->magic = MAGIC_RECT; d->device = device; d->iw = iw; d->ih = ih; d->N = iw * ih; d->nslots = nslots; d->nworkers = nworkers;
   d->maxrec_dev = d->N * 16 / 56;
   if (d->maxrec_dev > 65536) d->maxrec_dev = 65536;
-  d->prev_strong = dnew<int>((size_t)d->N);
-  RD_HIP(hipMemset(d->prev_strong, 0, sizeof(int) * (size_t)d->N));
+  d->prev_strong = dnew<int8_t>((size_t)d->N);
+  RD_HIP(hipMemset(d->prev_strong, 0, (size_t)d->N));
   d->use_graph = getenv("RD_NO_GRAPH") ? 0 : 1;
   d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : 1;
   d->force_redo = getenv("RD_POLY_FORCE_REDO") ? 1 : 0;
@@ -946,7 +946,7 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
   struct { const char *n; const void *p; size_t bytes; } tab[] = {
     { "plab0", s->plab0, N * 4 }, { "plab1", s->plab1, N * 4 }, { "lblur", s->bl[0], N * 4 }, { "vxy", s->vxy, N * 8 }, { "strength", s->strength, N * 4 },
     { "nms", s->nms, N * 4 }, { "mask0", s->mask0, N * 4 }, { "tidy", s->tidy, N * 4 }, { "label1", s->label1, N * 4 }, { "strsum", s->strsum, N * 4 },
-    { "edge500", s->edge500, N * 4 }, { "smooth", s->smooth, N * 4 }, { "quant", s->quant, N * 4 }, { "strong", s->strong, N * 4 }, { "junction", s->junction, N * 4 },
+    { "edge500", s->e8, N }, { "smooth", s->smooth, N * 4 }, { "quant", s->quant, N * 4 }, { "strong", s->strong, N * 4 }, { "junction", s->junction, N * 4 },
     { "mergemask", s->mergemask, N * 4 }, { "region", s->region, N * 4 }, { "region0", s->region0, N * 4 }, { "rsize", s->rsize, N * 4 }, { "boundarysrc", s->boundarysrc, N * 4 },
     { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 }, { "polyctr", rdk::poly_scratch_counters(s->ps), 64 * 4 }, { "iirflags", s->flags, 16 * 4 }, { "d2work", s->d2s + N, 16 * 4 },
   };
@@ -955,6 +955,14 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
       const size_t b = tab[i].bytes < max_bytes ? tab[i].bytes : max_bytes;
       if (!strcmp(name, "lsid")) rdk::polyline_ids(s->st, s->frame, 1, (int)N);   // not part of the frame path: built from the compact state
       RD_HIP(hipStreamSynchronize(s->st));
+      if (!strcmp(name, "edge500")) {       // kept as bytes on the device (the blur's mask); handed out as the int plane of oclrect.c:277-284
+        const size_t n = N * 4 <= max_bytes ? N : max_bytes / 4;
+        int8_t *tmp = (int8_t *)malloc(n ? n : 1);
+        RD_HIP(hipMemcpy(tmp, tab[i].p, n, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < n; k++) ((int *)dst)[k] = tmp[k];
+        free(tmp);
+        return n * 4;
+      }
       RD_HIP(hipMemcpy(dst, tab[i].p, b, hipMemcpyDeviceToHost));
       return b;
     }

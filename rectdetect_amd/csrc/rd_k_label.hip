@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void k_label_flatten(int *label, int n, int *v
 #define CS_T 1024      // hash slots per block (64 x 16 pixels, a third of them contributing)
 // (flatten: the labels arrive as the trees the border kernel left - phase 3 of the labelling, k_label_flatten, is done here on the way:
 //  each pixel walks to its root and stores it; any interleaving only ever stores roots)
-__global__ __launch_bounds__(256) void k_calc_strength(int *out, const float *__restrict__ edge, int *label, int iw, int ih, const int *__restrict__ add, int flatten) {
+__global__ __launch_bounds__(256) void k_calc_strength(int *out, const float *__restrict__ edge, int *label, int iw, int ih, const int8_t *__restrict__ add, int flatten) {
   __shared__ int keys[CS_T], vals[CS_T];
   const int tid = threadIdx.y * 64 + threadIdx.x;
   for (int t = tid; t < CS_T; t += 256) { keys[t] = -1; vals[t] = 0; }
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void k_filter_strength(int *label, const int *
 // the next frame - all the next frame needs from this one; interior pixels keep a label > 0 exactly when their sum
 // reaches t_strong, the frame ring is never filtered), the edge mask at t_edge as int and int8 (oclrect.c:277-284) - both from
 // the unfiltered labels - and the labels filtered at t_strong in place (filtering at t_edge first changes nothing).
-__global__ __launch_bounds__(256) void k_strength_masks(int *__restrict__ strong, int *__restrict__ strong2, int *__restrict__ edge, int8_t *__restrict__ edge8,
+__global__ __launch_bounds__(256) void k_strength_masks(int *__restrict__ strong, int8_t *__restrict__ strong2, int *__restrict__ edge, int8_t *__restrict__ edge8,
                                                          int *__restrict__ label, const int *__restrict__ str, int t_edge, int t_strong, int iw, int ih) {
   const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
   if (x >= iw || y >= ih) return;
@@ -366,8 +366,9 @@ __global__ __launch_bounds__(256) void k_strength_masks(int *__restrict__ strong
   const int sum = (l > 0 && interior) ? str[l] : 0;
   const int vs = (l > 0 && !(interior && sum < t_strong)) ? 1 : 0;
   const int ve = (l > 0 && !(interior && sum < t_edge)) ? 1 : 0;
-  strong[p] = vs; strong2[p] = vs;
-  edge[p] = ve; edge8[p] = (int8_t)ve;
+  strong[p] = vs; strong2[p] = (int8_t)vs;       // (the copy for the next frame: a byte plane - it is read once, as an addend)
+  if (edge != nullptr) edge[p] = ve;             // (the int form of the edge mask is a test plane only: rd_detector_debug_plane widens the bytes)
+  edge8[p] = (int8_t)ve;
   if (interior && l != -1 && (l <= 0 || sum < t_strong)) label[p] = -1;
 }
 
@@ -412,11 +413,11 @@ void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, i
   hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n, vt_table, vt_claim, vt_list);
 }
 
-void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int iw, int ih, const int *add, int flatten) {
+void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int iw, int ih, const int8_t *add, int flatten) {
   hipLaunchKernelGGL(k_calc_strength, dim3(cdiv(iw, 64), cdiv(ih, 4 * CS_ROWS)), block2, 0, s, out, edge, label, iw, ih, add, flatten);
 }
 
-void strength_masks(hipStream_t s, int *strong, int *strong2, int *edge, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih) {
+void strength_masks(hipStream_t s, int *strong, int8_t *strong2, int *edge, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih) {
   hipLaunchKernelGGL(k_strength_masks, grid2(iw, ih), block2, 0, s, strong, strong2, edge, edge8, label, str, t_edge, t_strong, iw, ih);
 }
 
