@@ -373,7 +373,7 @@ static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
   int **ip[] = { &s->i0, &s->i1, &s->mask0, &s->tidy, &s->label1, &s->strsum, &s->strong, &s->junction, &s->mergemask, &s->region, &s->rsize,
                  &s->boundarysrc, &s->boundary, &s->lsid, &s->region0 };
   for (size_t i = 0; i < sizeof(ip) / sizeof(ip[0]); i++) *ip[i] = dnew<int>(N);
-  s->scratch2 = dnew<int>(N * 3 + 256);      // region_merge: two proposal planes + flags + allow bytes
+  s->scratch2 = dnew<int>(N * 3 + 256);      // region_merge: the initial forest, flags + allow bytes, the second label plane of the rounds
   s->d2s = dnew<int>(RD_D2_SCRATCH_INTS(N));
   s->table = dnew<int>(N * 4); s->claim = dnew<int>(N); s->tlist = dnew<int>(N);
   rdk::reduce_ls_init(s->st, s->table, s->claim, s->tlist, (int)(N * 4 / 5));
@@ -461,10 +461,10 @@ static void frame_regions(rd_detector *d, Slot *s) {
   hipStream_t st = s->st;
   // regions (oclrect.c:325-336)
   int *d2scratch = s->d2s;
-  rdk::RegionPending pending;
+  int marked = 0;
   rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih, (d->diag_skip & 2) ? 0 : s->rounds,
-                    s->rsize, s->junction, &pending);   // H2: the sizes start from the junction counts (copied by the first kernel)
-  rdk::region_size(st, s->rsize, s->region0, N, d2scratch + N, &pending);      // (also lets the last round's proposals take effect)
+                    s->rsize, s->junction, &marked);   // H2: the sizes start from the junction counts (copied by the first kernel)
+  rdk::region_size(st, s->rsize, s->region0, N, d2scratch + N, marked);      // (also strips the rounds' marks from the labels)
   rdk::despeckle2(st, s->region, s->region0, d2scratch, s->rsize, 16, iw, ih, 1);
 
   // region boundaries and their components (oclrect.c:340-342)

@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const 
 // so every pixel leaves pointing either at the root of its initial tree (if that root lies in the tile) or at the first
 // pixel outside the tile on its way up/left; the few remaining tile-to-tile hops are left to k_region_flatten.
 #define RI_ROWS 16
-__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, int *__restrict__ prop, int *__restrict__ prop1, const int *__restrict__ pix, const int *__restrict__ mask,
+__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, int *__restrict__ plane_a, int *__restrict__ plane_b, const int *__restrict__ pix, const int *__restrict__ mask,
                                                      const int *__restrict__ edge, int iw, int ih, int *__restrict__ flags, int *__restrict__ size_out, const int *__restrict__ size_init) {
   __shared__ int par[64 * RI_ROWS];     // >= 0: tile-local index of the parent; < 0: -(global index) - 1 of a parent outside the tile
   // (also: the round / flatten flags start at zero, and the size plane starts from size_init - quirk H2 - without extra launches)
@@ -535,8 +535,8 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
           a |= 16;   // interior
         }
         allow[p] = (uint8_t)a;
-        prop[p] = 0x7f7f7f7f;      // no proposal (round tag 63: never current)
-        prop1[p] = 0x7f7f7f7f;
+        plane_a[p] = 0x7fffffff;      // the two label planes of the rounds start above every label (k_region_round)
+        plane_b[p] = 0x7fffffff;
         if (size_out) size_out[p] = si[k];
       }
       par[r * 64 + tx] = l;
@@ -566,50 +566,44 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
 // reference applies the same rule in place for 8 launches, which makes its result depend on the work-item order
 // (SURVEY.md H5); synchronous rounds to convergence are the order-free reading of the same rule.
 //
-// One launch per round.  The proposals of a round are not applied by a launch of their own: they stay in their plane
-// (`prop`: a pixel's own update and the updates for tree parents alike, atomicMin) and the next round reads every
-// label as  E(q) = min(label[q], prop[q])  - what an apply pass would have left in label[q].  The thread of pixel q
-// also stores E(q) back into label[q]; that store needs no ordering against the other threads' reads, because E(q) comes out
-// the same whether they see the old or the new label[q].  Two proposal planes alternate (a round reads the previous
-// round's while writing its own), and a proposal word carries the number of its round in its upper bits - (40 - round) <<
-// 25 | label - so that words left over from two rounds ago lose against every new proposal in the atomicMin and are ignored by
-// the readers: nothing is ever cleared between rounds.  (A plane of its own for the pixels' own updates, written with plain
-// stores, was a third plane to read for every label: 8 MB per round and 3 % of the frame rate.)  flags[round] = "this round proposed something" (a proposal always lowers
-// its pixel's own label), which is what the next round and the host test.
+// One launch per round, no launch that applies a round's proposals, and ONE label plane to read per round: the labels live in two
+// planes that alternate.  Round r reads every label from plane X (complete: the labels after round r-1) and writes into plane Y, which
+// still holds the labels of one round earlier.  Labels only ever go down, so what Y holds is an upper bound of what it should hold after
+// this round, and every update - a pixel's own new label, the proposals for tree parents - is an atomicMin into Y: no order among them
+// matters, nothing needs clearing, and a pixel whose label is the same in X, in Y and after this round writes nothing at all.  Which
+// pixels are "the same in Y" is carried by the words themselves: a word is  label << 1 | f,  f = 1 when the word was written by a
+// change (so the OTHER plane lags behind for this pixel); the pixel's thread then brings the other plane up to date in the next round
+// and clears the mark.  (Every pixel has a thread, the ones on the frame's ring too: they never adopt, but they are parents.)
+// The first two rounds fill the two planes completely (round 0 reads the plain labels the flattening left and writes plane B, round 1
+// reads B and writes plane A; both planes start at +infinity); from round 2 on only changes are written.  Rounds with an even
+// number write B, odd ones A, and every budget is even: the last round writes A, and once a round has changed nothing the planes
+// agree, so the labels are always taken from A (k_region_size strips the marks).
+// flags[round] = "this round proposed something" (a proposal always lowers its pixel's own label), which is what the next round
+// and the host test.
+// (Before: proposals in planes of their own with round tags, every label read as min(label, proposal) - a second plane to read for
+//  every label: 8 MB per round, 5 % of a frame's HBM traffic.)
 // Memory-latency bound: every thread handles RR_PX pixels (64 columns apart, so each load instruction stays coalesced) and
-// issues all of their label / proposal loads before using any, then the first pointer jumps together.
+// issues all of their label loads before using any, then the first pointer jumps together.
 #define RR_PX 2
-#define RR_VBITS 25
-#define RR_NONE 0x7fffffff
-// (the plane a round reads holds only words of that round's predecessor - tag `tag` - or of earlier rounds / the initial fill, whose
-//  tags are larger)
-__device__ __forceinline__ int rr_min2(int l, int wp, int tag) {
-  const int v = wp < ((tag + 1) << RR_VBITS) ? (wp & ((1 << RR_VBITS) - 1)) : RR_NONE;
-  return l < v ? l : v;
-}
-template <bool FIRST>
-__device__ __forceinline__ int rr_eff(const int *label, const int *propP, unsigned q, int tag) {
-  if (FIRST) return at32(label, q);
-  return rr_min2(at32(label, q), at32(propP, q), tag);
-}
-
-template <bool FIRST>
-__global__ __launch_bounds__(256) void k_region_round(int *label, const int *__restrict__ propP, int *propW,
-                                                       const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round) {
-  if (!FIRST && flags[round - 1] == 0) return;
+// MODE 0: first round (X holds plain labels; everything is written, marks clear: the other plane is rewritten anyway)
+// MODE 1: second round (everything is written); MODE 2: later rounds
+template <int MODE>
+__device__ __forceinline__ int rr_label(const int *X, unsigned q) { const int w = at32(X, q); return MODE == 0 ? w : w >> 1; }
+template <int MODE>
+__global__ __launch_bounds__(256) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round) {
+  if (MODE == 2 && flags[round - 1] == 0) return;       // (round 1 always runs: it is what fills plane A)
   __shared__ int hk[512], hv[512];
   const int tid = threadIdx.y * 64 + threadIdx.x;
   for (int t = tid; t < 512; t += 256) { hk[t] = -1; hv[t] = 0x7fffffff; }
   __syncthreads();
-  const int tagP = 41 - round, tagW = 40 - round;
   const int y = blockIdx.y * 4 + threadIdx.y;
   const int xb = blockIdx.x * (64 * RR_PX) + threadIdx.x;
-  int p0[RR_PX], og[RR_PX], g[RR_PX], nx[RR_PX];
+  int p0[RR_PX], og[RR_PX], g[RR_PX], nx[RR_PX], w0[RR_PX];
   unsigned a[RR_PX];
   bool valid[RR_PX], todo[RR_PX];
   {
     unsigned q[RR_PX][5];       // (unsigned element indices: the loads then take the plane's base from scalar registers and a 32-bit offset, no 64-bit address arithmetic per access)
-    int l[RR_PX][5], wp[RR_PX][5];
+    int l[RR_PX][5];
 #pragma unroll
     for (int k = 0; k < RR_PX; k++) {
       const int x = xb + k * 64;
@@ -623,18 +617,15 @@ __global__ __launch_bounds__(256) void k_region_round(int *label, const int *__r
       q[k][3] = (valid[k] && x < iw - 1) ? p0[k] + 1 : p0[k];
       q[k][4] = (valid[k] && y < ih - 1) ? p0[k] + iw : p0[k];
 #pragma unroll
-      for (int c = 0; c < 5; c++) {
-        l[k][c] = at32(label, q[k][c]);
-        if (!FIRST) wp[k][c] = at32(propP, q[k][c]);
-      }
+      for (int c = 0; c < 5; c++) l[k][c] = at32(X, q[k][c]);
     }
 #pragma unroll
     for (int k = 0; k < RR_PX; k++) {
       int e[5];
+      w0[k] = l[k][0];
 #pragma unroll
-      for (int c = 0; c < 5; c++) e[c] = FIRST ? l[k][c] : rr_min2(l[k][c], wp[k][c], tagP);
+      for (int c = 0; c < 5; c++) e[c] = MODE == 0 ? l[k][c] : l[k][c] >> 1;
       og[k] = e[0];
-      if (!FIRST && valid[k] && e[0] < l[k][0]) at32(label, (unsigned)p0[k]) = e[0];     // what the apply pass would have stored
       int m = e[0];
       if ((a[k] & 1) && e[1] < m) m = e[1];
       if ((a[k] & 2) && e[2] < m) m = e[2];
@@ -643,27 +634,26 @@ __global__ __launch_bounds__(256) void k_region_round(int *label, const int *__r
       g[k] = (a[k] & 16) ? m : e[0];
     }
   }
-  {
-    int l[RR_PX], wp[RR_PX];
 #pragma unroll
-    for (int k = 0; k < RR_PX; k++) { l[k] = at32(label, (unsigned)g[k]); if (!FIRST) wp[k] = at32(propP, (unsigned)g[k]); }     // rc:328: first of the eight pointer jumps (a root maps to itself)
-#pragma unroll
-    for (int k = 0; k < RR_PX; k++) nx[k] = FIRST ? l[k] : rr_min2(l[k], wp[k], tagP);
-  }
+  for (int k = 0; k < RR_PX; k++) nx[k] = rr_label<MODE>(X, (unsigned)g[k]);     // rc:328: first of the eight pointer jumps (a root maps to itself)
   bool any_todo = false;
 #pragma unroll
   for (int k = 0; k < RR_PX; k++) {
     if (a[k] & 16) {
       int n = nx[k];
-      for (int j = 1; j < 8 && n != g[k]; j++) { g[k] = n; n = rr_eff<FIRST>(label, propP, (unsigned)n, tagP); }
+      for (int j = 1; j < 8 && n != g[k]; j++) { g[k] = n; n = rr_label<MODE>(X, (unsigned)n); }
       if (n != g[k]) g[k] = n;          // (the eighth jump)
     }
     todo[k] = (a[k] & 16) && g[k] != og[k];
-    if (todo[k]) atomicMin(&propW[p0[k]], (tagW << RR_VBITS) | g[k]);   // own update (no value comes back: the thread does not wait for it)
+    // the pixel's own word in Y: its new label (marked), or - where Y lags behind or has never been written - the label it keeps
+    const bool lag = MODE == 2 && (w0[k] & 1) != 0;
+    if (valid[k] && (MODE < 2 || todo[k] || lag)) atomicMin(&Y[p0[k]], (g[k] << 1) | ((MODE != 0 && todo[k]) ? 1 : 0));     // (no value comes back: the thread does not wait for it; g == og unless todo)
+    if (valid[k] && lag) at32(X, (unsigned)p0[k]) = w0[k] & ~1;      // Y is up to date again (whoever reads this word meanwhile uses the label only)
     any_todo = any_todo || todo[k];
   }
   // Hooking the old parent: after flattening, all pixels of a tree share one parent, so the block first reduces its
   // (parent -> smallest proposal) pairs in a small LDS hash and then issues one guarded atomic per distinct parent.
+  const int mark = MODE != 0 ? 1 : 0;
 #pragma unroll
   for (int k = 0; k < RR_PX; k++) {
     // a lane whose (parent, proposal) pair repeats its left neighbour's adds nothing to a min: skip it (most lanes inside a region)
@@ -675,25 +665,14 @@ __global__ __launch_bounds__(256) void k_region_round(int *label, const int *__r
       const int kprev = atomicCAS(&hk[h], -1, og[k]);
       if (kprev == -1 || kprev == og[k]) { atomicMin(&hv[h], g[k]); break; }
       h = (h + 1) & 511;
-      if (++probes == 16) { const int w = (tagW << RR_VBITS) | g[k]; if (w < ld_agent(&propW[og[k]])) atomicMin(&propW[og[k]], w); break; }
+      if (++probes == 16) { const int w = (g[k] << 1) | mark; if (w < ld_agent(&Y[og[k]])) atomicMin(&Y[og[k]], w); break; }
     }
   }
   if (__any(any_todo) && threadIdx.x == 0) flags[round] = 1;
   __syncthreads();
   for (int t = tid; t < 512; t += 256) {
     const int key = hk[t];
-    if (key != -1) { const int w = (tagW << RR_VBITS) | hv[t]; if (w < ld_agent(&propW[key])) atomicMin(&propW[key], w); }
-  }
-}
-
-// the proposals of the last launched round (if it made any) take effect
-__global__ void k_region_finish(int *label, const int *__restrict__ propP, int n, const int *flags, int last_round) {
-  if (flags[last_round] == 0) return;
-  const int tag = 40 - last_round;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const int l = label[i];
-    const int e = rr_min2(l, propP[i], tag);
-    if (e < l) label[i] = e;
+    if (key != -1) { const int w = (hv[t] << 1) | mark; if (w < ld_agent(&Y[key])) atomicMin(&Y[key], w); }
   }
 }
 
@@ -739,9 +718,8 @@ __device__ __forceinline__ void rs_accum(int *keys, int *vals, int *out, int lab
   }
 }
 
-// (pend_*: the proposals of the region merge's last launched round, applied here on the way - see k_region_round / k_region_finish)
-__global__ __launch_bounds__(256) void k_region_size(int *out, int *__restrict__ label, int n, int *zero_me, const int *__restrict__ pend_prop,
-                                                      const int *__restrict__ pend_flags, int pend_round) {
+// (marked: the plane holds the words of k_region_round - label << 1 | mark; the plain labels are stored back on the way)
+__global__ __launch_bounds__(256) void k_region_size(int *out, int *__restrict__ label, int n, int *zero_me, int marked) {
   if (zero_me && blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;     // (a counter of the next stage: saves a fill launch)
   __shared__ int keys[RS_T], vals[RS_T];
   for (int i = threadIdx.x; i < RS_T; i += 256) { keys[i] = -1; vals[i] = 0; }
@@ -753,12 +731,11 @@ __global__ __launch_bounds__(256) void k_region_size(int *out, int *__restrict__
     const int i = begin + k * 256 + threadIdx.x;
     lks[k] = i < n ? label[i] : -1;
   }
-  if (pend_flags != nullptr && pend_flags[pend_round] != 0) {
-    const int tag = 40 - pend_round;
+  if (marked) {
 #pragma unroll
     for (int k = 0; k < RS_PER_THREAD; k++) {
       const int i = begin + k * 256 + threadIdx.x;
-      if (i < n) { const int e = rr_min2(lks[k], pend_prop[i], tag); if (e < lks[k]) { label[i] = e; lks[k] = e; } }
+      if (i < n) { lks[k] >>= 1; label[i] = lks[k]; }
     }
   }
 #pragma unroll
@@ -1350,31 +1327,34 @@ void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int 
   hipLaunchKernelGGL(k_mm_gather, dim3(wpr, cdiv(ih, MM_ROWS)), dim3(64, 4), 0, s, out, (const unsigned long long *)scratch, iw, ih, wpr);
 }
 
-// scratch: 3*N + 256 ints (proposals; round flags + allowed-direction bytes; the second proposal plane)
-void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS, int *size_out, const int *size_init, RegionPending *pending) {
+// scratch: 3*N + 256 ints (the plain labels of the initial forest; round flags + allowed-direction bytes; the second label plane of the rounds).
+// ROUNDS: 0 (diagnostics: the flattened initial forest is the result) or an even number >= 2; *marked <- whether `label` holds the rounds'
+// words (label << 1 | mark), which region_size turns into plain labels.
+void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS, int *size_out, const int *size_init, int *marked) {
   const int n = iw * ih;
+  if (ROUNDS != 0 && (ROUNDS < 2 || (ROUNDS & 1))) { fprintf(stderr, "region_merge: the number of rounds must be even (got %d)\n", ROUNDS); abort(); }
   // tile-to-tile hops left after k_region_init: at most ih/RI_ROWS + iw/64 + 2; each launch divides the depth by 16
   int FLAT = 1;
   for (long reach = 16; reach < ih / RI_ROWS + iw / 64 + 2; reach *= 16) FLAT++;
   int *flags = scratch + n, *fflags = flags + 32;
   uint8_t *allow = (uint8_t *)(flags + 64);
-  int *prop[2] = { scratch, scratch + 2 * (size_t)n };
-  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, label, allow, prop[0], prop[1], pix, mask, edge, iw, ih, flags, size_out, size_init);
+  int *P = ROUNDS > 0 ? scratch : label;          // the initial forest (plain labels)
+  int *A = label, *B = scratch + 2 * (size_t)n;   // the two planes of the rounds; the result is in A
+  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, P, allow, ROUNDS > 0 ? A : B, B, pix, mask, edge, iw, ih, flags, size_out, size_init);
   // the initial links are flattened first; the synchronous rounds then start from trees of depth 1
-  for (int r = 0; r < FLAT; r++) hipLaunchKernelGGL(k_region_flatten, dim3(ew_grid(n)), dim3(256), 0, s, label, n, fflags, r);
+  for (int r = 0; r < FLAT; r++) hipLaunchKernelGGL(k_region_flatten, dim3(ew_grid(n)), dim3(256), 0, s, P, n, fflags, r);
   const dim3 grid(cdiv(iw, 64 * RR_PX), cdiv(ih, 4));
   for (int r = 0; r < ROUNDS; r++) {
-    const int w = r & 1, p = w ^ 1;
-    if (r == 0) hipLaunchKernelGGL(k_region_round<true>, grid, block2, 0, s, label, (const int *)prop[p], prop[w], (const uint8_t *)allow, iw, ih, flags, r);
-    else hipLaunchKernelGGL(k_region_round<false>, grid, block2, 0, s, label, (const int *)prop[p], prop[w], (const uint8_t *)allow, iw, ih, flags, r);
+    if (r == 0) hipLaunchKernelGGL(k_region_round<0>, grid, block2, 0, s, P, B, (const uint8_t *)allow, iw, ih, flags, r);
+    else if (r == 1) hipLaunchKernelGGL(k_region_round<1>, grid, block2, 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r);
+    else if (r & 1) hipLaunchKernelGGL(k_region_round<2>, grid, block2, 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r);
+    else hipLaunchKernelGGL(k_region_round<2>, grid, block2, 0, s, A, B, (const uint8_t *)allow, iw, ih, flags, r);
   }
-  if (pending) { pending->prop = ROUNDS > 0 ? prop[(ROUNDS - 1) & 1] : nullptr; pending->flags = ROUNDS > 0 ? flags : nullptr; pending->last_round = ROUNDS - 1; }
-  else if (ROUNDS > 0) hipLaunchKernelGGL(k_region_finish, dim3(ew_grid(n)), dim3(256), 0, s, label, (const int *)prop[(ROUNDS - 1) & 1], n, (const int *)flags, ROUNDS - 1);
+  if (marked) *marked = ROUNDS > 0;
 }
 
-void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, const RegionPending *pending) {
-  hipLaunchKernelGGL(k_region_size, dim3(cdiv(n, 256 * RS_PER_THREAD)), dim3(256), 0, s, out, label, n, zero_me,
-                     pending ? pending->prop : (const int *)nullptr, pending ? pending->flags : (const int *)nullptr, pending ? pending->last_round : 0);
+void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, int marked) {
+  hipLaunchKernelGGL(k_region_size, dim3(cdiv(n, 256 * RS_PER_THREAD)), dim3(256), 0, s, out, label, n, zero_me, marked);
 }
 
 // scratch: RD_D2_SCRATCH_INTS(N) ints, scratch[N] (the first list counter) zeroed by the caller when count_is_zero; out must not

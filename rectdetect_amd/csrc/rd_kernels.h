@@ -61,10 +61,9 @@ void quant_lut_init(hipStream_t s);   // once per device before the first despec
 void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih, int quantize24);   // quantize24: `in` is quantised to 24 levels per field on the fly
 void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih);   // scratch: >= ih*ceil(iw/64)*4 ints
 // proposals of the last launched round of region_merge that have not taken effect yet (see k_region_round)
-struct RegionPending { const int *prop, *flags; int last_round; };
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int rounds,
-                  int *size_out, const int *size_init, RegionPending *pending = nullptr);   // rounds: 20 (at most; early-out on the device); size_out (optional) <- size_init, for region_size; scratch: 3N + 256 ints; pending (optional): the last round's proposals are left for region_size to apply
-void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, const RegionPending *pending = nullptr);   // accumulates into out; zero_me (optional): an int to clear on the way
+                  int *size_out, const int *size_init, int *marked);   // rounds: an even number <= 20 (early-out on the device) or 0; size_out (optional) <- size_init, for region_size; scratch: 3N + 256 ints; *marked <- 1 when `label` is left as label << 1 | mark words, which region_size(…, marked) turns into plain labels
+void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, int marked = 0);   // accumulates into out; zero_me (optional): an int to clear on the way
 #define RD_D2_SCRATCH_INTS(N) (5 * (size_t)(N) + 64)
 void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih, int count_is_zero);   // out != in; scratch: RD_D2_SCRATCH_INTS(N) ints (scratch[N] = 0 already if count_is_zero)
 struct PolyScratch;
