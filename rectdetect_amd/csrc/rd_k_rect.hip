@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const 
 // so every pixel leaves pointing either at the root of its initial tree (if that root lies in the tile) or at the first
 // pixel outside the tile on its way up/left; the few remaining tile-to-tile hops are left to k_region_flatten.
 #define RI_ROWS 16
-__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, int *__restrict__ plane_a, int *__restrict__ plane_b, const int *__restrict__ pix, const int *__restrict__ mask,
+__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, const int *__restrict__ pix, const int *__restrict__ mask,
                                                      const int *__restrict__ edge, int iw, int ih, int *__restrict__ flags, int *__restrict__ size_out, const int *__restrict__ size_init) {
   __shared__ int par[64 * RI_ROWS];     // >= 0: tile-local index of the parent; < 0: -(global index) - 1 of a parent outside the tile
   // (also: the round / flatten flags start at zero, and the size plane starts from size_init - quirk H2 - without extra launches)
@@ -535,8 +535,6 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
           a |= 16;   // interior
         }
         allow[p] = (uint8_t)a;
-        plane_a[p] = 0x7fffffff;      // the two label planes of the rounds start above every label (k_region_round)
-        plane_b[p] = 0x7fffffff;
         if (size_out) size_out[p] = si[k];
       }
       par[r * 64 + tx] = l;
@@ -574,10 +572,9 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
 // pixels are "the same in Y" is carried by the words themselves: a word is  label << 1 | f,  f = 1 when the word was written by a
 // change (so the OTHER plane lags behind for this pixel); the pixel's thread then brings the other plane up to date in the next round
 // and clears the mark.  (Every pixel has a thread, the ones on the frame's ring too: they never adopt, but they are parents.)
-// The first two rounds fill the two planes completely (round 0 reads the plain labels the flattening left and writes plane B, round 1
-// reads B and writes plane A; both planes start at +infinity); from round 2 on only changes are written.  Rounds with an even
-// number write B, odd ones A, and every budget is even: the last round writes A, and once a round has changed nothing the planes
-// agree, so the labels are always taken from A (k_region_size strips the marks).
+// Both planes start as copies of the flattened initial forest (k_region_flatten's last launch), so only changes are ever written.
+// Rounds with an even number read A and write B, odd ones read B and write A, and every budget is even: the last round writes A,
+// and once a round has changed nothing the planes agree, so the labels are always taken from A (k_region_size strips the marks).
 // flags[round] = "this round proposed something" (a proposal always lowers its pixel's own label), which is what the next round
 // and the host test.
 // (Before: proposals in planes of their own with round tags, every label read as min(label, proposal) - a second plane to read for
@@ -585,13 +582,9 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
 // Memory-latency bound: every thread handles RR_PX pixels (64 columns apart, so each load instruction stays coalesced) and
 // issues all of their label loads before using any, then the first pointer jumps together.
 #define RR_PX 2
-// MODE 0: first round (X holds plain labels; everything is written, marks clear: the other plane is rewritten anyway)
-// MODE 1: second round (everything is written); MODE 2: later rounds
-template <int MODE>
-__device__ __forceinline__ int rr_label(const int *X, unsigned q) { const int w = at32(X, q); return MODE == 0 ? w : w >> 1; }
-template <int MODE>
+__device__ __forceinline__ int rr_label(const int *X, unsigned q) { return at32(X, q) >> 1; }
 __global__ __launch_bounds__(256) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round) {
-  if (MODE == 2 && flags[round - 1] == 0) return;       // (round 1 always runs: it is what fills plane A)
+  if (round > 0 && flags[round - 1] == 0) return;
   __shared__ int hk[512], hv[512];
   const int tid = threadIdx.y * 64 + threadIdx.x;
   for (int t = tid; t < 512; t += 256) { hk[t] = -1; hv[t] = 0x7fffffff; }
@@ -624,7 +617,7 @@ __global__ __launch_bounds__(256) void k_region_round(int *X, int *Y, const uint
       int e[5];
       w0[k] = l[k][0];
 #pragma unroll
-      for (int c = 0; c < 5; c++) e[c] = MODE == 0 ? l[k][c] : l[k][c] >> 1;
+      for (int c = 0; c < 5; c++) e[c] = l[k][c] >> 1;
       og[k] = e[0];
       int m = e[0];
       if ((a[k] & 1) && e[1] < m) m = e[1];
@@ -635,25 +628,25 @@ __global__ __launch_bounds__(256) void k_region_round(int *X, int *Y, const uint
     }
   }
 #pragma unroll
-  for (int k = 0; k < RR_PX; k++) nx[k] = rr_label<MODE>(X, (unsigned)g[k]);     // rc:328: first of the eight pointer jumps (a root maps to itself)
+  for (int k = 0; k < RR_PX; k++) nx[k] = rr_label(X, (unsigned)g[k]);     // rc:328: first of the eight pointer jumps (a root maps to itself)
   bool any_todo = false;
 #pragma unroll
   for (int k = 0; k < RR_PX; k++) {
     if (a[k] & 16) {
       int n = nx[k];
-      for (int j = 1; j < 8 && n != g[k]; j++) { g[k] = n; n = rr_label<MODE>(X, (unsigned)n); }
+      for (int j = 1; j < 8 && n != g[k]; j++) { g[k] = n; n = rr_label(X, (unsigned)n); }
       if (n != g[k]) g[k] = n;          // (the eighth jump)
     }
     todo[k] = (a[k] & 16) && g[k] != og[k];
-    // the pixel's own word in Y: its new label (marked), or - where Y lags behind or has never been written - the label it keeps
-    const bool lag = MODE == 2 && (w0[k] & 1) != 0;
-    if (valid[k] && (MODE < 2 || todo[k] || lag)) atomicMin(&Y[p0[k]], (g[k] << 1) | ((MODE != 0 && todo[k]) ? 1 : 0));     // (no value comes back: the thread does not wait for it; g == og unless todo)
+    // the pixel's own word in Y: its new label (marked), or - where Y lags behind - the label it keeps
+    const bool lag = (w0[k] & 1) != 0;
+    if (valid[k] && (todo[k] || lag)) atomicMin(&Y[p0[k]], (g[k] << 1) | (todo[k] ? 1 : 0));     // (no value comes back: the thread does not wait for it; g == og unless todo)
     if (valid[k] && lag) at32(X, (unsigned)p0[k]) = w0[k] & ~1;      // Y is up to date again (whoever reads this word meanwhile uses the label only)
     any_todo = any_todo || todo[k];
   }
   // Hooking the old parent: after flattening, all pixels of a tree share one parent, so the block first reduces its
   // (parent -> smallest proposal) pairs in a small LDS hash and then issues one guarded atomic per distinct parent.
-  const int mark = MODE != 0 ? 1 : 0;
+  const int mark = 1;
 #pragma unroll
   for (int k = 0; k < RR_PX; k++) {
     // a lane whose (parent, proposal) pair repeats its left neighbour's adds nothing to a min: skip it (most lanes inside a region)
@@ -678,9 +671,11 @@ __global__ __launch_bounds__(256) void k_region_round(int *X, int *Y, const uint
 
 // In-place pointer jumping on the forest of initial links (parent index < child index): each launch replaces a
 // pixel's parent by an ancestor up to 16 links away (or the root); any interleaving only ever stores ancestors, so the iteration ends
-// with every pixel pointing at the root of its initial tree.
-__global__ void k_region_flatten(int *label, int n, int *flags, int round) {
-  if (round > 0 && flags[round - 1] == 0) return;
+// with every pixel pointing at the root of its initial tree.  flags[round] = some chain was not followed to its root yet.
+// The LAST launch (out_a, out_b given) also leaves the final labels, as the words of k_region_round (label << 1, mark clear), in the
+// two planes the rounds alternate between; it runs whatever the flags say.
+__global__ void k_region_flatten(int *label, int n, int *flags, int round, int *__restrict__ out_a, int *__restrict__ out_b) {
+  if (round > 0 && flags[round - 1] == 0 && out_a == nullptr) return;
   bool changed = false;
   const int stride = gridDim.x * blockDim.x;
   for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * 4) {     // four pixels per step: their first two jumps are in flight together
@@ -692,11 +687,16 @@ __global__ void k_region_flatten(int *label, int n, int *flags, int round) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int i = i0 + k * stride;
-      if (i >= n || a[k] == l[k]) continue;
-      int r = a[k];
-      for (int j = 0; j < 14; j++) { const int b = label[r]; if (b == r) break; r = b; }   // (most chains end after a jump or two)
-      label[i] = r;
-      changed = true;
+      if (i >= n) continue;
+      int r = l[k];
+      if (a[k] != l[k]) {
+        r = a[k];
+        bool root = false;
+        for (int j = 0; j < 14; j++) { const int b = label[r]; if (b == r) { root = true; break; } r = b; }   // (most chains end after a jump or two)
+        label[i] = r;
+        if (!root) changed = true;       // (a chain that was not seen to end: the next launch goes on; otherwise this pixel is done)
+      }
+      if (out_a != nullptr) { out_a[i] = r << 1; out_b[i] = r << 1; }
     }
   }
   if (__any(changed) && (threadIdx.x & 63) == 0) flags[round] = 1;
@@ -1340,15 +1340,16 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
   uint8_t *allow = (uint8_t *)(flags + 64);
   int *P = ROUNDS > 0 ? scratch : label;          // the initial forest (plain labels)
   int *A = label, *B = scratch + 2 * (size_t)n;   // the two planes of the rounds; the result is in A
-  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, P, allow, ROUNDS > 0 ? A : B, B, pix, mask, edge, iw, ih, flags, size_out, size_init);
-  // the initial links are flattened first; the synchronous rounds then start from trees of depth 1
-  for (int r = 0; r < FLAT; r++) hipLaunchKernelGGL(k_region_flatten, dim3(ew_grid(n)), dim3(256), 0, s, P, n, fflags, r);
+  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, P, allow, pix, mask, edge, iw, ih, flags, size_out, size_init);
+  // the initial links are flattened first; the synchronous rounds then start from trees of depth 1 (left in A and B by the last launch)
+  for (int r = 0; r < FLAT; r++) {
+    const bool last = r == FLAT - 1 && ROUNDS > 0;
+    hipLaunchKernelGGL(k_region_flatten, dim3(ew_grid(n)), dim3(256), 0, s, P, n, fflags, r, last ? A : (int *)nullptr, last ? B : (int *)nullptr);
+  }
   const dim3 grid(cdiv(iw, 64 * RR_PX), cdiv(ih, 4));
   for (int r = 0; r < ROUNDS; r++) {
-    if (r == 0) hipLaunchKernelGGL(k_region_round<0>, grid, block2, 0, s, P, B, (const uint8_t *)allow, iw, ih, flags, r);
-    else if (r == 1) hipLaunchKernelGGL(k_region_round<1>, grid, block2, 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r);
-    else if (r & 1) hipLaunchKernelGGL(k_region_round<2>, grid, block2, 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r);
-    else hipLaunchKernelGGL(k_region_round<2>, grid, block2, 0, s, A, B, (const uint8_t *)allow, iw, ih, flags, r);
+    if (r & 1) hipLaunchKernelGGL(k_region_round, grid, block2, 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r);
+    else hipLaunchKernelGGL(k_region_round, grid, block2, 0, s, A, B, (const uint8_t *)allow, iw, ih, flags, r);
   }
   if (marked) *marked = ROUNDS > 0;
 }
