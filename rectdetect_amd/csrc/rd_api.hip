@@ -758,7 +758,7 @@ extern "C" {
 rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nworkers) {
   if (rd_device_count() <= 0) exitf(-1, "rd_detector_create: no HIP device available - this library has no CPU path\n");
   if (iw < 16 || ih < 16) exitf(-1, "rd_detector_create: frame %dx%d too small\n", iw, ih);
-  if ((long long)iw * ih >= (1ll << 25)) exitf(-1, "rd_detector_create: frame %dx%d too large (region-merge proposals keep labels in 25 bits)\n", iw, ih);
+  if ((long long)iw * ih >= (1ll << 25)) exitf(-1, "rd_detector_create: frame %dx%d too large (pixel indices are kept below 2^25: hash keys and marked label words rely on the spare bits)\n", iw, ih);
   if (nslots < 1) nslots = 1;
   RD_HIP(hipSetDevice(device));
   rd_detector *d = (rd_detector *)calloc(1, sizeof(*d));
