@@ -569,9 +569,11 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
 // still holds the labels of one round earlier.  Labels only ever go down, so what Y holds is an upper bound of what it should hold after
 // this round, and every update - a pixel's own new label, the proposals for tree parents - is an atomicMin into Y: no order among them
 // matters, nothing needs clearing, and a pixel whose label is the same in X, in Y and after this round writes nothing at all.  Which
-// pixels are "the same in Y" is carried by the words themselves: a word is  label << 1 | f,  f = 1 when the word was written by a
-// change (so the OTHER plane lags behind for this pixel); the pixel's thread then brings the other plane up to date in the next round
-// and clears the mark.  (Every pixel has a thread, the ones on the frame's ring too: they never adopt, but they are parents.)
+// pixels are "the same in Y" is carried by the words themselves: a word is  label << 3 | m,  m = 1 + (round mod 7) when the word was
+// written by a change in that round (so the OTHER plane lags behind for this pixel), else 0; the pixel's thread sees the mark of the
+// round before its own and brings the other plane up to date.  Marks are never cleared: an old one only matches again 14 rounds later,
+// where it causes a harmless write of the same value.  (Every pixel has a thread, the ones on the frame's ring too: they never adopt,
+// but they are parents.)
 // Both planes start as copies of the flattened initial forest (k_region_flatten's last launch), so only changes are ever written.
 // Rounds with an even number read A and write B, odd ones read B and write A, and every budget is even: the last round writes A,
 // and once a round has changed nothing the planes agree, so the labels are always taken from A (k_region_size strips the marks).
@@ -582,13 +584,15 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
 // Memory-latency bound: every thread handles RR_PX pixels (64 columns apart, so each load instruction stays coalesced) and
 // issues all of their label loads before using any, then the first pointer jumps together.
 #define RR_PX 2
-__device__ __forceinline__ int rr_label(const int *X, unsigned q) { return at32(X, q) >> 1; }
+#define RR_MBITS 3
+__device__ __forceinline__ int rr_label(const int *X, unsigned q) { return at32(X, q) >> RR_MBITS; }
 __global__ __launch_bounds__(256) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round) {
   if (round > 0 && flags[round - 1] == 0) return;
   __shared__ int hk[512], hv[512];
   const int tid = threadIdx.y * 64 + threadIdx.x;
   for (int t = tid; t < 512; t += 256) { hk[t] = -1; hv[t] = 0x7fffffff; }
   __syncthreads();
+  const int mark = 1 + round % 7, mark_prev = round > 0 ? 1 + (round - 1) % 7 : 8;      // (8: matches nothing - before round 0 no plane lags)
   const int y = blockIdx.y * 4 + threadIdx.y;
   const int xb = blockIdx.x * (64 * RR_PX) + threadIdx.x;
   int p0[RR_PX], og[RR_PX], g[RR_PX], nx[RR_PX], w0[RR_PX];
@@ -617,7 +621,7 @@ __global__ __launch_bounds__(256) void k_region_round(int *X, int *Y, const uint
       int e[5];
       w0[k] = l[k][0];
 #pragma unroll
-      for (int c = 0; c < 5; c++) e[c] = l[k][c] >> 1;
+      for (int c = 0; c < 5; c++) e[c] = l[k][c] >> RR_MBITS;
       og[k] = e[0];
       int m = e[0];
       if ((a[k] & 1) && e[1] < m) m = e[1];
@@ -639,14 +643,12 @@ __global__ __launch_bounds__(256) void k_region_round(int *X, int *Y, const uint
     }
     todo[k] = (a[k] & 16) && g[k] != og[k];
     // the pixel's own word in Y: its new label (marked), or - where Y lags behind - the label it keeps
-    const bool lag = (w0[k] & 1) != 0;
-    if (valid[k] && (todo[k] || lag)) atomicMin(&Y[p0[k]], (g[k] << 1) | (todo[k] ? 1 : 0));     // (no value comes back: the thread does not wait for it; g == og unless todo)
-    if (valid[k] && lag) at32(X, (unsigned)p0[k]) = w0[k] & ~1;      // Y is up to date again (whoever reads this word meanwhile uses the label only)
+    const bool lag = (w0[k] & 7) == mark_prev;
+    if (valid[k] && (todo[k] || lag)) atomicMin(&Y[p0[k]], (g[k] << RR_MBITS) | (todo[k] ? mark : 0));     // (no value comes back: the thread does not wait for it; g == og unless todo)
     any_todo = any_todo || todo[k];
   }
   // Hooking the old parent: after flattening, all pixels of a tree share one parent, so the block first reduces its
   // (parent -> smallest proposal) pairs in a small LDS hash and then issues one guarded atomic per distinct parent.
-  const int mark = 1;
 #pragma unroll
   for (int k = 0; k < RR_PX; k++) {
     // a lane whose (parent, proposal) pair repeats its left neighbour's adds nothing to a min: skip it (most lanes inside a region)
@@ -658,21 +660,21 @@ __global__ __launch_bounds__(256) void k_region_round(int *X, int *Y, const uint
       const int kprev = atomicCAS(&hk[h], -1, og[k]);
       if (kprev == -1 || kprev == og[k]) { atomicMin(&hv[h], g[k]); break; }
       h = (h + 1) & 511;
-      if (++probes == 16) { const int w = (g[k] << 1) | mark; if (w < ld_agent(&Y[og[k]])) atomicMin(&Y[og[k]], w); break; }
+      if (++probes == 16) { const int w = (g[k] << RR_MBITS) | mark; if (w < ld_agent(&Y[og[k]])) atomicMin(&Y[og[k]], w); break; }
     }
   }
   if (__any(any_todo) && threadIdx.x == 0) flags[round] = 1;
   __syncthreads();
   for (int t = tid; t < 512; t += 256) {
     const int key = hk[t];
-    if (key != -1) { const int w = (hv[t] << 1) | mark; if (w < ld_agent(&Y[key])) atomicMin(&Y[key], w); }
+    if (key != -1) { const int w = (hv[t] << RR_MBITS) | mark; if (w < ld_agent(&Y[key])) atomicMin(&Y[key], w); }
   }
 }
 
 // In-place pointer jumping on the forest of initial links (parent index < child index): each launch replaces a
 // pixel's parent by an ancestor up to 16 links away (or the root); any interleaving only ever stores ancestors, so the iteration ends
 // with every pixel pointing at the root of its initial tree.  flags[round] = some chain was not followed to its root yet.
-// The LAST launch (out_a, out_b given) also leaves the final labels, as the words of k_region_round (label << 1, mark clear), in the
+// The LAST launch (out_a, out_b given) also leaves the final labels, as the words of k_region_round (label << 3, no mark), in the
 // two planes the rounds alternate between; it runs whatever the flags say.
 __global__ void k_region_flatten(int *label, int n, int *flags, int round, int *__restrict__ out_a, int *__restrict__ out_b) {
   if (round > 0 && flags[round - 1] == 0 && out_a == nullptr) return;
@@ -696,7 +698,7 @@ __global__ void k_region_flatten(int *label, int n, int *flags, int round, int *
         label[i] = r;
         if (!root) changed = true;       // (a chain that was not seen to end: the next launch goes on; otherwise this pixel is done)
       }
-      if (out_a != nullptr) { out_a[i] = r << 1; out_b[i] = r << 1; }
+      if (out_a != nullptr) { out_a[i] = r << RR_MBITS; out_b[i] = r << RR_MBITS; }
     }
   }
   if (__any(changed) && (threadIdx.x & 63) == 0) flags[round] = 1;
@@ -718,7 +720,7 @@ __device__ __forceinline__ void rs_accum(int *keys, int *vals, int *out, int lab
   }
 }
 
-// (marked: the plane holds the words of k_region_round - label << 1 | mark; the plain labels are stored back on the way)
+// (marked: the plane holds the words of k_region_round - label << 3 | mark; the plain labels are stored back on the way)
 __global__ __launch_bounds__(256) void k_region_size(int *out, int *__restrict__ label, int n, int *zero_me, int marked) {
   if (zero_me && blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;     // (a counter of the next stage: saves a fill launch)
   __shared__ int keys[RS_T], vals[RS_T];
@@ -735,7 +737,7 @@ __global__ __launch_bounds__(256) void k_region_size(int *out, int *__restrict__
 #pragma unroll
     for (int k = 0; k < RS_PER_THREAD; k++) {
       const int i = begin + k * 256 + threadIdx.x;
-      if (i < n) { lks[k] >>= 1; label[i] = lks[k]; }
+      if (i < n) { lks[k] >>= RR_MBITS; label[i] = lks[k]; }
     }
   }
 #pragma unroll
@@ -1329,7 +1331,7 @@ void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int 
 
 // scratch: 3*N + 256 ints (the plain labels of the initial forest; round flags + allowed-direction bytes; the second label plane of the rounds).
 // ROUNDS: 0 (diagnostics: the flattened initial forest is the result) or an even number >= 2; *marked <- whether `label` holds the rounds'
-// words (label << 1 | mark), which region_size turns into plain labels.
+// words (label << 3 | mark), which region_size turns into plain labels.
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS, int *size_out, const int *size_init, int *marked) {
   const int n = iw * ih;
   if (ROUNDS != 0 && (ROUNDS < 2 || (ROUNDS & 1))) { fprintf(stderr, "region_merge: the number of rounds must be even (got %d)\n", ROUNDS); abort(); }
