@@ -194,13 +194,25 @@ __host__ __device__ inline int if_nchunks(int H, int rows) {
   return n;
 }
 
+// One step of the recurrence (iu:551-556): d = i0 c0; d += c1 i1 + ... + c7 i7; d += c8 t0 + ... + c14 t6 - each of the two sums from left
+// to right.  The two sums are independent chains of seven products, so they run side by side in the two halves of packed single-precision
+// operations (v_pk_mul_f32 / v_pk_add_f32: the same IEEE multiply and add per half, not fused): the state is kept as pairs
+// q_k = (input k steps back, output k steps back), which is also the pair the k-th tap of each sum needs.
+typedef float iir_f2 __attribute__((ext_vector_type(2)));
+#define IIR_STATE iir_f2 q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, q6 = 0, q7 = 0
 #define IIR_STEP(i0v)                                                                                                  \
+  iir_f2 acc = (iir_f2){IIR_C1, IIR_C8} * q1;                                                                          \
+  acc = acc + (iir_f2){IIR_C2, IIR_C9} * q2;                                                                           \
+  acc = acc + (iir_f2){IIR_C3, IIR_C10} * q3;                                                                          \
+  acc = acc + (iir_f2){IIR_C4, IIR_C11} * q4;                                                                          \
+  acc = acc + (iir_f2){IIR_C5, IIR_C12} * q5;                                                                          \
+  acc = acc + (iir_f2){IIR_C6, IIR_C13} * q6;                                                                          \
+  acc = acc + (iir_f2){IIR_C7, IIR_C14} * q7;                                                                          \
   float d = (i0v) * IIR_C0;                                                                                            \
-  d += IIR_C1 * i1 + IIR_C2 * i2 + IIR_C3 * i3 + IIR_C4 * i4 + IIR_C5 * i5 + IIR_C6 * i6 + IIR_C7 * i7;               \
-  d += IIR_C8 * t0 + IIR_C9 * t1 + IIR_C10 * t2 + IIR_C11 * t3 + IIR_C12 * t4 + IIR_C13 * t5 + IIR_C14 * t6;
+  d += acc.x;                                                                                                          \
+  d += acc.y;
 #define IIR_SHIFT(i0v)                                                                                                 \
-  i7 = i6; i6 = i5; i5 = i4; i4 = i3; i3 = i2; i2 = i1; i1 = (i0v);                                                    \
-  t6 = t5; t5 = t4; t4 = t3; t3 = t2; t2 = t1; t1 = t0; t0 = d;
+  q7 = q6; q6 = q5; q5 = q4; q4 = q3; q3 = q2; q2 = q1; q1 = (iir_f2){(i0v), d};
 
 // TWO waves per block: wave 0 runs the causal sweep, wave 1 the anti-causal sweep of the same 64 columns AT THE SAME TIME.  Each parks
 // its raw outputs for the half of the block it reaches first in LDS; after one barrier in the middle each finishes the other half
@@ -253,8 +265,7 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
       _Pragma("unroll") for (int j = 0; j < IIR_CH; j++) cur[j] = nxt[j];                                                \
     }
     constexpr int HALF = IF_ROWS / 2 / IIR_CH;     // chunks per phase
-    float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
-    float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+    IIR_STATE;
     if (!anti) {   // causal: rows s0 - IF_WU .. s1 - 1
       const TS *p = in + (size_t)(s0 - IF_WU) * W;
 #pragma unroll
@@ -287,8 +298,7 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
 #undef IIR_CHUNK
 #undef IIR_CHUNK_
   } else {
-    float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
-    float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+    IIR_STATE;
     if (!anti) {   // ---------------- causal sweep: rows fb .. s1-1 (one barrier, before row `mid`)
       const int fb = (s0 - IF_WU <= ylo) ? ylo : s0 - IF_WU;
       const int total = s1 - fb;
@@ -387,8 +397,7 @@ __global__ __launch_bounds__(64) void k_iir_check_fix(P3 dst, P3c src, P3 fwd, c
   const float sc = k == 0 ? 1.0f / 4096 : 1.0f / 1024, hf = k == 0 ? 0.5f / 4096 : 0.5f / 1024;
   float *fw = fwd.p[k] + x;
   {
-    float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
-    float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+    IIR_STATE;
     for (int yy = -IIR_WARM; yy < H; yy++) {
       const float i0 = iir_field<SRC16>(in[(size_t)mirror1(yy, H) * W], sc, hf);
       IIR_STEP(i0);
@@ -397,8 +406,7 @@ __global__ __launch_bounds__(64) void k_iir_check_fix(P3 dst, P3c src, P3 fwd, c
     }
   }
   {
-    float i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0, i6 = 0, i7 = 0;
-    float t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, t5 = 0, t6 = 0;
+    IIR_STATE;
     for (int yy = H + IIR_WARM; yy >= 0; yy--) {
       const float i0 = iir_field<SRC16>(in[(size_t)mirror1(yy, H) * W], sc, hf);
       IIR_STEP(i0);
