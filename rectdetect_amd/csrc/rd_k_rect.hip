@@ -593,8 +593,8 @@ __global__ __launch_bounds__(256) void k_region_round(int *X, int *Y, const uint
   for (int t = tid; t < 512; t += 256) { hk[t] = -1; hv[t] = 0x7fffffff; }
   __syncthreads();
   const int mark = 1 + round % 7, mark_prev = round > 0 ? 1 + (round - 1) % 7 : 8;      // (8: matches nothing - before round 0 no plane lags)
-  const int y = blockIdx.y * 4 + threadIdx.y;
-  const int xb = blockIdx.x * (64 * RR_PX) + threadIdx.x;
+  const int yb = blockIdx.y * (4 * RR_PX) + threadIdx.y * RR_PX;      // the thread's RR_PX pixels lie below one another: each is the other's vertical neighbour
+  const int x = blockIdx.x * 64 + threadIdx.x;
   int p0[RR_PX], og[RR_PX], g[RR_PX], nx[RR_PX], w0[RR_PX];
   unsigned a[RR_PX];
   bool valid[RR_PX], todo[RR_PX];
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void k_region_round(int *X, int *Y, const uint
     int l[RR_PX][5];
 #pragma unroll
     for (int k = 0; k < RR_PX; k++) {
-      const int x = xb + k * 64;
+      const int y = yb + k;
       valid[k] = x < iw && y < ih;
       p0[k] = valid[k] ? y * iw + x : 0;
       a[k] = valid[k] ? allow[(unsigned)p0[k]] : 0u;
@@ -614,7 +614,13 @@ __global__ __launch_bounds__(256) void k_region_round(int *X, int *Y, const uint
       q[k][3] = (valid[k] && x < iw - 1) ? p0[k] + 1 : p0[k];
       q[k][4] = (valid[k] && y < ih - 1) ? p0[k] + iw : p0[k];
 #pragma unroll
-      for (int c = 0; c < 5; c++) l[k][c] = at32(X, q[k][c]);
+      for (int c = 0; c < 5; c++)
+        if (!((c == 1 && k > 0) || (c == 4 && k < RR_PX - 1))) l[k][c] = at32(X, q[k][c]);
+    }
+#pragma unroll
+    for (int k = 0; k < RR_PX; k++) {       // (the neighbours inside the thread's own column: no loads; an invalid pixel's word is never used - its neighbour above is on the ring)
+      if (k > 0) l[k][1] = l[k - 1][0];
+      if (k < RR_PX - 1) l[k][4] = l[k + 1][0];
     }
 #pragma unroll
     for (int k = 0; k < RR_PX; k++) {
@@ -1348,7 +1354,7 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
     const bool last = r == FLAT - 1 && ROUNDS > 0;
     hipLaunchKernelGGL(k_region_flatten, dim3(ew_grid(n)), dim3(256), 0, s, P, n, fflags, r, last ? A : (int *)nullptr, last ? B : (int *)nullptr);
   }
-  const dim3 grid(cdiv(iw, 64 * RR_PX), cdiv(ih, 4));
+  const dim3 grid(cdiv(iw, 64), cdiv(ih, 4 * RR_PX));
   for (int r = 0; r < ROUNDS; r++) {
     if (r & 1) hipLaunchKernelGGL(k_region_round, grid, block2, 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r);
     else hipLaunchKernelGGL(k_region_round, grid, block2, 0, s, A, B, (const uint8_t *)allow, iw, ih, flags, r);
