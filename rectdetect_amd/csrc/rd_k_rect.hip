@@ -581,9 +581,10 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
 // and the host test.
 // (Before: proposals in planes of their own with round tags, every label read as min(label, proposal) - a second plane to read for
 //  every label: 8 MB per round, 5 % of a frame's HBM traffic.)
-// Memory-latency bound: every thread handles RR_PX pixels (64 columns apart, so each load instruction stays coalesced) and
-// issues all of their label loads before using any, then the first pointer jumps together.
-#define RR_PX 2
+// Memory-latency bound: every thread handles RR_PX pixels below one another - each is the other's vertical neighbour, so a column of six
+// costs 6 + 2 + 12 label loads instead of 30 (measured at full rate, same box: 2, 3, 4, 6, 8 pixels: 2056, 2080, 2083 / 2067, 2079, 2062
+// frames/s) - and issues all of their label loads before using any, then the first pointer jumps together.
+#define RR_PX 6
 #define RR_MBITS 3
 __device__ __forceinline__ int rr_label(const int *X, unsigned q) { return at32(X, q) >> RR_MBITS; }
 __global__ __launch_bounds__(256) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round) {
