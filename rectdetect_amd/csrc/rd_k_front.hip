@@ -475,35 +475,10 @@ __device__ __forceinline__ float v5c(int i) {
 }
 
 // (pack_out, optional: the packed Lab of the pixel's own blurred L, a, b - iu:28-34 - on the way: saves the frame path a launch)
-__global__ __launch_bounds__(256) void k_edgevec(float2 *__restrict__ dst, const float *__restrict__ in, int iw, int ih, uint32_t *__restrict__ pack_out, const float *__restrict__ pa, const float *__restrict__ pb) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-  if (x >= iw || y >= ih) return;
-  if (pack_out != nullptr) { const int p = y * iw + x; pack_out[p] = pack_lab(in[p], pa[p], pb[p]); }
-  float vx = 0, vy = 0;
-  // (blocks whose 5x5 windows stay inside the frame address the 25 samples by constant offsets from five row pointers; same sums in the same order)
-  const bool interior = blockIdx.x > 0 && blockIdx.y > 0 && (int)(blockIdx.x * 64 + 66) <= iw && (int)(blockIdx.y * 4 + 6) <= ih;
-  if (interior) {
-#pragma unroll
-    for (int yy = -2; yy <= 2; yy++) {
-      const float *row = in + (size_t)(y + yy) * iw + x;
-#pragma unroll
-      for (int xx = -2; xx <= 2; xx++) {
-        const float s = row[xx];
-        vx += v5c((xx + 2) + (yy + 2) * 5) * s;
-        vy += v5c((yy + 2) + (xx + 2) * 5) * s;
-      }
-    }
-  } else {
-#pragma unroll
-    for (int yy = -2; yy <= 2; yy++) {
-#pragma unroll
-      for (int xx = -2; xx <= 2; xx++) {
-        const float s = in[mirror2(x + xx, y + yy, iw, ih)];
-        vx += v5c((xx + 2) + (yy + 2) * 5) * s;
-        vy += v5c((yy + 2) + (xx + 2) * 5) * s;
-      }
-    }
-  }
+// Every thread handles EV_PX pixels below one another: their 5x5 windows overlap in all but one row each, so a column of four
+// costs 8 x 5 loads instead of 100 (same sums in the same order per pixel).
+#define EV_PX 4
+__device__ __forceinline__ void ev_finish(float2 *__restrict__ dst, int p, float vx, float vy) {
   float len = vx * vx + vy * vy;
   if ((double)len > 1e-10) {
     len = 1.0f / sqrtf(len);
@@ -511,7 +486,55 @@ __global__ __launch_bounds__(256) void k_edgevec(float2 *__restrict__ dst, const
   } else {
     vx = vy = 0.70710678118f;
   }
-  dst[y * iw + x] = make_float2(vx, vy);
+  dst[p] = make_float2(vx, vy);
+}
+__global__ __launch_bounds__(256) void k_edgevec(float2 *__restrict__ dst, const float *__restrict__ in, int iw, int ih, uint32_t *__restrict__ pack_out, const float *__restrict__ pa, const float *__restrict__ pb) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y0 = (blockIdx.y * 4 + threadIdx.y) * EV_PX;
+  if (x >= iw || y0 >= ih) return;
+  if (pack_out != nullptr) {
+#pragma unroll
+    for (int k = 0; k < EV_PX; k++) if (y0 + k < ih) { const int p = (y0 + k) * iw + x; pack_out[p] = pack_lab(in[p], pa[p], pb[p]); }
+  }
+  // (blocks whose 5x5 windows stay inside the frame address their samples by constant offsets from the row pointers; same sums in the same order)
+  const bool interior = blockIdx.x > 0 && blockIdx.y > 0 && (int)(blockIdx.x * 64 + 66) <= iw && (int)((blockIdx.y * 4 + 4) * EV_PX + 2) <= ih;
+  if (interior) {
+    float w[EV_PX + 4][5];
+#pragma unroll
+    for (int r = 0; r < EV_PX + 4; r++) {
+      const float *row = in + (size_t)(y0 + r - 2) * iw + x;
+#pragma unroll
+      for (int c = 0; c < 5; c++) w[r][c] = row[c - 2];
+    }
+#pragma unroll
+    for (int k = 0; k < EV_PX; k++) {
+      float vx = 0, vy = 0;
+#pragma unroll
+      for (int yy = -2; yy <= 2; yy++)
+#pragma unroll
+        for (int xx = -2; xx <= 2; xx++) {
+          const float s = w[k + yy + 2][xx + 2];
+          vx += v5c((xx + 2) + (yy + 2) * 5) * s;
+          vy += v5c((yy + 2) + (xx + 2) * 5) * s;
+        }
+      ev_finish(dst, (y0 + k) * iw + x, vx, vy);
+    }
+  } else {
+    for (int k = 0; k < EV_PX; k++) {
+      const int y = y0 + k;
+      if (y >= ih) break;
+      float vx = 0, vy = 0;
+#pragma unroll
+      for (int yy = -2; yy <= 2; yy++) {
+#pragma unroll
+        for (int xx = -2; xx <= 2; xx++) {
+          const float s = in[mirror2(x + xx, y + yy, iw, ih)];
+          vx += v5c((xx + 2) + (yy + 2) * 5) * s;
+          vy += v5c((yy + 2) + (xx + 2) * 5) * s;
+        }
+      }
+      ev_finish(dst, y * iw + x, vx, vy);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ edge strength
@@ -879,7 +902,7 @@ void thincubic(hipStream_t s, float *out, const float *in, const float *vxy, int
   hipLaunchKernelGGL(k_thincubic, grid2(iw, ih), block2, 0, s, out, in, (const float2 *)vxy, iw, ih);
 }
 void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih, uint32_t *pack_out, const float *a, const float *b) {
-  hipLaunchKernelGGL(k_edgevec, grid2(iw, ih), block2, 0, s, (float2 *)vxy, in, iw, ih, pack_out, a, b);
+  hipLaunchKernelGGL(k_edgevec, dim3(cdiv(iw, 64), cdiv(ih, 4 * EV_PX)), block2, 0, s, (float2 *)vxy, in, iw, ih, pack_out, a, b);
 }
 void edge_plab(hipStream_t s, float *out, const uint32_t *in, int iw, int ih) {
   hipLaunchKernelGGL(k_edge_plab, grid2(iw, ih), block2, 0, s, out, in, iw, ih);
