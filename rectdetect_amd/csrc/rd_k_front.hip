@@ -541,31 +541,10 @@ __global__ __launch_bounds__(256) void k_edgevec(float2 *__restrict__ dst, const
 // iu:422-437 on the blurred packed Lab: per channel (NW-SE)(N+W-S-E) + (NE-SW)(N-W+E-S), clamped at 0, summed, sqrt
 // (blocks whose 3x3 windows stay inside the frame - all but the frame's rim - address their neighbours by constant offsets: the
 //  mirrored-index arithmetic of the general form costs as many instructions as the gradient itself)
-__global__ __launch_bounds__(256) void k_edge_plab(float *__restrict__ out, const uint32_t *__restrict__ in, int iw, int ih) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
-  if (x >= iw || y >= ih) return;
-  float n[3], s[3], w[3], e[3], nw[3], ne[3], sw[3], se[3];
-  const bool interior = blockIdx.x > 0 && blockIdx.y > 0 && (int)(blockIdx.x * 64 + 64) < iw && (int)(blockIdx.y * 4 + 4) < ih;
-  if (interior) {
-    const uint32_t *c = in + (size_t)y * iw + x;
-    unpack_lab(c[-iw], n[0], n[1], n[2]);
-    unpack_lab(c[iw], s[0], s[1], s[2]);
-    unpack_lab(c[-1], w[0], w[1], w[2]);
-    unpack_lab(c[1], e[0], e[1], e[2]);
-    unpack_lab(c[-iw - 1], nw[0], nw[1], nw[2]);
-    unpack_lab(c[-iw + 1], ne[0], ne[1], ne[2]);
-    unpack_lab(c[iw - 1], sw[0], sw[1], sw[2]);
-    unpack_lab(c[iw + 1], se[0], se[1], se[2]);
-  } else {
-    unpack_lab(in[mirror2(x, y - 1, iw, ih)], n[0], n[1], n[2]);
-    unpack_lab(in[mirror2(x, y + 1, iw, ih)], s[0], s[1], s[2]);
-    unpack_lab(in[mirror2(x - 1, y, iw, ih)], w[0], w[1], w[2]);
-    unpack_lab(in[mirror2(x + 1, y, iw, ih)], e[0], e[1], e[2]);
-    unpack_lab(in[mirror2(x - 1, y - 1, iw, ih)], nw[0], nw[1], nw[2]);
-    unpack_lab(in[mirror2(x + 1, y - 1, iw, ih)], ne[0], ne[1], ne[2]);
-    unpack_lab(in[mirror2(x - 1, y + 1, iw, ih)], sw[0], sw[1], sw[2]);
-    unpack_lab(in[mirror2(x + 1, y + 1, iw, ih)], se[0], se[1], se[2]);
-  }
+// (every thread handles EP_PX pixels below one another: a column of four unpacks 6 x 3 cells instead of 32)
+#define EP_PX 4
+__device__ __forceinline__ float ep_strength(const float (&n)[3], const float (&s)[3], const float (&w)[3], const float (&e)[3],
+                                             const float (&nw)[3], const float (&ne)[3], const float (&sw)[3], const float (&se)[3]) {
   float sum[3];
 #pragma unroll
   for (int c = 0; c < 3; c++) {
@@ -577,7 +556,39 @@ __global__ __launch_bounds__(256) void k_edge_plab(float *__restrict__ out, cons
     sum[c] = fmaxf(0.0f, acc);
   }
   const float tot = sum[0] + sum[1] + sum[2];
-  out[y * iw + x] = tot > 0 ? sqrtf(tot) : 0.0f;
+  return tot > 0 ? sqrtf(tot) : 0.0f;
+}
+__global__ __launch_bounds__(256) void k_edge_plab(float *__restrict__ out, const uint32_t *__restrict__ in, int iw, int ih) {
+  const int x = blockIdx.x * 64 + threadIdx.x, y0 = (blockIdx.y * 4 + threadIdx.y) * EP_PX;
+  if (x >= iw || y0 >= ih) return;
+  const bool interior = blockIdx.x > 0 && blockIdx.y > 0 && (int)(blockIdx.x * 64 + 64) < iw && (int)((blockIdx.y * 4 + 4) * EP_PX) < ih;
+  if (interior) {
+    float u[EP_PX + 2][3][3];       // [row][column][channel]
+#pragma unroll
+    for (int r = 0; r < EP_PX + 2; r++) {
+      const uint32_t *c = in + (size_t)(y0 + r - 1) * iw + x;
+#pragma unroll
+      for (int k = 0; k < 3; k++) unpack_lab(c[k - 1], u[r][k][0], u[r][k][1], u[r][k][2]);
+    }
+#pragma unroll
+    for (int k = 0; k < EP_PX; k++)
+      out[(y0 + k) * iw + x] = ep_strength(u[k][1], u[k + 2][1], u[k + 1][0], u[k + 1][2], u[k][0], u[k][2], u[k + 2][0], u[k + 2][2]);
+    return;
+  }
+  for (int k = 0; k < EP_PX; k++) {
+    const int y = y0 + k;
+    if (y >= ih) break;
+    float n[3], s[3], w[3], e[3], nw[3], ne[3], sw[3], se[3];
+    unpack_lab(in[mirror2(x, y - 1, iw, ih)], n[0], n[1], n[2]);
+    unpack_lab(in[mirror2(x, y + 1, iw, ih)], s[0], s[1], s[2]);
+    unpack_lab(in[mirror2(x - 1, y, iw, ih)], w[0], w[1], w[2]);
+    unpack_lab(in[mirror2(x + 1, y, iw, ih)], e[0], e[1], e[2]);
+    unpack_lab(in[mirror2(x - 1, y - 1, iw, ih)], nw[0], nw[1], nw[2]);
+    unpack_lab(in[mirror2(x + 1, y - 1, iw, ih)], ne[0], ne[1], ne[2]);
+    unpack_lab(in[mirror2(x - 1, y + 1, iw, ih)], sw[0], sw[1], sw[2]);
+    unpack_lab(in[mirror2(x + 1, y + 1, iw, ih)], se[0], se[1], se[2]);
+    out[y * iw + x] = ep_strength(n, s, w, e, nw, ne, sw, se);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ non-max suppression
@@ -905,7 +916,7 @@ void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih, uint32_
   hipLaunchKernelGGL(k_edgevec, dim3(cdiv(iw, 64), cdiv(ih, 4 * EV_PX)), block2, 0, s, (float2 *)vxy, in, iw, ih, pack_out, a, b);
 }
 void edge_plab(hipStream_t s, float *out, const uint32_t *in, int iw, int ih) {
-  hipLaunchKernelGGL(k_edge_plab, grid2(iw, ih), block2, 0, s, out, in, iw, ih);
+  hipLaunchKernelGGL(k_edge_plab, dim3(cdiv(iw, 64), cdiv(ih, 4 * EP_PX)), block2, 0, s, out, in, iw, ih);
 }
 void thinthres(hipStream_t s, float *out, const float *in, const float *vxy, int iw, int ih) {
   hipLaunchKernelGGL(k_thinthres, dim3(cdiv(iw, 64), cdiv(ih, TT_ROWS)), dim3(64, 4), 0, s, out, in, (const float2 *)vxy, iw, ih);
