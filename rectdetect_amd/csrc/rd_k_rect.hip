@@ -493,31 +493,37 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
   // (also: the round / flatten flags start at zero, and the size plane starts from size_init - quirk H2 - without extra launches)
   if (blockIdx.x == 0 && blockIdx.y == 0) { const int t = threadIdx.y * 64 + threadIdx.x; if (t < 64) flags[t] = 0; }
   const int tx = threadIdx.x, x = blockIdx.x * 64 + tx, y0 = blockIdx.y * RI_ROWS;
-  // four rows at a time, all of their loads in flight together (clamped addresses; what a pixel may not use is ignored)
+  // four rows below one another per thread (each the other's vertical neighbour: 31 instead of 40 loads), all of their loads in flight
+  // together (clamped addresses; what a pixel may not use is ignored)
 #pragma unroll
   for (int half = 0; half < RI_ROWS / 16; half++) {
     int v[4], vu[4], vl[4], vr[4], vd[4], mk[4], e0[4], er[4], ed[4], si[4];
     bool in[4], inter[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const int y = y0 + threadIdx.y + 4 * (half * 4 + k);
+      const int y = y0 + (half * 4 + threadIdx.y) * 4 + k;
       in[k] = x < iw && y < ih;
       inter[k] = in[k] && x > 0 && y > 0 && x < iw - 1 && y < ih - 1;
       const int p = in[k] ? y * iw + x : 0;
       v[k] = pix[p];
-      vu[k] = pix[(in[k] && y > 0) ? p - iw : p];
+      if (k == 0) vu[k] = pix[(in[k] && y > 0) ? p - iw : p];
       vl[k] = pix[(in[k] && x > 0) ? p - 1 : p];
       vr[k] = pix[inter[k] ? p + 1 : p];
-      vd[k] = pix[inter[k] ? p + iw : p];
+      if (k == 3) vd[k] = pix[inter[k] ? p + iw : p];
       mk[k] = mask[p];
       e0[k] = edge[p];
       er[k] = edge[inter[k] ? p + 1 : p];
-      ed[k] = edge[inter[k] ? p + iw : p];
+      if (k == 3) ed[k] = edge[inter[k] ? p + iw : p];
       si[k] = size_out ? size_init[p] : 0;
     }
 #pragma unroll
+    for (int k = 0; k < 4; k++) {      // (the vertical neighbours inside the thread's own column)
+      if (k > 0) vu[k] = v[k - 1];
+      if (k < 3) { vd[k] = v[k + 1]; ed[k] = e0[k + 1]; }
+    }
+#pragma unroll
     for (int k = 0; k < 4; k++) {
-      const int r = threadIdx.y + 4 * (half * 4 + k);
+      const int r = (half * 4 + threadIdx.y) * 4 + k;
       const int y = y0 + r;
       int l = r * 64 + tx;
       if (in[k]) {
