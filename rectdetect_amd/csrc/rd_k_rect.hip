@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void k_rect_tidy(int *__restrict__ mask0, int 
 //       c > n-1, or (centre on an edge ? !E[c] : !E[c] & E[c+1]).
 // Cells outside the frame are staged as zero, which makes the reference's `c < n-1` and `has side cell` tests redundant.
 // A pixel then reads its five relevant stop bits per direction and counts the leading clear ones.
-#define BE_ROWS 16
+#define BE_ROWS 32
 #define BE_NR (BE_ROWS + 11)          // rows y0-5 .. y0+BE_ROWS+5
 __global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ ext, const int8_t *__restrict__ edge, int iw, int ih) {
   typedef unsigned long long u64;
