@@ -449,7 +449,7 @@ __device__ __forceinline__ void mm_rows(const unsigned long long *sb, int r, uns
 // output row then evaluates the three tests for all 64 columns of its row at once - every (dy, dx) of a test is one shifted OR of
 // a 64-bit word instead of a 17-bit window test per pixel and row offset (262 -> 45 vector instructions per pixel) - and all
 // threads expand the result bits into the int plane.
-#define MM_ROWS 32
+#define MM_ROWS 64
 __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const unsigned long long *__restrict__ bits, int iw, int ih, int wpr) {
   __shared__ unsigned long long sb[(MM_ROWS + 16) * 6];
   __shared__ unsigned long long res[MM_ROWS];
