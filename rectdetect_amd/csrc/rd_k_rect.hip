@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const 
 // One block per 64 x RI_ROWS tile: the links that stay inside the tile are followed to their end in LDS (pointer doubling),
 // so every pixel leaves pointing either at the root of its initial tree (if that root lies in the tile) or at the first
 // pixel outside the tile on its way up/left; the few remaining tile-to-tile hops are left to k_region_flatten.
-#define RI_ROWS 16
+#define RI_ROWS 32
 __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, const int *__restrict__ pix, const int *__restrict__ mask,
                                                      const int *__restrict__ edge, int iw, int ih, int *__restrict__ flags, int *__restrict__ size_out, const int *__restrict__ size_init) {
   __shared__ int par[64 * RI_ROWS];     // >= 0: tile-local index of the parent; < 0: -(global index) - 1 of a parent outside the tile
