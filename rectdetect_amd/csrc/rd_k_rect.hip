@@ -591,16 +591,17 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
 // costs 6 + 2 + 12 label loads instead of 30 (measured at full rate, same box: 2, 3, 4, 6, 8 pixels: 2056, 2080, 2083 / 2067, 2079, 2062
 // frames/s) - and issues all of their label loads before using any, then the first pointer jumps together.
 #define RR_PX 6
+#define RR_TY 8          // thread rows per block (2 / 4 / 8 at full rate: 2094 / 2118 / 2124 frames/s)
 #define RR_MBITS 3
 __device__ __forceinline__ int rr_label(const int *X, unsigned q) { return at32(X, q) >> RR_MBITS; }
-__global__ __launch_bounds__(256) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round) {
+__global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round) {
   if (round > 0 && flags[round - 1] == 0) return;
   __shared__ int hk[512], hv[512];
   const int tid = threadIdx.y * 64 + threadIdx.x;
-  for (int t = tid; t < 512; t += 256) { hk[t] = -1; hv[t] = 0x7fffffff; }
+  for (int t = tid; t < 512; t += 64 * RR_TY) { hk[t] = -1; hv[t] = 0x7fffffff; }
   __syncthreads();
   const int mark = 1 + round % 7, mark_prev = round > 0 ? 1 + (round - 1) % 7 : 8;      // (8: matches nothing - before round 0 no plane lags)
-  const int yb = blockIdx.y * (4 * RR_PX) + threadIdx.y * RR_PX;      // the thread's RR_PX pixels lie below one another: each is the other's vertical neighbour
+  const int yb = blockIdx.y * (RR_TY * RR_PX) + threadIdx.y * RR_PX;      // the thread's RR_PX pixels lie below one another: each is the other's vertical neighbour
   const int x = blockIdx.x * 64 + threadIdx.x;
   int p0[RR_PX], og[RR_PX], g[RR_PX], nx[RR_PX], w0[RR_PX];
   unsigned a[RR_PX];
@@ -678,7 +679,7 @@ __global__ __launch_bounds__(256) void k_region_round(int *X, int *Y, const uint
   }
   if (__any(any_todo) && threadIdx.x == 0) flags[round] = 1;
   __syncthreads();
-  for (int t = tid; t < 512; t += 256) {
+  for (int t = tid; t < 512; t += 64 * RR_TY) {
     const int key = hk[t];
     if (key != -1) { const int w = (hv[t] << RR_MBITS) | mark; if (w < ld_agent(&Y[key])) atomicMin(&Y[key], w); }
   }
@@ -1361,10 +1362,10 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
     const bool last = r == FLAT - 1 && ROUNDS > 0;
     hipLaunchKernelGGL(k_region_flatten, dim3(ew_grid(n)), dim3(256), 0, s, P, n, fflags, r, last ? A : (int *)nullptr, last ? B : (int *)nullptr);
   }
-  const dim3 grid(cdiv(iw, 64), cdiv(ih, 4 * RR_PX));
+  const dim3 grid(cdiv(iw, 64), cdiv(ih, RR_TY * RR_PX));
   for (int r = 0; r < ROUNDS; r++) {
-    if (r & 1) hipLaunchKernelGGL(k_region_round, grid, block2, 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r);
-    else hipLaunchKernelGGL(k_region_round, grid, block2, 0, s, A, B, (const uint8_t *)allow, iw, ih, flags, r);
+    if (r & 1) hipLaunchKernelGGL(k_region_round, grid, dim3(64, RR_TY), 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r);
+    else hipLaunchKernelGGL(k_region_round, grid, dim3(64, RR_TY), 0, s, A, B, (const uint8_t *)allow, iw, ih, flags, r);
   }
   if (marked) *marked = ROUNDS > 0;
 }
