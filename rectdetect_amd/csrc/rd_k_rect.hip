@@ -167,7 +167,8 @@ __global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ e
 // (one fused multiply-add: float(s) * (1/w) + 0.5 * (1/w), rounded once - the explicit fma is part of the checked formula, not a contraction)
 __device__ __forceinline__ unsigned div_small_f(unsigned s, float2 rw) { return (unsigned)__fmaf_rn((float)s, rw.x, rw.y); }
 
-__global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih) {
+#define BP_TY 16         // thread rows per block (4 / 8 / 16 at full rate: 2003 / 2111 / 2126 frames/s)
+__global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih) {
   __shared__ uint2 src[(BP_ROWS + 8) * BP_SW + 1];
   __shared__ uint2 hz[(BP_ROWS + 8) * 64 + 1];
   __shared__ float2 rwt[16];                                     // (1 / w correctly rounded, half of it)
@@ -179,7 +180,7 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
   // that their latency overlaps the staging of the tile
   // (every load below is unconditional - the address of a cell outside the frame is clamped, its value replaced afterwards -
   //  so that all eight are in flight together: a block's critical path holds one trip to memory, not one per staging step)
-  constexpr int NH = (BP_ROWS + 8 + 15) / 16, NV = BP_ROWS / 16, NQ = ((BP_ROWS + 8) * 72 + 1023) / 1024;
+  constexpr int NT = 64 * BP_TY, NH = (BP_ROWS + 8 + BP_TY - 1) / BP_TY, NV = BP_ROWS / BP_TY, NQ = ((BP_ROWS + 8) * 72 + NT - 1) / NT;
   unsigned eh[NH], ev[NV];
   uint32_t q[NQ];
   bool okh[NH], okv[NV], okq[NQ];
@@ -190,13 +191,13 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
   if (interior) {
     const unsigned eb = (unsigned)((y0 - 4 + ty) * iw + x);
 #pragma unroll
-    for (int k = 0; k < NH; k++) { okh[k] = ty + 16 * k < BP_ROWS + 8; eh[k] = okh[k] ? atu(ext, eb + (unsigned)(16 * k * iw)) : (uint16_t)0; }
+    for (int k = 0; k < NH; k++) { okh[k] = ty + BP_TY * k < BP_ROWS + 8; eh[k] = okh[k] ? atu(ext, eb + (unsigned)(BP_TY * k * iw)) : (uint16_t)0; }
 #pragma unroll
-    for (int k = 0; k < NV; k++) { okv[k] = true; ev[k] = atu(ext, eb + (unsigned)((16 * k + 4) * iw)); }
+    for (int k = 0; k < NV; k++) { okv[k] = true; ev[k] = atu(ext, eb + (unsigned)((BP_TY * k + 4) * iw)); }
     const unsigned ib = (unsigned)((y0 - 4) * iw + x0 - 4);
 #pragma unroll
     for (int i = 0; i < NQ; i++) {
-      const int t = tid + 1024 * i;
+      const int t = tid + NT * i;
       const int r = t / 72, c = t % 72;
       okq[i] = t < (BP_ROWS + 8) * 72;
       q[i] = okq[i] ? atu(in, ib + (unsigned)(r * iw + c)) : 0u;
@@ -204,19 +205,19 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
   } else {
 #pragma unroll
   for (int k = 0; k < NH; k++) {
-    const int y = y0 - 4 + ty + 16 * k;
-    okh[k] = ty + 16 * k < BP_ROWS + 8 && x < iw && y >= 0 && y < ih;
+    const int y = y0 - 4 + ty + BP_TY * k;
+    okh[k] = ty + BP_TY * k < BP_ROWS + 8 && x < iw && y >= 0 && y < ih;
     eh[k] = atu(ext, okh[k] ? (unsigned)(y * iw + x) : 0u);
   }
 #pragma unroll
   for (int k = 0; k < NV; k++) {
-    const int y = y0 + ty + 16 * k;
+    const int y = y0 + ty + BP_TY * k;
     okv[k] = x < iw && y < ih;
     ev[k] = atu(ext, okv[k] ? (unsigned)(y * iw + x) : 0u);
   }
 #pragma unroll
   for (int i = 0; i < NQ; i++) {
-    const int t = tid + 1024 * i;
+    const int t = tid + NT * i;
     const int r = t / 72, c = t % 72;
     const int xx = x0 - 4 + c, yy = y0 - 4 + r;
     okq[i] = t < (BP_ROWS + 8) * 72 && xx >= 0 && xx < iw && yy >= 0 && yy < ih;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
   if (tid < 16) { const float r = tid >= 1 && tid <= 10 ? 1.0f / (float)tid : 0.0f; rwt[tid] = make_float2(r, 0.5f * r); }
 #pragma unroll
   for (int i = 0; i < NQ; i++) {
-    const int t = tid + 1024 * i;
+    const int t = tid + NT * i;
     const uint32_t v = okq[i] ? q[i] : 0u;
     if (t < (BP_ROWS + 8) * 72) src[(t / 72) * BP_SW + t % 72] = make_uint2((v & 4095u) | ((v << 4) & 0x3ff0000u), v >> 22);
   }
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < NH; k++) {
-    const int r = ty + 16 * k;
+    const int r = ty + BP_TY * k;
     if (r >= BP_ROWS + 8) break;
     const unsigned e = eh[k];
     const int nl = e & 7, nr = (e >> 3) & 7;
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(1024) void k_blblur_pair(uint32_t *__restrict__ out
   if (x >= iw) return;
 #pragma unroll
   for (int k = 0; k < NV; k++) {
-    const int r = ty + 16 * k;
+    const int r = ty + BP_TY * k;
     const int y = y0 + r;
     if (y >= ih) break;
     const unsigned e = ev[k] >> 6;
@@ -1328,7 +1329,7 @@ void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, in
   hipLaunchKernelGGL(k_blblur_extents, dim3(cdiv(iw, 64), cdiv(ih, BE_ROWS)), dim3(64, 4), 0, s, ext, edge, iw, ih);
 }
 void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih) {
-  hipLaunchKernelGGL(k_blblur_pair, dim3(cdiv(iw, 64), cdiv(ih, BP_ROWS)), dim3(64, 16), 0, s, out, ext, in, iw, ih);
+  hipLaunchKernelGGL(k_blblur_pair, dim3(cdiv(iw, 64), cdiv(ih, BP_ROWS)), dim3(64, BP_TY), 0, s, out, ext, in, iw, ih);
 }
 // fills the quantisation tables of the current device (once per device, before its first frame; the caller synchronises)
 void quant_lut_init(hipStream_t s) { hipLaunchKernelGGL(k_quant24_lut, dim3(20), dim3(256), 0, s); }
