@@ -169,10 +169,13 @@ __device__ __forceinline__ unsigned div_small_f(unsigned s, float2 rw) { return 
 
 #define BP_TY 16         // thread rows per block (4 / 8 / 16 at full rate: 2003 / 2111 / 2126 frames/s)
 __global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih) {
-  __shared__ uint2 src[(BP_ROWS + 8) * BP_SW + 1];
-  __shared__ uint2 hz[(BP_ROWS + 8) * 64 + 1];
+  // one array: the staged input, the horizontal result, and a REGION of zeros - the sample beyond a run is read at `zero region + the
+  // same constant offset as the sample inside the run`, so that a sample's address is one select between two registers and the offset
+  // travels in the load instruction (with single zero slots the compiler paid an add or a constant per sample)
+  constexpr int SRC_N = (BP_ROWS + 8) * BP_SW, HZ_N = (BP_ROWS + 8) * 64, ZR_N = 2048 / 8 + 8;
+  __shared__ uint2 lds[SRC_N + HZ_N + ZR_N];
+  uint2 *const src = lds, *const hz = lds + SRC_N;
   __shared__ float2 rwt[16];                                     // (1 / w correctly rounded, half of it)
-  const int ZS = (BP_ROWS + 8) * BP_SW, ZH = (BP_ROWS + 8) * 64;   // zero slots
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BP_ROWS;
   const int x = x0 + tx;
@@ -224,7 +227,9 @@ __global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict
     q[i] = atu(in, okq[i] ? (unsigned)(yy * iw + xx) : 0u);
   }
   }
-  if (tid == 0) { src[ZS] = make_uint2(0, 0); hz[ZH] = make_uint2(0, 0); }
+  if (tid < ZR_N) lds[SRC_N + HZ_N + tid] = make_uint2(0, 0);
+  unsigned zrs = (unsigned)(SRC_N + HZ_N) * 8u, zrh = (unsigned)ZR_N * 0u + (unsigned)HZ_N * 8u;      // the zero region's byte offset from `src` / from `hz`
+  asm volatile("" : "+v"(zrs), "+v"(zrh));      // (opaque to the optimiser: it would fold the per-sample constants into them again)
   if (tid < 16) { const float r = tid >= 1 && tid <= 10 ? 1.0f / (float)tid : 0.0f; rwt[tid] = make_float2(r, 0.5f * r); }
 #pragma unroll
   for (int i = 0; i < NQ; i++) {
@@ -246,11 +251,11 @@ __global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict
     const int c = r * BP_SW + tx + 4;
     uint2 v[10];
     // (byte addresses: a sample's address is `selected base + constant`, so the constant travels in the instruction)
-    const unsigned cb = (unsigned)c * 8u, zb = (unsigned)ZS * 8u;
+    const unsigned cb = (unsigned)c * 8u, cbm = cb - 32u;
 #pragma unroll
     for (int d = 0; d < 5; d++) {
-      v[d] = *(const uint2 *)((const char *)src + ((d < nl ? cb - 32u : zb - (32u - 8u * d)) + (32u - 8u * d)));
-      v[5 + d] = *(const uint2 *)((const char *)src + ((d < nr ? cb : zb - 8u * d) + 8u * d));
+      v[d] = *(const uint2 *)((const char *)src + ((d < nl ? cbm : zrs) + (32u - 8u * d)));
+      v[5 + d] = *(const uint2 *)((const char *)src + ((d < nr ? cb : zrs) + 8u * d));
     }
     unsigned lo = 0, hi = 0;
 #pragma unroll
@@ -274,11 +279,11 @@ __global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict
     const int nl = e & 7, nr = (e >> 3) & 7;
     const int c = (r + 4) * 64 + tx;
     uint2 v[10];
-    const unsigned cb = (unsigned)c * 8u, zb = (unsigned)ZH * 8u;
+    const unsigned cb = (unsigned)c * 8u, cbm = cb - 2048u;
 #pragma unroll
     for (int d = 0; d < 5; d++) {
-      v[d] = *(const uint2 *)((const char *)hz + ((d < nl ? cb - 2048u : zb - (2048u - 512u * d)) + (2048u - 512u * d)));
-      v[5 + d] = *(const uint2 *)((const char *)hz + ((d < nr ? cb : zb - 512u * d) + 512u * d));
+      v[d] = *(const uint2 *)((const char *)hz + ((d < nl ? cbm : zrh) + (2048u - 512u * d)));
+      v[5 + d] = *(const uint2 *)((const char *)hz + ((d < nr ? cb : zrh) + 512u * d));
     }
     unsigned lo = 0, hi = 0;
 #pragma unroll
