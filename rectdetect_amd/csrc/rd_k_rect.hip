@@ -643,11 +643,15 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
 #pragma unroll
       for (int c = 0; c < 5; c++) e[c] = l[k][c] >> RR_MBITS;
       og[k] = e[0];
+      // the smallest label among the pixel itself and the neighbours it may adopt from: a neighbour that is not allowed counts as
+      // +infinity (bit k of `a` spread over a word selects the label or 0x7fffffff: two operations per neighbour, no compares)
       int m = e[0];
-      if ((a[k] & 1) && e[1] < m) m = e[1];
-      if ((a[k] & 2) && e[2] < m) m = e[2];
-      if ((a[k] & 4) && e[3] < m) m = e[3];
-      if ((a[k] & 8) && e[4] < m) m = e[4];
+#pragma unroll
+      for (int c = 1; c < 5; c++) {
+        const int t = __builtin_amdgcn_sbfe((int)a[k], c - 1, 1);      // -1 if allowed, else 0
+        const int xk = (e[c] & t) | (0x7fffffff & ~t);
+        m = xk < m ? xk : m;
+      }
       g[k] = (a[k] & 16) ? m : e[0];
     }
   }
