@@ -3,10 +3,14 @@
 
 One "step" = one batch of FRAMES_PER_STEP consecutive frames of a synthetic 1920x1080 vidrect stream (BASELINE.json
 configs[4]: independent streams, one per GPU) pushed through the whole hot path: device stages on gfx950, read-back of
-segments + probes, host post-process -> rectangle lists.  Frames are resident in HBM before the timed region starts.
+segments + probes, host post-process -> rectangle lists.  `value`: frames resident in HBM before the timed region starts (the
+bench contract); `value_host_frames`: the same run with host buffers handed over, i.e. SURVEY.md 8(d)'s unit of work with the
+PCIe upload inside the timed region.  `configs`: the other single-GPU configurations of BASELINE.json (1280x720 x 300 frames,
+3840x2160 x 16 frames) measured by the same process, outside the timed region.
 
 Prints ONE JSON line on rank 0.  Multi-GPU: launched by torch.distributed.run, one rank per GPU, no data-path
-collective (frames are independent); only a barrier and a MAX-reduce of the elapsed time.
+collective (frames are independent); only a barrier, a MAX-reduce of the elapsed time and a gather of a few bytes per rank,
+over gloo (host side: no RCCL communicator and no extra stream on the device the detector is saturating).
 """
 import argparse
 import json
@@ -121,18 +125,64 @@ def pin_to_gpu_cores(L, dev):
         return None
 
 
+def side_config(ra, L, label, iw, ih, seed, nframes, slots, dev, min_seconds=1.5):
+    """one of the other single-GPU configurations of BASELINE.json, the way the headline is measured: `nframes` consecutive frames of the
+    synthetic stream resident in HBM, `slots` frames in flight, one untimed pass (graph capture, round budget), then whole passes over
+    the stream until `min_seconds` have gone by.  Returns the line's `configs` entry."""
+    from rectdetect_amd import synth
+    N = iw * ih
+    dframes = []
+    a = np.zeros((ih, iw, 3), np.uint8)
+    for t in range(nframes):
+        L.rd_synth_frame(a.ctypes.data, iw, ih, iw * 3, synth.SEED0 + seed, t, 1)
+        p = L.rd_device_alloc(a.nbytes)
+        L.rd_upload(p, a.ctypes.data, a.nbytes)
+        dframes.append(p)
+    det = ra.Detector(iw, ih, device=dev, nslots=slots, nworkers=1)
+    nrect = 0
+
+    def one_pass():
+        nonlocal nrect
+        inflight = 0
+        for p in dframes:
+            if inflight == slots:
+                nrect += len(det.poll(TAN_AOV)); inflight -= 1
+            det.enqueue(p, ws=iw * 3, on_device=True)
+            inflight += 1
+        while inflight:
+            nrect += len(det.poll(TAN_AOV)); inflight -= 1
+        det.drain()
+
+    one_pass()
+    nrect = 0
+    passes, t0 = 0, time.perf_counter()
+    while passes < 2 or time.perf_counter() - t0 < min_seconds:
+        one_pass()
+        passes += 1
+    dt = time.perf_counter() - t0
+    fps = passes * nframes / dt
+    out = {"workload": label, "frame": "%dx%d" % (iw, ih), "stream_frames": nframes, "passes": passes, "frames_in_flight": slots, "value": round(fps, 2), "unit": "frames/s",
+           "gpixel_per_s": round(fps * N / 1e9, 3), "roofline_frac": round(fps * B_ALG_PER_PIXEL * N / HBM_PEAK, 4), "rectangles_per_frame": round(nrect / (passes * nframes), 2),
+           "frames_repeated": {"round_budget": det.region_round_budget()[1], "polyline_overflow": det.redone_frames(), "absorption_slow_path": det.absorption()[2]}}
+    det.close()
+    for p in dframes:
+        L.rd_device_free(p)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames-per-step", type=int, default=64)
+    ap.add_argument("--frames-per-step", type=int, default=512, help="frames of the stream resident in HBM and handed over per step (512 x 6.2 MB = 3.2 GB; 20 steps then run about 5 s)")
     ap.add_argument("--slots", type=int, default=16, help="frames in flight per GPU (from three on: one stream per frame on four shared streams; from twelve on: sparse stages in batches of four)")
     ap.add_argument("--host-frames", action="store_true", help="hand over host buffers (PCIe upload inside the timed region); not the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="profiling runs only: skip the sequential verification pass and the host-frames pass (the line then says outputs_verified: null)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercises sharding/aggregation only (CPU tests)")
-    ap.add_argument("--backend", default=None)
+    ap.add_argument("--no-configs", action="store_true", help="skip the side measurements of the 1280x720 and 3840x2160 configurations")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend of the control plane (default gloo: barrier + MAX-reduce of a double need no device)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -143,7 +193,7 @@ def main():
         import torch
         import torch.distributed as dist_mod
         dist = dist_mod
-        backend = args.backend or ("gloo" if args.dry_run else "nccl")
+        backend = args.backend or "gloo"
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend)
@@ -207,9 +257,10 @@ def main():
                 results.append(d.poll(TAN_AOV))
                 inflight -= 1
             d.drain()
-            if dist is not None and dist.get_backend() == "nccl":
+            if dist is not None:
                 import torch
-                torch.cuda.synchronize()
+                if torch.cuda.is_available():      # (the contract's torch.cuda.synchronize(): the detector's own drain() above has already waited for its streams)
+                    torch.cuda.synchronize(dev)
 
     def timed(nsteps, d=None, slots=None):
         t0 = time.perf_counter()
@@ -241,7 +292,7 @@ def main():
         dist.barrier()
 
     # who did what: every rank reports its device, stream seed, frames and time (host-side gather of a few bytes, not a data-path collective)
-    mine = {"rank": rank, "device": None if args.dry_run else dev, "stream_seed": seed_stream, "frames": args.steps * F,
+    mine = {"rank": rank, "device": None if args.dry_run else dev, "stream_seed": seed_stream, "frames": args.steps * F, "frames_per_s": round(args.steps * F / own_elapsed, 2),
             "rectangles": int(sum(len(r) for r in results[args.warmup * F:])), "own_elapsed_s": round(own_elapsed, 4), "pinned_cpus": None if args.dry_run else pinned}
     per_rank = [mine]
     if dist is not None:
@@ -290,7 +341,10 @@ def main():
             "config": {"workload": "vidrect 1920x1080 synthetic stream per GPU (BASELINE.json configs[4]; configs[1] is one frame of it)",
                        "frames_per_step": F, "frames_in_flight": args.slots, "input": "BGR u8 host buffers (PCIe upload timed)" if args.host_frames else "BGR u8 frames resident in HBM", "parallelism": "independent streams, one per GPU, no collective"},
             "ranks": per_rank,
-            "value_host_frames": host_rate,     # frames/s with host BGR buffers handed over (upload inside the timed region), same run, N=1 only
+            "value_definition": "frames resident in HBM when the timed region starts (bench contract); value_host_frames = the same work with host BGR buffers handed over, "
+                                "memcpy into pinned memory + PCIe upload inside the timed region (SURVEY.md 8(d)'s unit of work), same process, N=1 only",
+            "value_host_frames": host_rate,
+            "roofline_frac_host_frames": round(host_rate * B_ALG_PER_PIXEL * N / HBM_PEAK, 4) if host_rate else None,
             "roofline": {"bound": "hbm", "kernel": "whole per-frame device pipeline (all stages, one stream per frame slot)",
                          "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
                          "algorithmic_bytes_per_frame": B_ALG_PER_PIXEL * N,
@@ -308,9 +362,13 @@ def main():
                          "postprocess": {"frames_on_device": post1[0] - post0[0], "frames_on_host": post1[1] - post0[1],
                                          "host_cpu_us_per_frame": round((post1[2] - post0[2]) / max(1, post1[1] - post0[1]), 1)},
                          "region_round_budget": det.region_round_budget()[0] if det is not None else None,
-                         "frames_per_budget_8_12_16_20": [ra.lib().rd_detector_counter(det.h, 6 + k) for k in range(4)] if det is not None else None,
-                         "frames_repeated": {"round_budget": det.region_round_budget()[1], "polyline_overflow": det.redone_frames()} if det is not None else None},
+                         "frames_per_launch_budget": {str(8 + 2 * k): ra.lib().rd_detector_counter(det.h, 20 + k) for k in range(7)} if det is not None else None,
+                         "frames_repeated": {"round_budget": det.region_round_budget()[1], "polyline_overflow": det.redone_frames(), "absorption_slow_path": det.absorption()[2]} if det is not None else None},
         }
+        if det is not None and world == 1 and not args.no_configs and not args.no_verify:
+            # BASELINE.json configs[2] and configs[3] (configs[1], the 1920x1080 still, is a frame of the headline stream), outside the timed region
+            out["configs"] = [side_config(ra, L, "vidrect 1280x720 synthetic 300-frame stream (BASELINE.json configs[2])", 1280, 720, 1, 300, args.slots, dev),
+                              side_config(ra, L, "vidrect 3840x2160 synthetic stream, 16 frames resident (BASELINE.json configs[3])", 3840, 2160, 4, 16, args.slots, dev)]
         out.update(verify or {"outputs_verified": None})
         if not args.dry_run and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()

@@ -30,8 +30,9 @@ typedef struct rd_detector rd_detector;
 /* nslots frames in flight (>= 1); nworkers != 0: the host post-process runs on worker threads, ONE PER SLOT (the value itself is
  * not a thread count), 0: on the polling thread.
  * 1-2 frames in flight: a frame spreads over two HIP streams (shortest latency); from 3 on: one stream per frame, and frames
- * beyond the fourth queue up on the same four streams (the device runs four hardware queues side by side) - 8 gives the highest
- * rate ("Execution"). */
+ * beyond the fourth queue up on the same four streams (the device runs four hardware queues side by side); from 12 on the
+ * sparse stages (polylines, votes, probes) of four consecutive slots share one set of launches - 16 gives the highest rate
+ * ("Execution"). */
 rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nworkers);
 void rd_detector_destroy(rd_detector *d);
 
@@ -43,6 +44,11 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
  * holds nItems), owned by the caller.  Blocks until that frame is done. */
 void *rd_detector_poll(rd_detector *d, double tanAOV);
 
+/* optional: the aperture (tan of half the horizontal angle of view) the polls to come will pass.  The reference's API hands it over with
+ * the poll, after the frame; work that runs ahead of the poll (worker threads, RD_DEVICE_POST=1) uses the last one seen, so without this
+ * call the first frames of a stream are post-processed at poll time on the polling thread. */
+void rd_detector_set_aperture(rd_detector *d, double tanAOV);
+
 /* device-side work only (no host post-process): waits until every enqueued frame has left the GPU */
 void rd_detector_drain(rd_detector *d);
 
@@ -53,11 +59,12 @@ int rd_detector_last_segments(rd_detector *d, void *dst, int max_records);
  * was repeated with the multi-launch path (same results, slower); 1 = device microseconds summed over the polled frames
  * (HIP events on the frame's stream: first kernel start to last copy end, so concurrent frames overlap); 2 = frames in that sum; 3 = host microseconds spent inside rd_detector_enqueue;
  * 4 = frames whose region merge had not settled within the launched round budget and were repeated with all 20 rounds;
- * 5 = the current round budget (8, 12, 16 or 20); 6..9 = frames launched with a budget of 8 / 12 / 16 / 20 rounds;
+ * 5 = the current launch budget of the region merge (8, 10, .. 20); 20..26 = frames launched with a budget of 8 / 10 / .. / 20;
  * 10 = frames with more line segments than the probe buffer holds (65535): the rest took no part in the rectangle search (a
  * message goes to stderr the first time); 11 / 12 = frames whose rectangles came from the device post-process (RD_DEVICE_POST=1:
  * candidate funnel + pose estimation in rd_k_post.hip) / from the host post-process; 13 = microseconds the worker threads spent in the
- * host post-process (sum over frames) */
+ * host post-process (sum over frames); 14 = frames whose small-region absorption (oclrect.cl:348-371) was finished by the slow path -
+ * rounds over work lists until nothing changes - because they left more undecided pixels than the single-block tail holds (frames made of small regions) */
 long rd_detector_counter(rd_detector *d, int which);
 
 /* Test hook: copy an internal plane of the most recently completed frame to host memory.  Returns bytes written,

@@ -708,11 +708,13 @@ void rdo_rect_frame(rdo_rect_t *c, const uint8_t *bgr, int ws) {
   if (c->region_mode == 0) {                               /* the reference in serial raster order */
     rdo_region_label_init(c->region, (const int *)c->quant, iw, ih);
     for (int i = 0; i < 8; i++) rdo_region_merge_pass(c->region, (const int *)c->quant, c->mergemask, c->label1, iw, ih);
-  } else c->region_rounds = rdo_region_sync(c->region, (const int *)c->quant, c->mergemask, c->label1, iw, ih, RDO_REGION_SYNC_MAX_ROUNDS);
+    c->region_rounds = 8;
+  } else                                                   /* the reference with concurrent work-items: 2 = its 8 launches, 1 = launched until nothing changes (SPEC) */
+    c->region_rounds = rdo_region_concurrent(c->region, (const int *)c->quant, c->mergemask, c->label1, iw, ih, c->region_mode == 2 ? 8 : RDO_REGION_MAX_LAUNCHES);
   memcpy(c->rsize, c->junction, sizeof(int) * N);          /* H2: size plane still holds the junction counts */
   rdo_region_size(c->rsize, c->region, N);
-  if (c->region_mode == 0) rdo_despeckle2(c->region, c->rsize, 16, iw, ih);
-  else c->absorb_rounds = rdo_despeckle2_jacobi_k(c->region, c->rsize, 16, iw, ih, NULL, RDO_DESPECKLE2_JACOBI_ROUNDS);
+  rdo_despeckle2(c->region, c->rsize, 16, iw, ih);        /* both modes: the serial raster order's result (what the HIP path computes exactly) */
+  c->absorb_rounds = 0;
 
   /* rh:340-342 region boundaries and their components */
   rdo_mark_boundary(c->boundary_src, c->region, iw, ih);
@@ -728,37 +730,42 @@ void rdo_rect_frame(rdo_rect_t *c, const uint8_t *bgr, int ws) {
   free(fa); free(fb); free(ba); free(bb); free(t0); free(t1); free(e8);
 }
 
-/* ------------------------------------------------------------------ SPEC of the order-free region schedule
+/* ------------------------------------------------------------------ SPEC of the region stages as the HIP path evaluates them
  *
- * The reference's labelMergeMain (rc:300-334, 8 in-place launches) and despeckle2 (rc:348-371, in place) give results that
- * depend on the order in which work-items run: a device is free to pick any order, the serial raster
- * order of rdo_region_merge_pass / rdo_despeckle2 above is only one of them, and no parallel schedule reproduces it.
- * The HIP path therefore evaluates the SAME per-pixel rules in a schedule that has no order in it, and this section is
- * the normative definition of that schedule ("region mode 1" of rdo_rect_frame).  GPU tests compare the region, rsize,
- * boundary_src, boundary and table planes bit for bit against it (tests/test_gpu_parity.py). */
+ * The reference's labelMergeMain (rc:300-334, 8 in-place launches) gives a result that depends on the order in which a device
+ * runs the work-items: the serial raster order of rdo_region_merge_pass above is one legal order, and no parallel
+ * schedule reproduces it.  The HIP path reproduces ANOTHER legal execution of the same kernel - all work-items of a launch
+ * concurrent - bit for bit, and keeps launching until a launch changes nothing ("region mode 1" of rdo_rect_frame; mode 2
+ * stops after the reference's 8 launches and is what oracle/_ref computes under rdcl_set_order(..., 0, 0, 5, 0)).
+ * despeckle2 (rc:348-371, in place; H6) is order dependent as well, but the serial raster order's result is a recurrence the
+ * HIP path evaluates EXACTLY (rd_k_rect.hip: k_absorb_tile / k_absorb_tail), so every mode uses rdo_despeckle2.
+ * GPU tests compare the region, rsize, boundary_src, boundary and table planes bit for bit against mode 1. */
 
-/* rc:289-334 evaluated in SYNCHRONOUS rounds.
- *   start:  every pixel points at the root of its tree of initial links (rc:289-298; links go to smaller indices, so one
- *           ascending sweep resolves them);
- *   round:  every interior pixel evaluates rc:308-333 on the labels of the PREVIOUS round - the smallest label among itself
- *           and the neighbours it may adopt from, followed by the kernel's 8 pointer jumps - and, when that differs from its
- *           label, proposes it for itself and for its old label's pixel; all proposals of a round take effect together
- *           (minimum per target), which is what atomic_min does to concurrent work-items;
- *   end:    the first round without a proposal, or max_rounds rounds (the HIP path launches at most 20).
- * Returns the number of rounds evaluated (the last one of which made no proposal unless max_rounds was hit). */
-int rdo_region_sync(int *label, const int *pix, const int *mask, const int *edge, int iw, int ih, int max_rounds) {
+/* rc:289-334 with the work-items of every launch running CONCURRENTLY: all of them read the labels the launch began with, and
+ * their atomic minima take effect together when it ends - a legal execution of the reference's kernel on a device (OpenCL gives
+ * no guarantee that a work-item sees another one's update within a launch), and the one a parallel device can reproduce bit for
+ * bit.  `launches` = 8 is what the reference enqueues (rh:325-331) - enough in serial orders, where a launch carries a label
+ * across the frame; concurrent work-items pass it on one hop (plus pointer jumps) per launch, and a 1920x1080 frame settles
+ * after about 12 - so the SPEC keeps launching until a launch changes nothing (every later launch would repeat it), at most
+ * `launches`.  The labels start from the raw links of rc:289-298 (the labels a work-item compares are whatever the trees hold at
+ * that moment, not their roots: which regions the merge mask joins depends on that), and the 8 pointer jumps of a work-item
+ * follow the labels as they were when the launch began.  Pixels on the frame's ring are never processed (rc:302) and keep
+ * their links unless a work-item hooks them.  Returns the number of launches evaluated.
+ * oracle/_ref runs the reference's own kernel this way under rdcl_set_order(..., 0, 0, 5, 0); tests/test_cpu_oracle.py
+ * compares the planes of 8 launches. */
+int rdo_region_concurrent(int *label, const int *pix, const int *mask, const int *edge, int iw, int ih, int launches) {
   const int N = iw * ih;
   rdo_region_label_init(label, pix, iw, ih);
-  for (int p = 0; p < N; p++) label[p] = label[label[p]];      /* label[p] <= p, and label[label[p]] is final already */
   int *nxt = (int *)malloc(sizeof(int) * N);
-  int rounds = 0;
-  while (rounds < max_rounds) {
+  int l = 0;
+  for (; l < launches; l++) {
     int changed = 0;
     memcpy(nxt, label, sizeof(int) * N);
     for (int y = 1; y < ih - 1; y++)
       for (int x = 1; x < iw - 1; x++) {
         const int p0 = y * iw + x;
         const int og = label[p0];
+        if (og == -1) continue;
         int g = og;
         const int any = mask[p0] != 0;
         int p1, s;
@@ -774,17 +781,17 @@ int rdo_region_sync(int *label, const int *pix, const int *mask, const int *edge
         }
       }
     memcpy(label, nxt, sizeof(int) * N);
-    rounds++;
-    if (!changed) break;
+    if (!changed) { l++; break; }       /* (a launch that changes nothing: every later one would repeat it) */
   }
   free(nxt);
-  return rounds;
+  return l;
 }
 
 /* rc:348-371 as `max_rounds` JACOBI rounds of the raster-order recurrence: in round r+1 a small-region pixel picks the
  * largest region among its 3x3 neighbourhood, reading the round-r labels of the four neighbours that precede it in raster
  * order (NW, N, NE, W) and the input labels of the others.  The fixed point of this iteration IS the serial raster result
- * (rdo_despeckle2); the HIP path evaluates 27 rounds.  Returns the rounds evaluated, *nsmall = pixels of small regions. */
+ * (rdo_despeckle2; CPU test) - that is the argument by which the HIP path's parallel evaluation is exact.  Returns the rounds
+ * evaluated, *nsmall = pixels of small regions. */
 int rdo_despeckle2_jacobi_k(int *label, const int *size, int thre, int iw, int ih, int *nsmall, int max_rounds) {
   const int N = iw * ih;
   int *old = (int *)malloc(sizeof(int) * N), *cur = (int *)malloc(sizeof(int) * N), *nxt = (int *)malloc(sizeof(int) * N);

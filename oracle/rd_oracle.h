@@ -54,10 +54,9 @@ void rdo_region_merge_pass(int *label, const int *pix, const int *mask, const in
 void rdo_region_size(int *out, const int *label, int n);
 void rdo_despeckle2(int *label, const int *size, int thre, int iw, int ih);
 void rdo_mark_boundary(int *out, const int *in, int iw, int ih);
-/* SPEC of the order-free schedule the HIP path uses for the region stages (see rd_oracle.c) */
-#define RDO_REGION_SYNC_MAX_ROUNDS 20
-#define RDO_DESPECKLE2_JACOBI_ROUNDS 27
-int rdo_region_sync(int *label, const int *pix, const int *mask, const int *edge, int iw, int ih, int max_rounds);
+/* the reference's region merge with concurrent work-items: what the HIP path reproduces (SPEC, see rd_oracle.c) */
+#define RDO_REGION_MAX_LAUNCHES 64
+int rdo_region_concurrent(int *label, const int *pix, const int *mask, const int *edge, int iw, int ih, int launches);
 int rdo_despeckle2_jacobi_k(int *label, const int *size, int thre, int iw, int ih, int *nsmall, int max_rounds);
 void rdo_reduce_ls(int *table, const int *boundary, const int *lsid, int iw, int ih, int nentry);
 
@@ -76,8 +75,8 @@ typedef struct {
   int *strong, *junction, *mergemask, *region, *rsize, *boundary_src, *boundary, *lsid;
   void *lslist;
   int *table;
-  int region_mode;      /* 0: the reference's in-place kernels in serial raster order; 1: the order-free SPEC schedule (rdo_region_sync + 27 Jacobi rounds) */
-  int region_rounds, absorb_rounds;   /* mode 1: rounds the last frame's merge / absorption evaluated */
+  int region_mode;      /* 0: the reference's in-place merge kernel in serial raster order, 8 launches; 1 (SPEC): with concurrent work-items, launched until nothing changes; 2: concurrent, 8 launches; the absorption always in serial raster order */
+  int region_rounds, absorb_rounds;   /* launches of the merge kernel the last frame evaluated (absorb_rounds: always 0) */
 } rdo_rect_t;
 
 rdo_rect_t *rdo_rect_new(int iw, int ih);

@@ -59,6 +59,7 @@ def _declare(L):
         "rd_detector_enqueue": (ctypes.c_long, [vp, vp, ci, ci]),
         "rd_detector_poll": (vp, [vp, cd]),
         "rd_detector_drain": (None, [vp]),
+        "rd_detector_set_aperture": (None, [vp, cd]),
         "rd_detector_counter": (ctypes.c_long, [vp, ci]),
         "rd_detector_last_segments": (ci, [vp, vp, ci]),
         "rd_detector_debug_plane": (cz, [vp, ctypes.c_char_p, vp, cz]),
@@ -245,12 +246,14 @@ class RectDetector:
 class Detector:
     """The rd_detector extension: frames may already live in HBM, several frames in flight."""
 
-    def __init__(self, iw, ih, device=0, nslots=2, nworkers=0):
+    def __init__(self, iw, ih, device=0, nslots=2, nworkers=0, aperture=None):
         L = lib()
         if L.rd_device_count() <= 0:
             raise RuntimeError("rectdetect_amd: no HIP device visible - there is no CPU fallback")
         self.iw, self.ih, self.N = iw, ih, iw * ih
         self.h = L.rd_detector_create(device, iw, ih, nslots, nworkers)
+        if aperture is not None:      # tan(AOV / 2) of the polls to come (rd_detector_set_aperture): work ahead of the first poll can use it
+            L.rd_detector_set_aperture(self.h, float(aperture))
 
     def enqueue(self, frame, ws=None, on_device=False):
         if on_device:
@@ -272,6 +275,13 @@ class Detector:
     def region_round_budget(self):
         """(current region-merge round budget, frames repeated with the full budget because theirs was too small)"""
         return lib().rd_detector_counter(self.h, 5), lib().rd_detector_counter(self.h, 4)
+
+    def absorption(self):
+        """(undecided pixels the tile kernel of the small-region absorption left to the single-block tail, sweeps the tail took) for the last
+        polled frame, and how many frames so far were finished by the slow path (rd_detector_counter 14)"""
+        w = self.plane("absorb", np.int32, 8)
+        self.absorb_trace = {"steps": int(w[3]), "us_gather": w[4] / 100.0, "us_sweeps": w[5] / 100.0, "us_choose": w[6] / 100.0, "us_pointers": w[7] / 100.0}
+        return int(w[1]), int(w[2]), lib().rd_detector_counter(self.h, 14)
 
     def device_time(self):
         """(summed device microseconds of the polled frames measured with HIP events, number of frames)"""

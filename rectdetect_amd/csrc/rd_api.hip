@@ -272,6 +272,7 @@ cl_event oclpolyline_execute(oclpolyline_t *thiz, cl_mem lsList, int lsListSize,
 }  // extern "C"
 
 // ================================================================================================ detector
+#define RD_NBUDGETS 7       // launch budgets of the region merge: 8, 10, .. 20 (kRoundBudgets)
 #define RD_MAXREC 512       // records copied back per frame without a second transfer (the copy runs at PCIe speed: 16 us for 2048)
 
 struct Slot {
@@ -281,6 +282,7 @@ struct Slot {
   hipEvent_t ev_fork, ev_mm, ev_join;
   hipEvent_t ev_begin, ev_done, ev_strong;   // ev_begin/ev_done carry timestamps: device time of the frame (rd_detector_counter)
   hipEvent_t ev_redo;                        // end of a repeated part of the frame (slot_finish_device)
+  hipStream_t st_redo;                       // created on first use: the slow absorption path (frame_absorb_slow)
   uint8_t *bgr;
   uint32_t *plab0, *plab1, *smooth, *quant;
   float *tr[3], *fw[3], *bw[3], *hz[3], *bl[3], *vxy, *strength, *nms;
@@ -304,7 +306,7 @@ struct Slot {
   int ws;
   // captured launch sequences (three segments, see enqueue_frame) and the stride they were captured for
   hipGraphExec_t gexec[3]; int graph_ws;   // gexec[2] unused: the last segment has one graph per round budget (gexec2)
-  hipGraphExec_t gexec2[8];                // [round budget index][polyline mode]
+  hipGraphExec_t gexec2[2 * RD_NBUDGETS];  // [round budget index][polyline mode]
   int poly_mode;                           // polyline mode of the frame in flight (1 = single launch, 0 = multi-launch)
   int rounds;                             // region-merge round budget of the frame in flight
   // post-process worker
@@ -333,10 +335,10 @@ struct rd_detector {
   long next_enqueue, next_poll;
   int last_polled_slot;
   void *last_segs; int last_nsegs;
-  int use_graph, poly_mode, force_redo, diag_no_post, diag_skip, fork_poly, fixed_rounds; long n_redo, n_redo_rounds;
+  int use_graph, poly_mode, force_redo, diag_no_post, diag_skip, fork_poly, fixed_rounds; long n_redo, n_redo_rounds, n_redo_absorb;
   int overflow_streak;
   int poly_overflows;                     // set once two frames in a row overflowed the single-launch polyline kernel: later frames go multi-launch
-  int rounds_budget, need_hist[64]; unsigned need_pos; long budget_count[4];
+  int rounds_budget, need_hist[64]; unsigned need_pos; long budget_count[RD_NBUDGETS];
   long host_enqueue_ns;      // wall time the caller spent inside rd_detector_enqueue
   long dev_us, dev_frames;   // sum over polled frames of (last kernel end - first kernel start) on the frame's stream, HIP events
   double tan_aov; int have_tan;    // what the workers use ahead of the poll that asks for the result
@@ -417,6 +419,7 @@ static void slot_free(Slot *s) {
   dfree(s->post_scratch); if (s->h_post) RD_HIP(hipHostFree(s->h_post));
   RD_HIP(hipEventDestroy(s->ev_begin)); RD_HIP(hipEventDestroy(s->ev_done)); RD_HIP(hipEventDestroy(s->ev_strong));
   RD_HIP(hipEventDestroy(s->ev_fork)); RD_HIP(hipEventDestroy(s->ev_mm)); RD_HIP(hipEventDestroy(s->ev_join)); RD_HIP(hipEventDestroy(s->ev_redo)); RD_HIP(hipEventDestroy(s->ev_dense));
+  if (s->st_redo) RD_HIP(hipStreamDestroy(s->st_redo));
   if (!s->shares_streams) {
     RD_HIP(hipStreamDestroy(s->st2));
     RD_HIP(hipStreamDestroy(s->st));
@@ -465,10 +468,24 @@ static void frame_regions(rd_detector *d, Slot *s) {
   rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih, (d->diag_skip & 2) ? 0 : s->rounds,
                     s->rsize, s->junction, &marked);   // H2: the sizes start from the junction counts (copied by the first kernel)
   rdk::region_size(st, s->rsize, s->region0, N, d2scratch + N, marked);      // (also strips the rounds' marks from the labels)
-  rdk::despeckle2(st, s->region, s->region0, d2scratch, s->rsize, 16, iw, ih, 1);
+  rdk::despeckle2(st, s->region, s->region0, d2scratch, s->rsize, 16, iw, ih, 1, s->scratch2 + N + 20);   // (status words: they travel to the host with the round flags)
 
   // region boundaries and their components (oclrect.c:340-342)
   rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, iw, ih, s->table, s->claim, s->tlist);   // (also undoes the previous frame's vote-table entries)
+}
+
+// The absorption of small regions again for a frame the two fast launches could not finish (h_ctr[52] != 0: more undecided pixels than
+// the single-block tail holds, or dependency chains that wind through more rows than it sweeps - frames that consist of small
+// regions), by rounds over work lists until nothing changes, then everything downstream of it.  Runs on a stream of the slot's own
+// that is never captured (the loop synchronises), after the frame's ev_done: nothing else touches the slot's planes.
+static void frame_absorb_slow(rd_detector *d, Slot *s) {
+  if (!s->st_redo) RD_HIP(hipStreamCreateWithFlags(&s->st_redo, hipStreamNonBlocking));
+  hipStream_t st = s->st_redo;
+  rdk::despeckle2_slow(st, s->region, s->region0, s->d2s, s->rsize, 16, d->iw, d->ih);
+  rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, d->iw, d->ih, s->table, s->claim, s->tlist);
+  frames_votes(d, s->frame, 1, st, 1, 0);
+  RD_HIP(hipStreamSynchronize(st));
+  s->h_ctr[52] = 0;
 }
 
 static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
@@ -544,12 +561,12 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
 // and every launched round costs two dispatches even when it exits at once, so the budget follows what recent frames
 // needed (+ margin).  A frame whose last launched round still changed something is repeated with the full budget
 // (slot_postprocess), so the result never depends on the budget.
-static const int kRoundBudgets[4] = { 8, 12, 16, 20 };
+static const int kRoundBudgets[RD_NBUDGETS] = { 8, 10, 12, 14, 16, 18, 20 };
 
 static void run_segment(rd_detector *d, Slot *s, int ws, int seg) {
   if (!d->use_graph) { frame_segment(d, s, ws, seg); return; }
   hipGraphExec_t *ge = &s->gexec[seg];
-  if (seg == 2) for (int k = 0; k < 4; k++) if (kRoundBudgets[k] == s->rounds) ge = &s->gexec2[k * 2 + ((d->batch == 1 && s->poly_mode) ? 1 : 0)];
+  if (seg == 2) for (int k = 0; k < RD_NBUDGETS; k++) if (kRoundBudgets[k] == s->rounds) ge = &s->gexec2[k * 2 + ((d->batch == 1 && s->poly_mode) ? 1 : 0)];
   if (!*ge) {
     hipGraph_t g = NULL;
     pthread_mutex_lock(&d->launch_mu);
@@ -566,7 +583,7 @@ static void run_segment(rd_detector *d, Slot *s, int ws, int seg) {
 static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   if (d->use_graph && s->graph_ws != ws) {
     for (int k = 0; k < 3; k++) if (s->gexec[k]) { RD_HIP(hipGraphExecDestroy(s->gexec[k])); s->gexec[k] = NULL; }
-    for (int k = 0; k < 8; k++) if (s->gexec2[k]) { RD_HIP(hipGraphExecDestroy(s->gexec2[k])); s->gexec2[k] = NULL; }
+    for (int k = 0; k < 2 * RD_NBUDGETS; k++) if (s->gexec2[k]) { RD_HIP(hipGraphExecDestroy(s->gexec2[k])); s->gexec2[k] = NULL; }
     s->graph_ws = ws;
   }
   RD_HIP(hipEventRecord(s->ev_begin, s->st));
@@ -578,7 +595,7 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   s->rounds = d->fixed_rounds ? d->fixed_rounds : __atomic_load_n(&d->rounds_budget, __ATOMIC_RELAXED);
   s->poly_mode = (d->poly_mode && !__atomic_load_n(&d->poly_overflows, __ATOMIC_RELAXED)) ? 1 : 0;
   if (d->batch == 1) { s->post_mode = d->device_post && d->have_tan; s->post_tan = d->tan_aov; }
-  for (int k = 0; k < 4; k++) if (kRoundBudgets[k] == s->rounds) d->budget_count[k]++;
+  for (int k = 0; k < RD_NBUDGETS; k++) if (kRoundBudgets[k] == s->rounds) d->budget_count[k]++;
   run_segment(d, s, ws, 2);
   if (d->batch > 1) { RD_HIP(hipEventRecord(s->ev_dense, s->st)); s->pending_sparse = 1; }
   else {
@@ -646,6 +663,11 @@ static void slot_finish_device(rd_detector *d, Slot *s) {
     RD_HIP(hipEventSynchronize(s->ev_redo));
     __atomic_add_fetch(&d->n_redo_rounds, 1, __ATOMIC_RELAXED);
   }
+  if (s->h_ctr[52] != 0 || (d->force_redo & 2)) {   // the absorption's fast path gave up on this frame: finish it the long way
+    s->post_mode = 0;
+    frame_absorb_slow(d, s);
+    __atomic_add_fetch(&d->n_redo_absorb, 1, __ATOMIC_RELAXED);
+  }
   {   // budget for the frames to come: what the last 64 frames needed (first round without a change, + 1 to see that) + 1.
       // (A long window on purpose: a frame that needs more than the budget is computed twice.)
     int need = 20;
@@ -655,14 +677,14 @@ static void slot_finish_device(rd_detector *d, Slot *s) {
     int mx = 0;
     for (int k = 0; k < 64; k++) mx = d->need_hist[k] > mx ? d->need_hist[k] : mx;
     int b = 20;
-    for (int k = 3; k >= 0; k--) if (d->need_pos >= 8 && kRoundBudgets[k] >= mx + 1) b = kRoundBudgets[k];
+    for (int k = RD_NBUDGETS - 1; k >= 0; k--) if (d->need_pos >= 8 && kRoundBudgets[k] >= mx + 1) b = kRoundBudgets[k];
     __atomic_store_n(&d->rounds_budget, b, __ATOMIC_RELAXED);
     pthread_mutex_unlock(&d->tan_mu);
   }
   // two overflows among the stream's recent frames (whichever slots they ran in): its frames do not fit the single-launch kernel (e.g. 4K) - stop trying
   if (s->poly_mode && s->h_ctr[25] != 0 && __atomic_add_fetch(&d->overflow_streak, 1, __ATOMIC_RELAXED) >= 2) __atomic_store_n(&d->poly_overflows, 1, __ATOMIC_RELAXED);
   if (s->poly_mode && s->h_ctr[25] == 0) __atomic_store_n(&d->overflow_streak, 0, __ATOMIC_RELAXED);
-  if ((s->poly_mode && s->h_ctr[25] != 0) || d->force_redo) {   // the single-launch polyline stage overflowed: repeat the tail the long way
+  if ((s->poly_mode && s->h_ctr[25] != 0) || (d->force_redo & 1)) {   // the single-launch polyline stage overflowed: repeat the tail the long way
     s->post_mode = 0;
     pthread_mutex_lock(&d->launch_mu);
     frame_tail(d, s, 0);
@@ -688,11 +710,12 @@ static void *slot_rectangles(rd_detector *d, Slot *s, double tanAOV, void **segs
     int at = 1;
     for (int c = 0; c < nc; c++) if (s->h_post[8 + c] != 0) memcpy(&ret[at++], recs + (size_t)c * sizeof(rect_t), sizeof(rect_t));
     ret[0].nItems = nv + 1;
-    const int maxrec0 = d->maxrec_dev < RD_MAXREC ? d->maxrec_dev : RD_MAXREC;
-    const int ns0 = n < maxrec0 ? n : maxrec0 - 1;
-    void *copy0 = malloc((size_t)(ns0 + 1) * 56);
-    memcpy(copy0, s->h_segs, (size_t)(ns0 + 1) * 56);
-    *segs_out = copy0; *nsegs_out = ns0;
+    // the segment list handed to rd_detector_last_segments: all n records, as on the host path - the pinned block holds the first
+    // RD_MAXREC of them, a frame with more fetches the list from the device
+    void *copy0 = malloc((size_t)(n + 1) * 56);
+    if (n + 1 <= RD_MAXREC) memcpy(copy0, s->h_segs, (size_t)(n + 1) * 56);
+    else RD_HIP(hipMemcpy(copy0, s->lslist, (size_t)(n + 1) * 56, hipMemcpyDeviceToHost));
+    *segs_out = copy0; *nsegs_out = n;
     __atomic_add_fetch(&d->n_post_device, 1, __ATOMIC_RELAXED);
     return ret;
   }
@@ -769,7 +792,7 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   RD_HIP(hipMemset(d->prev_strong, 0, (size_t)d->N));
   d->use_graph = getenv("RD_NO_GRAPH") ? 0 : 1;
   d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : 1;
-  d->force_redo = getenv("RD_POLY_FORCE_REDO") ? 1 : 0;
+  d->force_redo = (getenv("RD_POLY_FORCE_REDO") ? 1 : 0) | (getenv("RD_ABSORB_FORCE_SLOW") ? 2 : 0);   // tests: every frame also takes the polyline / absorption fallback
   d->diag_no_post = getenv("RD_DIAG_NO_POST") ? 1 : 0;
   d->device_post = getenv("RD_DEVICE_POST") ? atoi(getenv("RD_DEVICE_POST")) != 0 : 0;    // candidate funnel + pose estimation on the device (rd_k_post.hip)
   // The device runs four hardware queues side by side (more are time-sliced: measured 2x slower per frame).  With one or two
@@ -782,14 +805,16 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   // the merge has settled are no-ops, but each still costs two launches of a thousand blocks), frames that turn out to need more
   // are repeated with all 20; RD_REGION_ROUNDS_FIXED=8|12|16|20 pins the budget (20: never repeat anything).
   d->fixed_rounds = 0;
-  if (getenv("RD_REGION_ROUNDS_FIXED")) { const int r = atoi(getenv("RD_REGION_ROUNDS_FIXED")); d->fixed_rounds = (r == 8 || r == 12 || r == 16) ? r : 20; }
+  if (getenv("RD_REGION_ROUNDS_FIXED")) { const int r = atoi(getenv("RD_REGION_ROUNDS_FIXED")); d->fixed_rounds = (r >= 8 && r <= 20 && !(r & 1)) ? r : 20; }
   d->rounds_budget = 20;
   d->diag_skip = getenv("RD_DIAG_SKIP") ? atoi(getenv("RD_DIAG_SKIP")) : 0;   // timing diagnostics only: leaves stages out (wrong results)
   pthread_mutex_init(&d->tan_mu, NULL); pthread_cond_init(&d->tan_cv, NULL);
   pthread_mutex_init(&d->launch_mu, NULL);
   d->slots = (Slot *)calloc((size_t)nslots, sizeof(Slot));
-  // frames per set of sparse-stage launches: 4 from four frames in flight on (RD_BATCH=1..4 overrides), else every frame on its own
-  d->batch = nslots >= 4 ? 4 : 1;
+  // frames per set of sparse-stage launches: 4 from twelve frames in flight on - the deferral by one group below needs a third group of
+  // slots to keep the streams fed, and without it a batch is a barrier per group (measured 10 % slower than no batching) - else every
+  // frame on its own; RD_BATCH=1..4 overrides (tests: batching with any slot count)
+  d->batch = nslots >= 12 ? 4 : 1;
   if (getenv("RD_BATCH")) { const int b = atoi(getenv("RD_BATCH")); d->batch = b < 1 ? 1 : (b > RD_MAXB ? RD_MAXB : b); }
   if (d->fork_poly || d->batch > nslots) d->batch = d->fork_poly ? 1 : nslots;
   d->frames = (rdk::PolyFrame *)calloc((size_t)nslots, sizeof(rdk::PolyFrame));
@@ -828,7 +853,7 @@ void rd_detector_destroy(rd_detector *d) {
     }
     free(s->result); free(s->res_segs);
     for (int k = 0; k < 3; k++) if (s->gexec[k]) RD_HIP(hipGraphExecDestroy(s->gexec[k]));
-    for (int k = 0; k < 8; k++) if (s->gexec2[k]) RD_HIP(hipGraphExecDestroy(s->gexec2[k]));
+    for (int k = 0; k < 2 * RD_NBUDGETS; k++) if (s->gexec2[k]) RD_HIP(hipGraphExecDestroy(s->gexec2[k]));
     slot_free(s);
   }
   free(d->slots);
@@ -906,6 +931,17 @@ void *rd_detector_poll(rd_detector *d, double tanAOV) {
   return r;
 }
 
+// The reference hands the aperture over with the poll, i.e. after the frame (oclrect_pollTask); whatever runs ahead of the poll - the
+// worker threads' post-process, the rectangles on the device - uses the last one seen.  A caller that knows it beforehand says so here,
+// and the first frames of a stream are treated like all later ones.
+void rd_detector_set_aperture(rd_detector *d, double tanAOV) {
+  if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_set_aperture: bad handle\n");
+  pthread_mutex_lock(&d->tan_mu);
+  d->tan_aov = tanAOV; d->have_tan = 1;
+  pthread_cond_broadcast(&d->tan_cv);
+  pthread_mutex_unlock(&d->tan_mu);
+}
+
 void rd_detector_drain(rd_detector *d) {
   if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_drain: bad handle\n");
   RD_HIP(hipSetDevice(d->device));
@@ -919,11 +955,12 @@ long rd_detector_counter(rd_detector *d, int which) {
   if (which == 3) return d->host_enqueue_ns / 1000;
   if (which == 4) return __atomic_load_n(&d->n_redo_rounds, __ATOMIC_RELAXED);
   if (which == 5) return __atomic_load_n(&d->rounds_budget, __ATOMIC_RELAXED);
-  if (which >= 6 && which <= 9) return d->budget_count[which - 6];   // frames launched with a budget of 8 / 12 / 16 / 20 rounds
+  if (which >= 20 && which < 20 + RD_NBUDGETS) return d->budget_count[which - 20];   // frames launched with a budget of 8 / 10 / .. / 20 launches of the region merge
   if (which == 10) return __atomic_load_n(&d->n_truncated, __ATOMIC_RELAXED);
   if (which == 11) return __atomic_load_n(&d->n_post_device, __ATOMIC_RELAXED);
   if (which == 12) return __atomic_load_n(&d->n_post_host, __ATOMIC_RELAXED);
   if (which == 13) return __atomic_load_n(&d->host_post_ns, __ATOMIC_RELAXED) / 1000;
+  if (which == 14) return __atomic_load_n(&d->n_redo_absorb, __ATOMIC_RELAXED);
   if (which == 1) return d->dev_us;
   if (which == 2) return d->dev_frames;
   return which == 0 ? __atomic_load_n(&d->n_redo, __ATOMIC_RELAXED) : -1;
@@ -948,7 +985,7 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
     { "nms", s->nms, N * 4 }, { "mask0", s->mask0, N * 4 }, { "tidy", s->tidy, N * 4 }, { "label1", s->label1, N * 4 }, { "strsum", s->strsum, N * 4 },
     { "edge500", s->e8, N }, { "smooth", s->smooth, N * 4 }, { "quant", s->quant, N * 4 }, { "strong", s->strong, N * 4 }, { "junction", s->junction, N * 4 },
     { "mergemask", s->mergemask, N * 4 }, { "region", s->region, N * 4 }, { "region0", s->region0, N * 4 }, { "rsize", s->rsize, N * 4 }, { "boundarysrc", s->boundarysrc, N * 4 },
-    { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 }, { "polyctr", rdk::poly_scratch_counters(s->ps), 64 * 4 }, { "iirflags", s->flags, 16 * 4 }, { "d2work", s->d2s + N, 16 * 4 },
+    { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 }, { "polyctr", rdk::poly_scratch_counters(s->ps), 64 * 4 }, { "iirflags", s->flags, 16 * 4 }, { "d2work", s->d2s + N, 16 * 4 }, { "absorb", s->scratch2 + N + 20, 8 * 4 },
   };
   for (size_t i = 0; i < sizeof(tab) / sizeof(tab[0]); i++)
     if (!strcmp(tab[i].n, name)) {

@@ -1120,8 +1120,8 @@ void polyline(hipStream_t st, const PolyFrame *frames_host, int nb, int lslist_b
 
   if (mode == 1) {
     // fast path: initial segments, 15 subdivision rounds and the refinement in one persistent launch, one block per frame (overflow -> ctr[25])
-    static bool attr_set = false;
-    if (!attr_set) { (void)hipFuncSetAttribute((const void *)k_poly_persistent, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(pp_lds)); attr_set = true; }
+    static std::atomic<unsigned> lds_set{0};
+    set_max_lds_once((const void *)k_poly_persistent, (int)sizeof(pp_lds), lds_set);
     hipLaunchKernelGGL(k_poly_persistent, dim3(1, 1, nb), dim3(PP_T), sizeof(pp_lds), st, frames, lslist_bytes, minerror, iw);
     return;
   }

@@ -6,6 +6,7 @@
 #include "rd_kernels.h"
 #include "rd_tidy_tile.h"
 #include "rd_poly_scratch.h"
+#include <atomic>
 
 namespace {
 
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict
     q[i] = atu(in, okq[i] ? (unsigned)(yy * iw + xx) : 0u);
   }
   }
-  if (tid < ZR_N) lds[SRC_N + HZ_N + tid] = make_uint2(0, 0);
+  for (int t = tid; t < ZR_N; t += 64 * BP_TY) lds[SRC_N + HZ_N + t] = make_uint2(0, 0);     // (whatever the block size)
   unsigned zrs = (unsigned)(SRC_N + HZ_N) * 8u, zrh = (unsigned)ZR_N * 0u + (unsigned)HZ_N * 8u;      // the zero region's byte offset from `src` / from `hz`
   asm volatile("" : "+v"(zrs), "+v"(zrh));      // (opaque to the optimiser: it would fold the per-sample constants into them again)
   if (tid < 16) { const float r = tid >= 1 && tid <= 10 ? 1.0f / (float)tid : 0.0f; rwt[tid] = make_float2(r, 0.5f * r); }
@@ -308,7 +309,7 @@ __device__ __forceinline__ uint32_t quantize_plab(uint32_t v, int n0, int n1, in
 // Quantising a packed Lab word field by field costs a rounding and an IEEE division per field; each result depends on nothing but
 // the field's 12 / 10 bits, so the 24-level tables are built once per device by the very function above (k_quant24_lut) and the
 // frame path looks them up: g_quant24[0..4095] = quantised L field, [4096..5119] = quantised a / b field.
-__device__ uint16_t g_quant24[4096 + 1024];
+__device__ __attribute__((aligned(16))) uint16_t g_quant24[4096 + 1024];     // (read through 32-bit loads in k_despeckle<24>)
 __global__ void k_quant24_lut() {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < 4096) g_quant24[i] = (uint16_t)(quantize_plab((uint32_t)i, 24, 24, 24) & 4095u);
@@ -486,17 +487,15 @@ __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const 
 }
 
 // ------------------------------------------------------------------------------------------------ regions
-// rc:289-298 initial links (up if same colour, else left if same colour, else self), plus - because colours, merge mask
-// and edges do not change between the rounds - one byte per pixel telling from which of its 4 neighbours the pixel may
-// adopt a label (rc:308-326): bit0 up, bit1 left, bit2 right, bit3 down; 0 for frame-border pixels (never processed).
-// One block per 64 x RI_ROWS tile: the links that stay inside the tile are followed to their end in LDS (pointer doubling),
-// so every pixel leaves pointing either at the root of its initial tree (if that root lies in the tile) or at the first
-// pixel outside the tile on its way up/left; the few remaining tile-to-tile hops are left to k_region_flatten.
+// rc:289-298 initial links (up if same colour, else left if same colour, else self) - left exactly as the reference's kernel leaves
+// them, chains and all: the merge rounds start from these (see k_region_round) - plus, because colours, merge mask and edges do not
+// change between the rounds, one byte per pixel telling from which of its 4 neighbours the pixel may adopt a label (rc:308-326):
+// bit0 up, bit1 left, bit2 right, bit3 down, bit4 interior; 0 for frame-border pixels (never processed).
+// The links are written as the words of k_region_round (label << 3, no mark) into the two planes its rounds alternate between.
 #define RI_ROWS 32
-__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, uint8_t *__restrict__ allow, const int *__restrict__ pix, const int *__restrict__ mask,
+__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *__restrict__ B, uint8_t *__restrict__ allow, const int *__restrict__ pix, const int *__restrict__ mask,
                                                      const int *__restrict__ edge, int iw, int ih, int *__restrict__ flags, int *__restrict__ size_out, const int *__restrict__ size_init) {
-  __shared__ int par[64 * RI_ROWS];     // >= 0: tile-local index of the parent; < 0: -(global index) - 1 of a parent outside the tile
-  // (also: the round / flatten flags start at zero, and the size plane starts from size_init - quirk H2 - without extra launches)
+  // (also: the round flags start at zero, and the size plane starts from size_init - quirk H2 - without extra launches)
   if (blockIdx.x == 0 && blockIdx.y == 0) { const int t = threadIdx.y * 64 + threadIdx.x; if (t < 64) flags[t] = 0; }
   const int tx = threadIdx.x, x = blockIdx.x * 64 + tx, y0 = blockIdx.y * RI_ROWS;
   // four rows below one another per thread (each the other's vertical neighbour: 31 instead of 40 loads), all of their loads in flight
@@ -529,52 +528,38 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
     }
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const int r = (half * 4 + threadIdx.y) * 4 + k;
-      const int y = y0 + r;
-      int l = r * 64 + tx;
-      if (in[k]) {
-        const int p = y * iw + x;
-        if (y > 0 && v[k] == vu[k]) l = r > 0 ? l - 64 : -(p - iw) - 1;
-        else if (x > 0 && v[k] == vl[k]) l = tx > 0 ? l - 1 : -(p - 1) - 1;
-        unsigned a = 0;
-        if (inter[k]) {
-          const bool any = mk[k] != 0;
-          const bool z0 = e0[k] <= 0;
-          if ((v[k] == vu[k] || any) && z0) a |= 1;
-          if ((v[k] == vl[k] || any) && z0) a |= 2;
-          if ((v[k] == vr[k] || any) && er[k] <= 0) a |= 4;
-          if ((v[k] == vd[k] || any) && ed[k] <= 0) a |= 8;
-          a |= 16;   // interior
-        }
-        allow[p] = (uint8_t)a;
-        if (size_out) size_out[p] = si[k];
+      const int y = y0 + (half * 4 + threadIdx.y) * 4 + k;
+      if (!in[k]) continue;
+      const int p = y * iw + x;
+      int l = p;
+      if (y > 0 && v[k] == vu[k]) l = p - iw;
+      else if (x > 0 && v[k] == vl[k]) l = p - 1;
+      unsigned a = 0;
+      if (inter[k]) {
+        const bool any = mk[k] != 0;
+        const bool z0 = e0[k] <= 0;
+        if ((v[k] == vu[k] || any) && z0) a |= 1;
+        if ((v[k] == vl[k] || any) && z0) a |= 2;
+        if ((v[k] == vr[k] || any) && er[k] <= 0) a |= 4;
+        if ((v[k] == vd[k] || any) && ed[k] <= 0) a |= 8;
+        a |= 16;   // interior
       }
-      par[r * 64 + tx] = l;
+      allow[p] = (uint8_t)a;
+      if (size_out) size_out[p] = si[k];
+      A[p] = l << 3;
+      B[p] = l << 3;
     }
-  }
-  __syncthreads();
-  // a chain inside the tile is at most RI_ROWS + 64 links long: 7 doublings (any interleaving only ever stores ancestors)
-  for (int it = 0; it < 7; it++) {
-    for (int r = threadIdx.y; r < RI_ROWS; r += 4) {
-      const int i = r * 64 + tx;
-      const int a = par[i];
-      if (a >= 0 && a != i) par[i] = par[a];
-    }
-    __syncthreads();
-  }
-  if (x >= iw) return;
-  for (int r = threadIdx.y; r < RI_ROWS; r += 4) {
-    const int y = y0 + r;
-    if (y >= ih) break;
-    const int a = par[r * 64 + tx];
-    label[y * iw + x] = a >= 0 ? (y0 + a / 64) * iw + blockIdx.x * 64 + a % 64 : -a - 1;
   }
 }
 
-// rc:300-334 per-pixel rule, evaluated in SYNCHRONOUS rounds on the flattened initial forest: every pixel reads the labels of the previous round,
-// proposes `min` updates for itself and for its old parent, and the proposals take effect between rounds.  The
-// reference applies the same rule in place for 8 launches, which makes its result depend on the work-item order
-// (SURVEY.md H5); synchronous rounds to convergence are the order-free reading of the same rule.
+// rc:300-334, every launch with its work-items running CONCURRENTLY: all of them read the labels the launch began with, propose `min`
+// updates for themselves and for their old label's pixel, and the proposals take effect together when the launch ends - a legal
+// execution of the reference's kernel (OpenCL promises no work-item that it sees another one's update within a launch), and the one a
+// parallel device can reproduce bit for bit.  The reference enqueues the kernel 8 times (rh:325-331), which settles the labels in
+// serial orders; with concurrent work-items a 1080p frame needs about 12 launches, so the kernel is launched until a launch changes
+// nothing (the CPU restatement the tests compare with is itself checked against the reference's own kernel running that way:
+// DESIGN.md, "Region stages").  The rounds start from the reference's raw initial links: the labels a work-item compares are whatever the
+// trees hold at that moment, not their roots, and which regions the merge mask joins depends on exactly that.
 //
 // One launch per round, no launch that applies a round's proposals, and ONE label plane to read per round: the labels live in two
 // planes that alternate.  Round r reads every label from plane X (complete: the labels after round r-1) and writes into plane Y, which
@@ -586,7 +571,7 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
 // round before its own and brings the other plane up to date.  Marks are never cleared: an old one only matches again 14 rounds later,
 // where it causes a harmless write of the same value.  (Every pixel has a thread, the ones on the frame's ring too: they never adopt,
 // but they are parents.)
-// Both planes start as copies of the flattened initial forest (k_region_flatten's last launch), so only changes are ever written.
+// Both planes start as copies of the initial links (k_region_init), so only changes are ever written.
 // Rounds with an even number read A and write B, odd ones read B and write A, and every budget is even: the last round writes A,
 // and once a round has changed nothing the planes agree, so the labels are always taken from A (k_region_size strips the marks).
 // flags[round] = "this round proposed something" (a proposal always lowers its pixel's own label), which is what the next round
@@ -599,6 +584,7 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ label, ui
 #define RR_PX 6
 #define RR_TY 8          // thread rows per block (2 / 4 / 8 at full rate: 2094 / 2118 / 2124 frames/s)
 #define RR_MBITS 3
+#define RR_DEEP 3          // rounds in which the trees are still the chains of the initial links (a pixel's parent is 1, 10, 91 rows above it)
 __device__ __forceinline__ int rr_label(const int *X, unsigned q) { return at32(X, q) >> RR_MBITS; }
 __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round) {
   if (round > 0 && flags[round - 1] == 0) return;
@@ -655,29 +641,40 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
       g[k] = (a[k] & 16) ? m : e[0];
     }
   }
+  // rc:328: the eight pointer jumps (a root maps to itself), level by level for the thread's RR_PX pixels together: seven dependent
+  // trips to memory per thread, not seven per pixel - in the first rounds the trees are the raw chains of rc:289-298 and every jump is real
 #pragma unroll
-  for (int k = 0; k < RR_PX; k++) nx[k] = rr_label(X, (unsigned)g[k]);     // rc:328: first of the eight pointer jumps (a root maps to itself)
+  for (int k = 0; k < RR_PX; k++) nx[k] = (a[k] & 16) ? rr_label(X, (unsigned)g[k]) : g[k];
+  for (int j = 1; j < 8; j++) {
+    bool moving = false;
+#pragma unroll
+    for (int k = 0; k < RR_PX; k++) moving = moving || nx[k] != g[k];
+    if (!__any(moving)) break;
+#pragma unroll
+    for (int k = 0; k < RR_PX; k++) { g[k] = nx[k]; nx[k] = rr_label(X, (unsigned)nx[k]); }      // (a pixel that has arrived re-reads its root: same value)
+  }
   bool any_todo = false;
 #pragma unroll
   for (int k = 0; k < RR_PX; k++) {
-    if (a[k] & 16) {
-      int n = nx[k];
-      for (int j = 1; j < 8 && n != g[k]; j++) { g[k] = n; n = rr_label(X, (unsigned)n); }
-      if (n != g[k]) g[k] = n;          // (the eighth jump)
-    }
+    g[k] = (a[k] & 16) ? nx[k] : og[k];          // (after the loop nx is one jump ahead of g, or equal to it; ring pixels keep their label)
     todo[k] = (a[k] & 16) && g[k] != og[k];
     // the pixel's own word in Y: its new label (marked), or - where Y lags behind - the label it keeps
     const bool lag = (w0[k] & 7) == mark_prev;
     if (valid[k] && (todo[k] || lag)) atomicMin(&Y[p0[k]], (g[k] << RR_MBITS) | (todo[k] ? mark : 0));     // (no value comes back: the thread does not wait for it; g == og unless todo)
     any_todo = any_todo || todo[k];
   }
-  // Hooking the old parent: after flattening, all pixels of a tree share one parent, so the block first reduces its
+  // Hooking the old parent: once the trees are shallow, all pixels of a tree share one parent, so the block first reduces its
   // (parent -> smallest proposal) pairs in a small LDS hash and then issues one guarded atomic per distinct parent.
 #pragma unroll
   for (int k = 0; k < RR_PX; k++) {
     // a lane whose (parent, proposal) pair repeats its left neighbour's adds nothing to a min: skip it (most lanes inside a region)
     const int pog = __shfl_up(og[k], 1), pg = __shfl_up(g[k], 1), pt = __shfl_up((int)todo[k], 1);
     if (!todo[k] || (threadIdx.x > 0 && pt && pog == og[k] && pg == g[k])) continue;
+    if (round < RR_DEEP) {       // the first rounds climb the raw chains: every pixel has a parent of its own (the pixel above it), nothing to combine
+      const int w = (g[k] << RR_MBITS) | mark;
+      if (w < ld_agent(&Y[og[k]])) atomicMin(&Y[og[k]], w);
+      continue;
+    }
     unsigned h = ((unsigned)og[k] * 2654435761u) >> 23;
     int probes = 0;
     for (;;) {
@@ -693,39 +690,6 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
     const int key = hk[t];
     if (key != -1) { const int w = (hv[t] << RR_MBITS) | mark; if (w < ld_agent(&Y[key])) atomicMin(&Y[key], w); }
   }
-}
-
-// In-place pointer jumping on the forest of initial links (parent index < child index): each launch replaces a
-// pixel's parent by an ancestor up to 16 links away (or the root); any interleaving only ever stores ancestors, so the iteration ends
-// with every pixel pointing at the root of its initial tree.  flags[round] = some chain was not followed to its root yet.
-// The LAST launch (out_a, out_b given) also leaves the final labels, as the words of k_region_round (label << 3, no mark), in the
-// two planes the rounds alternate between; it runs whatever the flags say.
-__global__ void k_region_flatten(int *label, int n, int *flags, int round, int *__restrict__ out_a, int *__restrict__ out_b) {
-  if (round > 0 && flags[round - 1] == 0 && out_a == nullptr) return;
-  bool changed = false;
-  const int stride = gridDim.x * blockDim.x;
-  for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * 4) {     // four pixels per step: their first two jumps are in flight together
-    int l[4], a[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { const int i = i0 + k * stride; l[k] = label[i < n ? i : 0]; }
-#pragma unroll
-    for (int k = 0; k < 4; k++) a[k] = label[l[k]];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int i = i0 + k * stride;
-      if (i >= n) continue;
-      int r = l[k];
-      if (a[k] != l[k]) {
-        r = a[k];
-        bool root = false;
-        for (int j = 0; j < 14; j++) { const int b = label[r]; if (b == r) { root = true; break; } r = b; }   // (most chains end after a jump or two)
-        label[i] = r;
-        if (!root) changed = true;       // (a chain that was not seen to end: the next launch goes on; otherwise this pixel is done)
-      }
-      if (out_a != nullptr) { out_a[i] = r << RR_MBITS; out_b[i] = r << RR_MBITS; }
-    }
-  }
-  if (__any(changed) && (threadIdx.x & 63) == 0) flags[round] = 1;
 }
 
 // rc:336-346: out[label]++ for every pixel.  Most pixels belong to a handful of huge regions, so counts are
@@ -976,28 +940,365 @@ __global__ __launch_bounds__(256) void k_despeckle2_active(int *__restrict__ nxt
   d2_active_rounds(nxt, cur, list, count, list_out, count_out, count_zero, work_trace, stamp, tag, old, size, thre, iw, ih, blockIdx.x, gridDim.x, loc, nloc, base);
 }
 
-// The launches r0 .. r1-1 of despeckle2()'s loop in ONE single-block launch: from the fourth launch on the work lists hold a few
-// hundred pixels at most (measured on the bench stream: 74 k, 4.3 k, 300, 100, 45, 20, < 10 ...), so a launch is all latency; one
-// block walks through them with a barrier in between (whatever the list lengths are, the result is the same - only slower).
-// pa / pb: the two planes the launches alternate between (launch r writes pb if r is odd, else pa; reads the other one);
-// lists: the three rotating work lists (n ints each), counts: their counters (+ the per-launch trace behind them)
-__global__ __launch_bounds__(256) void k_despeckle2_tail(int *pa, int *pb, int *lists, int *counts, int *__restrict__ stamp, int r0, int r1, int n,
-                                                          const int *__restrict__ old, const int *__restrict__ size, int thre, int iw, int ih) {
-  __shared__ int loc[D2A_CAP];
-  __shared__ int nloc, base;
-  for (int r = r0; r < r1; r++) {
-    int *nx = (r & 1) ? pb : pa;
-    const int *cu = (r & 1) ? pa : pb;
-    const int li = r % 3, lo = (r + 1) % 3, lz = (r + 2) % 3;
-    if (counts[li] == 0) {        // (same value for every thread: written before the last barrier)
-      // an empty list: nothing changes any more, and the two planes agree on every pixel that is in no list - on all of them
-      for (int q = r + threadIdx.x; q < r1; q += 256) counts[3 + q] = 0;
-      break;
-    }
-    d2_active_rounds(nx, cu, lists + (size_t)li * n, counts + li, r == r1 - 1 ? (int *)nullptr : lists + (size_t)lo * n, counts + lo, counts + lz, counts + 3 + r, stamp, r + 1,
-                     old, size, thre, iw, ih, 0, 1, loc, nloc, base);
-    __syncthreads();
+// ---- the absorption, exactly (fast path) -------------------------------------------------------------------------------------------
+// rc:348-371 in the reference's serial raster order IS a recurrence on a DAG: a pixel of a small region takes the label of the
+// largest region among  new(NW), new(N), new(NE), new(W), old(C), old(E), old(SW), old(S), old(SE)  (first maximum in that
+// order), every other pixel keeps its label.  Two facts make it cheap to evaluate exactly:
+//   (1) chains of dependent small-region pixels are short almost everywhere (on the bench stream 97 % of the 74 k small-region
+//       pixels of a frame hang on chains of at most 8 pixels), so a tile that also loads a halo of AB_HK pixels to its left, top
+//       and right can evaluate nearly all of its own pixels from LDS, and it KNOWS which ones: a value is exact once the values
+//       of the pixel's small-region predecessors are exact, small-region pixels on the rim of what the tile loaded never are;
+//   (2) for the rest (a few runs along the frame's last row, as a rule: ~2 k pixels per 1080p frame)  T(p) = size of new(p)
+//       obeys  T(p) = max(T(NW), T(N), T(NE), T(W), sizes of the five old labels),  a pure max-propagation, and given T the label
+//       is that of the first predecessor with the same T (a pointer) or the first old label with that size (a constant):
+//       pointer doubling along the W links settles a run of a thousand pixels in ten steps instead of a thousand.
+// k_absorb_tile does (1) and lists the pixels it cannot decide (their `out` word = -(list index) - 2), k_absorb_tail does (2)
+// for up to AT_CAP of them in one block.  Whatever they cannot finish (status[0] != 0) is left to despeckle2_slow().
+#define AB_TW 64
+#define AB_TH 64        // (64 x 64 tiles: 510 blocks at 1920 x 1080, two per CU - all resident at once - and 1.96 loaded cells per pixel; 64 x 32: 2.39)
+#define AB_HK 16
+#define AB_LW (AB_TW + 2 * AB_HK + 2)       // loaded cells: the tile, AB_HK columns left and right, AB_HK rows above, and one more ring for the old 3x3 neighbourhoods
+#define AB_LH (AB_TH + AB_HK + 2)
+#define AB_NC (AB_LW * AB_LH)
+#define AB_NT 512
+#define AB_R 4                              // small-region cells per thread (more in a tile: its small-region pixels go to the tail)
+#define AB_INEXACT 0x40000000u
+typedef unsigned long long ab_word;         // a cell: (size of its label | AB_INEXACT) << 32 | label  (one 64-bit LDS word: readers always see a consistent pair)
+__device__ __forceinline__ ab_word ab_pack(int lab, unsigned t) { return ((ab_word)t << 32) | (unsigned)lab; }
+__device__ __forceinline__ int ab_lab(ab_word w) { return (int)(unsigned)w; }
+__device__ __forceinline__ unsigned ab_t(ab_word w) { return (unsigned)(w >> 32); }
+
+// A record per undecided pixel (AB_REC ints): [0] pixel, [1] best old label, [2] its size, [3 + j] predecessor j (NW, N, NE, W): its final
+// label if it is decided (-1: outside the frame) or -(its pixel index) - 2 if it is undecided itself, [7 + j] the size of that label (0: none).
+#define AB_REC 12
+__device__ __forceinline__ void ab_record(int *__restrict__ rec, int p, int rl, unsigned rs, const ab_word *cell, int c, int iw, int gx0, int gy0) {
+  const int d[4] = { -AB_LW - 1, -AB_LW, -AB_LW + 1, -1 };
+  int v[AB_REC];
+  v[0] = p; v[1] = rl; v[2] = (int)rs; v[11] = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int cj = c + d[j];
+    const ab_word w = cell[cj];
+    const bool undecided = (ab_t(w) & AB_INEXACT) != 0;
+    v[3 + j] = undecided ? -((gy0 + cj / AB_LW) * iw + gx0 + cj % AB_LW) - 2 : ab_lab(w);
+    v[7 + j] = undecided ? 0 : (int)ab_t(w);
   }
+#pragma unroll
+  for (int q = 0; q < AB_REC; q += 4) *(int4 *)(rec + q) = make_int4(v[q], v[q + 1], v[q + 2], v[q + 3]);
+}
+
+// (list: room for reccap records)
+__global__ __launch_bounds__(AB_NT) void k_absorb_tile(int *__restrict__ out, int *__restrict__ list, int reccap, int *count, const int *__restrict__ old, const int *__restrict__ size,
+                                                       int thre, int iw, int ih) {
+  __shared__ ab_word cell[AB_NC];
+  __shared__ unsigned short slist[AB_NT * AB_R];
+  __shared__ unsigned short rlist[AB_TW * AB_TH];      // undecided pixels of the tile (cell indices)
+  __shared__ int nsmall, nres, base;
+  const int tid = threadIdx.x;
+  if (tid == 0) { nsmall = 0; nres = 0; }
+  const int gx0 = blockIdx.x * AB_TW - AB_HK - 1, gy0 = blockIdx.y * AB_TH - AB_HK - 1;
+  // old labels and their region sizes for every loaded cell (cells outside the frame: size 0 - they never win a comparison)
+  {
+    constexpr int IT = (AB_NC + AB_NT - 1) / AB_NT;
+    int l[IT], sz[IT];
+    bool in[IT];
+#pragma unroll
+    for (int i = 0; i < IT; i++) {
+      const int t = tid + i * AB_NT;
+      const int cx = t % AB_LW, cy = t / AB_LW;
+      const int gx = gx0 + cx, gy = gy0 + cy;
+      in[i] = t < AB_NC && gx >= 0 && gx < iw && gy >= 0 && gy < ih;
+      l[i] = old[in[i] ? (unsigned)(gy * iw + gx) : 0u];
+    }
+#pragma unroll
+    for (int i = 0; i < IT; i++) sz[i] = size[(unsigned)l[i]];
+    __syncthreads();        // (nsmall = 0 is visible)
+#pragma unroll
+    for (int i = 0; i < IT; i++) {
+      const int t = tid + i * AB_NT;
+      if (t >= AB_NC) continue;
+      const int cx = t % AB_LW, cy = t / AB_LW;
+      const bool small = in[i] && sz[i] <= thre;
+      const bool inner = cx >= 1 && cx <= AB_LW - 2 && cy >= 1 && cy <= AB_LH - 2;      // cells this block evaluates (their 3x3 neighbourhood is loaded)
+      cell[t] = ab_pack(in[i] ? l[i] : -1, in[i] ? ((unsigned)sz[i] | (small ? AB_INEXACT : 0u)) : 0u);
+      if (small && inner) {
+        const int k = atomicAdd(&nsmall, 1);
+        if (k < AB_NT * AB_R) slist[k] = (unsigned short)t;
+      }
+    }
+  }
+  __syncthreads();
+  const int ns = nsmall;
+  int c[AB_R], rl[AB_R], slot[AB_R];
+  unsigned rs[AB_R];
+  bool open[AB_R];
+#pragma unroll
+  for (int k = 0; k < AB_R; k++) { open[k] = false; slot[k] = -1; c[k] = AB_LW + 1; rl[k] = 0; rs[k] = 0; }
+  const bool owned = ns > 0 && ns <= AB_NT * AB_R;       // (more small-region cells than the block has registers for: all of them stay undecided)
+  if (owned) {
+    // the best of the five old labels (C, E, SW, S, SE) per cell: these never change
+#pragma unroll
+    for (int k = 0; k < AB_R; k++) {
+      const int i = tid + k * AB_NT;
+      open[k] = i < ns;
+      c[k] = open[k] ? slist[i] : AB_LW + 1;
+      const ab_word w0 = cell[c[k]], w1 = cell[c[k] + 1], w2 = cell[c[k] + AB_LW - 1], w3 = cell[c[k] + AB_LW], w4 = cell[c[k] + AB_LW + 1];
+      rl[k] = ab_lab(w0); rs[k] = ab_t(w0) & ~AB_INEXACT;
+      unsigned t;
+      t = ab_t(w1) & ~AB_INEXACT; if (t > rs[k]) { rs[k] = t; rl[k] = ab_lab(w1); }
+      t = ab_t(w2) & ~AB_INEXACT; if (t > rs[k]) { rs[k] = t; rl[k] = ab_lab(w2); }
+      t = ab_t(w3) & ~AB_INEXACT; if (t > rs[k]) { rs[k] = t; rl[k] = ab_lab(w3); }
+      t = ab_t(w4) & ~AB_INEXACT; if (t > rs[k]) { rs[k] = t; rl[k] = ab_lab(w4); }
+    }
+    __syncthreads();
+    // rounds: a cell whose four predecessors are exact takes its final value and becomes exact; until nothing moves any more, AB_HK + 8 rounds at most
+    for (int round = 0; round < AB_HK + 8; round++) {      // (longer chains - the runs along the frame's outermost rows and columns - are the tail's: it settles them in log steps, here a pixel per round)
+      bool progress = false;
+#pragma unroll
+      for (int k = 0; k < AB_R; k++) {
+        if (!open[k]) continue;
+        const ab_word p0 = cell[c[k] - AB_LW - 1], p1 = cell[c[k] - AB_LW], p2 = cell[c[k] - AB_LW + 1], p3 = cell[c[k] - 1];
+        if ((ab_t(p0) | ab_t(p1) | ab_t(p2) | ab_t(p3)) & AB_INEXACT) continue;
+        unsigned bs = 0; int bl = rl[k];
+        if (ab_t(p0) > bs) { bs = ab_t(p0); bl = ab_lab(p0); }
+        if (ab_t(p1) > bs) { bs = ab_t(p1); bl = ab_lab(p1); }
+        if (ab_t(p2) > bs) { bs = ab_t(p2); bl = ab_lab(p2); }
+        if (ab_t(p3) > bs) { bs = ab_t(p3); bl = ab_lab(p3); }
+        if (rs[k] > bs) { bs = rs[k]; bl = rl[k]; }
+        cell[c[k]] = ab_pack(bl, bs);
+        open[k] = false;
+        progress = true;
+      }
+      if (!__syncthreads_or(progress)) break;
+    }
+    // the undecided cells among the tile's own pixels take a slot of the tile's share of the list
+#pragma unroll
+    for (int k = 0; k < AB_R; k++) {
+      const int cx = c[k] % AB_LW - (AB_HK + 1), cy = c[k] / AB_LW - (AB_HK + 1);
+      if (open[k] && cx >= 0 && cx < AB_TW && cy >= 0 && cy < AB_TH) slot[k] = atomicAdd(&nres, 1);
+    }
+  }
+  // the tile's own pixels: final labels (the undecided ones are written below)
+  const int tx = tid & 63, x = blockIdx.x * AB_TW + tx;
+  for (int r = tid >> 6; r < AB_TH; r += AB_NT / 64) {
+    const int y = blockIdx.y * AB_TH + r;
+    if (x >= iw || y >= ih) continue;
+    const int ci = (r + AB_HK + 1) * AB_LW + tx + AB_HK + 1;
+    const ab_word w = cell[ci];
+    if (!(ab_t(w) & AB_INEXACT)) out[(unsigned)(y * iw + x)] = ab_lab(w);
+    else if (!owned) rlist[atomicAdd(&nres, 1)] = (unsigned short)ci;
+  }
+  __syncthreads();
+  const int nr = nres;
+  if (nr == 0) return;
+  if (tid == 0) base = atomicAdd(count, nr);
+  __syncthreads();
+  if (owned) {
+#pragma unroll
+    for (int k = 0; k < AB_R; k++) {
+      if (slot[k] < 0) continue;
+      const int p = (gy0 + c[k] / AB_LW) * iw + gx0 + c[k] % AB_LW, at = base + slot[k];
+      out[(unsigned)p] = -at - 2;
+      if (at < reccap) ab_record(list + (size_t)at * AB_REC, p, rl[k], rs[k], cell, c[k], iw, gx0, gy0);
+    }
+  } else {
+    for (int i = tid; i < nr; i += AB_NT) {       // (no rounds ran: the cells still hold the old labels)
+      const int ci = rlist[i], p = (gy0 + ci / AB_LW) * iw + gx0 + ci % AB_LW, at = base + i;
+      out[(unsigned)p] = -at - 2;
+      if (at >= reccap) continue;
+      const ab_word w0 = cell[ci], w1 = cell[ci + 1], w2 = cell[ci + AB_LW - 1], w3 = cell[ci + AB_LW], w4 = cell[ci + AB_LW + 1];
+      int l = ab_lab(w0); unsigned m = ab_t(w0) & ~AB_INEXACT, t;
+      t = ab_t(w1) & ~AB_INEXACT; if (t > m) { m = t; l = ab_lab(w1); }
+      t = ab_t(w2) & ~AB_INEXACT; if (t > m) { m = t; l = ab_lab(w2); }
+      t = ab_t(w3) & ~AB_INEXACT; if (t > m) { m = t; l = ab_lab(w3); }
+      t = ab_t(w4) & ~AB_INEXACT; if (t > m) { m = t; l = ab_lab(w4); }
+      ab_record(list + (size_t)at * AB_REC, p, l, m, cell, ci, iw, gx0, gy0);
+    }
+  }
+}
+
+// The undecided pixels of a frame (n = *count of them, any order) in ONE block; see (2) above.
+//   W[i] = (x, lw, ln) in one 64-bit LDS word (readers always see a consistent triple): x = lower bound of T(i) that only ever holds sizes
+//   of true ancestors; lw / ln = the undecided pixel that the doubling along the row / along the column has reached (AT_NONE: it has
+//   passed the start of the run).  The long chains are runs of small-region pixels along the frame's outermost rows and columns - which
+//   the merge never touches (rc:302) - a thousand pixels long: a sweep = doubling steps until no link is left (about eleven), and every
+//   step also relaxes the two diagonal predecessors.  Sweeps repeat (links restored) until x is a fixed point of the recurrence.
+//   status[0] <- 1 if n > AT_CAP or the sweeps did not settle within AT_SWEEPS (then `out` keeps undecided words), status[1] <- n, status[2] <- sweeps
+#define AT_NT 1024
+#define AT_CAP 16383
+#define AT_NONE 0x3fffu
+#define AT_SWEEPS 64
+#define AT_XMASK 0x3ffffffull      // 26 bits: region sizes stay below 2^25 + 9 (rd_detector_create limits the frame)
+__device__ __forceinline__ ab_word at_pack(unsigned x, unsigned lw, unsigned ln) { return (ab_word)x | ((ab_word)lw << 26) | ((ab_word)ln << 40); }
+__device__ __forceinline__ unsigned at_x(ab_word w) { return (unsigned)(w & AT_XMASK); }
+__device__ __forceinline__ unsigned at_lw(ab_word w) { return (unsigned)(w >> 26) & AT_NONE; }
+__device__ __forceinline__ unsigned at_ln(ab_word w) { return (unsigned)(w >> 40) & AT_NONE; }
+__device__ __forceinline__ unsigned at_relax(const ab_word *W, unsigned ref, unsigned m) {
+  if (ref != AT_NONE) { const unsigned t = at_x(W[ref]); m = t > m ? t : m; }
+  return m;
+}
+
+// EPT pixels per thread (compile time: what a thread keeps per pixel between the phases - its four references - stays in registers; the
+// record itself is read twice, before and after the sweeps, rather than kept); the kernel picks the smallest EPT that covers n.
+template <int EPT>
+__device__ __forceinline__ void at_body(ab_word *W, int *__restrict__ out, const int *__restrict__ list, int n, const int *__restrict__ size, int nsteps, int *status) {
+  const int tid = threadIdx.x;
+  const unsigned long long t0 = wall_clock64();       // (100 MHz: the phases' durations go to status[4..7] in units of 10 ns - diagnostics)
+  unsigned rdiag[EPT], rwn[EPT];      // references NW | NE << 16 and W | N << 16 (indices into the list; AT_NONE: not an undecided pixel)
+  // the records, then - for predecessors that are undecided themselves - their places in the list (their words in `out`); four pixels at
+  // a time (two dependent trips to memory per group: more in flight would not fit the registers of a 1024-thread block)
+  constexpr int G = EPT < 4 ? EPT : 4;
+#pragma unroll
+  for (int k0 = 0; k0 < EPT; k0 += G) {
+    int pq[G][4];
+    unsigned c0[G];
+#pragma unroll
+    for (int kk = 0; kk < G; kk++) {
+      const int i = tid + (k0 + kk) * AT_NT;
+      const int4 *rec = (const int4 *)(list + (size_t)(i < n ? i : 0) * AB_REC);
+      const int4 a = rec[0], b = rec[1], d = rec[2];
+      pq[kk][0] = a.w; pq[kk][1] = b.x; pq[kk][2] = b.y; pq[kk][3] = b.z;
+      unsigned c = (unsigned)a.z;
+      c = (unsigned)b.w > c ? (unsigned)b.w : c; c = (unsigned)d.x > c ? (unsigned)d.x : c; c = (unsigned)d.y > c ? (unsigned)d.y : c; c = (unsigned)d.z > c ? (unsigned)d.z : c;
+      c0[kk] = c;
+    }
+    // (a predecessor that this pixel's tile could not decide - it lies in the tile's halo - may have been decided by its own tile: then
+    //  its word in `out` is a label, and its size joins the constant part)
+    int pv[G][4];
+#pragma unroll
+    for (int kk = 0; kk < G; kk++) {
+      const int i = tid + (k0 + kk) * AT_NT;
+#pragma unroll
+      for (int j = 0; j < 4; j++) pv[kk][j] = (i < n && pq[kk][j] < -1) ? out[(unsigned)(-pq[kk][j] - 2)] : -1;
+    }
+#pragma unroll
+    for (int kk = 0; kk < G; kk++) {
+      const int k = k0 + kk, i = tid + k * AT_NT;
+      unsigned ref[4], c = c0[kk];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const bool late = i < n && pq[kk][j] < -1 && pv[kk][j] >= 0;
+        const unsigned t = late ? (unsigned)size[(unsigned)pv[kk][j]] : 0u;
+        c = t > c ? t : c;
+        ref[j] = (i < n && pq[kk][j] < -1 && pv[kk][j] < 0) ? (unsigned)(-pv[kk][j] - 2) : AT_NONE;
+      }
+      rdiag[k] = ref[0] | (ref[2] << 16); rwn[k] = ref[3] | (ref[1] << 16);
+      if (i < n) W[i] = at_pack(c, ref[3], ref[1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  const unsigned long long t1 = wall_clock64();
+  int sweeps = 0, steps = 0;
+  bool settled = false;
+  for (; sweeps < AT_SWEEPS && !settled; sweeps++) {
+    for (int step = 0; step < nsteps; step++) {          // (a run lies in one row / one column and the links double their reach with every step: nsteps = log2 of the longer side, rounded up)
+#pragma unroll
+      for (int k = 0; k < EPT; k++) {
+        const int i = tid + k * AT_NT;
+        if (i >= n) continue;
+        const ab_word w = W[i];
+        unsigned xv = at_x(w), lw = at_lw(w), ln = at_ln(w);
+        const unsigned x0 = xv, had = lw & ln;
+        if (lw != AT_NONE) { const ab_word a = W[lw]; xv = at_x(a) > xv ? at_x(a) : xv; lw = at_lw(a); }
+        if (ln != AT_NONE) { const ab_word a = W[ln]; xv = at_x(a) > xv ? at_x(a) : xv; ln = at_ln(a); }
+        xv = at_relax(W, rdiag[k] & 0xffffu, xv);
+        xv = at_relax(W, rdiag[k] >> 16, xv);
+        if (xv != x0 || had != AT_NONE) W[i] = at_pack(xv, lw, ln);      // (nothing to store for a pixel without links whose value did not move)
+      }
+      steps++;
+      __syncthreads();
+    }
+    // is x a fixed point of T = max(constant part, T of the four predecessors)?  (The constant part went in at the start and x only grows.)
+    // If not: another sweep, links restored.
+    bool bad = false;
+    unsigned f[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+      const int i = tid + k * AT_NT;
+      f[k] = 0;
+      if (i >= n) continue;
+      const unsigned x0 = at_x(W[i]);
+      unsigned m = x0;
+      m = at_relax(W, rdiag[k] & 0xffffu, m);
+      m = at_relax(W, rdiag[k] >> 16, m);
+      m = at_relax(W, rwn[k] & 0xffffu, m);
+      m = at_relax(W, rwn[k] >> 16, m);
+      f[k] = m;
+      bad = bad || m != x0;
+    }
+    settled = !__syncthreads_or(bad);
+    if (!settled) {
+#pragma unroll
+      for (int k = 0; k < EPT; k++) { const int i = tid + k * AT_NT; if (i < n) W[i] = at_pack(f[k], rwn[k] & 0xffffu, rwn[k] >> 16); }
+      __syncthreads();
+    }
+  }
+  const unsigned long long t2 = wall_clock64();
+  if (tid == 0) { status[2] = sweeps; status[3] = steps; if (!settled) status[0] = 1; }
+  if (!settled) return;
+  // labels: the first predecessor (NW, N, NE, W) whose T equals the pixel's own hands its label on - a pointer if that pixel is
+  // undecided itself - else the best old label is it
+  int L[EPT], p[EPT];
+#pragma unroll
+  for (int k = 0; k < EPT; k++) {
+    const int i = tid + k * AT_NT;
+    L[k] = 0; p[k] = 0;
+    if (i >= n) continue;
+    const int4 *rec = (const int4 *)(list + (size_t)i * AB_REC);
+    const int4 a = rec[0], b = rec[1], d = rec[2];
+    p[k] = a.x;
+    int pl[4] = { a.w, b.x, b.y, b.z };
+    unsigned ps[4] = { (unsigned)b.w, (unsigned)d.x, (unsigned)d.y, (unsigned)d.z };
+    const unsigned ref[4] = { rdiag[k] & 0xffffu, rwn[k] >> 16, rdiag[k] >> 16, rwn[k] & 0xffffu };      // NW, N, NE, W
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (pl[j] < -1 && ref[j] == AT_NONE) { pl[j] = out[(unsigned)(-pl[j] - 2)]; ps[j] = (unsigned)size[(unsigned)pl[j]]; }     // (decided by its own tile, see above)
+    const unsigned T = at_x(W[i]);
+    int res = a.y;
+    bool found = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (found) continue;
+      if (ref[j] != AT_NONE) { if (at_x(W[ref[j]]) == T) { res = -(int)ref[j] - 1; found = true; } }
+      else if (ps[j] == T) { res = pl[j]; found = true; }       // (T >= 1: a pixel outside the frame, size 0, never matches)
+    }
+    L[k] = res;
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  __syncthreads();
+  const unsigned long long t3 = wall_clock64();
+  int *Lp = (int *)W;
+#pragma unroll
+  for (int k = 0; k < EPT; k++) { const int i = tid + k * AT_NT; if (i < n) Lp[i] = L[k]; }
+  __syncthreads();
+  for (int step = 0; step < 16; step++) {           // (pointer chains may wind through rows and columns: until none is left)
+    bool open = false;
+#pragma unroll
+    for (int k = 0; k < EPT; k++) {
+      const int i = tid + k * AT_NT;
+      if (i >= n || L[k] >= 0) continue;
+      L[k] = Lp[-L[k] - 1];            // the predecessor's label, or the pointer it still follows
+      Lp[i] = L[k];
+      open = open || L[k] < 0;
+    }
+    if (!__syncthreads_or(open)) break;
+  }
+#pragma unroll
+  for (int k = 0; k < EPT; k++) { const int i = tid + k * AT_NT; if (i < n) out[(unsigned)p[k]] = L[k]; }
+  if (tid == 0) { status[4] = (int)(t1 - t0); status[5] = (int)(t2 - t1); status[6] = (int)(t3 - t2); status[7] = (int)(wall_clock64() - t3); }
+}
+
+__global__ __launch_bounds__(AT_NT) void k_absorb_tail(int *__restrict__ out, const int *__restrict__ list, int reccap, const int *__restrict__ count, const int *__restrict__ size, int nsteps, int *status) {
+  extern __shared__ __attribute__((aligned(16))) ab_word at_lds[];
+  const int n = *count;
+  if (threadIdx.x == 0) { status[1] = n; status[0] = n > reccap ? 1 : 0; status[2] = 0; }
+  if (n == 0 || n > reccap) return;
+  if (n <= 2 * AT_NT) at_body<2>(at_lds, out, list, n, size, nsteps, status);
+  else if (n <= 4 * AT_NT) at_body<4>(at_lds, out, list, n, size, nsteps, status);
+  else if (n <= 8 * AT_NT) at_body<8>(at_lds, out, list, n, size, nsteps, status);
+  else at_body<16>(at_lds, out, list, n, size, nsteps, status);
 }
 
 // (rc:373-390, the region-boundary marks, are computed inside the labelling kernel: rd_k_label.hip, k_label_tile<true>)
@@ -1273,7 +1574,7 @@ __global__ __launch_bounds__(256) void k_reduce_box(const rdk::PolyFrames FRS, i
 struct ls_rec { float x0, y0, x1, y1; int startIndex, endIndex, leftPtr, rightPtr, startCount, endCount, maxDist, polyid, npix, level; };
 
 // The kernel also assembles the block that travels to the host in ONE copy (pack): [0,32) polyline counters, [32,52) region
-// round flags, [64, 64 + 14 * pack_records) segment records 0.., then 90 ints of probes per record.
+// round flags, [52,55) absorption status, [64, 64 + 14 * pack_records) segment records 0.., then 90 ints of probes per record.
 __global__ void k_sample_segments(const rdk::PolyFrames FRS, int max_records, int iw, int ih, int nentry, int pack_records) {
   RD_VFRAME;
   int *__restrict__ out = FRM.probes;
@@ -1287,7 +1588,7 @@ __global__ void k_sample_segments(const rdk::PolyFrames FRS, int max_records, in
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (pack) {
     if (t < 32) pack[t] = polyctr[t];
-    else if (t < 52) pack[t] = rflags[t - 32];
+    else if (t < 56) pack[t] = rflags[t - 32];        // (20 round flags of the region merge, then the 3 status words of the absorption)
     if (t < 14) pack[64 + t] = ((const int *)ls)[t];        // header record
   }
   const int i = t / 15 + 1, k = t % 15;
@@ -1353,63 +1654,74 @@ void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int 
   hipLaunchKernelGGL(k_mm_gather, dim3(wpr, cdiv(ih, MM_ROWS)), dim3(64, 4), 0, s, out, (const unsigned long long *)scratch, iw, ih, wpr);
 }
 
-// scratch: 3*N + 256 ints (the plain labels of the initial forest; round flags + allowed-direction bytes; the second label plane of the rounds).
-// ROUNDS: 0 (diagnostics: the flattened initial forest is the result) or an even number >= 2; *marked <- whether `label` holds the rounds'
-// words (label << 3 | mark), which region_size turns into plain labels.
+// scratch: 3*N + 256 ints ([N, N + 64): round flags, then the allowed-direction bytes; [2N, 3N): the second label plane of the rounds).
+// ROUNDS: the number of launches, even (the last one writes `label`); launches after one that changed nothing return at once.
+// *marked <- 1: `label` holds the rounds' words (label << 3 | mark), which region_size turns into plain labels.
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS, int *size_out, const int *size_init, int *marked) {
   const int n = iw * ih;
-  if (ROUNDS != 0 && (ROUNDS < 2 || (ROUNDS & 1))) { fprintf(stderr, "region_merge: the number of rounds must be even (got %d)\n", ROUNDS); abort(); }
-  // tile-to-tile hops left after k_region_init: at most ih/RI_ROWS + iw/64 + 2; each launch divides the depth by 16
-  int FLAT = 1;
-  for (long reach = 16; reach < ih / RI_ROWS + iw / 64 + 2; reach *= 16) FLAT++;
-  int *flags = scratch + n, *fflags = flags + 32;
+  if (ROUNDS < 0 || (ROUNDS & 1)) { fprintf(stderr, "region_merge: the number of rounds must be even (got %d)\n", ROUNDS); abort(); }
+  int *flags = scratch + n;
   uint8_t *allow = (uint8_t *)(flags + 64);
-  int *P = ROUNDS > 0 ? scratch : label;          // the initial forest (plain labels)
   int *A = label, *B = scratch + 2 * (size_t)n;   // the two planes of the rounds; the result is in A
-  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, P, allow, pix, mask, edge, iw, ih, flags, size_out, size_init);
-  // the initial links are flattened first; the synchronous rounds then start from trees of depth 1 (left in A and B by the last launch)
-  for (int r = 0; r < FLAT; r++) {
-    const bool last = r == FLAT - 1 && ROUNDS > 0;
-    hipLaunchKernelGGL(k_region_flatten, dim3(ew_grid(n)), dim3(256), 0, s, P, n, fflags, r, last ? A : (int *)nullptr, last ? B : (int *)nullptr);
-  }
+  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, A, B, allow, pix, mask, edge, iw, ih, flags, size_out, size_init);
   const dim3 grid(cdiv(iw, 64), cdiv(ih, RR_TY * RR_PX));
   for (int r = 0; r < ROUNDS; r++) {
     if (r & 1) hipLaunchKernelGGL(k_region_round, grid, dim3(64, RR_TY), 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r);
     else hipLaunchKernelGGL(k_region_round, grid, dim3(64, RR_TY), 0, s, A, B, (const uint8_t *)allow, iw, ih, flags, r);
   }
-  if (marked) *marked = ROUNDS > 0;
+  if (marked) *marked = 1;
 }
 
 void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, int marked) {
   hipLaunchKernelGGL(k_region_size, dim3(cdiv(n, 256 * RS_PER_THREAD)), dim3(256), 0, s, out, label, n, zero_me, marked);
 }
 
-// scratch: RD_D2_SCRATCH_INTS(N) ints, scratch[N] (the first list counter) zeroed by the caller when count_is_zero; out must not
-// alias in.  27 Jacobi rounds of the reference's in-place sweep; only pixels of small regions can change,
-// so every round after the first runs over work lists.
-void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih, int count_is_zero) {
-  // 1 + 2 * 13 = 27 Jacobi rounds.  The raster recurrence has dependency chains of hundreds of pixels (it takes 300-900
-  // rounds to reproduce the reference's plane exactly); what matters downstream settles much earlier: with 8 rounds the
-  // rectangle lists of busy frames differed from the reference's, from 24 rounds on they did not (CPU study with
-  // bounded-round Jacobi prototypes, 6 of 6 frames; DESIGN.md "Known deviation").
-  const int n = iw * ih, DOUBLE_ROUNDS = 13;   // odd: the last launch writes into `out`
-  int *tmp = scratch, *count = scratch + (size_t)n, *stamp = count + 16, *lists = stamp + (size_t)n;
+// rc:348-371 as the reference's serial raster order evaluates it, exactly.  scratch: RD_D2_SCRATCH_INTS(N) ints, scratch[N] (the list
+// counter) zeroed by the caller when count_is_zero; out must not alias in.  status (device, 3 ints): [0] != 0 <=> the two launches
+// could not finish the frame (more than AT_CAP undecided pixels, or the tail did not settle): `out` then still holds undecided
+// words (negative) and the caller runs despeckle2_slow(); [1] undecided pixels left by the tile kernel, [2] sweeps of the tail.
+void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih, int count_is_zero, int *status) {
+  const int n = iw * ih;
+  int *count = scratch + (size_t)n, *list = count + 16 + (size_t)n;       // (the list: the 3N ints of the slow path's work lists)
+  const int reccap = (int)(3 * (size_t)n / AB_REC) < AT_CAP ? (int)(3 * (size_t)n / AB_REC) : AT_CAP;
+  int nsteps = 1;
+  while ((1 << nsteps) < (iw > ih ? iw : ih)) nsteps++;
   if (!count_is_zero) (void)hipMemsetAsync(count, 0, sizeof(int), s);
+  hipLaunchKernelGGL(k_absorb_tile, dim3(cdiv(iw, AB_TW), cdiv(ih, AB_TH)), dim3(AB_NT), 0, s, out, list, reccap, count, in, size, thre, iw, ih);
+  static std::atomic<unsigned> lds_set{0};
+  set_max_lds_once((const void *)k_absorb_tail, (int)((AT_CAP + 1) * sizeof(ab_word)), lds_set);
+  hipLaunchKernelGGL(k_absorb_tail, dim3(1), dim3(AT_NT), (AT_CAP + 1) * sizeof(ab_word), s, out, (const int *)list, reccap, (const int *)count, size, nsteps, status);
+}
+
+// The same result by plain Jacobi rounds of the recurrence over work lists in global memory, two rounds per launch, until a launch
+// changes nothing (the fixed point of the rounds is the serial result; chains of dependent pixels can be thousands long on frames
+// that consist of small regions only, so this takes as many launches as it takes).  Synchronises `s` every few launches: for the
+// frames the fast path gives up on, outside captured graphs.  Same scratch as despeckle2().
+void despeckle2_slow(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih) {
+  const int n = iw * ih;
+  int *tmp = scratch, *count = scratch + (size_t)n, *stamp = count + 16, *lists = stamp + (size_t)n;
+  (void)hipMemsetAsync(count, 0, 16 * sizeof(int), s);
   // first round: tmp <- result, out <- input (both planes then agree on every pixel that is not in the list)
   hipLaunchKernelGGL(k_despeckle2_first, dim3(cdiv(iw, 64), cdiv(ih, D2_ROWS)), dim3(64, 4), 0, s, tmp, out, stamp, lists, count, in, size, thre, iw, ih);
   const int *cur = tmp;
-  const int HEAD = 4;       // launches with lists long enough to be worth more than one block
-  for (int r = 0; r < HEAD; r++) {
-    int *nxt = (r & 1) ? tmp : out;
-    const int li = r % 3, lo = (r + 1) % 3, lz = (r + 2) % 3;
-    // (the work lists shrink by an order of magnitude per launch: later launches need few blocks, and dispatching blocks that
-    //  find nothing to do is what an almost empty launch costs)
-    hipLaunchKernelGGL(k_despeckle2_active, dim3(r < 2 ? 512 : 128), dim3(256), 0, s, nxt, cur, (const int *)(lists + (size_t)li * n), (const int *)(count + li),
-                       lists + (size_t)lo * n, count + lo, count + lz, count + 3 + r, stamp, r + 1, in, size, thre, iw, ih);
-    cur = nxt;
+  int r = 0;
+  for (;;) {
+    for (int k = 0; k < 8; k++, r++) {
+      int *nxt = (r & 1) ? tmp : out;
+      const int li = r % 3, lo = (r + 1) % 3, lz = (r + 2) % 3;
+      hipLaunchKernelGGL(k_despeckle2_active, dim3(256), dim3(256), 0, s, nxt, cur, (const int *)(lists + (size_t)li * n), (const int *)(count + li),
+                         lists + (size_t)lo * n, count + lo, count + lz, count + 3, stamp, r + 1, in, size, thre, iw, ih);
+      cur = nxt;
+    }
+    int pending = 0;      // the list the last launch produced
+    (void)hipMemcpyAsync(&pending, count + (r % 3), sizeof(int), hipMemcpyDeviceToHost, s);
+    (void)hipStreamSynchronize(s);
+    if (pending == 0) break;
+    // (a dependency chain moves at least one pixel right or one row down per link: iw + 2 * ih bounds its length, and every launch settles two links)
+    if (r > iw + 2 * ih + 16) { fprintf(stderr, "despeckle2_slow: no fixed point after %d launches (internal error)\n", r); abort(); }
   }
-  // launches HEAD .. 12 in one (launch r writes `tmp` if r is odd, else `out`; DOUBLE_ROUNDS is odd: the last one writes `out`)
-  hipLaunchKernelGGL(k_despeckle2_tail, dim3(1), dim3(256), 0, s, out, tmp, lists, count, stamp, HEAD, DOUBLE_ROUNDS, n, in, size, thre, iw, ih);
+  // (launches with an odd number write `tmp`, and the last one had: the result moves to `out`)
+  if (cur != out) (void)hipMemcpyAsync(out, cur, sizeof(int) * (size_t)n, hipMemcpyDeviceToDevice, s);
 }
 
 // table: nentry*5 ints, claim: nentry ints, tlist: nentry+1 ints; all three are set up once by reduce_ls_init and kept

@@ -3,8 +3,20 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace rdk {
+
+// Kernels with more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once PER DEVICE (a process may drive
+// several GPUs from several threads): `done` holds one bit per device ordinal; a race only repeats an idempotent call.
+inline void set_max_lds_once(const void *func, int bytes, std::atomic<unsigned> &done) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned bit = 1u << (dev & 31);
+  if (done.load(std::memory_order_acquire) & bit) return;
+  (void)hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  done.fetch_or(bit, std::memory_order_release);
+}
 
 // ---- rd_k_front.hip: colour, blur, gradient, non-max suppression, element-wise ops
 void bgr2plab(hipStream_t s, uint32_t *out, const uint8_t *bgr, int iw, int ih, int ws);
@@ -65,7 +77,10 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
                   int *size_out, const int *size_init, int *marked);   // rounds: an even number <= 20 (early-out on the device) or 0; size_out (optional) <- size_init, for region_size; scratch: 3N + 256 ints; *marked <- 1 when `label` is left as label << 1 | mark words, which region_size(…, marked) turns into plain labels
 void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, int marked = 0);   // accumulates into out; zero_me (optional): an int to clear on the way
 #define RD_D2_SCRATCH_INTS(N) (5 * (size_t)(N) + 64)
-void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih, int count_is_zero);   // out != in; scratch: RD_D2_SCRATCH_INTS(N) ints (scratch[N] = 0 already if count_is_zero)
+// absorption of small regions (oclrect.cl:348-371) exactly as the reference's serial raster order gives it.  out != in; scratch: RD_D2_SCRATCH_INTS(N) ints
+// (scratch[N] = 0 already if count_is_zero); status: 3 device ints, [0] != 0 <=> not finished (out holds negative words): run despeckle2_slow()
+void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih, int count_is_zero, int *status);
+void despeckle2_slow(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih);   // the same result for any input; synchronises s (not for captured streams)
 struct PolyScratch;
 struct PolyFrame;      // rd_poly_scratch.h: per-frame descriptor of the sparse stages; launches cover nb <= RD_MAXB frames (frame = blockIdx.z), descriptors in HOST memory
 void reduce_ls_init(hipStream_t s, int *table, int *claim, int *tlist, int nentry);   // once per allocation

@@ -40,9 +40,10 @@ def oracle():
         O.rdo_rect_frame.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
         O.rdo_rect_set_region_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
         O.rdo_rect_info.argtypes = [ctypes.c_void_p, ctypes.c_int]
-        O.rdo_region_sync.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3
+        O.rdo_region_concurrent.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3
         O.rdo_despeckle2_jacobi_k.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
         O.rdo_region_size.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        O.rdo_despeckle2.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         O.rdo_mark_boundary.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
         O.rdo_label8.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         O.rdo_reduce_ls.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -56,8 +57,10 @@ def oracle():
     return _oracle
 
 
-REGION_REFERENCE_RASTER = 0   # the reference's in-place region kernels, work-items in serial raster order (what oracle/_ref runs)
-REGION_SPEC = 1               # the order-free schedule of the same rules that the HIP path implements (oracle/rd_oracle.c: rdo_region_sync, 27 Jacobi rounds)
+REGION_REFERENCE_RASTER = 0       # the reference's in-place region merge, work-items in serial raster order (what oracle/_ref runs by default)
+REGION_SPEC = 1                   # the same kernel with the work-items of a launch running concurrently, launched until nothing changes: what the HIP path reproduces bit for bit
+REGION_REFERENCE_CONCURRENT = 2   # concurrent work-items, the reference's 8 launches: what oracle/_ref computes under rdcl_set_order(..., 0, 0, 5, 0)
+# (the absorption of small regions is the serial raster order's result in every mode - the HIP path evaluates that recurrence exactly)
 
 
 class OracleRect:
@@ -70,7 +73,7 @@ class OracleRect:
         oracle().rdo_rect_set_region_mode(self.h, region_mode)
 
     def rounds(self):
-        """(merge rounds, absorption rounds) the last frame took in REGION_SPEC mode"""
+        """(launches of the merge kernel the last frame evaluated - in REGION_SPEC mode: including the one that changed nothing -, 0)"""
         return oracle().rdo_rect_info(self.h, 1), oracle().rdo_rect_info(self.h, 2)
 
     def frame(self, bgr):

@@ -103,3 +103,30 @@ def test_blur_division_formula_is_exact():
     checked for every operand pair the kernel can produce"""
     out = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tools", "check_div_small.py")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "exact" in out.stdout, out.stdout + out.stderr
+
+
+REFERENCE = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFERENCE, "rect.cpp")), reason="reference sources not present (only in the build container)")
+@pytest.mark.parametrize("app", ["rect", "poly", "vidrect", "vidpoly"])
+def test_reference_applications_compile_and_link_unchanged(app, tmp_path):
+    """north_star: "rect.cpp, poly.cpp and vidrect.cpp link unchanged".  The reference's demo programs are compiled WHERE THEY LIE
+    (nothing of them is copied) against include/*.h and linked with librectdetect_hip.so instead of libOpenCL + the reference's own
+    objects.  OpenCV is absent from this image, so its handful of names comes from a declarations-only stand-in
+    (tests/opencv_stub/opencv2/opencv.hpp); everything else - every oclrect / oclpolyline / oclimgutil / oclhelper / helper / cl*
+    symbol the programs import - must be resolved by the library.  The program then starts and prints its usage."""
+    obj, exe = tmp_path / (app + ".o"), tmp_path / app
+    subprocess.check_call(["g++", "-std=gnu++11", "-DCL_TARGET_OPENCL_VERSION=120", "-w", "-I", os.path.join(helpers.ROOT, "tests", "opencv_stub"),
+                           "-I", os.path.join(helpers.ROOT, "include"), "-c", os.path.join(REFERENCE, app + ".cpp"), "-o", str(obj)])
+    # what the program imports beyond libc / libstdc++: all of it must come from the library
+    L = ctypes.CDLL(ra.LIB_PATH)
+    undefined = [l.split()[-1] for l in subprocess.check_output(["nm", "-u", str(obj)], text=True).splitlines()]
+    ours = [u for u in undefined if re.match(r"(cl[A-Z]|ocl|init_ocl|dispose_ocl|simple|exitf|ce$|getDeviceName|loadPlan|savePlan|startProfiling|finishProfiling|"
+                                             r"currentTimeMillis|allocatePinnedMemory|freePinnedMemory|waitForEvent|clStrError|checkError)", u)]
+    assert len(ours) >= 8, ours
+    missing = [u for u in ours if not hasattr(L, u)]
+    assert not missing, f"{app}.cpp imports symbols the library does not export: {missing}"
+    subprocess.check_call(["g++", str(obj), "-o", str(exe), "-L", os.path.dirname(ra.LIB_PATH), "-lrectdetect_hip", "-Wl,-rpath," + os.path.dirname(ra.LIB_PATH), "-lm"])
+    p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
+    assert "Usage" in (p.stdout + p.stderr) or "usage" in (p.stdout + p.stderr), (p.returncode, p.stdout[-500:], p.stderr[-500:])

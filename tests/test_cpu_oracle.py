@@ -258,32 +258,64 @@ def test_region_spec_against_the_references_own_order_dependence():
 
 @pytest.mark.parametrize("iw,ih,seed", [(333, 217, 2), (640, 480, 5)])
 def test_region_spec_stage_relations(iw, ih, seed):
-    """REGION_SPEC mode: the synchronous merge settles well inside 20 rounds; a fixed point of the Jacobi absorption IS the serial
-    raster result of the reference's kernel (same inputs); the planes downstream follow from it by the order-independent stages"""
+    """REGION_SPEC mode: the merge kernel with concurrent work-items settles well inside the 20 launches the HIP path budgets for; its
+    first 8 launches are the REGION_REFERENCE_CONCURRENT plane; the fixed point of the Jacobi absorption IS the serial raster result of
+    the reference's kernel (same inputs) - the argument by which the HIP path's parallel evaluation of it is exact; the planes
+    downstream follow by the order-independent stages"""
     O, P = helpers.oracle(), helpers.P
     N = iw * ih
     img = synth.frame(synth.SEED0 + seed, iw, ih, 0)
     orc = helpers.OracleRect(iw, ih, helpers.REGION_SPEC)
     orc.frame(img)
-    merge_rounds, absorb_rounds = orc.rounds()
-    assert 1 <= merge_rounds < 20 and 1 <= absorb_rounds <= 27
+    launches, absorb_rounds = orc.rounds()
+    assert 2 <= launches < 20 and absorb_rounds == 0
     quant, mask, edge, junction = (orc.plane(n).view(np.int32) for n in ("quant", "mergemask", "label1", "junction"))
     lab = np.zeros(N, np.int32)
-    r = O.rdo_region_sync(P(lab), P(quant), P(mask), P(edge), iw, ih, 1000)
-    assert r == merge_rounds        # 20 was not the limit
-    again = lab.copy()
+    assert O.rdo_region_concurrent(P(lab), P(quant), P(mask), P(edge), iw, ih, 1000) == launches        # 64 was not the limit
+    one_less = np.zeros(N, np.int32)
+    O.rdo_region_concurrent(P(one_less), P(quant), P(mask), P(edge), iw, ih, launches - 1)
+    assert np.array_equal(one_less, lab), "the last launch must have changed nothing"
+    inner = np.zeros((ih, iw), bool)
+    inner[1:-1, 1:-1] = True
+    assert np.array_equal(lab[lab][inner.reshape(-1)], lab[inner.reshape(-1)]), "at the fixed point every processed pixel points at a root"
     size = junction.copy()
     O.rdo_region_size(P(size), P(lab), N)
     assert np.array_equal(size, orc.plane("rsize"))
     serial, jac = lab.copy(), lab.copy()
-    O.rdo_despeckle2.argtypes = [__import__("ctypes").c_void_p, __import__("ctypes").c_void_p] + [__import__("ctypes").c_int] * 3
     O.rdo_despeckle2(P(serial), P(size), 16, iw, ih)
     rounds = O.rdo_despeckle2_jacobi_k(P(jac), P(size), 16, iw, ih, None, 1 << 30)
     assert np.array_equal(serial, jac), "the fixed point of the Jacobi rounds must be the raster-order result"
-    if rounds <= 27:
-        assert np.array_equal(jac, orc.plane("region"))
+    assert rounds >= 1 and np.array_equal(serial, orc.plane("region"))      # the spec's absorption IS the serial raster result
     marks = np.zeros(N, np.int32)
     O.rdo_mark_boundary(P(marks), P(orc.plane("region")), iw, ih)
     assert np.array_equal(marks, orc.plane("boundary_src"))
-    assert np.array_equal(again, lab)
     orc.close()
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("iw,ih,seed,nframes", [(333, 217, 2, 2), (640, 480, 0, 2)])
+def test_concurrent_merge_restatement_equals_the_references_own_kernel(iw, ih, seed, nframes):
+    """pins rdo_region_concurrent: the reference itself (oracle/_ref: its kernels and host code) with the work-items of labelMergeMain
+    running concurrently (rdcl_set_order group order 5: every work-item reads the labels the launch began with, the atomic minima take
+    effect together) against the oracle in REGION_REFERENCE_CONCURRENT mode - region, size and boundary planes and the rectangle list,
+    bit for bit, on consecutive frames (the state carried from frame to frame included)"""
+    import ctypes
+    R = helpers.ref()
+    R.rdcl_set_order.argtypes = [ctypes.c_char_p] + [ctypes.c_int] * 4
+    tan = float(np.tan(36.0 / 180.0 * np.pi))
+    r = helpers.RefRect(iw, ih)
+    orc = helpers.OracleRect(iw, ih, helpers.REGION_REFERENCE_CONCURRENT)
+    try:
+        R.rdcl_set_order(b"rect:labelMergeMain", 0, 0, 5, 0)
+        for t in range(nframes):
+            img = synth.frame(synth.SEED0 + seed, iw, ih, t)
+            rects, snaps = r.execute_once(img, tan, snapshots=["region", "rsize", "boundary", "table"])
+            orc.frame(img)
+            for k in ("region", "rsize", "boundary"):
+                assert np.array_equal(snaps[k].view(np.int32), orc.plane(k).view(np.int32)), (t, k)
+            mine = ra.postprocess_planes(orc.segments(), orc.plane("boundary"), orc.plane("table"), iw, ih, tan)
+            assert helpers.rects_equal(rects, mine), t
+    finally:
+        R.rdcl_set_order(b"", 0, 0, 0, 0)
+        r.close()
+        orc.close()

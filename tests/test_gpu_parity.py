@@ -19,14 +19,30 @@ EXACT = [("plab0", "plab0", 1), ("lblur", "Lblur", 1), ("plab1", "plab1", 1), ("
          ("strong", "strong", 1), ("label1", "label1", 1), ("junction", "junction", 1), ("mergemask", "mergemask", 1), ("lsid", "lsid", 1)]
 # The region stages: the reference's labelMergeMain / despeckle2 update labels in place, so their result depends on the order
 # in which a device runs the work-items (tests/golden/hard_rect_orders.npz shows the reference's own
-# rectangle lists changing with it).  The HIP path evaluates the same rules in an order-free schedule whose normative
-# definition is the oracle's REGION_SPEC mode (oracle/rd_oracle.c: rdo_region_sync + 27 Jacobi rounds): these planes must be
-# bit-identical to THAT.
+# rectangle lists changing with it).  The HIP path reproduces ONE legal execution of the reference's kernels bit for bit: the
+# merge kernel with the work-items of a launch running concurrently, launched until a launch changes nothing, then the
+# absorption exactly as the serial raster order gives it.  Normative definition: the oracle's REGION_SPEC mode
+# (oracle/rd_oracle.c: rdo_region_concurrent - itself pinned to the reference's own kernel running that way, tests/test_cpu_oracle.py -
+# and rdo_despeckle2): these planes must be bit-identical to THAT.
 REGION_EXACT = [("region0", None), ("region", "region"), ("rsize", "rsize"), ("boundarysrc", "boundary_src"), ("boundary", "boundary"), ("table", "table")]
 TAN36 = float(np.tan(36.0 / 180.0 * np.pi))
-# (stream, frame) -> tolerance on the 3-D corners where the pose fit amplifies a 1e-13 difference of the image corners beyond 1e-4
-# (test_long_streams_in_the_benchmarked_configuration_vs_reference; the reference gives its raster-order value under all 32 sampled orders there)
-POSE_SENSITIVE = {("stream_1920x1080_s0_100", 55): 1e-2}
+
+
+def detector(iw, ih, device_post=False, tan=None, **kw):
+    """a detector; device_post: the rectangles come from the device (RD_DEVICE_POST=1: candidate funnel + pose estimation in
+    rd_k_post.hip) - the aperture of the polls to come is announced so that the first frame takes that path as well"""
+    if not device_post:
+        return ra.Detector(iw, ih, **kw)
+    old = os.environ.get("RD_DEVICE_POST")
+    os.environ["RD_DEVICE_POST"] = "1"
+    try:
+        return ra.Detector(iw, ih, aperture=TAN36 if tan is None else tan, **kw)
+    finally:
+        os.environ.pop("RD_DEVICE_POST", None) if old is None else os.environ.__setitem__("RD_DEVICE_POST", old)
+
+
+# frames of the long streams whose rectangle SET is bit-identical to the raster-order reference's (recorded; must not drop)
+EXACT_FRAMES_MIN = {"stream_1280x720_s1_300": 298, "stream_1920x1080_s0_100": 96, "stream_3840x2160_s4_16": 16, "stream_1920x1080_s0": 16, "stream_1280x720_s1": 30, "stream_3840x2160_s4": 3}
 
 
 def check_region_planes(det, orc, where=""):
@@ -47,8 +63,8 @@ def check_region_planes(det, orc, where=""):
     O.rdo_region_size(P(size), P(gp["region0"]), N)
     assert np.array_equal(size, gp["rsize"]), f"{where}: rsize != junction + histogram(region0)"
     lab = gp["region0"].copy()
-    O.rdo_despeckle2_jacobi_k(P(lab), P(gp["rsize"]), 16, iw, ih, None, 27)
-    assert np.array_equal(lab, gp["region"]), f"{where}: region != 27 Jacobi rounds of the absorption on (region0, rsize)"
+    O.rdo_despeckle2(P(lab), P(gp["rsize"]), 16, iw, ih)
+    assert np.array_equal(lab, gp["region"]), f"{where}: region != the reference's despeckle2 in serial raster order on (region0, rsize): {int((lab != gp['region']).sum())} pixels"
     marks = np.zeros(N, np.int32)
     O.rdo_mark_boundary(P(marks), P(gp["region"]), iw, ih)
     assert np.array_equal(marks, gp["boundarysrc"]), f"{where}: boundarysrc != markBoundary(region)"
@@ -117,12 +133,14 @@ def test_region_stages_bit_exact_vs_spec(iw, ih, seed, nframes):
     orc.close()
 
 
+@pytest.mark.parametrize("device_post", [False, True], ids=["host_post", "device_post"])
 @pytest.mark.parametrize("name", ["rect_640x480_s0", "rect_640x480_s5", "rect_333x217_s2", "rect_1280x720_s1", "rect_1920x1080_s0"])
-def test_rect_outputs_match_reference_golden(name):
-    """polyline vertex lists bit-exact and rectangle lists identical to what the reference produced"""
+def test_rect_outputs_match_reference_golden(name, device_post):
+    """polyline vertex lists bit-exact and rectangle lists identical to what the reference produced - with the rectangles computed
+    by the host post-process (rd_post.c) and by the device post-process (rd_k_post.hip), each directly against the reference's lists"""
     g = golden(name)
     iw, ih = int(g["iw"]), int(g["ih"])
-    det = ra.Detector(iw, ih, nslots=1)
+    det = detector(iw, ih, device_post, tan=float(g["tan_aov"]), nslots=1)
     for t in range(int(g["nframes"])):
         img = synth.frame(int(g["seed"]), iw, ih, t)
         det.enqueue(img)
@@ -136,6 +154,8 @@ def test_rect_outputs_match_reference_golden(name):
         assert np.abs(rects["c2"] - ref["c2"]).max(initial=0) <= 1e-4
         assert np.abs(rects["c3"] - ref["c3"]).max(initial=0) <= 1e-4
         assert np.abs(rects["value"] - ref["value"]).max(initial=0) <= 1e-4
+    if device_post:
+        assert ra.lib().rd_detector_counter(det.h, 11) == int(g["nframes"]), "every frame's rectangles must have come from the device"
     det.close()
 
 
@@ -198,21 +218,19 @@ def test_long_streams_in_the_benchmarked_configuration_vs_reference(name, nslots
                 assert not member.all()
                 by_order.append(t)
                 continue
-        # Otherwise: the same rectangles within the stated tolerance.  (Such frames exist: the spec's region planes are not the raster
-        # order's - 27 absorption rounds instead of the fixed point, DESIGN.md "Region stages" - which can move the box a segment is
-        # clipped to; the clipped piece lies on the same line, the corners move by 1e-13, and the 12-step conjugate-gradient pose fit
-        # amplifies that.  POSE_SENSITIVE lists the one frame where the amplified difference exceeds 1e-4, in c3 only.)
+        # Otherwise: the same rectangles within the stated tolerance, no exceptions (1e-4 on every float, north_star)
         assert len(rects) == len(ref), f"{name} frame {t}: {len(rects)} rectangles, reference {len(ref)}"
         rects, ref = canon(rects), canon(ref)
         assert np.array_equal(rects["status"], ref["status"])
         assert np.array_equal(np.rint(rects["c2"]), np.rint(ref["c2"]))
         assert np.abs(rects["c2"] - ref["c2"]).max(initial=0) <= 1e-4
-        tol3 = POSE_SENSITIVE.get((name, t), 1e-4)
-        assert np.abs(rects["c3"] - ref["c3"]).max(initial=0) <= tol3 and np.abs(rects["value"] - ref["value"]).max(initial=0) <= 1e-4
+        assert np.abs(rects["c3"] - ref["c3"]).max(initial=0) <= 1e-4 and np.abs(rects["value"] - ref["value"]).max(initial=0) <= 1e-4
         within.append((t, float(np.abs(rects["c2"] - ref["c2"]).max(initial=0)), float(np.abs(rects["c3"] - ref["c3"]).max(initial=0))))
     print(name, "slots", nslots, ": rectangle sets bit-identical to the reference's (raster order) on %d of %d frames (%d in the same list order); inside the reference's own order-dependence on frames %s; same rectangles within tolerance (frame, max |dc2|, max |dc3|): %s; round budget, repeats:" %
           (exact, nframes, same_order, by_order, within), det.region_round_budget())
     assert exact + len(by_order) + len(within) == nframes
+    assert within == [], "every frame must equal the reference's list or lie inside the reference's own order dependence"
+    assert exact >= EXACT_FRAMES_MIN[name], (exact, "frames bit-identical to the raster-order reference: fewer than recorded")
     det.close()
     for p in dptrs:
         L.rd_device_free(p)
@@ -230,6 +248,7 @@ def test_order_dependent_stream_frames_equal_the_spec(name):
     assert frames, "no recorded frames for this stream"
     det = ra.Detector(iw, ih, nslots=1)
     orc = helpers.OracleRect(iw, ih, helpers.REGION_SPEC)
+    raster = helpers.OracleRect(iw, ih, helpers.REGION_REFERENCE_RASTER)
     prev = np.zeros(iw * ih, np.int32)
     for t in range(max(frames) + 1):
         img = synth.frame(seed, iw, ih, t)
@@ -242,10 +261,76 @@ def test_order_dependent_stream_frames_equal_the_spec(name):
             check_region_planes(det, orc, f"{name} frame {t}")
             want = ra.postprocess_planes(orc.segments(), orc.plane("boundary"), orc.plane("table"), iw, ih, tan)
             assert helpers.rects_equal(rects, want), (name, t)
+            # REPORTED, not asserted: how far the planes are from the reference-mode oracle (the reference's kernels in serial raster
+            # order, same inherited state).  The merge's order-free schedule labels regions differently where the reference's in-place
+            # launches are order dependent; the partition of the frame into boundary / non-boundary pixels is what the votes see.
+            raster.set_prev_strong(prev)
+            raster.frame(img)
+            independent = bool(go[f"{name}_f{t}_member"].all())
+            gr, rr = det.plane("region"), raster.plane("region").view(np.int32)
+            gb, rb = det.plane("boundary"), raster.plane("boundary").view(np.int32)
+            print(f"{name} frame {t}: reference order-independent here: {independent}; pixels whose region label differs from the reference-mode oracle: {int((gr != rr).sum())}; "
+                  f"pixels on a region boundary in one and not in the other: {int(((gb > 0) != (rb > 0)).sum())} of {int((rb > 0).sum())}; "
+                  f"rectangle list == reference golden (raster order): {helpers.rects_equal(rects, g[f'f{t}_rects'])}")
+            if independent:
+                assert helpers.rects_equal(rects, g[f"f{t}_rects"]), "where the reference does not depend on the order, the list must be the reference's in every bit"
         if t + 1 in frames:
             prev = det.plane("strong")
     det.close()
     orc.close()
+    raster.close()
+
+
+def _absorb_reference(det):
+    """the reference's despeckle2 in serial raster order (oracle) on the GPU's own merged labels and sizes"""
+    O, P = helpers.oracle(), helpers.P
+    lab = det.plane("region0").copy()
+    O.rdo_despeckle2(P(lab), P(det.plane("rsize")), 16, det.iw, det.ih)
+    return lab
+
+
+@pytest.mark.parametrize("iw,ih,seed,nframes", [(1920, 1080, 0, 3), (1280, 720, 1, 2), (640, 480, 5, 2), (97, 61, 7, 1), (2049, 20, 3, 1), (33, 300, 3, 1)])
+def test_absorption_equals_the_references_serial_raster_order(iw, ih, seed, nframes, monkeypatch):
+    """oclrect.cl:348-371 updates labels in place; in the reference's serial raster order that is a recurrence whose dependency chains
+    run for hundreds of pixels along the frame's last row.  The HIP path evaluates it EXACTLY (tile kernel with a halo + single-block
+    tail on max-propagation and pointer doubling): the region plane must equal the oracle's serial sweep on the same inputs in every
+    pixel, on the fast path, and again when every frame is forced through the slow path (rounds over work lists to the fixed point)."""
+    for force_slow in (0, 1):
+        if force_slow:
+            monkeypatch.setenv("RD_ABSORB_FORCE_SLOW", "1")
+        det = ra.Detector(iw, ih, nslots=1)
+        monkeypatch.delenv("RD_ABSORB_FORCE_SLOW", raising=False)
+        for t in range(nframes):
+            det.enqueue(synth.frame(synth.SEED0 + seed, iw, ih, t))
+            det.poll(TAN36)
+            got, want = det.plane("region"), _absorb_reference(det)
+            assert got.min() >= 0, "undecided words left in the region plane"
+            assert np.array_equal(got, want), f"{iw}x{ih} frame {t} slow={force_slow}: {int((got != want).sum())} pixels differ from the serial raster sweep"
+            left, sweeps, slow = det.absorption()
+            assert slow == (t + 1 if force_slow else 0), (left, sweeps, slow)
+            if not force_slow:
+                print(f"absorption {iw}x{ih} frame {t}: {left} pixels left to the tail, {sweeps} sweeps, {det.absorb_trace}")
+        det.close()
+
+
+def test_absorption_of_frames_made_of_small_regions_takes_the_slow_path():
+    """busy stills (tests/golden/hard_rect.npz: colour tiles, noise) leave tens of thousands of undecided pixels - more than the
+    single-block tail holds: the frame is finished by the slow path, with the same exact result"""
+    g = golden("hard_rect")
+    kinds, params = g["kinds"].tolist(), g["params"].tolist()
+    took_slow = 0
+    for hi in (0, 3, 6, 9, 12):
+        seed, iw, ih = params[hi]
+        det = ra.Detector(iw, ih, nslots=1)
+        det.enqueue(synth.hard_frame(kinds[hi], seed, iw, ih))
+        det.poll(TAN36)
+        got, want = det.plane("region"), _absorb_reference(det)
+        assert got.min() >= 0 and np.array_equal(got, want), f"busy frame {hi} ({kinds[hi]}): {int((got != want).sum())} pixels differ from the serial raster sweep"
+        left, sweeps, slow = det.absorption()
+        print(f"absorption busy frame {hi} ({kinds[hi]} {iw}x{ih}): {left} pixels left to the tail, {sweeps} sweeps, slow path: {slow}")
+        took_slow += slow
+        det.close()
+    assert took_slow > 0
 
 
 def test_repeats_on_shared_streams_while_graphs_are_captured(monkeypatch):
@@ -534,10 +619,11 @@ def test_pipelined_workers_equal_sequential(nslots):
 
 
 @pytest.mark.parametrize("nslots,pattern", [(8, [1, 3, 8, 5, 2, 8, 8, 1]), (4, [4, 1, 2, 3]), (6, [6, 5, 6]), (5, [2, 5])])
-def test_batched_sparse_stages_any_polling_pattern(nslots, pattern):
-    """From four frame slots on, the sparse stages (polylines, votes, probes) of up to four consecutive slots run as one set of
-    launches (frame = blockIdx.z).  Whatever the caller's rhythm - groups filled completely, polled when partly filled, slot
-    counts that are no multiple of four - the results must equal one frame at a time on a single-slot detector."""
+def test_batched_sparse_stages_any_polling_pattern(nslots, pattern, monkeypatch):
+    """The sparse stages (polylines, votes, probes) of up to four consecutive slots can run as one set of launches (frame =
+    blockIdx.z; the default from 12 slots on, RD_BATCH=4 here).  Whatever the caller's rhythm - groups filled completely, polled
+    when partly filled, slot counts that are no multiple of four - the results must equal one frame at a time on a single-slot detector."""
+    monkeypatch.setenv("RD_BATCH", "4")
     iw, ih = 640, 480
     frames = [synth.frame(synth.SEED0 + 21, iw, ih, t) for t in range(sum(pattern))]
     seq = ra.Detector(iw, ih, nslots=1, nworkers=0)
@@ -582,15 +668,15 @@ def test_device_postprocess_equals_host_postprocess(nslots):
                 os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
             res, infl = [], 0
             det.enqueue(frames[0])              # (the first poll tells the detector the aperture)
-            res.append(det.poll(TAN36))
+            res.append((det.poll(TAN36), det.last_segments()))
             for f in frames[1:]:
                 if infl == nslots:
-                    res.append(det.poll(TAN36))
+                    res.append((det.poll(TAN36), det.last_segments()))
                     infl -= 1
                 det.enqueue(f)
                 infl += 1
             while infl:
-                res.append(det.poll(TAN36))
+                res.append((det.poll(TAN36), det.last_segments()))
                 infl -= 1
             on_device = ra.lib().rd_detector_counter(det.h, 11)
             det.close()
@@ -598,7 +684,9 @@ def test_device_postprocess_equals_host_postprocess(nslots):
         (host, n0), (dev, n1) = outs
         assert n0 == 0 and n1 >= len(frames) - 2, (iw, ih, n1)
         for t, (a, b) in enumerate(zip(host, dev)):
-            assert helpers.rects_equal(a, b), (iw, ih, t, len(a), len(b))
+            assert helpers.rects_equal(a[0], b[0]), (iw, ih, t, len(a[0]), len(b[0]))
+            assert helpers.segments_equal(a[1], b[1]), (iw, ih, t, "segment lists differ between the host and the device post-process path")
+        dev = [r for r, _ in dev]
         print("%dx%d: %d frames, %d post-processed on the device, rectangles %s" % (iw, ih, len(frames), n1, [len(r) for r in dev]))
 
 
@@ -866,7 +954,8 @@ def test_polyline_example_program_matches_operator_api(ctx, tmp_path):
     assert np.allclose(np.array(got), np.array(want, dtype=np.float64), atol=1e-3)
 
 
-def test_many_streams_final_outputs_equal_the_reference():
+@pytest.mark.parametrize("device_post", [False, True], ids=["host_post", "device_post"])
+def test_many_streams_final_outputs_equal_the_reference(device_post):
     """68 more frames (26 short streams, four sizes) against the reference's own rectangle and segment lists
     (tests/golden/many_rect.npz from tools/make_golden_many.py).  The segment lists must match exactly on every frame; the
     region stages are evaluated in another schedule than the reference's order-dependent one, so the
@@ -875,8 +964,9 @@ def test_many_streams_final_outputs_equal_the_reference():
     g = golden("many_rect")
     total = same = 0
     differing = []
+    on_device = 0
     for si, (iw, ih, seed, nframes) in enumerate(g["streams"].tolist()):
-        det = ra.Detector(iw, ih, nslots=1)
+        det = detector(iw, ih, device_post, nslots=1)
         for t in range(nframes):
             det.enqueue(synth.frame(synth.SEED0 + seed, iw, ih, t))
             rects = det.poll(TAN36)
@@ -886,9 +976,10 @@ def test_many_streams_final_outputs_equal_the_reference():
                 same += 1
             else:
                 differing.append((iw, ih, seed, t, len(rects), len(g["s%d_f%d_rects" % (si, t)])))
+        on_device += ra.lib().rd_detector_counter(det.h, 11)
         det.close()
-    print("rectangle lists identical to the reference's on %d of %d frames; differing:" % (same, total), differing)
-    assert same == total
+    print("rectangle lists identical to the reference's on %d of %d frames (%d post-processed on the device); differing:" % (same, total, on_device), differing)
+    assert same == total and on_device == (total if device_post else 0)
 
 
 def test_busy_inputs_final_outputs_vs_reference():
@@ -960,3 +1051,85 @@ def test_two_real_detector_processes_share_the_gpu():
     assert abs(out["ms_per_step"] * 2 / 1e3 - max(r["own_elapsed_s"] for r in ranks)) < 5e-3      # MAX over ranks
     assert abs(out["value"] - 96 / (out["ms_per_step"] * 2 / 1e3)) / out["value"] < 0.01             # whole-job frames / that time
     print("two ranks on one GPU:", out["value"], "frames/s;", ranks)
+
+
+def _bench_line(cmd, timeout=900):
+    import json
+    import subprocess
+    p = subprocess.run(cmd, cwd=helpers.ROOT, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_under_torchrun_with_one_rank_agrees_with_plain_bench():
+    """the driver's SCALE run at N = 1 (bench.py under torch.distributed.run with one rank) must report what the plain BENCH run
+    reports: same code path, same metric, rates within a few per cent of each other (measured ratio printed)"""
+    import socket
+    import sys
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    args = ["--gpus", "1", "--steps", "6", "--warmup", "2", "--frames-per-step", "256", "--no-cpu-baseline", "--no-configs"]
+    plain = _bench_line([sys.executable, os.path.join(helpers.ROOT, "bench.py")] + args)
+    launched = _bench_line([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                            os.path.join(helpers.ROOT, "bench.py")] + args)
+    for out in (plain, launched):
+        assert out["n_gpus"] == 1 and out["outputs_verified"] is True and out["metric"] == "1920x1080 frames/sec" and out["roofline"]["frac"] > 0
+        assert out["rect_list_crc32"] == plain["rect_list_crc32"]
+    ratio = launched["value"] / plain["value"]
+    print("bench.py plain %.1f frames/s, under torchrun (1 rank) %.1f frames/s, ratio %.3f" % (plain["value"], launched["value"], ratio))
+    assert 0.95 <= ratio <= 1.05
+
+
+def test_two_detectors_on_two_host_threads_in_one_process():
+    """one process may drive several detectors from several threads (the runtime's selected device is thread-local, kernels that need
+    a raised LDS limit set it per device, the quantisation tables are per device): two threads, each with its own detector and its
+    own stream, running at the same time, must return what each stream returns on its own"""
+    import threading
+    iw, ih, nframes = 640, 480, 12
+    streams = [[synth.frame(synth.SEED0 + 40 + k, iw, ih, t) for t in range(nframes)] for k in range(2)]
+    want = []
+    for frames in streams:
+        det = ra.Detector(iw, ih, nslots=1)
+        res = []
+        for f in frames:
+            det.enqueue(f)
+            res.append((det.poll(TAN36), det.last_segments()))
+        det.close()
+        want.append(res)
+    got, errs = [None, None], []
+    gate = threading.Barrier(2)
+
+    def run(k):
+        try:
+            ra.lib().rd_select_device(0)
+            det = ra.Detector(iw, ih, nslots=4, nworkers=1)
+            gate.wait()
+            res, infl = [], 0
+            for f in streams[k]:
+                if infl == 4:
+                    res.append((det.poll(TAN36), det.last_segments()))
+                    infl -= 1
+                det.enqueue(f)
+                infl += 1
+            while infl:
+                res.append((det.poll(TAN36), det.last_segments()))
+                infl -= 1
+            det.close()
+            got[k] = res
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not errs, errs
+    for k in range(2):
+        assert len(got[k]) == nframes
+        for (r1, s1), (r2, s2) in zip(want[k], got[k]):
+            assert helpers.rects_equal(r1, r2) and helpers.segments_equal(s1, s2)
