@@ -465,7 +465,7 @@ static void frame_regions(rd_detector *d, Slot *s) {
   // regions (oclrect.c:325-336)
   int *d2scratch = s->d2s;
   int marked = 0;
-  rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih, (d->diag_skip & 2) ? 0 : s->rounds,
+  rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih, (d->diag_skip & 2) ? 2 : s->rounds,
                     s->rsize, s->junction, &marked);   // H2: the sizes start from the junction counts (copied by the first kernel)
   rdk::region_size(st, s->rsize, s->region0, N, d2scratch + N, marked);      // (also strips the rounds' marks from the labels)
   rdk::despeckle2(st, s->region, s->region0, d2scratch, s->rsize, 16, iw, ih, 1, s->scratch2 + N + 20);   // (status words: they travel to the host with the round flags)
@@ -483,7 +483,15 @@ static void frame_absorb_slow(rd_detector *d, Slot *s) {
   hipStream_t st = s->st_redo;
   rdk::despeckle2_slow(st, s->region, s->region0, s->d2s, s->rsize, 16, d->iw, d->ih);
   rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, d->iw, d->ih, s->table, s->claim, s->tlist);
-  frames_votes(d, s->frame, 1, st, 1, 0);
+  // (a frame whose rectangles the device computes gets them again, from the finished regions, for the aperture known now)
+  int with_post = 0;
+  if (s->post_mode) {
+    pthread_mutex_lock(&d->tan_mu);
+    with_post = d->have_tan; s->post_tan = d->tan_aov;
+    pthread_mutex_unlock(&d->tan_mu);
+  }
+  frames_votes(d, s->frame, 1, st, 1, with_post);
+  s->post_mode = with_post;
   RD_HIP(hipStreamSynchronize(st));
   s->h_ctr[52] = 0;
 }
@@ -664,7 +672,6 @@ static void slot_finish_device(rd_detector *d, Slot *s) {
     __atomic_add_fetch(&d->n_redo_rounds, 1, __ATOMIC_RELAXED);
   }
   if (s->h_ctr[52] != 0 || (d->force_redo & 2)) {   // the absorption's fast path gave up on this frame: finish it the long way
-    s->post_mode = 0;
     frame_absorb_slow(d, s);
     __atomic_add_fetch(&d->n_redo_absorb, 1, __ATOMIC_RELAXED);
   }
@@ -695,6 +702,14 @@ static void slot_finish_device(rd_detector *d, Slot *s) {
   }
 }
 
+// device -> host copy for a slot whose device work is complete, from any thread: on the slot's private stream (never the legacy stream -
+// a plain hipMemcpy would make that depend on a stream another thread may be capturing a graph on)
+static void slot_fetch(Slot *s, void *dst, const void *src, size_t bytes) {
+  if (!s->st_redo) RD_HIP(hipStreamCreateWithFlags(&s->st_redo, hipStreamNonBlocking));
+  RD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->st_redo));
+  RD_HIP(hipStreamSynchronize(s->st_redo));
+}
+
 // host post-process of a slot whose device work is complete: rectangles for the given aperture + a copy of the segment list
 // (can run again for another aperture: touches nothing on the device but, for frames with very many segments, two copies)
 static void *slot_rectangles(rd_detector *d, Slot *s, double tanAOV, void **segs_out, int *nsegs_out) {
@@ -714,7 +729,7 @@ static void *slot_rectangles(rd_detector *d, Slot *s, double tanAOV, void **segs
     // RD_MAXREC of them, a frame with more fetches the list from the device
     void *copy0 = malloc((size_t)(n + 1) * 56);
     if (n + 1 <= RD_MAXREC) memcpy(copy0, s->h_segs, (size_t)(n + 1) * 56);
-    else RD_HIP(hipMemcpy(copy0, s->lslist, (size_t)(n + 1) * 56, hipMemcpyDeviceToHost));
+    else slot_fetch(s, copy0, s->lslist, (size_t)(n + 1) * 56);
     *segs_out = copy0; *nsegs_out = n;
     __atomic_add_fetch(&d->n_post_device, 1, __ATOMIC_RELAXED);
     return ret;
@@ -731,8 +746,8 @@ static void *slot_rectangles(rd_detector *d, Slot *s, double tanAOV, void **segs
       n = d->maxrec_dev - 1;
     }
     big_segs = malloc((size_t)(n + 1) * 56); big_probes = (int *)malloc((size_t)(n + 1) * 15 * 6 * sizeof(int));
-    RD_HIP(hipMemcpy(big_segs, s->lslist, (size_t)(n + 1) * 56, hipMemcpyDeviceToHost));
-    RD_HIP(hipMemcpy(big_probes, s->probes, (size_t)(n + 1) * 15 * 6 * sizeof(int), hipMemcpyDeviceToHost));
+    slot_fetch(s, big_segs, s->lslist, (size_t)(n + 1) * 56);
+    slot_fetch(s, big_probes, s->probes, (size_t)(n + 1) * 15 * 6 * sizeof(int));
     segs = big_segs; probes = big_probes; maxrec = n + 1;
   }
   // RD_DIAG_NO_POST (diagnostics only): an empty rectangle list instead of the host post-process, to see whether a run is host-bound

@@ -487,68 +487,103 @@ __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const 
 }
 
 // ------------------------------------------------------------------------------------------------ regions
-// rc:289-298 initial links (up if same colour, else left if same colour, else self) - left exactly as the reference's kernel leaves
-// them, chains and all: the merge rounds start from these (see k_region_round) - plus, because colours, merge mask and edges do not
-// change between the rounds, one byte per pixel telling from which of its 4 neighbours the pixel may adopt a label (rc:308-326):
-// bit0 up, bit1 left, bit2 right, bit3 down, bit4 interior; 0 for frame-border pixels (never processed).
-// The links are written as the words of k_region_round (label << 3, no mark) into the two planes its rounds alternate between.
+// rc:289-298 initial links (up if same colour, else left if same colour, else self) - exactly the reference's, chains and all - AND the
+// first launch of the merge kernel on them (see k_region_round for the rule), in one tile kernel without a single label load or atomic:
+// a raw link reaches one pixel up or left, so everything the first launch does to a pixel t is decided within 10 pixels of it -
+//   label1[t] = min( link[t],  G(t),  G(t + 1) if link[t + 1] == t,  G(t + iw) if link[t + iw] == t ),
+//   G(p) = the label pixel p proposes (smallest label among itself and the neighbours it may adopt from, then 8 jumps along the links),
+//          if p is processed (not on the frame's ring) and that differs from link[p]
+// (a proposal goes to the pixel itself and to its link's target, and only t, its right and its lower neighbour can link to t).
+// The tile loads colours for its cells plus 10 rows above / columns left (the jumps' reach) and 2 below / right (the neighbours' proposals).
+// Also written: one byte per pixel telling from which of its 4 neighbours the pixel may adopt a label in every launch (rc:308-326 - colours,
+// merge mask and edges do not change): bit0 up, bit1 left, bit2 right, bit3 down, bit4 processed; 0 for frame-border pixels.
+// The labels leave as the words of k_region_round (label << 3, no mark) in both planes its launches alternate between.
 #define RI_ROWS 32
+#define RI_H 10                         // halo above / left
+#define RI_RW (64 + RI_H + 2)
+#define RI_RH (RI_ROWS + RI_H + 2)
+#define RI_NC (RI_RW * RI_RH)
 __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *__restrict__ B, uint8_t *__restrict__ allow, const int *__restrict__ pix, const int *__restrict__ mask,
                                                      const int *__restrict__ edge, int iw, int ih, int *__restrict__ flags, int *__restrict__ size_out, const int *__restrict__ size_init) {
-  // (also: the round flags start at zero, and the size plane starts from size_init - quirk H2 - without extra launches)
-  if (blockIdx.x == 0 && blockIdx.y == 0) { const int t = threadIdx.y * 64 + threadIdx.x; if (t < 64) flags[t] = 0; }
-  const int tx = threadIdx.x, x = blockIdx.x * 64 + tx, y0 = blockIdx.y * RI_ROWS;
-  // four rows below one another per thread (each the other's vertical neighbour: 31 instead of 40 loads), all of their loads in flight
-  // together (clamped addresses; what a pixel may not use is ignored)
-#pragma unroll
-  for (int half = 0; half < RI_ROWS / 16; half++) {
-    int v[4], vu[4], vl[4], vr[4], vd[4], mk[4], e0[4], er[4], ed[4], si[4];
-    bool in[4], inter[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int y = y0 + (half * 4 + threadIdx.y) * 4 + k;
-      in[k] = x < iw && y < ih;
-      inter[k] = in[k] && x > 0 && y > 0 && x < iw - 1 && y < ih - 1;
-      const int p = in[k] ? y * iw + x : 0;
-      v[k] = pix[p];
-      if (k == 0) vu[k] = pix[(in[k] && y > 0) ? p - iw : p];
-      vl[k] = pix[(in[k] && x > 0) ? p - 1 : p];
-      vr[k] = pix[inter[k] ? p + 1 : p];
-      if (k == 3) vd[k] = pix[inter[k] ? p + iw : p];
-      mk[k] = mask[p];
-      e0[k] = edge[p];
-      er[k] = edge[inter[k] ? p + 1 : p];
-      if (k == 3) ed[k] = edge[inter[k] ? p + iw : p];
-      si[k] = size_out ? size_init[p] : 0;
+  __shared__ int col[RI_NC];                  // colours, then (in place) nothing: kept for the allow bits
+  __shared__ short lnk[RI_NC];                // raw link as a cell index of this tile's region (-1: cell outside the frame)
+  __shared__ short prop[RI_NC];               // G as a cell index, or 0x7fff
+  __shared__ unsigned char alw[RI_NC];
+  // (also: the round flags start at zero - flags[0] = 1: the first launch, evaluated here, counts as one that changed something - and the
+  //  size plane starts from size_init - quirk H2 - without extra launches)
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid < 64) flags[tid] = tid == 0 ? 1 : 0;
+  const int gx0 = blockIdx.x * 64 - RI_H, gy0 = blockIdx.y * RI_ROWS - RI_H;
+  // colours of the region (cells outside the frame: marked by lnk = -1 below)
+  stage_cells<RI_NC, 256>(tid, pix,
+    [&](int t, int &a) { const int gx = gx0 + t % RI_RW, gy = gy0 + t / RI_RW; a = gy * iw + gx; return gx >= 0 && gx < iw && gy >= 0 && gy < ih; },
+    [&](int t, bool ok, int v) { col[t] = v; lnk[t] = ok ? 0 : -1; });
+  __syncthreads();
+  // raw links (cells of the first row / column of the region cannot know theirs: nothing reads them, see RI_H)
+  for (int t = tid; t < RI_NC; t += 256) {
+    if (lnk[t] < 0) continue;
+    const int cx = t % RI_RW, cy = t / RI_RW;
+    const int gx = gx0 + cx, gy = gy0 + cy;
+    int l = t;
+    if (gy > 0 && cy > 0 && col[t] == col[t - RI_RW]) l = t - RI_RW;
+    else if (gx > 0 && cx > 0 && col[t] == col[t - 1]) l = t - 1;
+    lnk[t] = (short)l;
+  }
+  // allowed directions for the cells whose proposals are needed: the tile and one more row / column (mask and edges straight from memory)
+  for (int t = tid; t < (64 + 1) * (RI_ROWS + 1); t += 256) {
+    const int cx = RI_H + t % 65, cy = RI_H + t / 65, c = cy * RI_RW + cx;
+    const int gx = gx0 + cx, gy = gy0 + cy;
+    unsigned a = 0;
+    if (gx > 0 && gy > 0 && gx < iw - 1 && gy < ih - 1) {
+      const int p = gy * iw + gx;
+      const bool any = mask[p] != 0;
+      const bool z0 = edge[p] <= 0;
+      const int v = col[c];
+      if ((v == col[c - RI_RW] || any) && z0) a |= 1;
+      if ((v == col[c - 1] || any) && z0) a |= 2;
+      if ((v == col[c + 1] || any) && edge[p + 1] <= 0) a |= 4;
+      if ((v == col[c + RI_RW] || any) && edge[p + iw] <= 0) a |= 8;
+      a |= 16;
     }
+    alw[c] = (unsigned char)a;
+  }
+  __syncthreads();
+  // proposals
+  for (int t = tid; t < (64 + 1) * (RI_ROWS + 1); t += 256) {
+    const int cx = RI_H + t % 65, cy = RI_H + t / 65, c = cy * RI_RW + cx;
+    const unsigned a = alw[c];
+    int g = 0x7fff;
+    if (a & 16) {
+      const int og = lnk[c];
+      int m = og;      // (cell indices order like pixel indices: both are row-major over the same pixels)
+      if (a & 1) { const int s = lnk[c - RI_RW]; m = s < m ? s : m; }
+      if (a & 2) { const int s = lnk[c - 1]; m = s < m ? s : m; }
+      if (a & 4) { const int s = lnk[c + 1]; m = s < m ? s : m; }
+      if (a & 8) { const int s = lnk[c + RI_RW]; m = s < m ? s : m; }
 #pragma unroll
-    for (int k = 0; k < 4; k++) {      // (the vertical neighbours inside the thread's own column)
-      if (k > 0) vu[k] = v[k - 1];
-      if (k < 3) { vd[k] = v[k + 1]; ed[k] = e0[k + 1]; }
+      for (int j = 0; j < 8; j++) m = lnk[m];
+      if (m != og) g = m;
     }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int y = y0 + (half * 4 + threadIdx.y) * 4 + k;
-      if (!in[k]) continue;
-      const int p = y * iw + x;
-      int l = p;
-      if (y > 0 && v[k] == vu[k]) l = p - iw;
-      else if (x > 0 && v[k] == vl[k]) l = p - 1;
-      unsigned a = 0;
-      if (inter[k]) {
-        const bool any = mk[k] != 0;
-        const bool z0 = e0[k] <= 0;
-        if ((v[k] == vu[k] || any) && z0) a |= 1;
-        if ((v[k] == vl[k] || any) && z0) a |= 2;
-        if ((v[k] == vr[k] || any) && er[k] <= 0) a |= 4;
-        if ((v[k] == vd[k] || any) && ed[k] <= 0) a |= 8;
-        a |= 16;   // interior
-      }
-      allow[p] = (uint8_t)a;
-      if (size_out) size_out[p] = si[k];
-      A[p] = l << 3;
-      B[p] = l << 3;
-    }
+    prop[c] = (short)g;
+  }
+  __syncthreads();
+  // the labels after the first launch, the allow bytes, the sizes' start values
+  const int x = blockIdx.x * 64 + threadIdx.x;
+  if (x >= iw) return;
+  for (int r = threadIdx.y; r < RI_ROWS; r += 4) {
+    const int y = blockIdx.y * RI_ROWS + r;
+    if (y >= ih) break;
+    const int c = (r + RI_H) * RI_RW + threadIdx.x + RI_H, p = y * iw + x;
+    int l = lnk[c];
+    const int g0 = prop[c];
+    l = g0 < l ? g0 : l;
+    if (x + 1 < iw && lnk[c + 1] == c) { const int g1 = prop[c + 1]; l = g1 < l ? g1 : l; }
+    if (y + 1 < ih && lnk[c + RI_RW] == c) { const int g2 = prop[c + RI_RW]; l = g2 < l ? g2 : l; }
+    const int w = ((gy0 + l / RI_RW) * iw + gx0 + l % RI_RW) << 3;
+    A[p] = w;
+    B[p] = w;
+    allow[p] = alw[c];
+    if (size_out) size_out[p] = size_init[p];
   }
 }
 
@@ -1659,13 +1694,13 @@ void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int 
 // *marked <- 1: `label` holds the rounds' words (label << 3 | mark), which region_size turns into plain labels.
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS, int *size_out, const int *size_init, int *marked) {
   const int n = iw * ih;
-  if (ROUNDS < 0 || (ROUNDS & 1)) { fprintf(stderr, "region_merge: the number of rounds must be even (got %d)\n", ROUNDS); abort(); }
+  if (ROUNDS < 2 || (ROUNDS & 1)) { fprintf(stderr, "region_merge: the number of launches must be even and at least 2 (got %d)\n", ROUNDS); abort(); }
   int *flags = scratch + n;
   uint8_t *allow = (uint8_t *)(flags + 64);
   int *A = label, *B = scratch + 2 * (size_t)n;   // the two planes of the rounds; the result is in A
   hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, A, B, allow, pix, mask, edge, iw, ih, flags, size_out, size_init);
   const dim3 grid(cdiv(iw, 64), cdiv(ih, RR_TY * RR_PX));
-  for (int r = 0; r < ROUNDS; r++) {
+  for (int r = 1; r < ROUNDS; r++) {       // (launch 0 was evaluated by k_region_init)
     if (r & 1) hipLaunchKernelGGL(k_region_round, grid, dim3(64, RR_TY), 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r);
     else hipLaunchKernelGGL(k_region_round, grid, dim3(64, RR_TY), 0, s, A, B, (const uint8_t *)allow, iw, ih, flags, r);
   }
