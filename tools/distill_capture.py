@@ -4,6 +4,7 @@ usage: distill_capture.py <tag> <round prefix, e.g. r02_a>"""
 import sys, os, json, shutil, sqlite3, subprocess, collections
 
 tag, pre = sys.argv[1], sys.argv[2]
+ROUND = pre.split("_")[0]      # r03_a -> r03
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 C = os.path.join(R, "gpurun_out", "cap" + tag)
 P = os.path.join(R, "profiles")
@@ -24,7 +25,7 @@ for name, out in (("trace_default", "kernel_stats_1080p_default.txt"), ("trace_s
     con = sqlite3.connect(db)
     frames = con.execute("select total_calls from top_kernels where name like '%k_bgr2plab_t%'").fetchone()[0]
     head = "# rocprofv3 --kernel-trace --stats -- python bench.py %s (%d frames)\n" % (
-        "--steps 2 --warmup 1 --no-cpu-baseline --no-verify" if name == "trace_default" else "--steps 1 --warmup 1 --slots 1 --frames-per-step 8 --no-cpu-baseline --no-verify", frames)
+        "--steps 3 --warmup 1 --frames-per-step 64 --no-cpu-baseline --no-verify --no-configs" if name == "trace_default" else "--steps 1 --warmup 1 --slots 1 --frames-per-step 8 --no-cpu-baseline --no-verify --no-configs", frames)
     with open(os.path.join(P, pre + "_" + out), "w") as f:
         f.write(head + run(os.path.join(R, "tools", "prof_summary.py"), db, str(frames)))
 
@@ -47,7 +48,7 @@ def frames_in(db):
     return sqlite3.connect(db).execute("select count(*) from counters_collection where kernel_name like '%k_bgr2plab_t%'").fetchone()[0]
 
 
-TRAFFIC_CMD = "python bench.py --steps 2 --warmup 1 --frames-per-step 16 --no-cpu-baseline --no-verify"
+TRAFFIC_CMD = "python bench.py --steps 2 --warmup 1 --frames-per-step 16 --no-cpu-baseline --no-verify --no-configs"
 nf_rd, nf_wr = frames_in(os.path.join(C, "pmc_rd", "results.db")), frames_in(os.path.join(C, "pmc_wr", "results.db"))
 rd = total(os.path.join(C, "pmc_rd", "results.db"), "FETCH_SIZE") / nf_rd
 wr = total(os.path.join(C, "pmc_wr", "results.db"), "WRITE_SIZE") / nf_wr
@@ -64,8 +65,12 @@ with open(os.path.join(P, pre + "_pmc_traffic_1080p.txt"), "w") as f:
     f.write("# corrections: fetch x %.3f, write x %.3f\n" % (corr_rd, corr_wr))
 hbm = int((rd * corr_rd + wr * corr_wr) * 1024)
 commit = subprocess.run(["git", "-C", R, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
-with open(os.path.join(P, "r02_traffic.json"), "w") as f:
-    json.dump({"commit": commit + " (HEAD when the capture was distilled; the capture ran on the working tree)", "command": TRAFFIC_CMD, "frames": nf_rd,
+captured = open(os.path.join(C, "commit.txt")).read().strip() if os.path.exists(os.path.join(C, "commit.txt")) else None
+dirty = subprocess.run(["git", "-C", R, "status", "--porcelain", "--", "rectdetect_amd", "bench.py"], capture_output=True, text=True).stdout.strip()
+if captured != commit or dirty:
+    sys.exit("distill_capture: the capture ran at %s, HEAD is %s%s - profiles must describe the code that is benchmarked: capture again (tools/capture_round.sh)" % (captured, commit, " with uncommitted changes" if dirty else ""))
+with open(os.path.join(P, ROUND + "_traffic.json"), "w") as f:
+    json.dump({"commit": commit, "command": TRAFFIC_CMD, "frames": nf_rd,
                "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over the benchmarked configuration (default slots, graphs on; profiles/%s_pmc_traffic_1080p.txt); "
                "each corrected by the factor the calibration copy of 3 x 1 GiB (4 B/lane coalesced, tools/pmc_calibrate.py) yields in the same capture "
                "(FETCH_SIZE reports half of the bytes read on gfx950, as MI355X_MICROARCH.md describes)" % pre,

@@ -4,15 +4,16 @@ tag=${1:-x}
 R=$PWD
 O=$R/gpurun_out/cap$tag
 mkdir -p $O
+cp tools/.capture_commit $O/commit.txt 2>/dev/null
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
-python bench.py --slots 1 --no-cpu-baseline > $O/bench_slots1.json 2>> $O/bench_default.err
-python bench.py --slots 2 --no-cpu-baseline > $O/bench_slots2.json 2>> $O/bench_default.err
+python bench.py --slots 1 --no-cpu-baseline --no-configs --frames-per-step 128 > $O/bench_slots1.json 2>> $O/bench_default.err
+python bench.py --slots 2 --no-cpu-baseline --no-configs --frames-per-step 128 > $O/bench_slots2.json 2>> $O/bench_default.err
 SLOTS=16 python tools/size_sweep.py > $O/size_sweep.txt 2>&1
 export TMPDIR=/tmp
 cd /tmp
 # kernel trace of the default command (fewer steps) and of one frame slot alone
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_default -o t -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-verify > $O/trace_default.log 2>&1
-timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_slots1 -o t -- python $R/bench.py --steps 1 --warmup 1 --slots 1 --frames-per-step 8 --no-cpu-baseline --no-verify > $O/trace_slots1.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_default -o t -- python $R/bench.py --steps 3 --warmup 1 --frames-per-step 64 --no-cpu-baseline --no-verify --no-configs > $O/trace_default.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_slots1 -o t -- python $R/bench.py --steps 1 --warmup 1 --slots 1 --frames-per-step 8 --no-cpu-baseline --no-verify --no-configs > $O/trace_slots1.log 2>&1
 cd $R
 bash tools/gpu_pmc.sh cap$tag > $O/pmc.log 2>&1
 for d in sq rd wr calrd calwr; do mkdir -p $O/pmc_$d; cp $(find gpurun_out/pmccap${tag}_$d -name "*.db" | head -1) $O/pmc_$d/results.db; done

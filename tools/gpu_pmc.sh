@@ -8,8 +8,8 @@ export TMPDIR=/tmp
 R=$PWD
 mkdir -p $R/gpurun_out
 cd /tmp
-CMD1="python $R/bench.py --steps 1 --warmup 1 --slots 1 --frames-per-step 4 --no-cpu-baseline --no-verify"
-CMD="python $R/bench.py --steps 2 --warmup 1 --frames-per-step 16 --no-cpu-baseline --no-verify"
+CMD1="python $R/bench.py --steps 1 --warmup 1 --slots 1 --frames-per-step 4 --no-cpu-baseline --no-verify --no-configs"
+CMD="python $R/bench.py --steps 2 --warmup 1 --frames-per-step 16 --no-cpu-baseline --no-verify --no-configs"
 RD_NO_GRAPH=1 timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_BUSY_CYCLES --kernel-trace -d $R/gpurun_out/pmc${tag}_sq -o sq -- $CMD1 > $R/gpurun_out/pmc${tag}_sq.log 2>&1
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $R/gpurun_out/pmc${tag}_rd -o rd -- $CMD > $R/gpurun_out/pmc${tag}_rd.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $R/gpurun_out/pmc${tag}_wr -o wr -- $CMD > $R/gpurun_out/pmc${tag}_wr.log 2>&1
