@@ -362,6 +362,7 @@ def main():
                          "postprocess": {"frames_on_device": post1[0] - post0[0], "frames_on_host": post1[1] - post0[1],
                                          "host_cpu_us_per_frame": round((post1[2] - post0[2]) / max(1, post1[1] - post0[1]), 1)},
                          "region_round_budget": det.region_round_budget()[0] if det is not None else None,
+                         "frames_per_launch_need": {str(k): ra.lib().rd_detector_counter(det.h, 40 + k) for k in range(21) if ra.lib().rd_detector_counter(det.h, 40 + k)} if det is not None else None,
                          "frames_per_launch_budget": {str(8 + 2 * k): ra.lib().rd_detector_counter(det.h, 20 + k) for k in range(7)} if det is not None else None,
                          "frames_repeated": {"round_budget": det.region_round_budget()[1], "polyline_overflow": det.redone_frames(), "absorption_slow_path": det.absorption()[2]} if det is not None else None},
         }

@@ -59,9 +59,9 @@ int rd_detector_last_segments(rd_detector *d, void *dst, int max_records);
  * was repeated with the multi-launch path (same results, slower); 1 = device microseconds summed over the polled frames
  * (HIP events on the frame's stream: first kernel start to last copy end, so concurrent frames overlap); 2 = frames in that sum; 3 = host microseconds spent inside rd_detector_enqueue;
  * 4 = frames whose region merge had not settled within the launched round budget and were repeated with all 20 rounds;
- * 5 = the current launch budget of the region merge (8, 10, .. 20); 20..26 = frames launched with a budget of 8 / 10 / .. / 20;
- * 10 = frames with more line segments than the probe buffer holds (65535): the rest took no part in the rectangle search (a
- * message goes to stderr the first time); 11 / 12 = frames whose rectangles came from the device post-process (RD_DEVICE_POST=1:
+ * 5 = the current launch budget of the region merge (8, 10, .. 20); 20..26 = frames launched with a budget of 8 / 10 / .. / 20; 40 + k = frames whose merge needed k launches;
+ * 10 = frames with more line segments than a slot's probe buffer holds (65535), whose probes were taken again into a larger buffer (the list keeps the
+ * reference's capacity of 16N / 56 records; nothing is dropped); 11 / 12 = frames whose rectangles came from the device post-process (RD_DEVICE_POST=1:
  * candidate funnel + pose estimation in rd_k_post.hip) / from the host post-process; 13 = microseconds the worker threads spent in the
  * host post-process (sum over frames); 14 = frames whose small-region absorption (oclrect.cl:348-371) was finished by the slow path -
  * rounds over work lists until nothing changes - because they left more undecided pixels than the single-block tail holds (frames made of small regions) */

@@ -282,7 +282,8 @@ struct Slot {
   hipEvent_t ev_fork, ev_mm, ev_join;
   hipEvent_t ev_begin, ev_done, ev_strong;   // ev_begin/ev_done carry timestamps: device time of the frame (rd_detector_counter)
   hipEvent_t ev_redo;                        // end of a repeated part of the frame (slot_finish_device)
-  hipStream_t st_redo;                       // created on first use: the slow absorption path (frame_absorb_slow)
+  hipStream_t st_redo;                       // created on first use: the slow absorption path (frame_absorb_slow), fetches of long lists
+  int *big_probes; int big_probes_cap;       // probes of a frame with more segments than `probes` holds (grows on demand)
   uint8_t *bgr;
   uint32_t *plab0, *plab1, *smooth, *quant;
   float *tr[3], *fw[3], *bw[3], *hz[3], *bl[3], *vxy, *strength, *nms;
@@ -338,7 +339,7 @@ struct rd_detector {
   int use_graph, poly_mode, force_redo, diag_no_post, diag_skip, fork_poly, fixed_rounds; long n_redo, n_redo_rounds, n_redo_absorb;
   int overflow_streak;
   int poly_overflows;                     // set once two frames in a row overflowed the single-launch polyline kernel: later frames go multi-launch
-  int rounds_budget, need_hist[64]; unsigned need_pos; long budget_count[RD_NBUDGETS];
+  int rounds_budget, need_hist[64]; unsigned need_pos; long budget_count[RD_NBUDGETS], need_count[21];
   long host_enqueue_ns;      // wall time the caller spent inside rd_detector_enqueue
   long dev_us, dev_frames;   // sum over polled frames of (last kernel end - first kernel start) on the frame's stream, HIP events
   double tan_aov; int have_tan;    // what the workers use ahead of the poll that asks for the result
@@ -348,7 +349,7 @@ struct rd_detector {
   // a stream that is capturing must not be synchronised.  launch_mu serialises captures against the launches of a repeat; repeats wait
   // on an event of their own (ev_redo), never on the stream.
   pthread_mutex_t launch_mu;
-  long n_truncated;          // frames with more segment records than the probe buffer holds (maxrec_dev)
+  long n_truncated;          // frames with more segment records than the slots' probe buffers hold (maxrec_dev): probed again into a larger buffer
 };
 
 // share: the slot whose streams this one uses as well (NULL: own streams)
@@ -420,6 +421,7 @@ static void slot_free(Slot *s) {
   RD_HIP(hipEventDestroy(s->ev_begin)); RD_HIP(hipEventDestroy(s->ev_done)); RD_HIP(hipEventDestroy(s->ev_strong));
   RD_HIP(hipEventDestroy(s->ev_fork)); RD_HIP(hipEventDestroy(s->ev_mm)); RD_HIP(hipEventDestroy(s->ev_join)); RD_HIP(hipEventDestroy(s->ev_redo)); RD_HIP(hipEventDestroy(s->ev_dense));
   if (s->st_redo) RD_HIP(hipStreamDestroy(s->st_redo));
+  dfree(s->big_probes);
   if (!s->shares_streams) {
     RD_HIP(hipStreamDestroy(s->st2));
     RD_HIP(hipStreamDestroy(s->st));
@@ -680,6 +682,7 @@ static void slot_finish_device(rd_detector *d, Slot *s) {
     int need = 20;
     for (int r = 0; r < 20; r++) if (s->h_ctr[32 + r] == 0) { need = r + 1; break; }
     pthread_mutex_lock(&d->tan_mu);
+    d->need_count[need]++;
     d->need_hist[d->need_pos++ & 63] = need;
     int mx = 0;
     for (int k = 0; k < 64; k++) mx = d->need_hist[k] > mx ? d->need_hist[k] : mx;
@@ -739,15 +742,22 @@ static void *slot_rectangles(rd_detector *d, Slot *s, double tanAOV, void **segs
   void *big_segs = NULL; int *big_probes = NULL;
   int maxrec = d->maxrec_dev < RD_MAXREC ? d->maxrec_dev : RD_MAXREC;
   if (n + 1 > maxrec) {   // rare: more segments than the fixed-size transfer covers
+    const int *dev_probes = s->probes;
     if (n + 1 > d->maxrec_dev) {
-      // The list itself holds up to N*16/56 records like the reference's, the probe buffer RD_MAXREC_DEV of them: the rest is dropped, loudly
-      if (__atomic_add_fetch(&d->n_truncated, 1, __ATOMIC_RELAXED) == 1)
-        fprintf(stderr, "rectdetect: a frame has %d line segments; only the first %d take part in the rectangle search (rd_detector_counter 10 counts such frames)\n", n, d->maxrec_dev - 1);
-      n = d->maxrec_dev - 1;
+      // more records than the slot's probe buffer holds (the list itself has the reference's capacity, 16N / 56 records, pl:456): the
+      // probes of all of them are taken again into a buffer that grows on demand - nothing is ever dropped
+      if (!s->st_redo) RD_HIP(hipStreamCreateWithFlags(&s->st_redo, hipStreamNonBlocking));
+      if (s->big_probes_cap < n + 1) { dfree(s->big_probes); s->big_probes = dnew<int>((size_t)(n + 1) * 15 * 6); s->big_probes_cap = n + 1; }
+      rdk::PolyFrame f = *s->frame;
+      f.probes = s->big_probes; f.pack = NULL;
+      rdk::sample_segments(s->st_redo, &f, 1, n + 1, d->iw, d->ih, d->N * 4 / 5, 0);
+      rdrt::check_launch("probes of a frame with very many segments");
+      dev_probes = s->big_probes;
+      __atomic_add_fetch(&d->n_truncated, 1, __ATOMIC_RELAXED);      // (counter 10: frames that took this path)
     }
     big_segs = malloc((size_t)(n + 1) * 56); big_probes = (int *)malloc((size_t)(n + 1) * 15 * 6 * sizeof(int));
     slot_fetch(s, big_segs, s->lslist, (size_t)(n + 1) * 56);
-    slot_fetch(s, big_probes, s->probes, (size_t)(n + 1) * 15 * 6 * sizeof(int));
+    slot_fetch(s, big_probes, dev_probes, (size_t)(n + 1) * 15 * 6 * sizeof(int));
     segs = big_segs; probes = big_probes; maxrec = n + 1;
   }
   // RD_DIAG_NO_POST (diagnostics only): an empty rectangle list instead of the host post-process, to see whether a run is host-bound
@@ -802,7 +812,8 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   rd_detector *d = (rd_detector *)calloc(1, sizeof(*d));
   d->magic = MAGIC_RECT; d->device = device; d->iw = iw; d->ih = ih; d->N = iw * ih; d->nslots = nslots; d->nworkers = nworkers;
   d->maxrec_dev = d->N * 16 / 56;
-  if (d->maxrec_dev > 65536) d->maxrec_dev = 65536;
+  if (d->maxrec_dev > 65536) d->maxrec_dev = 65536;      // the slots' probe buffers; frames with more records are probed again into a buffer that grows (slot_rectangles)
+  if (getenv("RD_MAXREC_DEV")) { const int m = atoi(getenv("RD_MAXREC_DEV")); if (m >= 16 && m < d->maxrec_dev) d->maxrec_dev = m; }      // (tests: exercise that path)
   d->prev_strong = dnew<int8_t>((size_t)d->N);
   RD_HIP(hipMemset(d->prev_strong, 0, (size_t)d->N));
   d->use_graph = getenv("RD_NO_GRAPH") ? 0 : 1;
@@ -976,6 +987,7 @@ long rd_detector_counter(rd_detector *d, int which) {
   if (which == 12) return __atomic_load_n(&d->n_post_host, __ATOMIC_RELAXED);
   if (which == 13) return __atomic_load_n(&d->host_post_ns, __ATOMIC_RELAXED) / 1000;
   if (which == 14) return __atomic_load_n(&d->n_redo_absorb, __ATOMIC_RELAXED);
+  if (which >= 40 && which <= 60) return d->need_count[which - 40];      // frames whose region merge needed 0..20 launches (the one that changes nothing included; 20: or more)
   if (which == 1) return d->dev_us;
   if (which == 2) return d->dev_frames;
   return which == 0 ? __atomic_load_n(&d->n_redo, __ATOMIC_RELAXED) : -1;

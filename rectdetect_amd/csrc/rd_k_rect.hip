@@ -6,6 +6,7 @@
 #include "rd_kernels.h"
 #include "rd_tidy_tile.h"
 #include "rd_poly_scratch.h"
+#include "rd_post_core.h"
 #include <atomic>
 
 namespace {
@@ -1633,17 +1634,8 @@ __global__ void k_sample_segments(const rdk::PolyFrames FRS, int max_records, in
   if (packed && k < 14) pack[64 + i * 14 + k] = ((const int *)ls)[i * 14 + k];   // the record itself (14 ints), one int per probe thread
   int segid = 0;
   if (ls[i].polyid != 0) {
-    const double x0 = rint((double)ls[i].x0), y0 = rint((double)ls[i].y0), x1 = rint((double)ls[i].x1), y1 = rint((double)ls[i].y1);
-    const int j = k / 5, dist = k % 5 - 2;
-    const double ex = x1 - x0, ey = y1 - y0;
-    const double inv = 1.0 / (sqrt(ex * ex + ey * ey) + 1e-20);
-    const double dx = ex * inv, dy = ey * inv;
-    const double vdx = -dy, vdy = dx;
-    const double f = (j + 0.5) / 3;
-    const double px = x0 + ex * f, py = y0 + ey * f;
-    const double cx = px + vdx * dist, cy = py + vdy * dist;
-    const int sx = (int)(cx + 0.5), sy = (int)(cy + 0.5);
-    if (!(sx < 0 || sx >= iw || sy < 0 || sy >= ih)) segid = boundary[sx + sy * iw];
+    int sx, sy;
+    if (rdp_probe_pixel(ls[i].x0, ls[i].y0, ls[i].x1, ls[i].y1, k, iw, ih, &sx, &sy)) segid = boundary[sx + sy * iw];
   }
   int v[6] = { segid, 0, 0, 0, 0, 0 };
   if (segid > 0) {

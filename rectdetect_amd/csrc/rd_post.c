@@ -214,7 +214,8 @@ void *rd_post_run(const void *segs, int max_records, const int *probes, int iw, 
   return ret;
 }
 
-/* probes computed on the host from full planes, exactly like rh:1066-1098 does it */
+/* Test tap: the probes of every segment taken on the host from full planes - what rh:1066-1098 reads from the planes it copied back -
+ * then the post-process proper.  (The frame path takes the probes on the device: k_sample_segments, same rdp_probe_pixel.) */
 void *rd_postprocess_planes(const void *segs, const int32_t *boundary, const int32_t *table, int iw, int ih, double tanAOV) {
   const linesegment_t *ls = (const linesegment_t *)segs;
   const int n = ((const int *)segs)[0];
@@ -222,23 +223,16 @@ void *rd_postprocess_planes(const void *segs, const int32_t *boundary, const int
   int *probes = (int *)calloc((size_t)(n + 1) * 15 * 6, sizeof(int));
   for (int i = 1; i <= n; i++) {
     if (ls[i].polyid == 0) continue;
-    const double x0 = rint(ls[i].x0), y0 = rint(ls[i].y0), x1 = rint(ls[i].x1), y1 = rint(ls[i].y1);
-    const vec2 d = normalize2(minus2(cvec2(x1, y1), cvec2(x0, y0)));
-    const vec2 vd = cvec2(-d.a[1], d.a[0]);
-    for (int j = 0; j < 3; j++)
-      for (int dist = -2; dist <= 2; dist++) {
-        const vec2 p = plus2(cvec2(x0, y0), dot2(minus2(cvec2(x1, y1), cvec2(x0, y0)), (j + 0.5) / 3));
-        const vec2 c = plus2(p, dot2(vd, dist));
-        const int x = (int)(c.a[0] + 0.5), y = (int)(c.a[1] + 0.5);
-        int *pr = probes + (size_t)(i * 15 + j * 5 + dist + 2) * 6;
-        if (x < 0 || x >= iw || y < 0 || y >= ih) continue;
-        const int segid = boundary[x + y * iw];
-        pr[0] = segid;
-        if (segid > 0) {
-          const unsigned slot = (((uint32_t)i * (uint32_t)segid) & 0x7fffffffu) % nentry;
-          for (int q = 0; q < 5; q++) pr[1 + q] = table[(size_t)slot * 5 + q];
-        }
-      }
+    for (int k = 0; k < 15; k++) {
+      int sx, sy;
+      if (!rdp_probe_pixel(ls[i].x0, ls[i].y0, ls[i].x1, ls[i].y1, k, iw, ih, &sx, &sy)) continue;
+      int *rec = probes + (size_t)(i * 15 + k) * 6;
+      const int bid = boundary[sx + sy * iw];
+      rec[0] = bid;
+      if (bid <= 0) continue;
+      const int32_t *slot = table + (size_t)((((uint32_t)i * (uint32_t)bid) & 0x7fffffffu) % nentry) * 5;      /* the vote table's slot of (segment, boundary): rc:426-464 */
+      for (int q = 0; q < 5; q++) rec[1 + q] = slot[q];
+    }
   }
   void *r = rd_post_run(segs, n + 1, probes, iw, ih, tanAOV);
   free(probes);

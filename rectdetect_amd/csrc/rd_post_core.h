@@ -56,6 +56,19 @@ RD_HD rdp_p2 rdp_sub(rdp_p2 p, rdp_p2 q) { return rdp_pt(p.x - q.x, p.y - q.y); 
 RD_HD rdp_p2 rdp_unit(rdp_p2 p) { const double k = 1.0 / (sqrt(p.x * p.x + p.y * p.y) + 1e-20); return rdp_pt(p.x * k, p.y * k); }
 RD_HD float rdp_sqlen(const rdp_seg *s) { return (float)rdp_d2(s->e0, s->e1); }      /* rh:390: narrowed to float */
 
+/* Probe k (0..14) of a segment (rh:1066-1098): point k / 5 of three along the segment between its end points rounded to integers, moved
+ * k % 5 - 2 pixels along the segment's normal; the pixel it falls on goes to (*sx, *sy).  Returns 0 when that lies outside the frame.
+ * Shared by the sampling kernel (rd_k_rect.hip: k_sample_segments) and rd_postprocess_planes. */
+RD_HD int rdp_probe_pixel(float fx0, float fy0, float fx1, float fy1, int k, int iw, int ih, int *sx, int *sy) {
+  const rdp_p2 a = rdp_pt(rint((double)fx0), rint((double)fy0)), b = rdp_pt(rint((double)fx1), rint((double)fy1));
+  const rdp_p2 e = rdp_sub(b, a), u = rdp_unit(e);
+  const double f = (k / 5 + 0.5) / 3;
+  const int off = k % 5 - 2;
+  const double cx = (a.x + e.x * f) + -u.y * off, cy = (a.y + e.y * f) + u.x * off;
+  *sx = (int)(cx + 0.5); *sy = (int)(cy + 0.5);
+  return !(*sx < 0 || *sx >= iw || *sy < 0 || *sy >= ih);
+}
+
 /* foot of the perpendicular from p on the LINE through v, w (rh:400-406) */
 RD_HD rdp_p2 rdp_foot(rdp_p2 v, rdp_p2 w, rdp_p2 p) {
   const double l2 = rdp_d2(v, w);
