@@ -470,10 +470,23 @@ static void frame_regions(rd_detector *d, Slot *s) {
   rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih, (d->diag_skip & 2) ? 2 : s->rounds,
                     s->rsize, s->junction, &marked);   // H2: the sizes start from the junction counts (copied by the first kernel)
   rdk::region_size(st, s->rsize, s->region0, N, d2scratch + N, marked);      // (also strips the rounds' marks from the labels)
-  rdk::despeckle2(st, s->region, s->region0, d2scratch, s->rsize, 16, iw, ih, 1, s->scratch2 + N + 20);   // (status words: they travel to the host with the round flags)
+  rdk::despeckle2(st, s->region, s->region0, d2scratch, s->rsize, 16, iw, ih, 1, s->scratch2 + N + 64);   // (status words: they travel to the host with the round flags)
 
   // region boundaries and their components (oclrect.c:340-342)
   rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, iw, ih, s->table, s->claim, s->tlist);   // (also undoes the previous frame's vote-table entries)
+}
+
+// votes and probes of a frame whose regions were computed again (a frame whose rectangles the device computes gets them again as well,
+// from the new regions, for the aperture known now)
+static void redo_votes(rd_detector *d, Slot *s, hipStream_t st) {
+  int with_post = 0;
+  if (s->post_mode) {
+    pthread_mutex_lock(&d->tan_mu);
+    with_post = d->have_tan; s->post_tan = d->tan_aov;
+    pthread_mutex_unlock(&d->tan_mu);
+  }
+  frames_votes(d, s->frame, 1, st, 1, with_post);
+  s->post_mode = with_post;
 }
 
 // The absorption of small regions again for a frame the two fast launches could not finish (h_ctr[52] != 0: more undecided pixels than
@@ -485,15 +498,7 @@ static void frame_absorb_slow(rd_detector *d, Slot *s) {
   hipStream_t st = s->st_redo;
   rdk::despeckle2_slow(st, s->region, s->region0, s->d2s, s->rsize, 16, d->iw, d->ih);
   rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, d->iw, d->ih, s->table, s->claim, s->tlist);
-  // (a frame whose rectangles the device computes gets them again, from the finished regions, for the aperture known now)
-  int with_post = 0;
-  if (s->post_mode) {
-    pthread_mutex_lock(&d->tan_mu);
-    with_post = d->have_tan; s->post_tan = d->tan_aov;
-    pthread_mutex_unlock(&d->tan_mu);
-  }
-  frames_votes(d, s->frame, 1, st, 1, with_post);
-  s->post_mode = with_post;
+  redo_votes(d, s, st);
   RD_HIP(hipStreamSynchronize(st));
   s->h_ctr[52] = 0;
 }
@@ -662,12 +667,11 @@ static void sparse_flush(rd_detector *d, int si) {
 // What remains to be done on the device for a finished slot, once per frame (on the polling thread or on the slot's worker): the two
 // rare repeats and the bookkeeping of the round budget.
 static void slot_finish_device(rd_detector *d, Slot *s) {
-  if (s->rounds < 20 && s->h_ctr[32 + s->rounds - 1] != 0) {   // the region merge was still changing in its last launched round: repeat with the full budget
-    s->rounds = 20;
-    s->post_mode = 0;                            // (the rectangles computed on the device belong to the discarded regions: the host path takes this frame)
+  if (s->rounds <= 20 && s->h_ctr[32 + s->rounds - 1] != 0) {   // the region merge was still changing in its last launch: again with as many launches as it takes (at most 64, like the definition)
+    s->rounds = 64;
     pthread_mutex_lock(&d->launch_mu);
     frame_regions(d, s);
-    frame_votes(d, s, 1);
+    redo_votes(d, s, s->st);
     RD_HIP(hipEventRecord(s->ev_redo, s->st));
     pthread_mutex_unlock(&d->launch_mu);
     RD_HIP(hipEventSynchronize(s->ev_redo));
@@ -677,15 +681,17 @@ static void slot_finish_device(rd_detector *d, Slot *s) {
     frame_absorb_slow(d, s);
     __atomic_add_fetch(&d->n_redo_absorb, 1, __ATOMIC_RELAXED);
   }
-  {   // budget for the frames to come: what the last 64 frames needed (first round without a change, + 1 to see that) + 1.
-      // (A long window on purpose: a frame that needs more than the budget is computed twice.)
+  {   // budget for the frames to come (need = launches up to and including the first one that changed nothing)
     int need = 20;
     for (int r = 0; r < 20; r++) if (s->h_ctr[32 + r] == 0) { need = r + 1; break; }
     pthread_mutex_lock(&d->tan_mu);
     d->need_count[need]++;
     d->need_hist[d->need_pos++ & 63] = need;
-    int mx = 0;
-    for (int k = 0; k < 64; k++) mx = d->need_hist[k] > mx ? d->need_hist[k] : mx;
+    // what all but the three most demanding of the last 64 frames needed (a repeat costs a region stage, ~90 launches; a launch too many
+    // costs 5 us in EVERY frame: on the bench stream 97 % of the frames need 9-11 launches, one in 150 needs 17 or more)
+    int cnt[22] = { 0 }, seen = 0, mx = 20;
+    for (int k = 0; k < 64; k++) cnt[d->need_hist[k] > 20 ? 20 : d->need_hist[k]]++;
+    for (int v = 20; v >= 0; v--) { seen += cnt[v]; if (seen > 3) { mx = v; break; } }
     int b = 20;
     for (int k = RD_NBUDGETS - 1; k >= 0; k--) if (d->need_pos >= 8 && kRoundBudgets[k] >= mx + 1) b = kRoundBudgets[k];
     __atomic_store_n(&d->rounds_budget, b, __ATOMIC_RELAXED);
@@ -1012,7 +1018,7 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
     { "nms", s->nms, N * 4 }, { "mask0", s->mask0, N * 4 }, { "tidy", s->tidy, N * 4 }, { "label1", s->label1, N * 4 }, { "strsum", s->strsum, N * 4 },
     { "edge500", s->e8, N }, { "smooth", s->smooth, N * 4 }, { "quant", s->quant, N * 4 }, { "strong", s->strong, N * 4 }, { "junction", s->junction, N * 4 },
     { "mergemask", s->mergemask, N * 4 }, { "region", s->region, N * 4 }, { "region0", s->region0, N * 4 }, { "rsize", s->rsize, N * 4 }, { "boundarysrc", s->boundarysrc, N * 4 },
-    { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 }, { "polyctr", rdk::poly_scratch_counters(s->ps), 64 * 4 }, { "iirflags", s->flags, 16 * 4 }, { "d2work", s->d2s + N, 16 * 4 }, { "absorb", s->scratch2 + N + 20, 8 * 4 },
+    { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 }, { "polyctr", rdk::poly_scratch_counters(s->ps), 64 * 4 }, { "iirflags", s->flags, 16 * 4 }, { "d2work", s->d2s + N, 16 * 4 }, { "absorb", s->scratch2 + N + 64, 8 * 4 },
   };
   for (size_t i = 0; i < sizeof(tab) / sizeof(tab[0]); i++)
     if (!strcmp(tab[i].n, name)) {

@@ -499,6 +499,7 @@ __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const 
 // Also written: one byte per pixel telling from which of its 4 neighbours the pixel may adopt a label in every launch (rc:308-326 - colours,
 // merge mask and edges do not change): bit0 up, bit1 left, bit2 right, bit3 down, bit4 processed; 0 for frame-border pixels.
 // The labels leave as the words of k_region_round (label << 3, no mark) in both planes its launches alternate between.
+#define RR_NFLAGS 96                    // ints in front of the allow bytes: [0, 64) one flag per launch of the merge, [64, 72) status words of the absorption
 #define RI_ROWS 32
 #define RI_H 10                         // halo above / left
 #define RI_RW (64 + RI_H + 2)
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
   // (also: the round flags start at zero - flags[0] = 1: the first launch, evaluated here, counts as one that changed something - and the
   //  size plane starts from size_init - quirk H2 - without extra launches)
   const int tid = threadIdx.y * 64 + threadIdx.x;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid < 64) flags[tid] = tid == 0 ? 1 : 0;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid < RR_NFLAGS) flags[tid] = tid == 0 ? 1 : 0;
   const int gx0 = blockIdx.x * 64 - RI_H, gy0 = blockIdx.y * RI_ROWS - RI_H;
   // colours of the region (cells outside the frame: marked by lnk = -1 below)
   stage_cells<RI_NC, 256>(tid, pix,
@@ -1610,7 +1611,7 @@ __global__ __launch_bounds__(256) void k_reduce_box(const rdk::PolyFrames FRS, i
 struct ls_rec { float x0, y0, x1, y1; int startIndex, endIndex, leftPtr, rightPtr, startCount, endCount, maxDist, polyid, npix, level; };
 
 // The kernel also assembles the block that travels to the host in ONE copy (pack): [0,32) polyline counters, [32,52) region
-// round flags, [52,55) absorption status, [64, 64 + 14 * pack_records) segment records 0.., then 90 ints of probes per record.
+// round flags, [52,60) absorption status, [64, 64 + 14 * pack_records) segment records 0.., then 90 ints of probes per record.
 __global__ void k_sample_segments(const rdk::PolyFrames FRS, int max_records, int iw, int ih, int nentry, int pack_records) {
   RD_VFRAME;
   int *__restrict__ out = FRM.probes;
@@ -1624,7 +1625,8 @@ __global__ void k_sample_segments(const rdk::PolyFrames FRS, int max_records, in
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (pack) {
     if (t < 32) pack[t] = polyctr[t];
-    else if (t < 56) pack[t] = rflags[t - 32];        // (20 round flags of the region merge, then the 3 status words of the absorption)
+    else if (t < 52) pack[t] = rflags[t - 32];        // (the flags of the first 20 launches of the region merge)
+    else if (t < 60) pack[t] = rflags[64 + t - 52];   // (the status words of the absorption)
     if (t < 14) pack[64 + t] = ((const int *)ls)[t];        // header record
   }
   const int i = t / 15 + 1, k = t % 15;
@@ -1681,14 +1683,14 @@ void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int 
   hipLaunchKernelGGL(k_mm_gather, dim3(wpr, cdiv(ih, MM_ROWS)), dim3(64, 4), 0, s, out, (const unsigned long long *)scratch, iw, ih, wpr);
 }
 
-// scratch: 3*N + 256 ints ([N, N + 64): round flags, then the allowed-direction bytes; [2N, 3N): the second label plane of the rounds).
+// scratch: 3*N + 256 ints ([N, N + 96): a flag per launch and the absorption's status words, then the allowed-direction bytes; [2N, 3N): the second label plane of the rounds).
 // ROUNDS: the number of launches, even (the last one writes `label`); launches after one that changed nothing return at once.
 // *marked <- 1: `label` holds the rounds' words (label << 3 | mark), which region_size turns into plain labels.
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS, int *size_out, const int *size_init, int *marked) {
   const int n = iw * ih;
-  if (ROUNDS < 2 || (ROUNDS & 1)) { fprintf(stderr, "region_merge: the number of launches must be even and at least 2 (got %d)\n", ROUNDS); abort(); }
+  if (ROUNDS < 2 || (ROUNDS & 1) || ROUNDS > 64) { fprintf(stderr, "region_merge: the number of launches must be even, 2..64 (got %d)\n", ROUNDS); abort(); }
   int *flags = scratch + n;
-  uint8_t *allow = (uint8_t *)(flags + 64);
+  uint8_t *allow = (uint8_t *)(flags + RR_NFLAGS);
   int *A = label, *B = scratch + 2 * (size_t)n;   // the two planes of the rounds; the result is in A
   hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, A, B, allow, pix, mask, edge, iw, ih, flags, size_out, size_init);
   const dim3 grid(cdiv(iw, 64), cdiv(ih, RR_TY * RR_PX));

@@ -1137,8 +1137,8 @@ def test_two_detectors_on_two_host_threads_in_one_process():
 
 def test_frames_with_more_segments_than_the_probe_buffer_lose_nothing(monkeypatch):
     """the segment list has the reference's capacity (16N / 56 records, oclpolyline.cl:456); a slot's probe buffer is smaller (65536
-    records), and a frame with more is probed again into a buffer that grows on demand: with the probe buffer shrunk to 300 records, the
-    busy frames (600-1500 segments) must return exactly what they return with the full-size buffer - rectangles and complete segment list"""
+    records), and a frame with more is probed again into a buffer that grows on demand: with the probe buffer shrunk to 64 records, the
+    busy frames (100-1500 segments) must return exactly what they return with the full-size buffer - rectangles and complete segment list"""
     g = golden("hard_rect")
     kinds, params = g["kinds"].tolist(), g["params"].tolist()
     for hi in (0, 6, 12):
@@ -1147,7 +1147,7 @@ def test_frames_with_more_segments_than_the_probe_buffer_lose_nothing(monkeypatc
         outs = []
         for small in (False, True):
             if small:
-                monkeypatch.setenv("RD_MAXREC_DEV", "300")
+                monkeypatch.setenv("RD_MAXREC_DEV", "64")
             det = ra.Detector(iw, ih, nslots=1)
             monkeypatch.delenv("RD_MAXREC_DEV", raising=False)
             det.enqueue(img)
@@ -1155,6 +1155,6 @@ def test_frames_with_more_segments_than_the_probe_buffer_lose_nothing(monkeypatc
             outs.append((rects, det.last_segments(), ra.lib().rd_detector_counter(det.h, 10)))
             det.close()
         (r0, s0, c0), (r1, s1, c1) = outs
-        assert int(s0.view("i4")[0]) > 300 and c0 == 0 and c1 == 1
+        assert int(s0.view("i4")[0]) > 64 and c0 == 0 and c1 == 1
         assert helpers.rects_equal(r0, r1) and helpers.segments_equal(s0, s1)
         assert helpers.segments_equal(s1, g["h%d_segments" % hi])
