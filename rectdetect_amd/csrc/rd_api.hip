@@ -846,7 +846,7 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   // frames per set of sparse-stage launches: 4 from twelve frames in flight on - the deferral by one group below needs a third group of
   // slots to keep the streams fed, and without it a batch is a barrier per group (measured 10 % slower than no batching) - else every
   // frame on its own; RD_BATCH=1..4 overrides (tests: batching with any slot count)
-  d->batch = nslots >= 12 ? 4 : 1;
+  d->batch = nslots >= 24 ? 8 : (nslots >= 12 ? 4 : 1);      // (these stages are latency-bound chains of gathers: eight frames take a launch as long as four)
   if (getenv("RD_BATCH")) { const int b = atoi(getenv("RD_BATCH")); d->batch = b < 1 ? 1 : (b > RD_MAXB ? RD_MAXB : b); }
   if (d->fork_poly || d->batch > nslots) d->batch = d->fork_poly ? 1 : nslots;
   d->frames = (rdk::PolyFrame *)calloc((size_t)nslots, sizeof(rdk::PolyFrame));

@@ -516,10 +516,30 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
   const int tid = threadIdx.y * 64 + threadIdx.x;
   if (blockIdx.x == 0 && blockIdx.y == 0 && tid < RR_NFLAGS) flags[tid] = tid == 0 ? 1 : 0;
   const int gx0 = blockIdx.x * 64 - RI_H, gy0 = blockIdx.y * RI_ROWS - RI_H;
-  // colours of the region (cells outside the frame: marked by lnk = -1 below)
+  // colours of the region (cells outside the frame: marked by lnk = -1 below), and - for the tile and two more rows / columns - "merge mask
+  // set" and "strong edge" as two bits (all loads of a thread in flight together)
   stage_cells<RI_NC, 256>(tid, pix,
     [&](int t, int &a) { const int gx = gx0 + t % RI_RW, gy = gy0 + t / RI_RW; a = gy * iw + gx; return gx >= 0 && gx < iw && gy >= 0 && gy < ih; },
     [&](int t, bool ok, int v) { col[t] = v; lnk[t] = ok ? 0 : -1; });
+  constexpr int MW = 64 + 2, MH = RI_ROWS + 2, MN = MW * MH;       // cells (RI_H .. RI_H + 65, RI_H .. RI_H + RI_ROWS + 1)
+  {
+    constexpr int IT = (MN + 255) / 256;
+    int mv[IT], ev[IT];
+    bool ok[IT];
+#pragma unroll
+    for (int i = 0; i < IT; i++) {
+      const int t = tid + i * 256;
+      const int gx = gx0 + RI_H + t % MW, gy = gy0 + RI_H + t / MW;
+      ok[i] = t < MN && gx < iw && gy < ih;
+      const unsigned a = ok[i] ? (unsigned)(gy * iw + gx) : 0u;
+      mv[i] = at32(mask, a); ev[i] = at32(edge, a);
+    }
+#pragma unroll
+    for (int i = 0; i < IT; i++) {
+      const int t = tid + i * 256;
+      if (t < MN) alw[(RI_H + t / MW) * RI_RW + RI_H + t % MW] = (unsigned char)(ok[i] ? ((mv[i] != 0 ? 1 : 0) | (ev[i] <= 0 ? 2 : 0)) : 0);      // bit 0: mask set, bit 1: NOT a strong edge
+    }
+  }
   __syncthreads();
   // raw links (cells of the first row / column of the region cannot know theirs: nothing reads them, see RI_H)
   for (int t = tid; t < RI_NC; t += 256) {
@@ -531,42 +551,64 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
     else if (gx > 0 && cx > 0 && col[t] == col[t - 1]) l = t - 1;
     lnk[t] = (short)l;
   }
-  // allowed directions for the cells whose proposals are needed: the tile and one more row / column (mask and edges straight from memory)
-  for (int t = tid; t < (64 + 1) * (RI_ROWS + 1); t += 256) {
-    const int cx = RI_H + t % 65, cy = RI_H + t / 65, c = cy * RI_RW + cx;
-    const int gx = gx0 + cx, gy = gy0 + cy;
+  __syncthreads();
+  // allowed directions for the cells whose proposals are needed: the tile and one more row / column (in place of the two bits: a cell's
+  // byte is read by itself - its own bits - and by its left and upper neighbours - bit 1 -, so the bytes are rewritten after a barrier)
+  unsigned char anew[((64 + 1) * (RI_ROWS + 1) + 255) / 256];
+#pragma unroll
+  for (int i = 0; i < (int)sizeof(anew); i++) {
+    const int t = tid + i * 256;
     unsigned a = 0;
-    if (gx > 0 && gy > 0 && gx < iw - 1 && gy < ih - 1) {
-      const int p = gy * iw + gx;
-      const bool any = mask[p] != 0;
-      const bool z0 = edge[p] <= 0;
-      const int v = col[c];
-      if ((v == col[c - RI_RW] || any) && z0) a |= 1;
-      if ((v == col[c - 1] || any) && z0) a |= 2;
-      if ((v == col[c + 1] || any) && edge[p + 1] <= 0) a |= 4;
-      if ((v == col[c + RI_RW] || any) && edge[p + iw] <= 0) a |= 8;
-      a |= 16;
+    if (t < (64 + 1) * (RI_ROWS + 1)) {
+      const int cx = RI_H + t % 65, cy = RI_H + t / 65, c = cy * RI_RW + cx;
+      const int gx = gx0 + cx, gy = gy0 + cy;
+      if (gx > 0 && gy > 0 && gx < iw - 1 && gy < ih - 1) {
+        const unsigned b0 = alw[c];
+        const bool any = (b0 & 1) != 0, z0 = (b0 & 2) != 0;
+        const int v = col[c];
+        if ((v == col[c - RI_RW] || any) && z0) a |= 1;
+        if ((v == col[c - 1] || any) && z0) a |= 2;
+        if ((v == col[c + 1] || any) && (alw[c + 1] & 2)) a |= 4;
+        if ((v == col[c + RI_RW] || any) && (alw[c + RI_RW] & 2)) a |= 8;
+        a |= 16;
+      }
     }
-    alw[c] = (unsigned char)a;
+    anew[i] = (unsigned char)a;
   }
   __syncthreads();
-  // proposals
-  for (int t = tid; t < (64 + 1) * (RI_ROWS + 1); t += 256) {
-    const int cx = RI_H + t % 65, cy = RI_H + t / 65, c = cy * RI_RW + cx;
-    const unsigned a = alw[c];
-    int g = 0x7fff;
-    if (a & 16) {
-      const int og = lnk[c];
-      int m = og;      // (cell indices order like pixel indices: both are row-major over the same pixels)
-      if (a & 1) { const int s = lnk[c - RI_RW]; m = s < m ? s : m; }
-      if (a & 2) { const int s = lnk[c - 1]; m = s < m ? s : m; }
-      if (a & 4) { const int s = lnk[c + 1]; m = s < m ? s : m; }
-      if (a & 8) { const int s = lnk[c + RI_RW]; m = s < m ? s : m; }
 #pragma unroll
-      for (int j = 0; j < 8; j++) m = lnk[m];
-      if (m != og) g = m;
+  for (int i = 0; i < (int)sizeof(anew); i++) {
+    const int t = tid + i * 256;
+    if (t < (64 + 1) * (RI_ROWS + 1)) alw[(RI_H + t / 65) * RI_RW + RI_H + t % 65] = anew[i];
+  }
+  __syncthreads();
+  // proposals (the jumps level by level for all of a thread's cells: eight dependent LDS reads per thread, not per cell)
+  {
+    constexpr int NP = ((64 + 1) * (RI_ROWS + 1) + 255) / 256;
+    int m[NP], og[NP], cc[NP];
+    bool act[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+      const int t = tid + i * 256;
+      const bool in = t < (64 + 1) * (RI_ROWS + 1);
+      const int c = in ? (RI_H + t / 65) * RI_RW + RI_H + t % 65 : RI_H * RI_RW + RI_H;
+      const unsigned a = in ? alw[c] : 0u;
+      cc[i] = in ? c : -1;
+      act[i] = (a & 16) != 0;
+      og[i] = act[i] ? lnk[c] : RI_H * RI_RW + RI_H;      // (a cell that proposes nothing walks from the tile's first pixel: always inside the frame)
+      int mm = og[i];      // (cell indices order like pixel indices: both are row-major over the same pixels)
+      if (a & 1) { const int s = lnk[c - RI_RW]; mm = s < mm ? s : mm; }
+      if (a & 2) { const int s = lnk[c - 1]; mm = s < mm ? s : mm; }
+      if (a & 4) { const int s = lnk[c + 1]; mm = s < mm ? s : mm; }
+      if (a & 8) { const int s = lnk[c + RI_RW]; mm = s < mm ? s : mm; }
+      m[i] = mm;
     }
-    prop[c] = (short)g;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+#pragma unroll
+      for (int i = 0; i < NP; i++) m[i] = lnk[m[i]];
+#pragma unroll
+    for (int i = 0; i < NP; i++) if (cc[i] >= 0) prop[cc[i]] = (short)((act[i] && m[i] != og[i]) ? m[i] : 0x7fff);
   }
   __syncthreads();
   // the labels after the first launch, the allow bytes, the sizes' start values
@@ -1191,7 +1233,7 @@ __device__ __forceinline__ void at_body(ab_word *W, int *__restrict__ out, const
     unsigned c0[G];
 #pragma unroll
     for (int kk = 0; kk < G; kk++) {
-      const int i = tid + (k0 + kk) * AT_NT;
+      const int i = k0 + kk < EPT ? tid + (k0 + kk) * AT_NT : n;
       const int4 *rec = (const int4 *)(list + (size_t)(i < n ? i : 0) * AB_REC);
       const int4 a = rec[0], b = rec[1], d = rec[2];
       pq[kk][0] = a.w; pq[kk][1] = b.x; pq[kk][2] = b.y; pq[kk][3] = b.z;
@@ -1204,12 +1246,13 @@ __device__ __forceinline__ void at_body(ab_word *W, int *__restrict__ out, const
     int pv[G][4];
 #pragma unroll
     for (int kk = 0; kk < G; kk++) {
-      const int i = tid + (k0 + kk) * AT_NT;
+      const int i = k0 + kk < EPT ? tid + (k0 + kk) * AT_NT : n;
 #pragma unroll
       for (int j = 0; j < 4; j++) pv[kk][j] = (i < n && pq[kk][j] < -1) ? out[(unsigned)(-pq[kk][j] - 2)] : -1;
     }
 #pragma unroll
     for (int kk = 0; kk < G; kk++) {
+      if (k0 + kk >= EPT) continue;
       const int k = k0 + kk, i = tid + k * AT_NT;
       unsigned ref[4], c = c0[kk];
 #pragma unroll
@@ -1333,7 +1376,10 @@ __global__ __launch_bounds__(AT_NT) void k_absorb_tail(int *__restrict__ out, co
   if (threadIdx.x == 0) { status[1] = n; status[0] = n > reccap ? 1 : 0; status[2] = 0; }
   if (n == 0 || n > reccap) return;
   if (n <= 2 * AT_NT) at_body<2>(at_lds, out, list, n, size, nsteps, status);
+  else if (n <= 3 * AT_NT) at_body<3>(at_lds, out, list, n, size, nsteps, status);
   else if (n <= 4 * AT_NT) at_body<4>(at_lds, out, list, n, size, nsteps, status);
+  else if (n <= 5 * AT_NT) at_body<5>(at_lds, out, list, n, size, nsteps, status);
+  else if (n <= 6 * AT_NT) at_body<6>(at_lds, out, list, n, size, nsteps, status);
   else if (n <= 8 * AT_NT) at_body<8>(at_lds, out, list, n, size, nsteps, status);
   else at_body<16>(at_lds, out, list, n, size, nsteps, status);
 }

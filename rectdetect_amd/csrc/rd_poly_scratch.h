@@ -44,7 +44,7 @@ struct PolyFrame {
 };
 #define RD_POST_MAXC 1024  // candidates per frame the device post-process holds (more: the host path takes the frame)
 
-#define RD_MAXB 4        // frames per launch of the sparse stages (4 descriptors = 1.4 KB of kernel arguments)
+#define RD_MAXB 8        // frames per launch of the sparse stages (8 descriptors = 2.8 KB of kernel arguments; the limit is 4 KB)
 struct PolyFrames { PolyFrame f[RD_MAXB]; };
 inline PolyFrames pack_frames(const PolyFrame *frames, int nb) {
   PolyFrames r;
