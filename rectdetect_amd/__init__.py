@@ -16,7 +16,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librectdetect_hip.so")
+LIB_PATH = os.environ.get("RD_LIB_PATH") or os.path.join(_HERE, "librectdetect_hip.so")      # (RD_LIB_PATH: tuning builds, tools/variants.sh)
 
 RECT_DTYPE = np.dtype([("c2", "<f8", (4, 2)), ("c3", "<f8", (4, 3)), ("value", "<f8"), ("status", "<u4"), ("_pad", "<u4")])
 LS_DTYPE = np.dtype([("x0", "<f4"), ("y0", "<f4"), ("x1", "<f4"), ("y1", "<f4"), ("startIndex", "<i4"), ("endIndex", "<i4"),

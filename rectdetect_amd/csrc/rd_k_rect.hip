@@ -500,7 +500,9 @@ __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const 
 // merge mask and edges do not change): bit0 up, bit1 left, bit2 right, bit3 down, bit4 processed; 0 for frame-border pixels.
 // The labels leave as the words of k_region_round (label << 3, no mark) in both planes its launches alternate between.
 #define RR_NFLAGS 96                    // ints in front of the allow bytes: [0, 64) one flag per launch of the merge, [64, 72) status words of the absorption
+#ifndef RI_ROWS
 #define RI_ROWS 32
+#endif
 #define RI_H 10                         // halo above / left
 #define RI_RW (64 + RI_H + 2)
 #define RI_RH (RI_ROWS + RI_H + 2)
@@ -660,10 +662,16 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
 // Memory-latency bound: every thread handles RR_PX pixels below one another - each is the other's vertical neighbour, so a column of six
 // costs 6 + 2 + 12 label loads instead of 30 (measured at full rate, same box: 2, 3, 4, 6, 8 pixels: 2056, 2080, 2083 / 2067, 2079, 2062
 // frames/s) - and issues all of their label loads before using any, then the first pointer jumps together.
+#ifndef RR_PX
 #define RR_PX 6
+#endif
+#ifndef RR_TY
 #define RR_TY 8          // thread rows per block (2 / 4 / 8 at full rate: 2094 / 2118 / 2124 frames/s)
+#endif
 #define RR_MBITS 3
+#ifndef RR_DEEP
 #define RR_DEEP 3          // rounds in which the trees are still the chains of the initial links (a pixel's parent is 1, 10, 91 rows above it)
+#endif
 __device__ __forceinline__ int rr_label(const int *X, unsigned q) { return at32(X, q) >> RR_MBITS; }
 __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round) {
   if (round > 0 && flags[round - 1] == 0) return;
@@ -775,7 +783,9 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
 // aggregated per wave (runs of equal labels among its 64 consecutive pixels), then per block in an LDS hash, before touching
 // global atomics.
 #define RS_T 1024
+#ifndef RS_PER_THREAD
 #define RS_PER_THREAD 32
+#endif
 __device__ __forceinline__ void rs_accum(int *keys, int *vals, int *out, int label, int cnt) {
   unsigned h = ((unsigned)label * 2654435761u) >> 22;
   int probes = 0;
@@ -1034,12 +1044,18 @@ __global__ __launch_bounds__(256) void k_despeckle2_active(int *__restrict__ nxt
 // k_absorb_tile does (1) and lists the pixels it cannot decide (their `out` word = -(list index) - 2), k_absorb_tail does (2)
 // for up to AT_CAP of them in one block.  Whatever they cannot finish (status[0] != 0) is left to despeckle2_slow().
 #define AB_TW 64
+#ifndef AB_TH
 #define AB_TH 64        // (64 x 64 tiles: 510 blocks at 1920 x 1080, two per CU - all resident at once - and 1.96 loaded cells per pixel; 64 x 32: 2.39)
+#endif
+#ifndef AB_HK
 #define AB_HK 16
+#endif
 #define AB_LW (AB_TW + 2 * AB_HK + 2)       // loaded cells: the tile, AB_HK columns left and right, AB_HK rows above, and one more ring for the old 3x3 neighbourhoods
 #define AB_LH (AB_TH + AB_HK + 2)
 #define AB_NC (AB_LW * AB_LH)
+#ifndef AB_NT
 #define AB_NT 512
+#endif
 #define AB_R 4                              // small-region cells per thread (more in a tile: its small-region pixels go to the tail)
 #define AB_INEXACT 0x40000000u
 typedef unsigned long long ab_word;         // a cell: (size of its label | AB_INEXACT) << 32 | label  (one 64-bit LDS word: readers always see a consistent pair)
