@@ -337,7 +337,7 @@ struct rd_detector {
   long next_enqueue, next_poll;
   int last_polled_slot;
   void *last_segs; int last_nsegs;
-  int use_graph, poly_mode, force_redo, diag_no_post, diag_skip, fork_poly, fixed_rounds; long n_redo, n_redo_rounds, n_redo_absorb;
+  int use_graph, poly_mode, force_redo, diag_no_post, diag_skip, fork_poly, fixed_rounds, budget_cycle; long n_redo, n_redo_rounds, n_redo_absorb;
   int overflow_streak;
   int poly_overflows;                     // set once two frames in a row overflowed the single-launch polyline kernel: later frames go multi-launch
   int rounds_budget, need_hist[64]; unsigned need_pos; long budget_count[RD_NBUDGETS], need_count[21];
@@ -609,6 +609,7 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   RD_HIP(hipEventRecord(s->ev_strong, s->st));
   d->last_strong = s->ev_strong; d->have_last_strong = 1;
   s->rounds = d->fixed_rounds ? d->fixed_rounds : __atomic_load_n(&d->rounds_budget, __ATOMIC_RELAXED);
+  if (d->budget_cycle) s->rounds = kRoundBudgets[2 + (int)((s->seq / d->budget_cycle) % (RD_NBUDGETS - 2))];      // (tests: a new graph every few frames)
   s->poly_mode = (d->poly_mode && !__atomic_load_n(&d->poly_overflows, __ATOMIC_RELAXED)) ? 1 : 0;
   if (d->batch == 1) { s->post_mode = d->device_post && d->have_tan; s->post_tan = d->tan_aov; }
   for (int k = 0; k < RD_NBUDGETS; k++) if (kRoundBudgets[k] == s->rounds) d->budget_count[k]++;
@@ -665,6 +666,8 @@ static void sparse_flush(rd_detector *d, int si) {
   if (d->deferred_slot >= g0 && d->deferred_slot <= g1) d->deferred_slot = -1;
 }
 
+static void wait_event_outside_captures(rd_detector *d, hipEvent_t ev);
+
 // What remains to be done on the device for a finished slot, once per frame (on the polling thread or on the slot's worker): the two
 // rare repeats and the bookkeeping of the round budget.
 static void slot_finish_device(rd_detector *d, Slot *s) {
@@ -675,7 +678,7 @@ static void slot_finish_device(rd_detector *d, Slot *s) {
     redo_votes(d, s, s->st);
     RD_HIP(hipEventRecord(s->ev_redo, s->st));
     pthread_mutex_unlock(&d->launch_mu);
-    RD_HIP(hipEventSynchronize(s->ev_redo));
+    wait_event_outside_captures(d, s->ev_redo);
     __atomic_add_fetch(&d->n_redo_rounds, 1, __ATOMIC_RELAXED);
   }
   if (s->h_ctr[52] != 0 || (d->force_redo & 2)) {   // the absorption's fast path gave up on this frame: finish it the long way
@@ -707,8 +710,25 @@ static void slot_finish_device(rd_detector *d, Slot *s) {
     frame_tail(d, s, 0);
     RD_HIP(hipEventRecord(s->ev_redo, s->st));
     pthread_mutex_unlock(&d->launch_mu);
-    RD_HIP(hipEventSynchronize(s->ev_redo));
+    wait_event_outside_captures(d, s->ev_redo);
     __atomic_add_fetch(&d->n_redo, 1, __ATOMIC_RELAXED);
+  }
+}
+
+// Waiting for an event from a thread that is not the enqueueing one.  Slots share streams, and the enqueueing thread records a new graph
+// on a slot's stream whenever a (slot, launch budget) pair is used for the first time - in the middle of a run, since the budget of the
+// region merge follows the stream.  HIP refuses hipEventSynchronize / hipEventQuery on an event whose stream is being captured ("operation
+// not permitted on an event last recorded in a capturing stream"), so the wait is a poll whose queries exclude captures (launch_mu: held by
+// run_segment for the duration of a capture, a few hundred microseconds).
+static void wait_event_outside_captures(rd_detector *d, hipEvent_t ev) {
+  for (;;) {
+    pthread_mutex_lock(&d->launch_mu);
+    const hipError_t e = hipEventQuery(ev);
+    pthread_mutex_unlock(&d->launch_mu);
+    if (e == hipSuccess) return;
+    if (e != hipErrorNotReady) { RD_HIP(e); }
+    struct timespec ts = { 0, 30000 };
+    nanosleep(&ts, NULL);
   }
 }
 
@@ -796,7 +816,7 @@ static void *slot_worker(void *arg) {
     const double tan = d->tan_aov;
     pthread_mutex_unlock(&d->tan_mu);
     if (s->quit) return NULL;
-    RD_HIP(hipEventSynchronize(s->ev_done));
+    wait_event_outside_captures(d, s->ev_done);
     void *segs = NULL; int ns = 0;
     slot_finish_device(d, s);
     void *r = slot_rectangles(d, s, tan, &segs, &ns);
@@ -848,6 +868,7 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->fixed_rounds = 0;
   if (getenv("RD_REGION_ROUNDS_FIXED")) { const int r = atoi(getenv("RD_REGION_ROUNDS_FIXED")); d->fixed_rounds = (r >= 8 && r <= 20 && !(r & 1)) ? r : 20; }
   d->rounds_budget = 20;
+  d->budget_cycle = getenv("RD_BUDGET_CYCLE") ? atoi(getenv("RD_BUDGET_CYCLE")) : 0;      // tests: the launch budget changes every so many frames (12, 14, .. 20, 12, ..)
   d->diag_skip = getenv("RD_DIAG_SKIP") ? atoi(getenv("RD_DIAG_SKIP")) : 0;   // timing diagnostics only: leaves stages out (wrong results)
   pthread_mutex_init(&d->tan_mu, NULL); pthread_cond_init(&d->tan_cv, NULL);
   pthread_mutex_init(&d->launch_mu, NULL);

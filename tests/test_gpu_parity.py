@@ -1158,3 +1158,34 @@ def test_frames_with_more_segments_than_the_probe_buffer_lose_nothing(monkeypatc
         assert int(s0.view("i4")[0]) > 64 and c0 == 0 and c1 == 1
         assert helpers.rects_equal(r0, r1) and helpers.segments_equal(s0, s1)
         assert helpers.segments_equal(s1, g["h%d_segments" % hi])
+
+
+def test_graphs_recorded_in_the_middle_of_a_run_while_workers_wait(monkeypatch):
+    """The launch budget of the region merge follows the stream, so (slot, budget) pairs that were never used before come up in the middle
+    of a run and their graphs are recorded then - on streams that other slots share and whose events worker threads are waiting for (HIP
+    refuses waits on events of a capturing stream: a crash of the default bench run, once).  Here the budget changes every three
+    frames (RD_BUDGET_CYCLE), 8 slots on 4 streams, one worker per slot: results must equal the sequential run."""
+    iw, ih = 640, 480
+    frames = [synth.frame(synth.SEED0 + 50, iw, ih, t) for t in range(72)]
+    seq = ra.Detector(iw, ih, nslots=1, nworkers=0)
+    want = []
+    for f in frames:
+        seq.enqueue(f)
+        want.append((seq.poll(TAN36), seq.last_segments()))
+    seq.close()
+    monkeypatch.setenv("RD_BUDGET_CYCLE", "3")
+    par = ra.Detector(iw, ih, nslots=8, nworkers=1)
+    monkeypatch.delenv("RD_BUDGET_CYCLE")
+    got, inflight = [], 0
+    for f in frames:
+        if inflight == 8:
+            got.append((par.poll(TAN36), par.last_segments()))
+            inflight -= 1
+        par.enqueue(f)
+        inflight += 1
+    while inflight:
+        got.append((par.poll(TAN36), par.last_segments()))
+        inflight -= 1
+    par.close()
+    for (r1, s1), (r2, s2) in zip(want, got):
+        assert helpers.rects_equal(r1, r2) and helpers.segments_equal(s1, s2)
