@@ -286,6 +286,7 @@ struct Slot {
   hipStream_t st_redo;                       // created on first use: the slow absorption path (frame_absorb_slow), fetches of long lists
   int *big_probes; int big_probes_cap;       // probes of a frame with more segments than `probes` holds (grows on demand)
   uint8_t *bgr;
+  const uint8_t *src;                     // where the frame in flight is read from: bgr (uploaded) or the caller's device buffer
   uint32_t *plab0, *plab1, *smooth, *quant;
   float *tr[3], *fw[3], *bw[3], *hz[3], *bl[3], *vxy, *strength, *nms;
   int *i0, *i1, *mask0, *tidy, *label1, *strsum, *strong, *junction, *mergemask, *region, *rsize, *scratch2, *d2s, *boundarysrc, *boundary, *lsid, *table, *claim, *probes, *region0, *tlist;
@@ -509,8 +510,9 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
   hipStream_t st = s->st;
   if (seg == 0) {
 
-  // colour -> sigma=1 blur of L, a, b -> packed blurred Lab (oclrect.c:245-251)
-  rdk::bgr2plab_transposed(st, s->plab0, s->tr, s->bgr, iw, ih, ws);
+  // (colour conversion, oclrect.c:245: launched by enqueue_frame in front of this segment, outside the recorded graph - its source is the
+  //  caller's device buffer when the frame is resident in HBM: no copy of the frame)
+  // sigma=1 blur of L, a, b -> packed blurred Lab (oclrect.c:246-251)
   { const float *c[3] = { s->tr[0], s->tr[1], s->tr[2] }; rdk::iir_blur_pass(st, s->hz, c, s->fw, s->bw, 3, ih, iw, 1, s->tails, s->flags, 1); }    // along x (source: 16-bit fields)
   { const float *c[3] = { s->hz[0], s->hz[1], s->hz[2] }; rdk::iir_blur_pass(st, s->bl, c, s->fw, s->bw, 3, iw, ih, 0, s->tails, s->flags + 1); }   // along y
   // gradient direction (+ the packing of the blurred Lab, oclrect.c:251, on the way), strength, non-max suppression (oclrect.c:253-258)
@@ -603,6 +605,7 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
     s->graph_ws = ws;
   }
   RD_HIP(hipEventRecord(s->ev_begin, s->st));
+  rdk::bgr2plab_transposed(s->st, s->plab0, s->tr, s->src, d->iw, d->ih, ws);
   run_segment(d, s, ws, 0);
   if (d->have_last_strong) RD_HIP(hipStreamWaitEvent(s->st, d->last_strong, 0));
   run_segment(d, s, ws, 1);
@@ -936,8 +939,8 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
   Slot *s = &d->slots[d->next_enqueue % d->nslots];
   s->seq = d->next_enqueue; s->ws = ws;
   const size_t bytes = (size_t)ws * d->ih;
-  if (on_device) RD_HIP(hipMemcpyAsync(s->bgr, frame, bytes, hipMemcpyDeviceToDevice, s->st));
-  else { memcpy(s->h_bgr, frame, bytes); RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, bytes, hipMemcpyHostToDevice, s->st)); }
+  if (on_device) s->src = (const uint8_t *)frame;      // read where it lies (the caller keeps it valid until the frame's poll returned)
+  else { memcpy(s->h_bgr, frame, bytes); RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, bytes, hipMemcpyHostToDevice, s->st)); s->src = s->bgr; }
   enqueue_frame(d, s, ws);
   if (d->batch == 1) slot_submitted(d, s);
   else {
