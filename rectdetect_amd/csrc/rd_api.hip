@@ -851,13 +851,13 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->force_redo = (getenv("RD_POLY_FORCE_REDO") ? 1 : 0) | (getenv("RD_ABSORB_FORCE_SLOW") ? 2 : 0);   // tests: every frame also takes the polyline / absorption fallback
   d->diag_no_post = getenv("RD_DIAG_NO_POST") ? 1 : 0;
   // candidate funnel + pose estimation on the device (rd_k_post.hip) instead of on one worker thread per frame slot: RD_DEVICE_POST=0|1 decides;
-  // otherwise the host path (0.3 ms of CPU time per 1080p frame, measured faster at full rate where the cores exist) unless this process
-  // may run on fewer than two cores per frame slot - there the workers would be the bottleneck
+  // otherwise the host path - 0.3 ms of CPU time per 1080p frame, i.e. 0.6 of a core at 2000 frames/s: measured 2050 frames/s on 8 cores
+  // as on 256, against 1830 for the device path - unless this process may run on one or two cores only
   if (getenv("RD_DEVICE_POST")) d->device_post = atoi(getenv("RD_DEVICE_POST")) != 0;
   else {
     cpu_set_t set;
     const int ncpu = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : 0;
-    d->device_post = (nworkers > 0 && ncpu > 0 && ncpu < 2 * nslots) ? 1 : 0;
+    d->device_post = (nworkers > 0 && ncpu > 0 && ncpu <= 2) ? 1 : 0;
   }
   // The device runs four hardware queues side by side (more are time-sliced: measured 2x slower per frame).  With one or two
   // frames in flight a frame spreads over two streams (polyline chain beside the blur chain: shortest latency); from three
