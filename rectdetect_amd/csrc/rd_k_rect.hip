@@ -676,8 +676,11 @@ __device__ __forceinline__ int rr_label(const int *X, unsigned q) { return at32(
 __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round) {
   if (round > 0 && flags[round - 1] == 0) return;
   __shared__ int hk[512], hv[512];
+  __shared__ int tmin[64 * RR_TY * RR_PX];      // launch 1 only: the smallest proposal for each pixel of the block's tile (see below)
   const int tid = threadIdx.y * 64 + threadIdx.x;
+  const bool near = round == 1;               // the trees are still the first launch's: a pixel's parent lies ~10 rows above it, mostly inside the tile
   for (int t = tid; t < 512; t += 64 * RR_TY) { hk[t] = -1; hv[t] = 0x7fffffff; }
+  if (near) for (int t = tid; t < 64 * RR_TY * RR_PX; t += 64 * RR_TY) tmin[t] = 0x7fffffff;
   __syncthreads();
   const int mark = 1 + round % 7, mark_prev = round > 0 ? 1 + (round - 1) % 7 : 8;      // (8: matches nothing - before round 0 no plane lags)
   const int yb = blockIdx.y * (RR_TY * RR_PX) + threadIdx.y * RR_PX;      // the thread's RR_PX pixels lie below one another: each is the other's vertical neighbour
@@ -747,8 +750,42 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
     todo[k] = (a[k] & 16) && g[k] != og[k];
     // the pixel's own word in Y: its new label (marked), or - where Y lags behind - the label it keeps
     const bool lag = (w0[k] & 7) == mark_prev;
-    if (valid[k] && (todo[k] || lag)) atomicMin(&Y[p0[k]], (g[k] << RR_MBITS) | (todo[k] ? mark : 0));     // (no value comes back: the thread does not wait for it; g == og unless todo)
+    if (!near && valid[k] && (todo[k] || lag)) atomicMin(&Y[p0[k]], (g[k] << RR_MBITS) | (todo[k] ? mark : 0));     // (no value comes back: the thread does not wait for it; g == og unless todo)
     any_todo = any_todo || todo[k];
+  }
+  if (near) {
+    // Launch 1: every pixel has a parent of its own and proposes to it - two million atomics on top of the two million own words.  The
+    // parent is the pixel ~10 rows above, for four out of five pixels inside the block's tile: those proposals meet in LDS and leave with the
+    // parent's own word, as ONE atomic per pixel; the rest go to memory as in the other launches.
+    const int origin = blockIdx.y * (RR_TY * RR_PX) * iw + blockIdx.x * 64;
+    const float inv_iw = 1.0f / (float)iw;
+#pragma unroll
+    for (int k = 0; k < RR_PX; k++) {
+      if (!todo[k]) continue;
+      const int d = og[k] - origin;
+      bool inside = false;
+      int cell = 0;
+      if (d >= 0 && d < RR_TY * RR_PX * iw) {        // (below 2^24 for every frame this library accepts rows of: exact in single precision up to the correction)
+        int row = (int)((float)d * inv_iw), col = d - row * iw;
+        if (col < 0) { row--; col += iw; } else if (col >= iw) { row++; col -= iw; }
+        inside = col < 64 && row < RR_TY * RR_PX;
+        cell = row * 64 + col;
+      }
+      if (inside) atomicMin(&tmin[cell], g[k]);
+      else { const int w = (g[k] << RR_MBITS) | mark; if (w < ld_agent(&Y[og[k]])) atomicMin(&Y[og[k]], w); }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < RR_PX; k++) {
+      if (!valid[k]) continue;
+      const bool lag = (w0[k] & 7) == mark_prev;
+      int w = (todo[k] || lag) ? ((g[k] << RR_MBITS) | (todo[k] ? mark : 0)) : 0x7fffffff;
+      const int h = tmin[(threadIdx.y * RR_PX + k) * 64 + threadIdx.x];
+      if (h != 0x7fffffff) { const int wh = (h << RR_MBITS) | mark; w = wh < w ? wh : w; }
+      if (w != 0x7fffffff) atomicMin(&Y[p0[k]], w);
+    }
+    if (__any(any_todo) && threadIdx.x == 0) flags[round] = 1;
+    return;
   }
   // Hooking the old parent: once the trees are shallow, all pixels of a tree share one parent, so the block first reduces its
   // (parent -> smallest proposal) pairs in a small LDS hash and then issues one guarded atomic per distinct parent.
