@@ -309,8 +309,8 @@ struct Slot {
   int ws;
   // captured launch sequences (three segments, see enqueue_frame) and the stride they were captured for
   hipGraphExec_t gexec[3]; int graph_ws;   // gexec[2] unused: the last segment has one graph per round budget (gexec2)
-  hipGraphExec_t gexec2[2 * RD_NBUDGETS];  // [round budget index][polyline mode]
-  int poly_mode;                           // polyline mode of the frame in flight (1 = single launch, 0 = multi-launch)
+  hipGraphExec_t gexec2[3 * RD_NBUDGETS];  // [round budget index][polyline mode]
+  int poly_mode;                           // polyline mode of the frame in flight (1 = single block, 2 = one cooperative launch of several blocks, 0 = multi-launch)
   int rounds;                             // region-merge round budget of the frame in flight
   // post-process worker
   pthread_t th; pthread_mutex_t mu; pthread_cond_t cv;
@@ -579,12 +579,22 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
 // and every launched round costs two dispatches even when it exits at once, so the budget follows what recent frames
 // needed (+ margin).  A frame whose last launched round still changed something is repeated with the full budget
 // (slot_postprocess), so the result never depends on the budget.
+// how the polyline stage of the next frame is launched: the single-block kernel (1) until two frames in a row overflowed its on-chip tables
+// (e.g. 3840x2160), from then on the ~85-launch form (0), which is also what repeats a frame that another mode gave up on.  RD_POLY_COOP=1:
+// the same stage as ONE cooperative launch of several blocks per frame (2) for every frame - bit-identical, but measured SLOWER at full
+// rate than the 85 launches (3840x2160: 487 against 545 frames/s): its blocks hold their CUs while they wait at ~50 grid barriers, and every
+// barrier's device-scope fences write back and invalidate the L2s under the dense kernels of the other streams.
+static int current_poly_mode(const rd_detector *d) {
+  if (d->poly_mode == 0 || d->poly_mode == 2) return d->poly_mode;
+  return __atomic_load_n(&d->poly_overflows, __ATOMIC_RELAXED) ? 0 : 1;
+}
+
 static const int kRoundBudgets[RD_NBUDGETS] = { 8, 10, 12, 14, 16, 18, 20 };
 
 static void run_segment(rd_detector *d, Slot *s, int ws, int seg) {
   if (!d->use_graph) { frame_segment(d, s, ws, seg); return; }
   hipGraphExec_t *ge = &s->gexec[seg];
-  if (seg == 2) for (int k = 0; k < RD_NBUDGETS; k++) if (kRoundBudgets[k] == s->rounds) ge = &s->gexec2[k * 2 + ((d->batch == 1 && s->poly_mode) ? 1 : 0)];
+  if (seg == 2) for (int k = 0; k < RD_NBUDGETS; k++) if (kRoundBudgets[k] == s->rounds) ge = &s->gexec2[k * 3 + (d->batch == 1 ? s->poly_mode : 0)];
   if (!*ge) {
     hipGraph_t g = NULL;
     pthread_mutex_lock(&d->launch_mu);
@@ -601,7 +611,7 @@ static void run_segment(rd_detector *d, Slot *s, int ws, int seg) {
 static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   if (d->use_graph && s->graph_ws != ws) {
     for (int k = 0; k < 3; k++) if (s->gexec[k]) { RD_HIP(hipGraphExecDestroy(s->gexec[k])); s->gexec[k] = NULL; }
-    for (int k = 0; k < 2 * RD_NBUDGETS; k++) if (s->gexec2[k]) { RD_HIP(hipGraphExecDestroy(s->gexec2[k])); s->gexec2[k] = NULL; }
+    for (int k = 0; k < 3 * RD_NBUDGETS; k++) if (s->gexec2[k]) { RD_HIP(hipGraphExecDestroy(s->gexec2[k])); s->gexec2[k] = NULL; }
     s->graph_ws = ws;
   }
   RD_HIP(hipEventRecord(s->ev_begin, s->st));
@@ -613,7 +623,7 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   d->last_strong = s->ev_strong; d->have_last_strong = 1;
   s->rounds = d->fixed_rounds ? d->fixed_rounds : __atomic_load_n(&d->rounds_budget, __ATOMIC_RELAXED);
   if (d->budget_cycle) s->rounds = kRoundBudgets[2 + (int)((s->seq / d->budget_cycle) % (RD_NBUDGETS - 2))];      // (tests: a new graph every few frames)
-  s->poly_mode = (d->poly_mode && !__atomic_load_n(&d->poly_overflows, __ATOMIC_RELAXED)) ? 1 : 0;
+  s->poly_mode = current_poly_mode(d);
   if (d->batch == 1) { s->post_mode = d->device_post && d->have_tan; s->post_tan = d->tan_aov; }
   for (int k = 0; k < RD_NBUDGETS; k++) if (kRoundBudgets[k] == s->rounds) d->budget_count[k]++;
   run_segment(d, s, ws, 2);
@@ -644,7 +654,7 @@ static void sparse_launch(rd_detector *d, int a, int b) {
   Slot *host = &d->slots[a + (int)(d->sparse_rot++ % (unsigned)nb)];
   hipStream_t st = d->sparse_st ? d->sparse_st : host->st;
   for (int i = a; i <= b; i++) if (d->slots[i].st != st) RD_HIP(hipStreamWaitEvent(st, d->slots[i].ev_dense, 0));
-  const int pm = (d->poly_mode && !__atomic_load_n(&d->poly_overflows, __ATOMIC_RELAXED)) ? 1 : 0;
+  const int pm = current_poly_mode(d);
   const rdk::PolyFrame *frames = d->frames + a;
   if (!(d->diag_skip & 4)) rdk::polyline(st, frames, nb, d->N * 16, 1, 4.0f, 20, d->iw, d->ih, pm);
   const int with_post = d->device_post && d->have_tan;
@@ -705,8 +715,8 @@ static void slot_finish_device(rd_detector *d, Slot *s) {
     pthread_mutex_unlock(&d->tan_mu);
   }
   // two overflows among the stream's recent frames (whichever slots they ran in): its frames do not fit the single-launch kernel (e.g. 4K) - stop trying
-  if (s->poly_mode && s->h_ctr[25] != 0 && __atomic_add_fetch(&d->overflow_streak, 1, __ATOMIC_RELAXED) >= 2) __atomic_store_n(&d->poly_overflows, 1, __ATOMIC_RELAXED);
-  if (s->poly_mode && s->h_ctr[25] == 0) __atomic_store_n(&d->overflow_streak, 0, __ATOMIC_RELAXED);
+  if (s->poly_mode == 1 && s->h_ctr[25] != 0 && __atomic_add_fetch(&d->overflow_streak, 1, __ATOMIC_RELAXED) >= 2) __atomic_store_n(&d->poly_overflows, 1, __ATOMIC_RELAXED);
+  if (s->poly_mode == 1 && s->h_ctr[25] == 0) __atomic_store_n(&d->overflow_streak, 0, __ATOMIC_RELAXED);
   if ((s->poly_mode && s->h_ctr[25] != 0) || (d->force_redo & 1)) {   // the single-launch polyline stage overflowed: repeat the tail the long way
     s->post_mode = 0;
     pthread_mutex_lock(&d->launch_mu);
@@ -847,7 +857,7 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->prev_strong = dnew<int8_t>((size_t)d->N);
   RD_HIP(hipMemset(d->prev_strong, 0, (size_t)d->N));
   d->use_graph = getenv("RD_NO_GRAPH") ? 0 : 1;
-  d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : 1;
+  d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : (getenv("RD_POLY_COOP") ? 2 : 1);      // (RD_POLY_COOP: the cooperative launch for every frame - tests)
   d->force_redo = (getenv("RD_POLY_FORCE_REDO") ? 1 : 0) | (getenv("RD_ABSORB_FORCE_SLOW") ? 2 : 0);   // tests: every frame also takes the polyline / absorption fallback
   d->diag_no_post = getenv("RD_DIAG_NO_POST") ? 1 : 0;
   // candidate funnel + pose estimation on the device (rd_k_post.hip) instead of on one worker thread per frame slot: RD_DEVICE_POST=0|1 decides;
@@ -918,7 +928,7 @@ void rd_detector_destroy(rd_detector *d) {
     }
     free(s->result); free(s->res_segs);
     for (int k = 0; k < 3; k++) if (s->gexec[k]) RD_HIP(hipGraphExecDestroy(s->gexec[k]));
-    for (int k = 0; k < 2 * RD_NBUDGETS; k++) if (s->gexec2[k]) RD_HIP(hipGraphExecDestroy(s->gexec2[k]));
+    for (int k = 0; k < 3 * RD_NBUDGETS; k++) if (s->gexec2[k]) RD_HIP(hipGraphExecDestroy(s->gexec2[k]));
     slot_free(s);
   }
   free(d->slots);

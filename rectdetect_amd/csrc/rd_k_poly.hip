@@ -173,6 +173,7 @@ __global__ __launch_bounds__(256) void k_compact1(const rdk::PolyFrames FRS, int
   unsigned long long *state = s.cstate + (size_t)MODE * nblk;
   const int *genp = s.csync;
   ls_rec *ls = (MODE == 2 && init_ls) ? (ls_rec *)FRM.lslist : nullptr;
+  if (MODE == 2 && blockIdx.x == 0 && threadIdx.x == 0) s.csync[2] = 0;      // (the grid barrier of k_poly_coop counts from zero)
   if (MODE == 2 && ls != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
     ls_rec z = {};
     ls[0] = z;
@@ -460,7 +461,7 @@ __global__ void k_sub_union(const rdk::PolyFrames FRS) {
 // ------------------------------------------------------------------------------------------------ initial segments (pl:439-506)
 #define FITS(g, bytes) ((g) >= 0 && (long long)(bytes) > (long long)((g) + 1) * 56ll)
 
-__global__ void k_seg_clear(const rdk::PolyFrames FRS, int lsbytes) {
+__device__ __forceinline__ void d_seg_clear(const rdk::PolyFrames &FRS, int lsbytes) {
   RD_FRAME;
   ls_rec *ls = (ls_rec *)FRM.lslist;
   const int K = s.ctr[1];
@@ -474,8 +475,9 @@ __global__ void k_seg_clear(const rdk::PolyFrames FRS, int lsbytes) {
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { for (int k = 2; k < 24; k++) s.ctr[k] = 0; s.ctr[25] = 0; }
 }
+__global__ void k_seg_clear(const rdk::PolyFrames FRS, int lsbytes) { d_seg_clear(FRS, lsbytes); }
 
-__global__ void k_seg_pass0a(const rdk::PolyFrames FRS, int lsbytes) {
+__device__ __forceinline__ void d_seg_pass0a(const rdk::PolyFrames &FRS, int lsbytes) {
   RD_FRAME;
   ls_rec *ls = (ls_rec *)FRM.lslist;
   const int *__restrict__ number = s.num[1];
@@ -490,8 +492,9 @@ __global__ void k_seg_pass0a(const rdk::PolyFrames FRS, int lsbytes) {
     atomicMax(&ls[g].endIndex, n);
   }
 }
+__global__ void k_seg_pass0a(const rdk::PolyFrames FRS, int lsbytes) { d_seg_pass0a(FRS, lsbytes); }
 
-__global__ void k_seg_pass0b(const rdk::PolyFrames FRS, int lsbytes) {
+__device__ __forceinline__ void d_seg_pass0b(const rdk::PolyFrames &FRS, int lsbytes) {
   RD_FRAME;
   ls_rec *ls = (ls_rec *)FRM.lslist;
   const int *__restrict__ number = s.num[1];
@@ -504,8 +507,9 @@ __global__ void k_seg_pass0b(const rdk::PolyFrames FRS, int lsbytes) {
     if (ls[g].startCount == 1 && ls[g].npix >= 2) { atomicAdd(&ls[g].endCount, 1); atomicMin(&s.segaux[2 * g + 1], i); }
   }
 }
+__global__ void k_seg_pass0b(const rdk::PolyFrames FRS, int lsbytes) { d_seg_pass0b(FRS, lsbytes); }
 
-__global__ void k_seg_finish(const rdk::PolyFrames FRS, int lsbytes, int iw) {
+__device__ __forceinline__ void d_seg_finish(const rdk::PolyFrames &FRS, int lsbytes, int iw) {
   RD_FRAME;
   ls_rec *ls = (ls_rec *)FRM.lslist;
   const int K = s.ctr[1];
@@ -522,13 +526,14 @@ __global__ void k_seg_finish(const rdk::PolyFrames FRS, int lsbytes, int iw) {
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) { const int maxrec = lsbytes / 56; *(int *)ls = K < maxrec - 1 ? K : (maxrec >= 2 ? maxrec - 2 : 0); }
 }
+__global__ void k_seg_finish(const rdk::PolyFrames FRS, int lsbytes, int iw) { d_seg_finish(FRS, lsbytes, iw); }
 
 // ------------------------------------------------------------------------------------------------ subdivision rounds (pl:509-646)
 __device__ __forceinline__ float dist2f(float vx, float vy, float wx, float wy) { return (vx - wx) * (vx - wx) + (vy - wy) * (vy - wy); }
 
 // pass 3 of the previous round (pixels beyond the new end move right) fused with pass 1 of this round (distance to
 // the chord with integer-truncated end points, tie-breaking hash, per-segment maximum)
-__global__ void k_split_move_dist(const rdk::PolyFrames FRS, int lsbytes, int iw, int do_dist) {
+__device__ __forceinline__ void d_split_move_dist(const rdk::PolyFrames &FRS, int lsbytes, int iw, int do_dist) {
   RD_FRAME;
   ls_rec *ls = (ls_rec *)FRM.lslist;
   const int *__restrict__ number = s.num[1];
@@ -558,11 +563,12 @@ __global__ void k_split_move_dist(const rdk::PolyFrames FRS, int lsbytes, int iw
     atomicMax(&ls[g].maxDist, d);
   }
 }
+__global__ void k_split_move_dist(const rdk::PolyFrames FRS, int lsbytes, int iw, int do_dist) { d_split_move_dist(FRS, lsbytes, iw, do_dist); }
 
 // pass 2, detection: the pixel that realises its segment's maximum distance and passes the split tests becomes a
 // candidate; everything pass 2 needs from the OLD list is stored with the candidate (the reference reads a snapshot).
 // cand record: {i, g, n, maxDist, oldEndIndex, oldRight, x1 bits, y1 bits}
-__global__ void k_split_detect(const rdk::PolyFrames FRS, int lsbytes, float minerror, int iw, int round) {
+__device__ __forceinline__ void d_split_detect(const rdk::PolyFrames &FRS, int lsbytes, float minerror, int iw, int round) {
   RD_FRAME;
   const ls_rec *ls = (const ls_rec *)FRM.lslist;
   const int *__restrict__ number = s.num[1];
@@ -588,10 +594,11 @@ __global__ void k_split_detect(const rdk::PolyFrames FRS, int lsbytes, float min
     e[6] = __float_as_int(r.x1); e[7] = __float_as_int(r.y1);
   }
 }
+__global__ void k_split_detect(const rdk::PolyFrames FRS, int lsbytes, float minerror, int iw, int round) { d_split_detect(FRS, lsbytes, minerror, iw, round); }
 
 // pass 2, application: new ids follow the raster order of the candidates (rank by pixel index); when several
 // candidates share a segment the one latest in raster order decides the shared fields, as a serial execution would.
-__global__ void k_split_apply(const rdk::PolyFrames FRS, int lsbytes, int iw, int round) {
+__device__ __forceinline__ void d_split_apply(const rdk::PolyFrames &FRS, int lsbytes, int iw, int round) {
   RD_FRAME;
   ls_rec *ls = (ls_rec *)FRM.lslist;
   const int C = s.ctr[2 + round];
@@ -621,15 +628,17 @@ __global__ void k_split_apply(const rdk::PolyFrames FRS, int lsbytes, int iw, in
     }
   }
 }
+__global__ void k_split_apply(const rdk::PolyFrames FRS, int lsbytes, int iw, int round) { d_split_apply(FRS, lsbytes, iw, round); }
 
-__global__ void k_split_commit(const rdk::PolyFrames FRS, int round) {
+__device__ __forceinline__ void d_split_commit(const rdk::PolyFrames &FRS, int round) {
   RD_FRAME;
   ls_rec *ls = (ls_rec *)FRM.lslist;
   if (blockIdx.x == 0 && threadIdx.x == 0) *(int *)ls += s.ctr[2 + round];
 }
+__global__ void k_split_commit(const rdk::PolyFrames FRS, int round) { d_split_commit(FRS, round); }
 
 // ------------------------------------------------------------------------------------------------ refinement (pl:680-809)
-__global__ void k_refine0(const rdk::PolyFrames FRS, int maxrec) {
+__device__ __forceinline__ void d_refine0(const rdk::PolyFrames &FRS, int maxrec) {
   RD_FRAME;
   const ls_rec *ls = (const ls_rec *)FRM.lslist;
   const int n = *(const int *)ls;
@@ -646,8 +655,9 @@ __global__ void k_refine0(const rdk::PolyFrames FRS, int maxrec) {
     sx[g] = z;
   }
 }
+__global__ void k_refine0(const rdk::PolyFrames FRS, int maxrec) { d_refine0(FRS, maxrec); }
 
-__global__ void k_refine1(const rdk::PolyFrames FRS, int maxrec, int iw) {
+__device__ __forceinline__ void d_refine1(const rdk::PolyFrames &FRS, int maxrec, int iw) {
   RD_FRAME;
   const ls_rec *ls = (const ls_rec *)FRM.lslist;
   const int nlive = s.ctr[24];
@@ -669,8 +679,9 @@ __global__ void k_refine1(const rdk::PolyFrames FRS, int maxrec, int iw) {
     atomicAdd((unsigned long long *)&sx[g].my1, (unsigned long long)(long long)rintf((float)ax1 * (float)ay));
   }
 }
+__global__ void k_refine1(const rdk::PolyFrames FRS, int maxrec, int iw) { d_refine1(FRS, maxrec, iw); }
 
-__global__ void k_refine2(const rdk::PolyFrames FRS, int maxrec) {
+__device__ __forceinline__ void d_refine2(const rdk::PolyFrames &FRS, int maxrec) {
   RD_FRAME;
   ls_rec *ls = (ls_rec *)FRM.lslist;
   const int n = *(const int *)ls;
@@ -687,13 +698,14 @@ __global__ void k_refine2(const rdk::PolyFrames FRS, int maxrec) {
     ls[g].x1 += (float)sx[g].vx * (as0 + as1); ls[g].y1 += (float)sx[g].vy * (as0 + as1);
   }
 }
+__global__ void k_refine2(const rdk::PolyFrames FRS, int maxrec) { d_refine2(FRS, maxrec); }
 
 // pl:772-809.  Segment g joins its end point with the start point of its right neighbour h, and h's own step reads that
 // start point, so the result depends on the order of the steps; the canonical order is ascending g.
 // Steps of non-adjacent segments commute, hence the serial result is obtained by letting a segment run as soon as every
 // neighbour with a smaller id has run and keeping neighbours with larger ids waiting: one block, rounds separated by
 // barriers; `done` lives in global scratch.
-__global__ __launch_bounds__(1024) void k_refine3(const rdk::PolyFrames FRS, int maxrec) {
+__device__ __forceinline__ void d_refine3(const rdk::PolyFrames &FRS, int maxrec) {
   RD_FRAME;
   ls_rec *ls = (ls_rec *)FRM.lslist;
   __shared__ int progress;
@@ -742,6 +754,59 @@ __global__ __launch_bounds__(1024) void k_refine3(const rdk::PolyFrames FRS, int
     if (!progress) break;
     __syncthreads();
   }
+}
+__global__ __launch_bounds__(1024) void k_refine3(const rdk::PolyFrames FRS, int maxrec) { d_refine3(FRS, maxrec); }
+
+// ------------------------------------------------------------------------------------------------ cooperative variant
+// The same launches as the multi-launch path - initial segments, up to 15 split rounds, refinement, end-point joining - as ONE launch of
+// PC_NB blocks per frame with grid barriers in between (every phase is the body of the kernel above, unchanged): for frames whose live
+// pixels or records do not fit the single block of k_poly_persistent (3840x2160: ~35 k live pixels).  About 50 barriers instead of 85
+// launches.  The barrier: a counter per frame (csync[2], zeroed by k_compact1<2>), release / acquire fences at device scope around it; the
+// blocks of a launch are far fewer than the chip holds, so all of them are resident.  A barrier that does not complete within ~10 ms
+// (never seen; it would mean that the blocks are not co-resident) makes the launch give up: ctr[25] <- 1, and the caller repeats the stage
+// with the multi-launch path, like an overflow of the single-block kernel.
+#define PC_NB 8
+#define PC_T 1024
+__device__ __forceinline__ bool pc_barrier(int *ctr, int &phase) {
+  __threadfence();
+  __syncthreads();
+  bool ok = true;
+  if (threadIdx.x == 0) {
+    phase++;
+    atomicAdd(ctr, 1);
+    const int target = phase * PC_NB;
+    int spins = 0;
+    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      if (++spins > (1 << 21)) { ok = false; break; }
+      __builtin_amdgcn_s_sleep(8);
+    }
+  }
+  ok = __syncthreads_and(ok) != 0;
+  __threadfence();
+  return ok;
+}
+#define PC_BAR do { if (!pc_barrier(bar, phase)) { if (threadIdx.x == 0) s.ctr[25] = 1; return; } } while (0)
+__global__ __launch_bounds__(PC_T) void k_poly_coop(const rdk::PolyFrames FRS, int lsbytes, float minerror, int iw, int maxrec) {
+  RD_FRAME;
+  int *bar = s.csync + 2;
+  int phase = 0;
+  d_seg_clear(FRS, lsbytes); PC_BAR;
+  d_seg_pass0a(FRS, lsbytes); PC_BAR;
+  d_seg_pass0b(FRS, lsbytes); PC_BAR;
+  d_seg_finish(FRS, lsbytes, iw); PC_BAR;
+  for (int r = 0; r < 15; r++) {
+    d_split_move_dist(FRS, lsbytes, iw, 1); PC_BAR;
+    d_split_detect(FRS, lsbytes, minerror, iw, r); PC_BAR;
+    const int C = __hip_atomic_load(&s.ctr[2 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (C == 0) break;                       // (no candidate in this round: every later round would find the same; uniform over the blocks)
+    d_split_apply(FRS, lsbytes, iw, r); PC_BAR;
+    d_split_commit(FRS, r); PC_BAR;
+  }
+  d_split_move_dist(FRS, lsbytes, iw, 0); PC_BAR;
+  d_refine0(FRS, maxrec); PC_BAR;
+  d_refine1(FRS, maxrec, iw); PC_BAR;
+  d_refine2(FRS, maxrec); PC_BAR;
+  if (blockIdx.x == 0) d_refine3(FRS, maxrec);
 }
 
 // ------------------------------------------------------------------------------------------------ persistent variant
@@ -1118,6 +1183,11 @@ void polyline(hipStream_t st, const PolyFrame *frames_host, int nb, int lslist_b
   hipLaunchKernelGGL(k_compact1<1>, cg, dim3(256), 0, st, frames, N, nblk, sizeThre, 0);
   hipLaunchKernelGGL(k_compact1<2>, cg, dim3(256), 0, st, frames, N, nblk, 0, mode == 1 ? 1 : 0);
 
+  if (mode == 2) {
+    // frames too large for the single block below: the multi-launch stage as one cooperative launch (failure -> ctr[25])
+    hipLaunchKernelGGL(k_poly_coop, dim3(PC_NB, 1, nb), dim3(PC_T), 0, st, frames, lslist_bytes, minerror, iw, maxrec);
+    return;
+  }
   if (mode == 1) {
     // fast path: initial segments, 15 subdivision rounds and the refinement in one persistent launch, one block per frame (overflow -> ctr[25])
     static std::atomic<unsigned> lds_set{0};

@@ -718,16 +718,17 @@ def test_polyline_single_launch_equals_multilaunch(iw, ih, seed):
     fast, n0 = _run_with_env({}, iw, ih, frames)
     slow, n1 = _run_with_env({"RD_POLY_MULTILAUNCH": "1"}, iw, ih, frames)
     redo, n2 = _run_with_env({"RD_POLY_FORCE_REDO": "1"}, iw, ih, frames)
-    assert n0 == 0 and n1 == 0 and n2 == len(frames)
-    for (r0, s0), (r1, s1), (r2, s2) in zip(fast, slow, redo):
-        assert helpers.segments_equal(s0, s1) and helpers.segments_equal(s0, s2)
-        assert helpers.rects_equal(r0, r1) and helpers.rects_equal(r0, r2)
+    coop, n3 = _run_with_env({"RD_POLY_COOP": "1"}, iw, ih, frames)       # the multi-launch stage as one cooperative launch of 8 blocks per frame (an option: slower at full rate than the 85 launches)
+    assert n0 == 0 and n1 == 0 and n2 == len(frames) and n3 == 0
+    for (r0, s0), (r1, s1), (r2, s2), (r3, s3) in zip(fast, slow, redo, coop):
+        assert helpers.segments_equal(s0, s1) and helpers.segments_equal(s0, s2) and helpers.segments_equal(s0, s3)
+        assert helpers.rects_equal(r0, r1) and helpers.rects_equal(r0, r2) and helpers.rects_equal(r0, r3)
 
 
 def test_polyline_overflow_takes_fallback_and_matches_oracle():
     """a frame with far more chains than the single-launch kernel's on-chip tables hold: the overflow flag must come
     back, the stage is repeated with the multi-launch path, and the segments still equal the oracle's; after two such
-    frames in a row the detector stops trying the single-launch kernel for this stream"""
+    frames in a row the detector stops trying the single-block kernel for this stream"""
     iw, ih = 1280, 720
     rng = np.random.default_rng(77)
     tiles = rng.integers(0, 256, (ih // 16, iw // 16, 3), dtype=np.uint8)
@@ -747,7 +748,7 @@ def test_polyline_overflow_takes_fallback_and_matches_oracle():
         det.poll(TAN36)
         orc.frame(img)
         assert helpers.segments_equal(det.last_segments(), orc.segments())
-    assert det.redone_frames() == 2          # the second overflow in a row made the multi-launch path the default
+    assert det.redone_frames() == 2          # the second overflow in a row made the multi-launch path the default: no more repeats
     assert len(first) > 1024                 # more records than the single-launch kernel holds
     det.close()
     orc.close()
