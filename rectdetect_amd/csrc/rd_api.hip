@@ -680,18 +680,26 @@ static void sparse_flush(rd_detector *d, int si) {
 }
 
 static void wait_event_outside_captures(rd_detector *d, hipEvent_t ev);
+static void slot_fetch(Slot *s, void *dst, const void *src, size_t bytes);
 
 // What remains to be done on the device for a finished slot, once per frame (on the polling thread or on the slot's worker): the two
 // rare repeats and the bookkeeping of the round budget.
 static void slot_finish_device(rd_detector *d, Slot *s) {
-  if (s->rounds <= 20 && s->h_ctr[32 + s->rounds - 1] != 0) {   // the region merge was still changing in its last launch: again with as many launches as it takes (at most 64, like the definition)
-    s->rounds = 64;
-    pthread_mutex_lock(&d->launch_mu);
-    frame_regions(d, s);
-    redo_votes(d, s, s->st);
-    RD_HIP(hipEventRecord(s->ev_redo, s->st));
-    pthread_mutex_unlock(&d->launch_mu);
-    wait_event_outside_captures(d, s->ev_redo);
+  if (s->rounds <= 20 && s->h_ctr[32 + s->rounds - 1] != 0) {   // the region merge was still changing in its last launch: again with as many launches as it takes
+    // (32 first - the frames that exceed a budget of 12-14 need 13-20 as a rule, and every launch after the settling one still costs a
+    //  dispatch of the whole grid - then the definition's limit of 64)
+    for (int budget = 32; budget <= 64; budget *= 2) {
+      s->rounds = budget;
+      pthread_mutex_lock(&d->launch_mu);
+      frame_regions(d, s);
+      redo_votes(d, s, s->st);
+      RD_HIP(hipEventRecord(s->ev_redo, s->st));
+      pthread_mutex_unlock(&d->launch_mu);
+      wait_event_outside_captures(d, s->ev_redo);
+      int still = 0;
+      if (budget < 64) slot_fetch(s, &still, s->scratch2 + d->N + budget - 1, sizeof(int));      // the flag of the budget's last launch
+      if (!still) break;
+    }
     __atomic_add_fetch(&d->n_redo_rounds, 1, __ATOMIC_RELAXED);
   }
   if (s->h_ctr[52] != 0 || (d->force_redo & 2)) {   // the absorption's fast path gave up on this frame: finish it the long way

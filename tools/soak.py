@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import rectdetect_amd as ra
 from rectdetect_amd import synth
 
-iw, ih, nframes = 1920, 1080, int(sys.argv[1]) if len(sys.argv) > 1 else 512
+nframes = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+iw, ih = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1920, 1080)
 L = ra.lib()
 TAN = float(np.tan(36.0 / 180 * np.pi))
 frames = []
