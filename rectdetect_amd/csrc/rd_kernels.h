@@ -72,9 +72,12 @@ void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32
 void quant_lut_init(hipStream_t s);   // once per device before the first despeckle(quantize24 = 1): builds the 24-level quantisation tables on the device
 void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih, int quantize24);   // quantize24: `in` is quantised to 24 levels per field on the fly
 void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih);   // scratch: >= ih*ceil(iw/64)*4 ints
-// proposals of the last launched round of region_merge that have not taken effect yet (see k_region_round)
-void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int rounds,
-                  int *size_out, const int *size_init, int *marked);   // rounds: an even number <= 20 (early-out on the device) or 0; size_out (optional) <- size_init, for region_size; scratch: 3N + 256 ints; *marked <- 1 when `label` is left as label << 1 | mark words, which region_size(…, marked) turns into plain labels
+// oclrect.cl:289-334 with the work-items of a launch concurrent (rd_k_rect.hip: k_region_init = the links and launch 0, k_region_round = the others).
+// launches: even, 2..64 (launches after one that changed nothing return at once; flag r of scratch[N + r] = launch r changed something);
+// size_out (optional) <- size_init, for region_size; scratch: 3N + 256 ints; *marked <- 1: `label` is left as label << 3 | mark words,
+// which region_size(…, marked) turns into plain labels
+void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int launches,
+                  int *size_out, const int *size_init, int *marked);
 void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, int marked = 0);   // accumulates into out; zero_me (optional): an int to clear on the way
 #define RD_D2_SCRATCH_INTS(N) (5 * (size_t)(N) + 64)
 // absorption of small regions (oclrect.cl:348-371) exactly as the reference's serial raster order gives it.  out != in; scratch: RD_D2_SCRATCH_INTS(N) ints

@@ -8,6 +8,7 @@ and the configurations at (or near) their full length (rect_t lists and segment 
   stream_1280x720_s1_300.npz    all 300 frames of configs[2]
   stream_1920x1080_s0_100.npz   100 frames of the benchmark stream
   stream_3840x2160_s4_16.npz    16 frames of configs[3]
+  stream_1920x1080_s7_100.npz   100 frames of another 1920x1080 stream (seed 7): held out
 Per frame: the rect_t list and the line-segment list.  Only runs where /root/reference exists."""
 import os
 import sys
@@ -23,7 +24,9 @@ from tests import helpers  # noqa: E402
 CASES = {"stream_1920x1080_s0": (1920, 1080, 0, 16, 36.0), "stream_1280x720_s1": (1280, 720, 1, 30, 36.0),
          "stream_3840x2160_s4": (3840, 2160, 4, 3, 36.0),      # BASELINE.json configs[3]
          "stream_1280x720_s1_300": (1280, 720, 1, 300, 36.0), "stream_1920x1080_s0_100": (1920, 1080, 0, 100, 36.0),
-         "stream_3840x2160_s4_16": (3840, 2160, 4, 16, 36.0)}
+         "stream_3840x2160_s4_16": (3840, 2160, 4, 16, 36.0),
+         # round 3: a second 1920x1080 stream (another seed) that no design decision was made on - a held-out check of the region stages
+         "stream_1920x1080_s7_100": (1920, 1080, 7, 100, 36.0)}
 DEFAULT = ["stream_1920x1080_s0", "stream_1280x720_s1", "stream_3840x2160_s4"]      # (the long ones by name: 6-10 minutes each)
 
 
