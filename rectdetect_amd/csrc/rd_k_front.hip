@@ -70,11 +70,20 @@ __global__ __launch_bounds__(256) void k_bgr2plab_t(uint32_t *__restrict__ out, 
   __syncthreads();
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
   const int x = x0 + threadIdx.x;
-  for (int r = threadIdx.y; r < 64; r += 4) {
+  // the thread's 16 pixels: all of their bytes are requested before the first is used (one wait for memory instead of sixteen)
+  uint8_t pb[16], pg[16], pr[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int y = y0 + threadIdx.y + 4 * k;
+    const uint8_t *p = bgr + ((x < iw && y < ih) ? (size_t)y * ws + x * 3 : 0);
+    pb[k] = p[0]; pg[k] = p[1]; pr[k] = p[2];
+  }
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    const int r = threadIdx.y + 4 * k;
     const int y = y0 + r;
     if (x >= iw || y >= ih) continue;
-    const uint8_t *p = bgr + (size_t)y * ws + x * 3;
-    const int ib = s_s2l[p[0]], ig = s_s2l[p[1]], ir = s_s2l[p[2]];
+    const int ib = s_s2l[pb[k]], ig = s_s2l[pg[k]], ir = s_s2l[pr[k]];
     const int cx = (((ir * 6758 + ig * 5859 + ib * 2956 + (1 << 14)) >> 15) * 34476 + (1 << 10)) >> 11;
     const int cy = ((ir * 3484 + ig * 11717 + ib * 1182) + (1 << 10)) >> 11;
     const int cz = (((ir * 317 + ig * 1953 + ib * 15569 + (1 << 14)) >> 15) * 30097 + (1 << 10)) >> 11;
