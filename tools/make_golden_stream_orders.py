@@ -29,7 +29,8 @@ from tools.make_golden_orders import ORDERS as STILL_ORDERS  # noqa: E402
 ORDERS = STILL_ORDERS + [(0, 0, 5, 0), (64, 4, 3, 7), (16, 16, 3, 9), (128, 2, 3, 3), (32, 32, 3, 1), (4, 4, 3, 2)]
 
 # (round 2: the frames on which the HIP path of that round differed; round 3 - region merge with concurrent work-items, exact absorption - adds 161 / 70, 76, 90)
-FRAMES = {"stream_1280x720_s1_300": [32, 161, 162], "stream_1920x1080_s0_100": [42, 55, 57, 70, 76, 90, 98], "stream_3840x2160_s4_16": [3, 7]}
+FRAMES = {"stream_1280x720_s1_300": [32, 161, 162], "stream_1920x1080_s0_100": [42, 55, 57, 70, 76, 90, 98], "stream_3840x2160_s4_16": [3, 7],
+          "stream_1920x1080_s7_100": [0, 5, 63, 64, 71, 72]}      # (the held-out stream of round 3: tools/stream_mismatch.py)
 PARALLEL = 8
 
 
