@@ -21,7 +21,9 @@ inline dim3 grid2(int iw, int ih) { return dim3(cdiv(iw, 64), cdiv(ih, 4)); }
 // count-leading-zeros), unions between the rows of the tile, path compression; the tile's pixels leave pointing at the
 // GLOBAL index of their tile-local root, which is the smallest index of the component's part inside the tile.
 #define LT_W 64
+#ifndef LT_H
 #define LT_H 32
+#endif
 __device__ __forceinline__ int lt_find(const volatile int *lab, int a) {
   int l = lab[a];
   while (l != a) { a = l; l = lab[a]; }
@@ -39,7 +41,10 @@ __device__ __forceinline__ void lt_union(int *lab, int a, int b) {
   }
 }
 
-#define LT_TY 4       // thread rows per block (16 is ~20% faster run alone, but costs 50% more wave-cycles: worse with frames in flight)
+#ifndef LT_TY
+#define LT_TY 4
+#endif
+// LT_TY: thread rows per block (16 is ~20% faster run alone, but costs 50% more wave-cycles: worse with frames in flight)
 #define LT_MP 68      // row pitch of the staged region tile of the boundary variant (64 + 2 x 2 cells of halo)
 // BOUNDARY = false: the pixel values are read from `pix`.  BOUNDARY = true: they are the region-boundary marks of oclrect.cl:373-390,
 // computed here from the region plane `src` (a pixel of the interior whose 5x5 window holds another label carries its own label,
@@ -49,7 +54,7 @@ __device__ __forceinline__ void lt_union(int *lab, int a, int b) {
 // SRC == 2: the pixel values are the rect-variant edge tidy of the NMS response `nms` (rd_tidy_tile.h), computed here and written to
 // mask0 / pix_out (and zero_plane cleared) as k_rect_tidy would.
 template <int SRC>
-__global__ __launch_bounds__(256) void k_label_tile(int *__restrict__ label, const int *__restrict__ pix, int bgc, int iw, int ih, int *__restrict__ pix_out,
+__global__ __launch_bounds__(64 * LT_TY) void k_label_tile(int *__restrict__ label, const int *__restrict__ pix, int bgc, int iw, int ih, int *__restrict__ pix_out,
                                                     const float *__restrict__ nms, int *__restrict__ mask0, int *__restrict__ zero_plane) {
   constexpr bool BOUNDARY = SRC == 1;
   __shared__ int lab[LT_W * LT_H];
