@@ -298,6 +298,8 @@ struct Slot {
   rdk::PolyFrame *frame;                  // this slot's descriptor for the sparse stages (element `slot index` of the detector's array)
   hipEvent_t ev_dense;                    // batched mode: the frame's dense stages are done (the batch's sparse stages wait for it)
   int pending_sparse;                     // batched mode: dense stages enqueued, sparse stages not launched yet
+  int pending_dense;                      // group mode (rd_detector::zb > 1): frame handed over, nothing launched yet
+  hipGraphExec_t gz0, gz2[3 * RD_NBUDGETS]; int gz_ws;      // group mode, first slot of a group: the group's launch sequences (dense stages up to the first labelling; everything after the strong masks)
   // rectangles on the device (RD_DEVICE_POST): scratch, result block in pinned host memory, whether this frame's block is valid and for which aperture
   int *post_scratch, *h_post, *h_post_dev;
   int post_mode; double post_tan;
@@ -333,6 +335,9 @@ struct rd_detector {
   int defer, deferred_slot;               // batched mode: a complete group's sparse stages are launched only once the NEXT group's dense stages are enqueued (deferred_slot: a slot of the waiting group or -1)
   rdk::PolyFrame *frames;                 // nslots descriptors (host memory; they travel as kernel arguments), slot order
   Slot *slots;
+  int nstreams;
+  int zb;                 // frames per launch of the DENSE stages as well (groups of zb consecutive slots, frame = blockIdx.z): small frames, whose launches do not fill the device
+  char *arena; size_t slot_pitch;      // zb > 1: all slots' planes in one allocation, slot k at arena + k * slot_pitch
   int8_t *prev_strong;    // strong-edge mask of the previous frame (reference quirk H1), one byte per pixel
   hipEvent_t last_strong; int have_last_strong;
   long next_enqueue, next_poll;
@@ -354,6 +359,43 @@ struct rd_detector {
   long n_truncated;          // frames with more segment records than the slots' probe buffers hold (maxrec_dev): probed again into a larger buffer
 };
 
+// The device planes of a slot.  With frames batched per launch (rd_detector::zb > 1) every slot's planes are carved out of one allocation at
+// the same offsets, so that the planes of slot k + z lie a constant number of bytes (the slot pitch) behind those of slot k: a kernel of a
+// group launch reaches frame z's planes as `pointer + blockIdx.z * pitch`.  Otherwise every plane is an allocation of its own.
+struct PlaneAlloc {
+  char *base; size_t at; int mode;       // mode 0: hipMalloc per plane; 1: carve from base; 2: count bytes only
+  template <typename T> T *get(size_t n) {
+    if (mode == 0) return dnew<T>(n);
+    const size_t bytes = (((n ? n : 1) * sizeof(T)) + 255) & ~(size_t)255;
+    T *p = mode == 1 ? (T *)(base + at) : (T *)nullptr;
+    at += bytes;
+    return p;
+  }
+  bool real() const { return mode != 2; }
+};
+
+static void slot_planes(rd_detector *d, Slot *s, PlaneAlloc &A) {
+  const size_t N = (size_t)d->N;
+  s->bgr = A.get<uint8_t>(N * 4);
+  s->plab0 = A.get<uint32_t>(N); s->plab1 = A.get<uint32_t>(N); s->smooth = A.get<uint32_t>(N); s->quant = A.get<uint32_t>(N);
+  for (int k = 0; k < 3; k++) { s->tr[k] = A.get<float>(N); s->fw[k] = A.get<float>(N); s->bw[k] = A.get<float>(N); s->hz[k] = A.get<float>(N); s->bl[k] = A.get<float>(N); }
+  s->vxy = A.get<float>(N * 2); s->strength = A.get<float>(N); s->nms = A.get<float>(N);
+  int **ip[] = { &s->i0, &s->i1, &s->mask0, &s->tidy, &s->label1, &s->strsum, &s->strong, &s->junction, &s->mergemask, &s->region, &s->rsize,
+                 &s->boundarysrc, &s->boundary, &s->lsid, &s->region0 };
+  for (size_t i = 0; i < sizeof(ip) / sizeof(ip[0]); i++) *ip[i] = A.get<int>(N);
+  s->scratch2 = A.get<int>(N * 3 + 256);      // region_merge: the initial forest, flags + allow bytes, the second label plane of the rounds
+  s->d2s = A.get<int>(RD_D2_SCRATCH_INTS(N));
+  s->table = A.get<int>(N * 4); s->claim = A.get<int>(N); s->tlist = A.get<int>(N);
+  if (A.real()) rdk::reduce_ls_init(s->st, s->table, s->claim, s->tlist, (int)(N * 4 / 5));
+  s->e8 = A.get<int8_t>(N);
+  s->ext = A.get<uint16_t>(N);
+  { size_t a = rdk::iir_pass_scratch_floats(3, d->ih, d->iw), b = rdk::iir_pass_scratch_floats(3, d->iw, d->ih); s->tails = A.get<float>(a > b ? a : b); }
+  s->flags = A.get<int>(16); if (A.real()) { RD_HIP(hipMemset(s->flags, 0, 16 * sizeof(int))); RD_HIP(hipStreamSynchronize(0)); }
+  s->iir_chunked = 1;
+  s->lslist = A.get<uint8_t>(N * 16);
+  s->probes = A.get<int>((size_t)d->maxrec_dev * 15 * 6);
+}
+
 // share: the slot whose streams this one uses as well (NULL: own streams)
 static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
   const size_t N = (size_t)d->N;
@@ -371,24 +413,7 @@ static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
   RD_HIP(hipEventCreateWithFlags(&s->ev_strong, hipEventDisableTiming));
   RD_HIP(hipEventCreateWithFlags(&s->ev_redo, hipEventDisableTiming));
   RD_HIP(hipEventCreateWithFlags(&s->ev_dense, hipEventDisableTiming));
-  s->bgr = dnew<uint8_t>(N * 4);
-  s->plab0 = dnew<uint32_t>(N); s->plab1 = dnew<uint32_t>(N); s->smooth = dnew<uint32_t>(N); s->quant = dnew<uint32_t>(N);
-  for (int k = 0; k < 3; k++) { s->tr[k] = dnew<float>(N); s->fw[k] = dnew<float>(N); s->bw[k] = dnew<float>(N); s->hz[k] = dnew<float>(N); s->bl[k] = dnew<float>(N); }
-  s->vxy = dnew<float>(N * 2); s->strength = dnew<float>(N); s->nms = dnew<float>(N);
-  int **ip[] = { &s->i0, &s->i1, &s->mask0, &s->tidy, &s->label1, &s->strsum, &s->strong, &s->junction, &s->mergemask, &s->region, &s->rsize,
-                 &s->boundarysrc, &s->boundary, &s->lsid, &s->region0 };
-  for (size_t i = 0; i < sizeof(ip) / sizeof(ip[0]); i++) *ip[i] = dnew<int>(N);
-  s->scratch2 = dnew<int>(N * 3 + 256);      // region_merge: the initial forest, flags + allow bytes, the second label plane of the rounds
-  s->d2s = dnew<int>(RD_D2_SCRATCH_INTS(N));
-  s->table = dnew<int>(N * 4); s->claim = dnew<int>(N); s->tlist = dnew<int>(N);
-  rdk::reduce_ls_init(s->st, s->table, s->claim, s->tlist, (int)(N * 4 / 5));
-  s->e8 = dnew<int8_t>(N);
-  s->ext = dnew<uint16_t>(N);
-  { size_t a = rdk::iir_pass_scratch_floats(3, d->ih, d->iw), b = rdk::iir_pass_scratch_floats(3, d->iw, d->ih); s->tails = dnew<float>(a > b ? a : b); }
-  s->flags = dnew<int>(16); RD_HIP(hipMemset(s->flags, 0, 16 * sizeof(int))); RD_HIP(hipStreamSynchronize(0));
-  s->iir_chunked = 1;
-  s->lslist = dnew<uint8_t>(N * 16);
-  s->probes = dnew<int>((size_t)d->maxrec_dev * 15 * 6);
+  { PlaneAlloc A = { d->arena ? d->arena + (size_t)(s - d->slots) * d->slot_pitch : NULL, 0, d->arena ? 1 : 0 }; slot_planes(d, s, A); }
   s->ps = rdk::poly_scratch_create(d->iw, d->ih);
   RD_HIP(hipHostMalloc(&s->h_bgr, N * 4, hipHostMallocDefault));
   const size_t pack_ints = 64 + (size_t)RD_MAXREC * (14 + 15 * 6);
@@ -415,8 +440,10 @@ static void slot_free(Slot *s) {
   RD_HIP(hipStreamSynchronize(s->st));
   void *all[] = { s->bgr, s->plab0, s->plab1, s->smooth, s->quant, s->vxy, s->strength, s->nms, s->i0, s->i1, s->mask0, s->tidy, s->label1, s->strsum, s->strong,
                   s->junction, s->mergemask, s->region, s->rsize, s->scratch2, s->d2s, s->boundarysrc, s->boundary, s->lsid, s->table, s->claim, s->tlist, s->region0, s->probes, s->e8, s->ext, s->tails, s->flags, s->lslist };
+  if (!s->owner->arena) {
   for (void *p : all) dfree(p);
   for (int k = 0; k < 3; k++) { dfree(s->tr[k]); dfree(s->fw[k]); dfree(s->bw[k]); dfree(s->hz[k]); dfree(s->bl[k]); }
+  }
   rdk::poly_scratch_destroy(s->ps);
   RD_HIP(hipHostFree(s->h_bgr)); RD_HIP(hipHostFree(s->h_pack));
   dfree(s->post_scratch); if (s->h_post) RD_HIP(hipHostFree(s->h_post));
@@ -505,9 +532,9 @@ static void frame_absorb_slow(rd_detector *d, Slot *s) {
   s->h_ctr[52] = 0;
 }
 
-static void frame_segment(rd_detector *d, Slot *s, int ws, int seg) {
+static void frame_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t st_over = NULL) {
   const int iw = d->iw, ih = d->ih, N = d->N;
-  hipStream_t st = s->st;
+  hipStream_t st = st_over ? st_over : s->st;
   if (seg == 0) {
 
   // (colour conversion, oclrect.c:245: launched by enqueue_frame in front of this segment, outside the recorded graph - its source is the
@@ -591,21 +618,22 @@ static int current_poly_mode(const rd_detector *d) {
 
 static const int kRoundBudgets[RD_NBUDGETS] = { 8, 10, 12, 14, 16, 18, 20 };
 
-static void run_segment(rd_detector *d, Slot *s, int ws, int seg) {
-  if (!d->use_graph) { frame_segment(d, s, ws, seg); return; }
+static void run_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t st_over = NULL) {      // st_over (segment 1 only): another stream than the slot's
+  hipStream_t lst = st_over ? st_over : s->st;
+  if (!d->use_graph) { frame_segment(d, s, ws, seg, lst); return; }
   hipGraphExec_t *ge = &s->gexec[seg];
   if (seg == 2) for (int k = 0; k < RD_NBUDGETS; k++) if (kRoundBudgets[k] == s->rounds) ge = &s->gexec2[k * 3 + (d->batch == 1 ? s->poly_mode : 0)];
   if (!*ge) {
     hipGraph_t g = NULL;
     pthread_mutex_lock(&d->launch_mu);
-    RD_HIP(hipStreamBeginCapture(s->st, hipStreamCaptureModeThreadLocal));
-    frame_segment(d, s, ws, seg);
-    RD_HIP(hipStreamEndCapture(s->st, &g));
+    RD_HIP(hipStreamBeginCapture(lst, hipStreamCaptureModeThreadLocal));
+    frame_segment(d, s, ws, seg, lst);
+    RD_HIP(hipStreamEndCapture(lst, &g));
     pthread_mutex_unlock(&d->launch_mu);
     RD_HIP(hipGraphInstantiate(ge, g, NULL, NULL, 0));
     RD_HIP(hipGraphDestroy(g));
   }
-  RD_HIP(hipGraphLaunch(*ge, s->st));
+  RD_HIP(hipGraphLaunch(*ge, lst));
 }
 
 static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
@@ -633,6 +661,125 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
     RD_HIP(hipEventRecord(s->ev_done, s->st));
   }
   rdrt::check_launch("rect frame");
+}
+
+
+// ---- group mode (rd_detector::zb > 1): the frames of zb consecutive slots in ONE set of launches, dense stages included (frame =
+// blockIdx.z; the slots' planes lie slot_pitch bytes apart).  For frames so small that a launch does not fill the device (a 640x480
+// plane is 75 tiles for 256 CUs): the frame rate is then set by the number of launches the four hardware queues get through, and a
+// group needs as many as a single frame.  What cannot be shared is the short middle segment - a frame's strength sums start from
+// the strong mask of the frame before it (H1) - which runs frame by frame between the two group segments, on the same stream.
+static hipStream_t group_stream(rd_detector *d, int g0) { return d->slots[(g0 / d->zb) % (d->nstreams > 0 ? d->nstreams : 1)].st; }
+
+static void group_segment(rd_detector *d, Slot *s, int nz, int seg, hipStream_t st) {      // s: the group's first slot
+  const int iw = d->iw, ih = d->ih, N = d->N;
+  const size_t zs = d->slot_pitch;
+  if (seg == 0) {
+    { const float *c[3] = { s->tr[0], s->tr[1], s->tr[2] }; rdk::iir_blur_pass(st, s->hz, c, s->fw, s->bw, 3, ih, iw, 1, s->tails, s->flags, 1, nz, zs); }
+    { const float *c[3] = { s->hz[0], s->hz[1], s->hz[2] }; rdk::iir_blur_pass(st, s->bl, c, s->fw, s->bw, 3, iw, ih, 0, s->tails, s->flags + 1, 0, nz, zs); }
+    rdk::edgevec(st, s->vxy, s->bl[0], iw, ih, s->plab1, s->bl[1], s->bl[2], nz, zs);
+    rdk::edge_plab(st, s->strength, s->plab1, iw, ih, nz, zs);
+    rdk::thinthres(st, s->nms, s->strength, s->vxy, iw, ih, nz, zs);
+    rdk::label8_tidy(st, s->label1, s->mask0, s->tidy, s->nms, s->strsum, iw, ih, 1, nz, zs);
+    return;
+  }
+  // seg 2: everything after the strong masks, in the order of a single frame on one stream (frame_segment, RD_NO_FORK)
+  rdk::blblur_extents(st, s->ext, s->e8, iw, ih, nz, zs);
+  { const uint32_t *src = s->plab0;
+    for (int i = 0; i < 10; i++) { uint32_t *dst = (i & 1) ? s->smooth : (uint32_t *)s->i0; rdk::blblur_pair(st, dst, s->ext, src, iw, ih, nz, zs); src = dst; } }
+  rdk::despeckle(st, s->quant, s->smooth, s->nms, iw, ih, 1, nz, zs);
+  rdk::junction(st, s->junction, s->label1, 0, iw, ih, s->scratch2, nz, zs);
+  rdk::merge_mask(st, s->mergemask, s->scratch2, NULL, iw, ih, nz, zs);
+  int marked = 0;
+  rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih, s->rounds, s->rsize, s->junction, &marked, nz, zs);
+  rdk::region_size(st, s->rsize, s->region0, N, s->d2s + N, marked, nz, zs);
+  rdk::despeckle2(st, s->region, s->region0, s->d2s, s->rsize, 16, iw, ih, 1, s->scratch2 + N + 64, nz, zs);
+  rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, iw, ih, s->table, s->claim, s->tlist, nz, zs);
+  rdk::polyline(st, s->frame, nz, N * 16, 1, 4.0f, 20, iw, ih, s->poly_mode);
+  frames_votes(d, s->frame, nz, st, 1, 0);
+}
+
+static void run_group_segment(rd_detector *d, Slot *s, int nz, int seg, hipStream_t st) {
+  if (!d->use_graph) { group_segment(d, s, nz, seg, st); return; }
+  hipGraphExec_t *ge = &s->gz0;
+  if (seg == 2) for (int k = 0; k < RD_NBUDGETS; k++) if (kRoundBudgets[k] == s->rounds) ge = &s->gz2[k * 3 + s->poly_mode];
+  if (!*ge) {
+    hipGraph_t g = NULL;
+    pthread_mutex_lock(&d->launch_mu);
+    RD_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    group_segment(d, s, nz, seg, st);
+    RD_HIP(hipStreamEndCapture(st, &g));
+    pthread_mutex_unlock(&d->launch_mu);
+    RD_HIP(hipGraphInstantiate(ge, g, NULL, NULL, 0));
+    RD_HIP(hipGraphDestroy(g));
+  }
+  RD_HIP(hipGraphLaunch(*ge, st));
+}
+
+static void enqueue_frame(rd_detector *d, Slot *s, int ws);
+static void slot_submitted(rd_detector *d, Slot *s);
+
+// the frames waiting in the group that starts at slot g0: all zb of them with one row stride -> one set of launches; anything else (a poll
+// that wants a result before the group is full, the end of a stream) -> frame by frame, the way a detector without groups launches them
+static void group_launch(rd_detector *d, int g0) {
+  const int zb = d->zb;
+  int cnt = 0, same_ws = 1;
+  for (int i = g0; i < g0 + zb && i < d->nslots; i++) { Slot *s = &d->slots[i]; if (s->pending_dense) { cnt++; if (s->ws != d->slots[g0].ws) same_ws = 0; } }
+  if (cnt == 0) return;
+  if (cnt < zb || !same_ws) {
+    for (int i = g0; i < g0 + zb && i < d->nslots; i++) {
+      Slot *s = &d->slots[i];
+      if (!s->pending_dense) continue;
+      s->pending_dense = 0;
+      if (s->src == s->bgr) RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, (size_t)s->ws * d->ih, hipMemcpyHostToDevice, s->st));
+      enqueue_frame(d, s, s->ws);
+      slot_submitted(d, s);
+    }
+    return;
+  }
+  Slot *lead = &d->slots[g0];
+  hipStream_t st = group_stream(d, g0);
+  const int ws = lead->ws;
+  if (d->use_graph && lead->gz_ws != ws) {
+    if (lead->gz0) { RD_HIP(hipGraphExecDestroy(lead->gz0)); lead->gz0 = NULL; }
+    for (int k = 0; k < 3 * RD_NBUDGETS; k++) if (lead->gz2[k]) { RD_HIP(hipGraphExecDestroy(lead->gz2[k])); lead->gz2[k] = NULL; }
+    lead->gz_ws = ws;
+  }
+  const uint8_t *srcs[RD_ZB_MAX];
+  for (int i = 0; i < zb; i++) {
+    Slot *s = &d->slots[g0 + i];
+    s->pending_dense = 0;
+    if (s->src == s->bgr) RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, (size_t)ws * d->ih, hipMemcpyHostToDevice, st));
+    srcs[i] = s->src;
+    RD_HIP(hipEventRecord(s->ev_begin, st));
+  }
+  rdk::bgr2plab_transposed(st, lead->plab0, lead->tr, srcs, d->iw, d->ih, ws, zb, d->slot_pitch);
+  run_group_segment(d, lead, zb, 0, st);
+  for (int i = 0; i < zb; i++) {      // the strong masks, frame by frame (each on top of its predecessor's)
+    Slot *s = &d->slots[g0 + i];
+    if (d->have_last_strong) RD_HIP(hipStreamWaitEvent(st, d->last_strong, 0));
+    run_segment(d, s, ws, 1, st);
+    RD_HIP(hipEventRecord(s->ev_strong, st));
+    d->last_strong = s->ev_strong; d->have_last_strong = 1;
+  }
+  const int rounds = d->fixed_rounds ? d->fixed_rounds : __atomic_load_n(&d->rounds_budget, __ATOMIC_RELAXED);
+  const int pm = current_poly_mode(d);
+  for (int i = 0; i < zb; i++) {
+    Slot *s = &d->slots[g0 + i];
+    s->rounds = rounds; s->poly_mode = pm; s->post_mode = 0;
+    if (d->budget_cycle) s->rounds = kRoundBudgets[2 + (int)((lead->seq / d->budget_cycle) % (RD_NBUDGETS - 2))];
+    for (int k = 0; k < RD_NBUDGETS; k++) if (kRoundBudgets[k] == s->rounds) d->budget_count[k]++;
+  }
+  run_group_segment(d, lead, zb, 2, st);
+  const int with_post = d->device_post && d->have_tan;
+  if (with_post) rdk::post_device(st, lead->frame, zb, d->maxrec_dev, d->iw, d->ih, d->tan_aov);
+  for (int i = 0; i < zb; i++) {
+    Slot *s = &d->slots[g0 + i];
+    s->post_mode = with_post; s->post_tan = d->tan_aov;
+    RD_HIP(hipEventRecord(s->ev_done, st));
+  }
+  rdrt::check_launch("rect frames, group launch");
+  for (int i = 0; i < zb; i++) slot_submitted(d, &d->slots[g0 + i]);
 }
 
 // the frame is on its way: its worker thread may start waiting for ev_done (which has been recorded by now - an event that was never
@@ -910,6 +1057,20 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   // that have nothing to do with each other, while a queued frame keeps its queue busy as soon as its predecessor is done
   // (the host's turn-around between "frame polled" and "next frame enqueued" otherwise idles a quarter of the device).
   const int nstreams = getenv("RD_STREAMS") ? atoi(getenv("RD_STREAMS")) : 4;
+  d->nstreams = nstreams < nslots ? nstreams : nslots;
+  // Group mode: four frames per launch from twelve frame slots on (three groups: one being filled, two in flight), two from six on;
+  // RD_ZBATCH=k overrides (k frames per launch, 2..8; 0 / 1: off).
+  d->zb = nslots >= 12 ? 4 : (nslots >= 6 ? 2 : 1);
+  if (getenv("RD_ZBATCH")) { const int z = atoi(getenv("RD_ZBATCH")); d->zb = z < 1 ? 1 : (z > RD_ZB_MAX ? RD_ZB_MAX : z); }
+  if (d->fork_poly || d->zb > nslots || nstreams <= 0) d->zb = 1;
+  if (d->zb > 1) { d->batch = 1; d->defer = 0; }      // (a group's sparse stages follow its dense stages on the same stream)
+  if (d->zb > 1) {
+    Slot tmp; memset(&tmp, 0, sizeof(tmp));
+    PlaneAlloc A = { NULL, 0, 2 };
+    slot_planes(d, &tmp, A);
+    d->slot_pitch = A.at;
+    d->arena = dnew<char>((size_t)nslots * d->slot_pitch);
+  }
   for (int i = 0; i < nslots; i++) {
     Slot *s = &d->slots[i];
     slot_alloc(d, s, (!d->fork_poly && nstreams > 0 && i >= nstreams) ? &d->slots[i % nstreams] : NULL);
@@ -937,12 +1098,15 @@ void rd_detector_destroy(rd_detector *d) {
     free(s->result); free(s->res_segs);
     for (int k = 0; k < 3; k++) if (s->gexec[k]) RD_HIP(hipGraphExecDestroy(s->gexec[k]));
     for (int k = 0; k < 3 * RD_NBUDGETS; k++) if (s->gexec2[k]) RD_HIP(hipGraphExecDestroy(s->gexec2[k]));
+    if (s->gz0) RD_HIP(hipGraphExecDestroy(s->gz0));
+    for (int k = 0; k < 3 * RD_NBUDGETS; k++) if (s->gz2[k]) RD_HIP(hipGraphExecDestroy(s->gz2[k]));
     slot_free(s);
   }
   free(d->slots);
   free(d->frames);
   if (d->sparse_st) RD_HIP(hipStreamDestroy(d->sparse_st));
   dfree(d->prev_strong);
+  dfree(d->arena);
   free(d->last_segs);
   d->magic = 0;
   free(d);
@@ -958,9 +1122,16 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
   s->seq = d->next_enqueue; s->ws = ws;
   const size_t bytes = (size_t)ws * d->ih;
   if (on_device) s->src = (const uint8_t *)frame;      // read where it lies (the caller keeps it valid until the frame's poll returned)
-  else { memcpy(s->h_bgr, frame, bytes); RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, bytes, hipMemcpyHostToDevice, s->st)); s->src = s->bgr; }
+  else { memcpy(s->h_bgr, frame, bytes); if (d->zb == 1) RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, bytes, hipMemcpyHostToDevice, s->st)); s->src = s->bgr; }
+  if (d->zb > 1) {      // group mode: launched together with the other frames of its group, once that is full (or a poll needs one of them)
+    const int si = (int)(s - d->slots);
+    s->pending_dense = 1;
+    if (si % d->zb == d->zb - 1) group_launch(d, si / d->zb * d->zb);
+  } else {
   enqueue_frame(d, s, ws);
-  if (d->batch == 1) slot_submitted(d, s);
+  }
+  if (d->zb > 1) ;
+  else if (d->batch == 1) slot_submitted(d, s);
   else {
     const int si = (int)(s - d->slots);
     if (si % d->batch == d->batch - 1 || si == d->nslots - 1) {      // the group is complete
@@ -986,6 +1157,7 @@ void *rd_detector_poll(rd_detector *d, double tanAOV) {
   Slot *s = &d->slots[si];
   void *r = NULL, *segs = NULL; int ns = 0;
   if (s->pending_sparse) sparse_flush(d, si);       // (an incomplete group: the caller wants a result before handing over more frames)
+  if (s->pending_dense) group_launch(d, si / d->zb * d->zb);
   pthread_mutex_lock(&d->tan_mu);
   d->tan_aov = tanAOV; d->have_tan = 1;            // what workers and the device post-process of later frames run ahead with
   pthread_cond_broadcast(&d->tan_cv);
@@ -1029,6 +1201,7 @@ void rd_detector_drain(rd_detector *d) {
   if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_drain: bad handle\n");
   RD_HIP(hipSetDevice(d->device));
   if (d->batch > 1) for (int i = 0; i < d->nslots; i += d->batch) sparse_flush(d, i);
+  if (d->zb > 1) for (int i = 0; i < d->nslots; i += d->zb) group_launch(d, i);
   for (int i = 0; i < d->nslots; i++) RD_HIP(hipStreamSynchronize(d->slots[i].st));
   if (d->sparse_st) RD_HIP(hipStreamSynchronize(d->sparse_st));
 }

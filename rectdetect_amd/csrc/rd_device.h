@@ -110,6 +110,25 @@ __device__ __forceinline__ T &atu(T *base, unsigned idx) { return *(T *)((char *
 template <typename T>
 __device__ __forceinline__ const T &atu(const T *base, unsigned idx) { return *(const T *)((const char *)base + idx * (unsigned)sizeof(T)); }
 
+// Frames batched per launch (small frames): frame z of a group launch works on planes that lie z * zs bytes behind the ones the launch
+// was given (all planes of a frame slot are carved out of one allocation at the same offsets, rd_api.hip: slot_planes).  A kernel of the
+// frame path starts with  RD_ZSHIFT(zs, out, in, ...)  on its plane pointers (null pointers - optional planes - stay null); with
+// gridDim.z == 1 or zs == 0 nothing moves.  Scalar arithmetic: the offset is the same for all lanes.
+template <typename T> __device__ __forceinline__ T *rd_zs_ptr(T *p, size_t off) { return p ? (T *)((char *)p + off) : p; }
+#define RD_ZS1(p) (p) = rd_zs_ptr((p), rd_zoff_)
+#define RD_ZS0(zs) const size_t rd_zoff_ = (size_t)blockIdx.z * (zs)
+#define RD_ZS_2(zs, a) RD_ZS0(zs); RD_ZS1(a)
+#define RD_ZS_3(zs, a, b) RD_ZS_2(zs, a); RD_ZS1(b)
+#define RD_ZS_4(zs, a, b, c) RD_ZS_3(zs, a, b); RD_ZS1(c)
+#define RD_ZS_5(zs, a, b, c, d) RD_ZS_4(zs, a, b, c); RD_ZS1(d)
+#define RD_ZS_6(zs, a, b, c, d, e) RD_ZS_5(zs, a, b, c, d); RD_ZS1(e)
+#define RD_ZS_7(zs, a, b, c, d, e, f) RD_ZS_6(zs, a, b, c, d, e); RD_ZS1(f)
+#define RD_ZS_8(zs, a, b, c, d, e, f, g) RD_ZS_7(zs, a, b, c, d, e, f); RD_ZS1(g)
+#define RD_ZS_9(zs, a, b, c, d, e, f, g, h) RD_ZS_8(zs, a, b, c, d, e, f, g); RD_ZS1(h)
+#define RD_ZS_10(zs, a, b, c, d, e, f, g, h, i) RD_ZS_9(zs, a, b, c, d, e, f, g, h); RD_ZS1(i)
+#define RD_ZS_PICK(_1, _2, _3, _4, _5, _6, _7, _8, _9, _10, NAME, ...) NAME
+#define RD_ZSHIFT(...) RD_ZS_PICK(__VA_ARGS__, RD_ZS_10, RD_ZS_9, RD_ZS_8, RD_ZS_7, RD_ZS_6, RD_ZS_5, RD_ZS_4, RD_ZS_3, RD_ZS_2, RD_ZS_1)(__VA_ARGS__)
+
 // L2-coherent (device-scope) load: used to guard hot atomics so that later waves see an earlier wave's update instead of
 // a stale L1 line and skip the atomic
 __device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

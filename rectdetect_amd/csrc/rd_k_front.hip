@@ -16,6 +16,7 @@ using namespace rd;
 
 struct P3 { float *p[3]; };
 struct P3c { const float *p[3]; };
+struct SrcZ { const uint8_t *p[RD_ZB_MAX]; };      // the source frames of a group launch (caller's buffers: no common pitch)
 
 inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 inline dim3 grid2(int iw, int ih) { return dim3(cdiv(iw, 64), cdiv(ih, 4)); }
@@ -61,7 +62,9 @@ __global__ __launch_bounds__(256) void k_bgr2plab(uint32_t *__restrict__ out, co
 // saves re-reading the packed plane and one launch per frame.  The transposed planes hold the integer FIELDS (16 bits each; the
 // sweep turns them into the floats of iu:36-39 as it loads them, iir_field): the blocked sweep reads its source three times over,
 // and those reads come from HBM.
-__global__ __launch_bounds__(256) void k_bgr2plab_t(uint32_t *__restrict__ out, P3 dst, const uint8_t *__restrict__ bgr, int iw, int ih, int ws) {
+__global__ __launch_bounds__(256) void k_bgr2plab_t(uint32_t *__restrict__ out, P3 dst, SrcZ srcz, int iw, int ih, int ws, size_t zs) {
+  const uint8_t *__restrict__ bgr = srcz.p[blockIdx.z];
+  RD_ZSHIFT(zs, out, dst.p[0], dst.p[1], dst.p[2]);
   __shared__ unsigned short s_s2l[RD_LUT_S2L_N], s_cf[RD_LUT_CF_N], s_cf2[RD_LUT_CF_N];
   __shared__ unsigned short tile[3][64][66];
   const int tid = threadIdx.y * 64 + threadIdx.x;
@@ -237,12 +240,14 @@ template <int SRC16, typename T> __device__ __forceinline__ float iir_field(T v,
   return (float)v;
 }
 template <int TOUT, int IF_ROWS, int SRC16>
-__global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__restrict__ tails, int W, int H, int nchunks, int *bad) {
+__global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__restrict__ tails, int W, int H, int nchunks, int *bad, int np, size_t zs) {
   __shared__ float fwt[(IF_ROWS + 8) * IF_PITCH];
   const int lane = threadIdx.x & 63, anti = threadIdx.x >> 6;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *bad = 0;      // diagnostics flag of the check that follows this launch
+  // (grid: x = 64-column strips, y = plane + np * frame of a group launch, z = blocks of rows)
+  const int k = blockIdx.y % np, c = blockIdx.z;
+  { const size_t rd_zoff_ = (size_t)(blockIdx.y / np) * zs; RD_ZS1(dst.p[0]); RD_ZS1(dst.p[1]); RD_ZS1(dst.p[2]); RD_ZS1(src.p[0]); RD_ZS1(src.p[1]); RD_ZS1(src.p[2]); RD_ZS1(tails); RD_ZS1(bad); }
+  if (blockIdx.x == 0 && k == 0 && blockIdx.z == 0 && threadIdx.x == 0) *bad = 0;      // diagnostics flag of the check that follows this launch
   const int x = blockIdx.x * 64 + lane;
-  const int k = blockIdx.y, c = blockIdx.z;
   const bool xin = x < W;
   typedef typename iir_src<SRC16>::T TS;
   const TS *__restrict__ in = (const TS *)src.p[k] + (xin ? x : W - 1);
@@ -382,9 +387,10 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
 // IIR_WARM rows of run-in) by the lane that found it, through the `fwd` scratch plane (two chunks of one column may both do
 // that: they write the same values).  `force` (diagnostics) treats every column of chunk 0 as different.
 template <int TOUT, int SRC16>
-__global__ __launch_bounds__(64) void k_iir_check_fix(P3 dst, P3c src, P3 fwd, const float *__restrict__ tails, int *bad, int W, int H, int nchunks, int IF_ROWS, int force) {
+__global__ __launch_bounds__(64) void k_iir_check_fix(P3 dst, P3c src, P3 fwd, const float *__restrict__ tails, int *bad, int W, int H, int nchunks, int IF_ROWS, int force, int np, size_t zs) {
   const int x = blockIdx.x * 64 + threadIdx.x;
-  const int k = blockIdx.y, c = blockIdx.z;
+  const int k = blockIdx.y % np, c = blockIdx.z;
+  { const size_t rd_zoff_ = (size_t)(blockIdx.y / np) * zs; RD_ZS1(dst.p[0]); RD_ZS1(dst.p[1]); RD_ZS1(dst.p[2]); RD_ZS1(src.p[0]); RD_ZS1(src.p[1]); RD_ZS1(src.p[2]); RD_ZS1(fwd.p[0]); RD_ZS1(fwd.p[1]); RD_ZS1(fwd.p[2]); RD_ZS1(tails); RD_ZS1(bad); }
   if (x >= W) return;
   const int s0 = c * IF_ROWS, s1 = (c == nchunks - 1) ? H : s0 + IF_ROWS;
   const float *me = tails + ((size_t)(k * nchunks + c) * 4 * 7) * W + x;
@@ -497,7 +503,8 @@ __device__ __forceinline__ void ev_finish(float2 *__restrict__ dst, int p, float
   }
   dst[p] = make_float2(vx, vy);
 }
-__global__ __launch_bounds__(256) void k_edgevec(float2 *__restrict__ dst, const float *__restrict__ in, int iw, int ih, uint32_t *__restrict__ pack_out, const float *__restrict__ pa, const float *__restrict__ pb) {
+__global__ __launch_bounds__(256) void k_edgevec(float2 *__restrict__ dst, const float *__restrict__ in, int iw, int ih, uint32_t *__restrict__ pack_out, const float *__restrict__ pa, const float *__restrict__ pb, size_t zs) {
+  RD_ZSHIFT(zs, dst, in, pack_out, pa, pb);
   const int x = blockIdx.x * 64 + threadIdx.x, y0 = (blockIdx.y * 4 + threadIdx.y) * EV_PX;
   if (x >= iw || y0 >= ih) return;
   if (pack_out != nullptr) {
@@ -567,7 +574,8 @@ __device__ __forceinline__ float ep_strength(const float (&n)[3], const float (&
   const float tot = sum[0] + sum[1] + sum[2];
   return tot > 0 ? sqrtf(tot) : 0.0f;
 }
-__global__ __launch_bounds__(256) void k_edge_plab(float *__restrict__ out, const uint32_t *__restrict__ in, int iw, int ih) {
+__global__ __launch_bounds__(256) void k_edge_plab(float *__restrict__ out, const uint32_t *__restrict__ in, int iw, int ih, size_t zs) {
+  RD_ZSHIFT(zs, out, in);
   const int x = blockIdx.x * 64 + threadIdx.x, y0 = (blockIdx.y * 4 + threadIdx.y) * EP_PX;
   if (x >= iw || y0 >= ih) return;
   const bool interior = blockIdx.x > 0 && blockIdx.y > 0 && (int)(blockIdx.x * 64 + 64) < iw && (int)((blockIdx.y * 4 + 4) * EP_PX) < ih;
@@ -636,7 +644,8 @@ __device__ __forceinline__ float bicubic_lds(const float *t, float x, float y, i
 // a third of the pixels of a noisy frame, scattered over every wave - need the two outer samples.  Evaluated inside the same
 // loop, the outer samples would be computed by whole waves for the sake of a few lanes: the block collects its maxima in an LDS
 // list instead and works the list off with all lanes busy.
-__global__ __launch_bounds__(256) void k_thinthres(float *__restrict__ out, const float *__restrict__ in, const float2 *__restrict__ vxy, int iw, int ih) {
+__global__ __launch_bounds__(256) void k_thinthres(float *__restrict__ out, const float *__restrict__ in, const float2 *__restrict__ vxy, int iw, int ih, size_t zs) {
+  RD_ZSHIFT(zs, out, in, vxy);
   __shared__ float tile[(TT_ROWS + 7) * TT_PITCH];
   __shared__ float4 lst[64 * TT_ROWS];          // a maximum: {its inner samples am1, ap1, its direction}
   __shared__ int lpix[64 * TT_ROWS];            // ... and its tile cell (row * 64 + column)
@@ -836,9 +845,14 @@ namespace rdk {
 void bgr2plab(hipStream_t s, uint32_t *out, const uint8_t *bgr, int iw, int ih, int ws) {
   hipLaunchKernelGGL(k_bgr2plab, dim3(cdiv(iw, 64), cdiv(ih, 16)), block2, 0, s, out, bgr, iw, ih, ws);
 }
-void bgr2plab_transposed(hipStream_t s, uint32_t *out, float *const dst[3], const uint8_t *bgr, int iw, int ih, int ws) {
+void bgr2plab_transposed(hipStream_t s, uint32_t *out, float *const dst[3], const uint8_t *const *bgr, int iw, int ih, int ws, int nz, size_t zs) {
   P3 d = { { dst[0], dst[1], dst[2] } };
-  hipLaunchKernelGGL(k_bgr2plab_t, dim3(cdiv(iw, 64), cdiv(ih, 64)), block2, 0, s, out, d, bgr, iw, ih, ws);
+  SrcZ z;
+  for (int i = 0; i < RD_ZB_MAX; i++) z.p[i] = bgr[i < nz ? i : 0];
+  hipLaunchKernelGGL(k_bgr2plab_t, dim3(cdiv(iw, 64), cdiv(ih, 64), nz), block2, 0, s, out, d, z, iw, ih, ws, zs);
+}
+void bgr2plab_transposed(hipStream_t s, uint32_t *out, float *const dst[3], const uint8_t *bgr, int iw, int ih, int ws) {
+  bgr2plab_transposed(s, out, dst, &bgr, iw, ih, ws, 1, 0);
 }
 void unpack_plab(hipStream_t s, float *L, float *a, float *b, const uint32_t *in, int n) {
   hipLaunchKernelGGL(k_unpack_plab, dim3(ew_grid(n)), dim3(256), 0, s, L, a, b, in, n);
@@ -875,11 +889,11 @@ size_t iir_pass_scratch_floats(int np, int W, int H) { return (size_t)np * if_nc
 // iir_pass_scratch_floats() floats.
 // src16 (only with transpose_out): the source planes hold 16-bit Lab fields (bgr2plab_transposed), plane 0 = L
 void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3], float *const fwd[3], float *const bwd[3], int np, int W, int H,
-                   int transpose_out, float *tails, int *bad, int src16) {
+                   int transpose_out, float *tails, int *bad, int src16, int nz, size_t zs) {
   const int rows = if_pick_rows(np, W, H, transpose_out);
   const int nchunks = if_nchunks(H, rows);
-  const dim3 grid(cdiv(W, 64), np, nchunks);
-#define IF_LAUNCH(T, R, S16) hipLaunchKernelGGL((k_iir_fused<T, R, S16>), grid, dim3(128), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks, bad)
+  const dim3 grid(cdiv(W, 64), np * nz, nchunks);
+#define IF_LAUNCH(T, R, S16) hipLaunchKernelGGL((k_iir_fused<T, R, S16>), grid, dim3(128), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks, bad, np, zs)
 #define IF_LAUNCH_R(R) { if (transpose_out && src16) IF_LAUNCH(1, R, 1); else if (transpose_out) IF_LAUNCH(1, R, 0); else IF_LAUNCH(0, R, 0); }
   switch (rows) {
     case 32: IF_LAUNCH_R(32); break;
@@ -891,9 +905,9 @@ void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3]
 #undef IF_LAUNCH
   if (nchunks > 1) {
     const int force = getenv("RD_IIR_FORCE_FIX") ? 1 : 0;             // diagnostics: every column takes the full-length path
-    if (transpose_out && src16) hipLaunchKernelGGL((k_iir_check_fix<1, 1>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force);
-    else if (transpose_out) hipLaunchKernelGGL((k_iir_check_fix<1, 0>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force);
-    else hipLaunchKernelGGL((k_iir_check_fix<0, 0>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force);
+    if (transpose_out && src16) hipLaunchKernelGGL((k_iir_check_fix<1, 1>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force, np, zs);
+    else if (transpose_out) hipLaunchKernelGGL((k_iir_check_fix<1, 0>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force, np, zs);
+    else hipLaunchKernelGGL((k_iir_check_fix<0, 0>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force, np, zs);
   }
   (void)bwd;
 }
@@ -921,14 +935,14 @@ void edgevec_plab(hipStream_t s, float *vxy, const uint32_t *in, int iw, int ih)
 void thincubic(hipStream_t s, float *out, const float *in, const float *vxy, int iw, int ih) {
   hipLaunchKernelGGL(k_thincubic, grid2(iw, ih), block2, 0, s, out, in, (const float2 *)vxy, iw, ih);
 }
-void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih, uint32_t *pack_out, const float *a, const float *b) {
-  hipLaunchKernelGGL(k_edgevec, dim3(cdiv(iw, 64), cdiv(ih, 4 * EV_PX)), block2, 0, s, (float2 *)vxy, in, iw, ih, pack_out, a, b);
+void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih, uint32_t *pack_out, const float *a, const float *b, int nz, size_t zs) {
+  hipLaunchKernelGGL(k_edgevec, dim3(cdiv(iw, 64), cdiv(ih, 4 * EV_PX), nz), block2, 0, s, (float2 *)vxy, in, iw, ih, pack_out, a, b, zs);
 }
-void edge_plab(hipStream_t s, float *out, const uint32_t *in, int iw, int ih) {
-  hipLaunchKernelGGL(k_edge_plab, dim3(cdiv(iw, 64), cdiv(ih, 4 * EP_PX)), block2, 0, s, out, in, iw, ih);
+void edge_plab(hipStream_t s, float *out, const uint32_t *in, int iw, int ih, int nz, size_t zs) {
+  hipLaunchKernelGGL(k_edge_plab, dim3(cdiv(iw, 64), cdiv(ih, 4 * EP_PX), nz), block2, 0, s, out, in, iw, ih, zs);
 }
-void thinthres(hipStream_t s, float *out, const float *in, const float *vxy, int iw, int ih) {
-  hipLaunchKernelGGL(k_thinthres, dim3(cdiv(iw, 64), cdiv(ih, TT_ROWS)), dim3(64, 4), 0, s, out, in, (const float2 *)vxy, iw, ih);
+void thinthres(hipStream_t s, float *out, const float *in, const float *vxy, int iw, int ih, int nz, size_t zs) {
+  hipLaunchKernelGGL(k_thinthres, dim3(cdiv(iw, 64), cdiv(ih, TT_ROWS), nz), dim3(64, 4), 0, s, out, in, (const float2 *)vxy, iw, ih, zs);
 }
 void threshold_f(hipStream_t s, float *out, const float *in, float lo, float thr, float hi, int n) {
   hipLaunchKernelGGL(k_threshold_f, dim3(ew_grid(n)), dim3(256), 0, s, out, in, lo, thr, hi, n);

@@ -55,8 +55,9 @@ __device__ __forceinline__ void lt_union(int *lab, int a, int b) {
 // mask0 / pix_out (and zero_plane cleared) as k_rect_tidy would.
 template <int SRC>
 __global__ __launch_bounds__(64 * LT_TY) void k_label_tile(int *__restrict__ label, const int *__restrict__ pix, int bgc, int iw, int ih, int *__restrict__ pix_out,
-                                                    const float *__restrict__ nms, int *__restrict__ mask0, int *__restrict__ zero_plane) {
+                                                    const float *__restrict__ nms, int *__restrict__ mask0, int *__restrict__ zero_plane, size_t zs) {
   constexpr bool BOUNDARY = SRC == 1;
+  RD_ZSHIFT(zs, label, pix, pix_out, nms, mask0, zero_plane);
   __shared__ int lab[LT_W * LT_H];
   __shared__ int pv[LT_W * LT_H];
   const int tx = threadIdx.x, x = blockIdx.x * LT_W + tx, y0 = blockIdx.y * LT_H;
@@ -209,7 +210,8 @@ __device__ __forceinline__ void border_union(int *label, int la, int lb, bool wa
 }
 
 // (both kinds of border in one launch - unions commute: the first `hblocks` blocks take the horizontal borders)
-__global__ __launch_bounds__(256) void k_label_border(int *label, const int *__restrict__ pix, int bgc, int iw, int ih, int hblocks) {
+__global__ __launch_bounds__(256) void k_label_border(int *label, const int *__restrict__ pix, int bgc, int iw, int ih, int hblocks, size_t zs) {
+  RD_ZSHIFT(zs, label, pix);
   const bool horizontal = (int)blockIdx.x < hblocks;
   const int t = (horizontal ? blockIdx.x : blockIdx.x - hblocks) * blockDim.x + threadIdx.x;
   if (horizontal) {
@@ -261,7 +263,8 @@ __global__ __launch_bounds__(256) void k_label_border(int *label, const int *__r
 // Phase 3: path compression to the root
 // (vt_*, optional: block 0 also undoes the previous frame's entries of the vote tables - what k_reduce_clean does - so that the
 //  vote kernels that follow the boundary labelling find them clean without a launch of their own)
-__global__ __launch_bounds__(256) void k_label_flatten(int *label, int n, int *vt_table, int *vt_claim, int *vt_list) {
+__global__ __launch_bounds__(256) void k_label_flatten(int *label, int n, int *vt_table, int *vt_claim, int *vt_list, size_t zs) {
+  RD_ZSHIFT(zs, label, vt_table, vt_claim, vt_list);
   const int stride = gridDim.x * blockDim.x;
   for (int i0 = blockIdx.x * blockDim.x + threadIdx.x; i0 < n; i0 += stride * 4) {      // four pixels per step: their first loads are in flight together
     int l[4];
@@ -382,42 +385,43 @@ __global__ __launch_bounds__(256) void k_strength_masks(int *__restrict__ strong
 namespace rdk {
 
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, int skip_flatten) {
-  hipLaunchKernelGGL(k_label_tile<0>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, pix, bgc, iw, ih, (int *)nullptr, (const float *)nullptr, (int *)nullptr, (int *)nullptr);
+  const size_t zs = 0;
+  hipLaunchKernelGGL(k_label_tile<0>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, pix, bgc, iw, ih, (int *)nullptr, (const float *)nullptr, (int *)nullptr, (int *)nullptr, zs);
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
-  if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb), dim3(256), 0, s, label, pix, bgc, iw, ih, hb);
+  if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb), dim3(256), 0, s, label, pix, bgc, iw, ih, hb, zs);
   if (skip_flatten) return;        // (the caller's next kernel walks to the roots itself: calc_strength)
   const int n = iw * ih;
   int g = cdiv(n, 256 * 4);
-  hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n, (int *)nullptr, (int *)nullptr, (int *)nullptr);
+  hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n, (int *)nullptr, (int *)nullptr, (int *)nullptr, zs);
 }
 
 // rect_tidy(mask0, tidy, nms, zero_plane) + label8(label, tidy, background -1, skip_flatten) with the tidy computed inside the tile kernel
-void label8_tidy(hipStream_t s, int *label, int *mask0, int *tidy, const float *nms, int *zero_plane, int iw, int ih, int skip_flatten) {
-  hipLaunchKernelGGL(k_label_tile<2>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, (const int *)nullptr, -1, iw, ih, tidy, nms, mask0, zero_plane);
+void label8_tidy(hipStream_t s, int *label, int *mask0, int *tidy, const float *nms, int *zero_plane, int iw, int ih, int skip_flatten, int nz, size_t zs) {
+  hipLaunchKernelGGL(k_label_tile<2>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H), nz), dim3(64, LT_TY), 0, s, label, (const int *)nullptr, -1, iw, ih, tidy, nms, mask0, zero_plane, zs);
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
   // (this plane is labelled with its background, one component that spans the frame: uniting the tiles of a row first and the rows
   //  afterwards keeps the trees that the concurrent unions walk shorter than doing both at once - measured 49 against 56 us alone, 2129
   //  against 2098 frames/s at full rate; blocks of 256 rather than 64 threads: +0.35 % at full rate; the boundary labelling, whose
   //  components are small, is better off with one launch: 2130 against 2123)
-  if (vb > 0) hipLaunchKernelGGL(k_label_border, dim3(vb), dim3(256), 0, s, label, (const int *)tidy, -1, iw, ih, 0);
-  if (hb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb), dim3(256), 0, s, label, (const int *)tidy, -1, iw, ih, hb);
+  if (vb > 0) hipLaunchKernelGGL(k_label_border, dim3(vb, 1, nz), dim3(256), 0, s, label, (const int *)tidy, -1, iw, ih, 0, zs);
+  if (hb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb, 1, nz), dim3(256), 0, s, label, (const int *)tidy, -1, iw, ih, hb, zs);
   if (skip_flatten) return;
   const int n = iw * ih;
   int g = cdiv(n, 256 * 4);
-  hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n, (int *)nullptr, (int *)nullptr, (int *)nullptr);
+  hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g, 1, nz), dim3(256), 0, s, label, n, (int *)nullptr, (int *)nullptr, (int *)nullptr, zs);
 }
 
 // region boundaries (oclrect.cl:373-390) marked into `marks` and their 8-connected components labelled into `label`
-void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih, int *vt_table, int *vt_claim, int *vt_list) {
-  hipLaunchKernelGGL(k_label_tile<1>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, region, -1, iw, ih, marks, (const float *)nullptr, (int *)nullptr, (int *)nullptr);
+void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih, int *vt_table, int *vt_claim, int *vt_list, int nz, size_t zs) {
+  hipLaunchKernelGGL(k_label_tile<1>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H), nz), dim3(64, LT_TY), 0, s, label, region, -1, iw, ih, marks, (const float *)nullptr, (int *)nullptr, (int *)nullptr, zs);
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
-  if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb), dim3(256), 0, s, label, (const int *)marks, -1, iw, ih, hb);
+  if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb, 1, nz), dim3(256), 0, s, label, (const int *)marks, -1, iw, ih, hb, zs);
   const int n = iw * ih;
   int g = cdiv(n, 256 * 4);
-  hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n, vt_table, vt_claim, vt_list);
+  hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g, 1, nz), dim3(256), 0, s, label, n, vt_table, vt_claim, vt_list, zs);
 }
 
 void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int iw, int ih, const int8_t *add, int flatten) {

@@ -23,7 +23,8 @@ inline int ew_grid(int n) { int g = cdiv(n, 256 * 4); return g < 1 ? 1 : (g > 40
 // ------------------------------------------------------------------------------------------------ edge tidy
 // rc:74-95 (`> 0`) and pl:66-87 (`!= 0`): 3x3 population count of on-pixels, 1 -> 0, frame border 0
 // (bits, optional: the two bit rows per 64 pixels that k_mm_gather reads - "counted pixel", "curve end" - see k_mm_bits)
-__global__ __launch_bounds__(256) void k_junction(int *__restrict__ out, const int *__restrict__ in, int nz, int iw, int ih, unsigned long long *__restrict__ bits, int wpr) {
+__global__ __launch_bounds__(256) void k_junction(int *__restrict__ out, const int *__restrict__ in, int nz, int iw, int ih, unsigned long long *__restrict__ bits, int wpr, size_t zs) {
+  RD_ZSHIFT(zs, out, in, bits);
   RD_XY;
   const bool inside = x < iw && y < ih;
   const int p = inside ? y * iw + x : 0;
@@ -75,7 +76,8 @@ __global__ __launch_bounds__(256) void k_rect_tidy(int *__restrict__ mask0, int 
 // A pixel then reads its five relevant stop bits per direction and counts the leading clear ones.
 #define BE_ROWS 32
 #define BE_NR (BE_ROWS + 11)          // rows y0-5 .. y0+BE_ROWS+5
-__global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ ext, const int8_t *__restrict__ edge, int iw, int ih) {
+__global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ ext, const int8_t *__restrict__ edge, int iw, int ih, size_t zs) {
+  RD_ZSHIFT(zs, ext, edge);
   typedef unsigned long long u64;
   __shared__ u64 EA[BE_NR + 1], EB[BE_NR + 1];   // mask != 0 for columns x0-8 .. x0+55 (A) and x0+56 .. x0+71 (B)
   __shared__ u64 HLa[BE_NR], HLb[BE_NR], HRa[BE_NR], HRb[BE_NR];   // along x: stop bits towards smaller / larger x (centre not on an edge)
@@ -170,7 +172,8 @@ __global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ e
 __device__ __forceinline__ unsigned div_small_f(unsigned s, float2 rw) { return (unsigned)__fmaf_rn((float)s, rw.x, rw.y); }
 
 #define BP_TY 16         // thread rows per block (4 / 8 / 16 at full rate: 2003 / 2111 / 2126 frames/s)
-__global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih) {
+__global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih, size_t zs) {
+  RD_ZSHIFT(zs, out, ext, in);
   // one array: the staged input, the horizontal result, and a REGION of zeros - the sample beyond a run is read at `zero region + the
   // same constant offset as the sample inside the run`, so that a sample's address is one select between two registers and the offset
   // travels in the load instruction (with single zero slots the compiler paid an add or a constant per sample)
@@ -325,7 +328,8 @@ __global__ void k_quant24_lut() {
 #define DS_P 66
 // QN > 0: the input is quantised to QN levels per field on the fly (rc:207-216 fused in: no separate pass over the plane)
 template <int QN>
-__global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, const uint32_t *__restrict__ in, const float *__restrict__ edge, int iw, int ih) {
+__global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, const uint32_t *__restrict__ in, const float *__restrict__ edge, int iw, int ih, size_t zs) {
+  RD_ZSHIFT(zs, out, in, edge);
   constexpr int NC = (DS_ROWS + 2) * DS_P, IT = (NC + 255) / 256;
   __shared__ uint32_t tq[NC];
   __shared__ uint8_t tf[NC];        // bit 0: replaced as a centre (!(e < 1e-6)), bit 1: skipped as a neighbour (e >= 1e-6), bit 2: outside the frame
@@ -458,7 +462,8 @@ __device__ __forceinline__ void mm_rows(const unsigned long long *sb, int r, uns
 // a 64-bit word instead of a 17-bit window test per pixel and row offset (262 -> 45 vector instructions per pixel) - and all
 // threads expand the result bits into the int plane.
 #define MM_ROWS 64
-__global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const unsigned long long *__restrict__ bits, int iw, int ih, int wpr) {
+__global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const unsigned long long *__restrict__ bits, int iw, int ih, int wpr, size_t zs) {
+  RD_ZSHIFT(zs, out, bits);
   __shared__ unsigned long long sb[(MM_ROWS + 16) * 6];
   __shared__ unsigned long long res[MM_ROWS];
   const int k = blockIdx.x;                 // word holding this block's own 64 columns
@@ -508,7 +513,8 @@ __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const 
 #define RI_RH (RI_ROWS + RI_H + 2)
 #define RI_NC (RI_RW * RI_RH)
 __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *__restrict__ B, uint8_t *__restrict__ allow, const int *__restrict__ pix, const int *__restrict__ mask,
-                                                     const int *__restrict__ edge, int iw, int ih, int *__restrict__ flags, int *__restrict__ size_out, const int *__restrict__ size_init) {
+                                                     const int *__restrict__ edge, int iw, int ih, int *__restrict__ flags, int *__restrict__ size_out, const int *__restrict__ size_init, size_t zs) {
+  RD_ZSHIFT(zs, A, B, allow, pix, mask, edge, flags, size_out, size_init);
   __shared__ int col[RI_NC];                  // colours, then (in place) nothing: kept for the allow bits
   __shared__ short lnk[RI_NC];                // raw link as a cell index of this tile's region (-1: cell outside the frame)
   __shared__ short prop[RI_NC];               // G as a cell index, or 0x7fff
@@ -673,7 +679,8 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
 #define RR_DEEP 3          // rounds in which the trees are still the chains of the initial links (a pixel's parent is 1, 10, 91 rows above it)
 #endif
 __device__ __forceinline__ int rr_label(const int *X, unsigned q) { return at32(X, q) >> RR_MBITS; }
-__global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round) {
+__global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round, size_t zs) {
+  RD_ZSHIFT(zs, X, Y, allow, flags);
   if (round > 0 && flags[round - 1] == 0) return;
   __shared__ int hk[512], hv[512];
   __shared__ int tmin[64 * RR_TY * RR_PX];      // launch 1 only: the smallest proposal for each pixel of the block's tile (see below)
@@ -835,7 +842,8 @@ __device__ __forceinline__ void rs_accum(int *keys, int *vals, int *out, int lab
 }
 
 // (marked: the plane holds the words of k_region_round - label << 3 | mark; the plain labels are stored back on the way)
-__global__ __launch_bounds__(256) void k_region_size(int *out, int *__restrict__ label, int n, int *zero_me, int marked) {
+__global__ __launch_bounds__(256) void k_region_size(int *out, int *__restrict__ label, int n, int *zero_me, int marked, size_t zs) {
+  RD_ZSHIFT(zs, out, label, zero_me);
   if (zero_me && blockIdx.x == 0 && threadIdx.x == 0) *zero_me = 0;     // (a counter of the next stage: saves a fill launch)
   __shared__ int keys[RS_T], vals[RS_T];
   for (int i = threadIdx.x; i < RS_T; i += 256) { keys[i] = -1; vals[i] = 0; }
@@ -1121,7 +1129,8 @@ __device__ __forceinline__ void ab_record(int *__restrict__ rec, int p, int rl, 
 
 // (list: room for reccap records)
 __global__ __launch_bounds__(AB_NT) void k_absorb_tile(int *__restrict__ out, int *__restrict__ list, int reccap, int *count, const int *__restrict__ old, const int *__restrict__ size,
-                                                       int thre, int iw, int ih) {
+                                                       int thre, int iw, int ih, size_t zs) {
+  RD_ZSHIFT(zs, out, list, count, old, size);
   __shared__ ab_word cell[AB_NC];
   __shared__ unsigned short slist[AB_NT * AB_R];
   __shared__ unsigned short rlist[AB_TW * AB_TH];      // undecided pixels of the tile (cell indices)
@@ -1423,7 +1432,8 @@ __device__ __forceinline__ void at_body(ab_word *W, int *__restrict__ out, const
   if (tid == 0) { status[4] = (int)(t1 - t0); status[5] = (int)(t2 - t1); status[6] = (int)(t3 - t2); status[7] = (int)(wall_clock64() - t3); }
 }
 
-__global__ __launch_bounds__(AT_NT) void k_absorb_tail(int *__restrict__ out, const int *__restrict__ list, int reccap, const int *__restrict__ count, const int *__restrict__ size, int nsteps, int *status) {
+__global__ __launch_bounds__(AT_NT) void k_absorb_tail(int *__restrict__ out, const int *__restrict__ list, int reccap, const int *__restrict__ count, const int *__restrict__ size, int nsteps, int *status, size_t zs) {
+  RD_ZSHIFT(zs, out, list, count, size, status);
   extern __shared__ __attribute__((aligned(16))) ab_word at_lds[];
   const int n = *count;
   if (threadIdx.x == 0) { status[1] = n; status[0] = n > reccap ? 1 : 0; status[2] = 0; }
@@ -1757,68 +1767,68 @@ __global__ void k_sample_segments(const rdk::PolyFrames FRS, int max_records, in
 
 namespace rdk {
 
-void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih, int *merge_mask_scratch) {
-  hipLaunchKernelGGL(k_junction, grid2(iw, ih), block2, 0, s, out, in, nonzero_variant, iw, ih, (unsigned long long *)merge_mask_scratch, cdiv(iw, 64));
+void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih, int *merge_mask_scratch, int nzf, size_t zs) {
+  hipLaunchKernelGGL(k_junction, dim3(cdiv(iw, 64), cdiv(ih, 4), nzf), block2, 0, s, out, in, nonzero_variant, iw, ih, (unsigned long long *)merge_mask_scratch, cdiv(iw, 64), zs);
 }
 void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, int ih, int *zero_plane) {
   hipLaunchKernelGGL(k_rect_tidy, dim3(cdiv(iw, 64), cdiv(ih, TD_ROWS)), dim3(64, 4), 0, s, mask0, tidy, nms, iw, ih, zero_plane);
 }
-void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih) {
-  hipLaunchKernelGGL(k_blblur_extents, dim3(cdiv(iw, 64), cdiv(ih, BE_ROWS)), dim3(64, 4), 0, s, ext, edge, iw, ih);
+void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih, int nz, size_t zs) {
+  hipLaunchKernelGGL(k_blblur_extents, dim3(cdiv(iw, 64), cdiv(ih, BE_ROWS), nz), dim3(64, 4), 0, s, ext, edge, iw, ih, zs);
 }
-void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih) {
-  hipLaunchKernelGGL(k_blblur_pair, dim3(cdiv(iw, 64), cdiv(ih, BP_ROWS)), dim3(64, BP_TY), 0, s, out, ext, in, iw, ih);
+void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih, int nz, size_t zs) {
+  hipLaunchKernelGGL(k_blblur_pair, dim3(cdiv(iw, 64), cdiv(ih, BP_ROWS), nz), dim3(64, BP_TY), 0, s, out, ext, in, iw, ih, zs);
 }
 // fills the quantisation tables of the current device (once per device, before its first frame; the caller synchronises)
 void quant_lut_init(hipStream_t s) { hipLaunchKernelGGL(k_quant24_lut, dim3(20), dim3(256), 0, s); }
-void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih, int quantize24) {
-  if (quantize24) hipLaunchKernelGGL(k_despeckle<24>, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS)), dim3(64, 4), 0, s, out, in, edge, iw, ih);
-  else hipLaunchKernelGGL(k_despeckle<0>, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS)), dim3(64, 4), 0, s, out, in, edge, iw, ih);
+void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih, int quantize24, int nz, size_t zs) {
+  if (quantize24) hipLaunchKernelGGL(k_despeckle<24>, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS), nz), dim3(64, 4), 0, s, out, in, edge, iw, ih, zs);
+  else hipLaunchKernelGGL(k_despeckle<0>, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS), nz), dim3(64, 4), 0, s, out, in, edge, iw, ih, zs);
 }
 // scratch: ih * ceil(iw/64) * 2 64-bit words
-void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih) {
+void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih, int nz, size_t zs) {
   const int wpr = cdiv(iw, 64);
   if (junction != nullptr) hipLaunchKernelGGL(k_mm_bits, grid2(iw, ih), block2, 0, s, (unsigned long long *)scratch, junction, iw, ih, wpr);   // (nullptr: rdk::junction has left the bit rows in scratch)
-  hipLaunchKernelGGL(k_mm_gather, dim3(wpr, cdiv(ih, MM_ROWS)), dim3(64, 4), 0, s, out, (const unsigned long long *)scratch, iw, ih, wpr);
+  hipLaunchKernelGGL(k_mm_gather, dim3(wpr, cdiv(ih, MM_ROWS), nz), dim3(64, 4), 0, s, out, (const unsigned long long *)scratch, iw, ih, wpr, zs);
 }
 
 // scratch: 3*N + 256 ints ([N, N + 96): a flag per launch and the absorption's status words, then the allowed-direction bytes; [2N, 3N): the second label plane of the rounds).
 // ROUNDS: the number of launches, even (the last one writes `label`); launches after one that changed nothing return at once.
 // *marked <- 1: `label` holds the rounds' words (label << 3 | mark), which region_size turns into plain labels.
-void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS, int *size_out, const int *size_init, int *marked) {
+void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS, int *size_out, const int *size_init, int *marked, int nz, size_t zs) {
   const int n = iw * ih;
   if (ROUNDS < 2 || (ROUNDS & 1) || ROUNDS > 64) { fprintf(stderr, "region_merge: the number of launches must be even, 2..64 (got %d)\n", ROUNDS); abort(); }
   int *flags = scratch + n;
   uint8_t *allow = (uint8_t *)(flags + RR_NFLAGS);
   int *A = label, *B = scratch + 2 * (size_t)n;   // the two planes of the rounds; the result is in A
-  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS)), dim3(64, 4), 0, s, A, B, allow, pix, mask, edge, iw, ih, flags, size_out, size_init);
-  const dim3 grid(cdiv(iw, 64), cdiv(ih, RR_TY * RR_PX));
+  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS), nz), dim3(64, 4), 0, s, A, B, allow, pix, mask, edge, iw, ih, flags, size_out, size_init, zs);
+  const dim3 grid(cdiv(iw, 64), cdiv(ih, RR_TY * RR_PX), nz);
   for (int r = 1; r < ROUNDS; r++) {       // (launch 0 was evaluated by k_region_init)
-    if (r & 1) hipLaunchKernelGGL(k_region_round, grid, dim3(64, RR_TY), 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r);
-    else hipLaunchKernelGGL(k_region_round, grid, dim3(64, RR_TY), 0, s, A, B, (const uint8_t *)allow, iw, ih, flags, r);
+    if (r & 1) hipLaunchKernelGGL(k_region_round, grid, dim3(64, RR_TY), 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r, zs);
+    else hipLaunchKernelGGL(k_region_round, grid, dim3(64, RR_TY), 0, s, A, B, (const uint8_t *)allow, iw, ih, flags, r, zs);
   }
   if (marked) *marked = 1;
 }
 
-void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, int marked) {
-  hipLaunchKernelGGL(k_region_size, dim3(cdiv(n, 256 * RS_PER_THREAD)), dim3(256), 0, s, out, label, n, zero_me, marked);
+void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, int marked, int nz, size_t zs) {
+  hipLaunchKernelGGL(k_region_size, dim3(cdiv(n, 256 * RS_PER_THREAD), 1, nz), dim3(256), 0, s, out, label, n, zero_me, marked, zs);
 }
 
 // rc:348-371 as the reference's serial raster order evaluates it, exactly.  scratch: RD_D2_SCRATCH_INTS(N) ints, scratch[N] (the list
 // counter) zeroed by the caller when count_is_zero; out must not alias in.  status (device, 3 ints): [0] != 0 <=> the two launches
 // could not finish the frame (more than AT_CAP undecided pixels, or the tail did not settle): `out` then still holds undecided
 // words (negative) and the caller runs despeckle2_slow(); [1] undecided pixels left by the tile kernel, [2] sweeps of the tail.
-void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih, int count_is_zero, int *status) {
+void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih, int count_is_zero, int *status, int nz, size_t zs) {
   const int n = iw * ih;
   int *count = scratch + (size_t)n, *list = count + 16 + (size_t)n;       // (the list: the 3N ints of the slow path's work lists)
   const int reccap = (int)(3 * (size_t)n / AB_REC) < AT_CAP ? (int)(3 * (size_t)n / AB_REC) : AT_CAP;
   int nsteps = 1;
   while ((1 << nsteps) < (iw > ih ? iw : ih)) nsteps++;
-  if (!count_is_zero) (void)hipMemsetAsync(count, 0, sizeof(int), s);
-  hipLaunchKernelGGL(k_absorb_tile, dim3(cdiv(iw, AB_TW), cdiv(ih, AB_TH)), dim3(AB_NT), 0, s, out, list, reccap, count, in, size, thre, iw, ih);
+  if (!count_is_zero) { if (nz != 1) { fprintf(stderr, "despeckle2: a group launch needs count_is_zero\n"); abort(); } (void)hipMemsetAsync(count, 0, sizeof(int), s); }
+  hipLaunchKernelGGL(k_absorb_tile, dim3(cdiv(iw, AB_TW), cdiv(ih, AB_TH), nz), dim3(AB_NT), 0, s, out, list, reccap, count, in, size, thre, iw, ih, zs);
   static std::atomic<unsigned> lds_set{0};
   set_max_lds_once((const void *)k_absorb_tail, (int)((AT_CAP + 1) * sizeof(ab_word)), lds_set);
-  hipLaunchKernelGGL(k_absorb_tail, dim3(1), dim3(AT_NT), (AT_CAP + 1) * sizeof(ab_word), s, out, (const int *)list, reccap, (const int *)count, size, nsteps, status);
+  hipLaunchKernelGGL(k_absorb_tail, dim3(1, 1, nz), dim3(AT_NT), (AT_CAP + 1) * sizeof(ab_word), s, out, (const int *)list, reccap, (const int *)count, size, nsteps, status, zs);
 }
 
 // The same result by plain Jacobi rounds of the recurrence over work lists in global memory, two rounds per launch, until a launch

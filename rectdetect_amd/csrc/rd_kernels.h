@@ -5,6 +5,10 @@
 #include <stdint.h>
 #include <atomic>
 
+// Group launches (small frames, rd_api.hip): launchers of the frame path take `nz` frames per launch and `zs`, the byte pitch between the planes
+// of consecutive frame slots (rd_device.h: RD_ZSHIFT); the defaults launch one frame.
+#define RD_ZB_MAX 8
+
 namespace rdk {
 
 // Kernels with more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize raised once PER DEVICE (a process may drive
@@ -21,7 +25,8 @@ inline void set_max_lds_once(const void *func, int bytes, std::atomic<unsigned> 
 // ---- rd_k_front.hip: colour, blur, gradient, non-max suppression, element-wise ops
 void bgr2plab(hipStream_t s, uint32_t *out, const uint8_t *bgr, int iw, int ih, int ws);
 // colour conversion that also leaves the unpacked L, a, b planes transposed (ih wide, iw tall) for the first blur sweep
-void bgr2plab_transposed(hipStream_t s, uint32_t *out, float *const dst[3], const uint8_t *bgr, int iw, int ih, int ws);   // dst: the three planes transposed, as 16-bit integer fields (iir_blur_pass src16)
+void bgr2plab_transposed(hipStream_t s, uint32_t *out, float *const dst[3], const uint8_t *bgr, int iw, int ih, int ws);
+void bgr2plab_transposed(hipStream_t s, uint32_t *out, float *const dst[3], const uint8_t *const *bgr, int iw, int ih, int ws, int nz, size_t zs);   // bgr: nz source frames   // dst: the three planes transposed, as 16-bit integer fields (iir_blur_pass src16)
 void unpack_plab(hipStream_t s, float *L, float *a, float *b, const uint32_t *in, int n);
 void pack_plab(hipStream_t s, uint32_t *out, const float *L, const float *a, const float *b, int n);
 // transposes of `np` float planes (src planes W x H row-major -> dst planes H x W); src may be packed Lab (np = 3)
@@ -29,10 +34,10 @@ void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], 
 // one complete blur pass (causal + anti-causal sweep + combination) in a single launch, see rd_k_front.hip
 size_t iir_pass_scratch_floats(int np, int W, int H);
 void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3], float *const fwd[3], float *const bwd[3], int np, int W, int H,
-                   int transpose_out, float *tails, int *bad, int src16 = 0);
+                   int transpose_out, float *tails, int *bad, int src16 = 0, int nz = 1, size_t zs = 0);
 void iir_blur_lines(hipStream_t s, float *dst, const float *src, float *fw, float *bw, int W, int H, int r);   // any radius 0..31, full-length sweeps along y; dst may be fw or bw
 #define RD_IIR_MAX_R 31
-void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih, uint32_t *pack_out = nullptr, const float *a = nullptr, const float *b = nullptr);   // pack_out (optional): pack_plab(in, a, b) on the way
+void edgevec(hipStream_t s, float *vxy, const float *in, int iw, int ih, uint32_t *pack_out = nullptr, const float *a = nullptr, const float *b = nullptr, int nz = 1, size_t zs = 0);   // pack_out (optional): pack_plab(in, a, b) on the way
 // visualisers / operators no application calls (oclimgutil.h:84-98)
 void convert_bgr_lumaf(hipStream_t s, uint8_t *out, const float *in, float f, int iw, int ih, int ws);
 void convert_bgr_labeli(hipStream_t s, uint8_t *out, const int *in, int bgc, int iw, int ih, int ws);
@@ -40,8 +45,8 @@ void plab2bgr(hipStream_t s, uint8_t *out, const uint32_t *in, int iw, int ih, i
 void edge_f(hipStream_t s, float *out, const float *in, int iw, int ih);
 void edgevec_plab(hipStream_t s, float *vxy, const uint32_t *in, int iw, int ih);
 void thincubic(hipStream_t s, float *out, const float *in, const float *vxy, int iw, int ih);
-void edge_plab(hipStream_t s, float *out, const uint32_t *in, int iw, int ih);
-void thinthres(hipStream_t s, float *out, const float *in, const float *vxy, int iw, int ih);
+void edge_plab(hipStream_t s, float *out, const uint32_t *in, int iw, int ih, int nz = 1, size_t zs = 0);
+void thinthres(hipStream_t s, float *out, const float *in, const float *vxy, int iw, int ih, int nz = 1, size_t zs = 0);
 void threshold_f(hipStream_t s, float *out, const float *in, float lo, float thr, float hi, int n);
 void threshold_i(hipStream_t s, int *out, const int *in, int lo, int thr, int hi, int n);
 void cast_i_f(hipStream_t s, int *out, const float *in, float scale, int n);
@@ -53,8 +58,8 @@ void rand_i(hipStream_t s, int *out, uint64_t seed, int n);
 // ---- rd_k_label.hip: connected components and per-label reductions
 // 8-connected components of equal `pix` value, pixels equal to bgc -> -1, label = smallest pixel index
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, int skip_flatten = 0);   // label = smallest index of the 8-connected component of equal value, -1 for bgc; skip_flatten: the final walk to the roots is left to calc_strength(flatten = 1)
-void label8_tidy(hipStream_t s, int *label, int *mask0, int *tidy, const float *nms, int *zero_plane, int iw, int ih, int skip_flatten = 0);   // rect_tidy + label8(tidy, background -1) in the same tile kernel
-void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih, int *vt_table = nullptr, int *vt_claim = nullptr, int *vt_list = nullptr);   // mark_boundary + label8(marks, background -1) with the marking fused into the tile kernel
+void label8_tidy(hipStream_t s, int *label, int *mask0, int *tidy, const float *nms, int *zero_plane, int iw, int ih, int skip_flatten = 0, int nz = 1, size_t zs = 0);   // rect_tidy + label8(tidy, background -1) in the same tile kernel
+void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih, int *vt_table = nullptr, int *vt_claim = nullptr, int *vt_list = nullptr, int nz = 1, size_t zs = 0);   // mark_boundary + label8(marks, background -1) with the marking fused into the tile kernel
 // add (optional): a plane whose non-zero elements are added to out element by element in the same launch (out = zeros + add + sums)
 void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int iw, int ih, const int8_t *add = nullptr, int flatten = 0);   // add (optional): a 0/1 byte plane added to the sums (H1)
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih);
@@ -62,27 +67,27 @@ void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw
 void strength_masks(hipStream_t s, int *strong, int8_t *strong2, int *edge /* may be NULL */, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih);
 
 // ---- rd_k_rect.hip: rect-path stages
-void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih, int *merge_mask_scratch = nullptr);   // merge_mask_scratch (optional): also leaves merge_mask's bit rows there (then call merge_mask with junction = nullptr)
+void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih, int *merge_mask_scratch = nullptr, int nz = 1, size_t zs = 0);   // merge_mask_scratch (optional): also leaves merge_mask's bit rows there (then call merge_mask with junction = nullptr)
 // mask0 = (nms > 0), tidy = thin(thin(close_gaps(junction(mask0)), parity 0), parity 1) in one launch (oclrect.cl:74-135)
 void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, int ih, int *zero_plane = nullptr);   // zero_plane (optional): cleared on the way
 // run extents of the edge-stopped blur (depend on the edge mask only): ext[p] = nl_h | nr_h<<3 | nl_v<<6 | nr_v<<9
-void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih);
+void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih, int nz = 1, size_t zs = 0);
 // one horizontal + vertical pass pair; out must not alias in
-void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih);
+void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih, int nz = 1, size_t zs = 0);
 void quant_lut_init(hipStream_t s);   // once per device before the first despeckle(quantize24 = 1): builds the 24-level quantisation tables on the device
-void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih, int quantize24);   // quantize24: `in` is quantised to 24 levels per field on the fly
-void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih);   // scratch: >= ih*ceil(iw/64)*4 ints
+void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih, int quantize24, int nz = 1, size_t zs = 0);   // quantize24: `in` is quantised to 24 levels per field on the fly
+void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih, int nz = 1, size_t zs = 0);   // scratch: >= ih*ceil(iw/64)*4 ints
 // oclrect.cl:289-334 with the work-items of a launch concurrent (rd_k_rect.hip: k_region_init = the links and launch 0, k_region_round = the others).
 // launches: even, 2..64 (launches after one that changed nothing return at once; flag r of scratch[N + r] = launch r changed something);
 // size_out (optional) <- size_init, for region_size; scratch: 3N + 256 ints; *marked <- 1: `label` is left as label << 3 | mark words,
 // which region_size(…, marked) turns into plain labels
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int launches,
-                  int *size_out, const int *size_init, int *marked);
-void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, int marked = 0);   // accumulates into out; zero_me (optional): an int to clear on the way
+                  int *size_out, const int *size_init, int *marked, int nz = 1, size_t zs = 0);
+void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, int marked = 0, int nz = 1, size_t zs = 0);   // accumulates into out; zero_me (optional): an int to clear on the way
 #define RD_D2_SCRATCH_INTS(N) (5 * (size_t)(N) + 64)
 // absorption of small regions (oclrect.cl:348-371) exactly as the reference's serial raster order gives it.  out != in; scratch: RD_D2_SCRATCH_INTS(N) ints
 // (scratch[N] = 0 already if count_is_zero); status: 3 device ints, [0] != 0 <=> not finished (out holds negative words): run despeckle2_slow()
-void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih, int count_is_zero, int *status);
+void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih, int count_is_zero, int *status, int nz = 1, size_t zs = 0);
 void despeckle2_slow(hipStream_t s, int *out, const int *in, int *scratch, const int *size, int thre, int iw, int ih);   // the same result for any input; synchronises s (not for captured streams)
 struct PolyScratch;
 struct PolyFrame;      // rd_poly_scratch.h: per-frame descriptor of the sparse stages; launches cover nb <= RD_MAXB frames (frame = blockIdx.z), descriptors in HOST memory
