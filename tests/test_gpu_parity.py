@@ -626,6 +626,7 @@ def test_batched_sparse_stages_any_polling_pattern(nslots, pattern, monkeypatch)
     blockIdx.z; the default from 12 slots on, RD_BATCH=4 here).  Whatever the caller's rhythm - groups filled completely, polled
     when partly filled, slot counts that are no multiple of four - the results must equal one frame at a time on a single-slot detector."""
     monkeypatch.setenv("RD_BATCH", "4")
+    monkeypatch.setenv("RD_ZBATCH", "0")      # (group launches - next test - replace this arrangement by default; it remains what RD_ZBATCH=0 selects)
     iw, ih = 640, 480
     frames = [synth.frame(synth.SEED0 + 21, iw, ih, t) for t in range(sum(pattern))]
     seq = ra.Detector(iw, ih, nslots=1, nworkers=0)
@@ -647,6 +648,53 @@ def test_batched_sparse_stages_any_polling_pattern(nslots, pattern, monkeypatch)
         assert len(got) == len(want)
         for t, ((r1, s1), (r2, s2)) in enumerate(zip(want, got)):
             assert helpers.rects_equal(r1, r2) and helpers.segments_equal(s1, s2), (workers, t)
+
+
+@pytest.mark.parametrize("zb,nslots,pattern,on_device", [(4, 16, [16, 16, 3, 16, 1, 7], True), (4, 16, [16, 5, 16], False), (2, 8, [8, 3, 8, 1, 8], True), (8, 16, [16, 9, 16], True),
+                                                          (4, 9, [9, 9, 4], True), (3, 6, [6, 2, 6], False), (None, 16, [16, 16, 6], True), (None, 8, [8, 8, 3], False)])
+def test_group_launches_any_polling_pattern(zb, nslots, pattern, on_device, monkeypatch):
+    """Group launches: the frames of zb consecutive slots run as ONE set of launches, dense stages included (frame = blockIdx.z, the slots'
+    planes at a constant pitch; the default from six slots on: None = whatever the library picks).  Full groups, groups polled when partly
+    filled (launched frame by frame then), slot counts that are no multiple of the group size, frames resident in HBM or handed over as
+    host buffers (with different row strides inside one group: not groupable) - every frame's lists must equal one frame at a time on a
+    single-slot detector, and with them the state that travels from frame to frame (H1)."""
+    if zb is not None: monkeypatch.setenv("RD_ZBATCH", str(zb))
+    iw, ih = 640, 480
+    n = sum(pattern)
+    frames = [synth.frame(synth.SEED0 + 33, iw, ih, t) for t in range(n)]
+    seq = ra.Detector(iw, ih, nslots=1, nworkers=0)
+    want = []
+    for f in frames:
+        seq.enqueue(f)
+        want.append((seq.poll(TAN36), seq.last_segments()))
+    seq.close()
+    L = ra.lib()
+    dptrs = []
+    if on_device:
+        for f in frames:
+            p = L.rd_device_alloc(f.nbytes); L.rd_upload(p, f.ctypes.data, f.nbytes); dptrs.append(p)
+    else:
+        # every third frame in a buffer with padded rows: a group with two strides cannot be one launch
+        padded = []
+        for t, f in enumerate(frames):
+            if t % 3 == 1:
+                g = np.zeros((ih, iw * 3 + 24), np.uint8); g[:, :iw * 3] = f.reshape(ih, iw * 3); padded.append(g)
+            else: padded.append(f)
+    for workers in (0, 1):
+        det = ra.Detector(iw, ih, nslots=nslots, nworkers=workers)
+        got, k = [], 0
+        for burst in pattern:
+            for _ in range(burst):
+                if on_device: det.enqueue(dptrs[k], ws=iw * 3, on_device=True)
+                else: det.enqueue(padded[k], ws=padded[k].shape[1] if padded[k].ndim == 2 else iw * 3)
+                k += 1
+            for _ in range(burst):
+                got.append((det.poll(TAN36), det.last_segments()))
+        det.close()
+        assert len(got) == len(want)
+        for t, ((r1, s1), (r2, s2)) in enumerate(zip(want, got)):
+            assert helpers.rects_equal(r1, r2) and helpers.segments_equal(s1, s2), (workers, t)
+    for p in dptrs: L.rd_device_free(p)
 
 
 @pytest.mark.parametrize("nslots", [1, 2, 8])
