@@ -386,10 +386,12 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
 // check is what guarantees the result - is evaluated again by the full-length sweeps (iu:580-589 / iu:629-637, mirrored ends,
 // IIR_WARM rows of run-in) by the lane that found it, through the `fwd` scratch plane (two chunks of one column may both do
 // that: they write the same values).  `force` (diagnostics) treats every column of chunk 0 as different.
+#define IC_CH 4
 template <int TOUT, int SRC16>
-__global__ __launch_bounds__(64) void k_iir_check_fix(P3 dst, P3c src, P3 fwd, const float *__restrict__ tails, int *bad, int W, int H, int nchunks, int IF_ROWS, int force, int np, size_t zs) {
+__global__ __launch_bounds__(64 * IC_CH) void k_iir_check_fix(P3 dst, P3c src, P3 fwd, const float *__restrict__ tails, int *bad, int W, int H, int nchunks, int IF_ROWS, int force, int np, size_t zs) {
   const int x = blockIdx.x * 64 + threadIdx.x;
-  const int k = blockIdx.y % np, c = blockIdx.z;
+  const int k = blockIdx.y % np, c = blockIdx.z * IC_CH + threadIdx.y;      // (one wave per chunk, IC_CH chunks per block: a block per wave was 6000 dispatches per plane set)
+  if (c >= nchunks) return;
   { const size_t rd_zoff_ = (size_t)(blockIdx.y / np) * zs; RD_ZS1(dst.p[0]); RD_ZS1(dst.p[1]); RD_ZS1(dst.p[2]); RD_ZS1(src.p[0]); RD_ZS1(src.p[1]); RD_ZS1(src.p[2]); RD_ZS1(fwd.p[0]); RD_ZS1(fwd.p[1]); RD_ZS1(fwd.p[2]); RD_ZS1(tails); RD_ZS1(bad); }
   if (x >= W) return;
   const int s0 = c * IF_ROWS, s1 = (c == nchunks - 1) ? H : s0 + IF_ROWS;
@@ -904,10 +906,11 @@ void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3]
 #undef IF_LAUNCH_R
 #undef IF_LAUNCH
   if (nchunks > 1) {
+    const dim3 cgrid(grid.x, grid.y, cdiv(nchunks, IC_CH)), cblock(64, IC_CH);
     const int force = getenv("RD_IIR_FORCE_FIX") ? 1 : 0;             // diagnostics: every column takes the full-length path
-    if (transpose_out && src16) hipLaunchKernelGGL((k_iir_check_fix<1, 1>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force, np, zs);
-    else if (transpose_out) hipLaunchKernelGGL((k_iir_check_fix<1, 0>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force, np, zs);
-    else hipLaunchKernelGGL((k_iir_check_fix<0, 0>), grid, dim3(64), 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force, np, zs);
+    if (transpose_out && src16) hipLaunchKernelGGL((k_iir_check_fix<1, 1>), cgrid, cblock, 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force, np, zs);
+    else if (transpose_out) hipLaunchKernelGGL((k_iir_check_fix<1, 0>), cgrid, cblock, 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force, np, zs);
+    else hipLaunchKernelGGL((k_iir_check_fix<0, 0>), cgrid, cblock, 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force, np, zs);
   }
   (void)bwd;
 }
