@@ -161,7 +161,7 @@ def side_config(ra, L, label, iw, ih, seed, nframes, slots, dev, min_seconds=1.5
         passes += 1
     dt = time.perf_counter() - t0
     fps = passes * nframes / dt
-    out = {"workload": label, "frame": "%dx%d" % (iw, ih), "stream_frames": nframes, "passes": passes, "frames_in_flight": slots, "value": round(fps, 2), "unit": "frames/s",
+    out = {"workload": label, "frame": "%dx%d" % (iw, ih), "stream_frames": nframes, "passes": passes, "frames_in_flight": slots, "frames_per_launch": det.frames_per_launch(), "value": round(fps, 2), "unit": "frames/s",
            "gpixel_per_s": round(fps * N / 1e9, 3), "roofline_frac": round(fps * B_ALG_PER_PIXEL * N / HBM_PEAK, 4), "rectangles_per_frame": round(nrect / (passes * nframes), 2),
            "frames_repeated": {"round_budget": det.region_round_budget()[1], "polyline_overflow": det.redone_frames(), "absorption_slow_path": det.absorption()[2]}}
     det.close()
@@ -339,7 +339,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i32/f32 (bit-exact integer + IEEE f32 stencil path)", "data": "synthetic",
             "config": {"workload": "vidrect 1920x1080 synthetic stream per GPU (BASELINE.json configs[4]; configs[1] is one frame of it)",
-                       "frames_per_step": F, "frames_in_flight": args.slots, "input": "BGR u8 host buffers (PCIe upload timed)" if args.host_frames else "BGR u8 frames resident in HBM", "parallelism": "independent streams, one per GPU, no collective"},
+                       "frames_per_step": F, "frames_in_flight": args.slots, "frames_per_launch": None if args.dry_run else det.frames_per_launch(), "input": "BGR u8 host buffers (PCIe upload timed)" if args.host_frames else "BGR u8 frames resident in HBM", "parallelism": "independent streams, one per GPU, no collective"},
             "ranks": per_rank,
             "value_definition": "frames resident in HBM when the timed region starts (bench contract); value_host_frames = the same work with host BGR buffers handed over, "
                                 "memcpy into pinned memory + PCIe upload inside the timed region (SURVEY.md 8(d)'s unit of work), same process, N=1 only",
@@ -356,7 +356,7 @@ def main():
                          "traffic": traffic, "traffic_unit": "bytes/frame", "traffic_source": traffic_src,
                          # HIP events on each frame's own stream over the timed region (rank 0): first kernel start -> last copy end.
                          # With several frames in flight these intervals overlap, which is why `achieved` is taken from the aggregate rate.
-                         "frame_device_us_avg": round((dev1[0] - dev0[0]) / max(1, dev1[1] - dev0[1]), 1), "frames_in_flight": args.slots,
+                         "frame_device_us_avg": round((dev1[0] - dev0[0]) / max(1, dev1[1] - dev0[1]), 1), "frames_in_flight": args.slots, "frames_per_launch": None if args.dry_run else det.frames_per_launch(),
                          "host_enqueue_us_avg": round((enq1 - enq0) / max(1, dev1[1] - dev0[1]), 1),
                          # rectangles from segments + probes: on the host's worker threads (one per frame slot, CPU time per frame) or - RD_DEVICE_POST=1 - on the device
                          "postprocess": {"frames_on_device": post1[0] - post0[0], "frames_on_host": post1[1] - post0[1],

@@ -272,6 +272,10 @@ class Detector:
         """frames whose polyline stage overflowed the single-launch kernel and was repeated the long way"""
         return lib().rd_detector_counter(self.h, 0)
 
+    def frames_per_launch(self):
+        """frames that share one set of launches (group launches, rd_detector_counter 15)"""
+        return lib().rd_detector_counter(self.h, 15)
+
     def region_round_budget(self):
         """(current region-merge round budget, frames repeated with the full budget because theirs was too small)"""
         return lib().rd_detector_counter(self.h, 5), lib().rd_detector_counter(self.h, 4)

@@ -1217,6 +1217,7 @@ long rd_detector_counter(rd_detector *d, int which) {
   if (which == 12) return __atomic_load_n(&d->n_post_host, __ATOMIC_RELAXED);
   if (which == 13) return __atomic_load_n(&d->host_post_ns, __ATOMIC_RELAXED) / 1000;
   if (which == 14) return __atomic_load_n(&d->n_redo_absorb, __ATOMIC_RELAXED);
+  if (which == 15) return d->zb;      // frames per group launch (1: every frame its own launches)
   if (which >= 40 && which <= 60) return d->need_count[which - 40];      // frames whose region merge needed 0..20 launches (the one that changes nothing included; 20: or more)
   if (which == 1) return d->dev_us;
   if (which == 2) return d->dev_frames;
