@@ -68,10 +68,13 @@ hbm = int((rd * corr_rd + wr * corr_wr) * 1024)
 commit = subprocess.run(["git", "-C", R, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
 captured = open(os.path.join(C, "commit.txt")).read().strip() if os.path.exists(os.path.join(C, "commit.txt")) else None
 dirty = subprocess.run(["git", "-C", R, "status", "--porcelain", "--", "rectdetect_amd", "bench.py"], capture_output=True, text=True).stdout.strip()
-if captured != commit or dirty:
+# (the measured code - library, bench, capture scripts - must be what HEAD holds; commits that touch nothing of it, e.g. this script, may lie between)
+MEASURED = ["rectdetect_amd", "include", "bench.py", "tools/gpu_capture.sh", "tools/gpu_pmc.sh", "tools/pmc_calibrate.py", "tools/size_sweep.py"]
+moved = captured is None or subprocess.run(["git", "-C", R, "diff", "--quiet", captured, "HEAD", "--"] + MEASURED).returncode != 0
+if moved or dirty:
     sys.exit("distill_capture: the capture ran at %s, HEAD is %s%s - profiles must describe the code that is benchmarked: capture again (tools/capture_round.sh)" % (captured, commit, " with uncommitted changes" if dirty else ""))
 with open(os.path.join(P, ROUND + "_traffic.json"), "w") as f:
-    json.dump({"commit": commit, "command": TRAFFIC_CMD, "frames": nf_rd,
+    json.dump({"commit": captured, "command": TRAFFIC_CMD, "frames": nf_rd,
                "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over the benchmarked configuration (default slots, graphs on; profiles/%s_pmc_traffic_1080p.txt); "
                "each corrected by the factor the calibration copy of 3 x 1 GiB (4 B/lane coalesced, tools/pmc_calibrate.py) yields in the same capture "
                "(FETCH_SIZE reports half of the bytes read on gfx950, as MI355X_MICROARCH.md describes)" % pre,
