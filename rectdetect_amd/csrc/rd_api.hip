@@ -285,6 +285,7 @@ struct Slot {
   hipEvent_t ev_redo;                        // end of a repeated part of the frame (slot_finish_device)
   hipStream_t st_redo;                       // created on first use: the slow absorption path (frame_absorb_slow), fetches of long lists
   int *big_probes; int big_probes_cap;       // probes of a frame with more segments than `probes` holds (grows on demand)
+  const int8_t *prev_in;                  // the strong mask this slot's frame read (plane of rd_detector::prev_ring)
   uint8_t *bgr;
   const uint8_t *src;                     // where the frame in flight is read from: bgr (uploaded) or the caller's device buffer
   uint32_t *plab0, *plab1, *smooth, *quant;
@@ -338,7 +339,10 @@ struct rd_detector {
   int nstreams;
   int zb;                 // frames per launch of the DENSE stages as well (groups of zb consecutive slots, frame = blockIdx.z): small frames, whose launches do not fill the device
   char *arena; size_t slot_pitch;      // zb > 1: all slots' planes in one allocation, slot k at arena + k * slot_pitch
-  int8_t *prev_strong;    // strong-edge mask of the previous frame (reference quirk H1), one byte per pixel
+  // strong-edge masks of the last frames (reference quirk H1: a frame's strength sums start from the mask of the frame before), one byte per
+  // pixel: a ring of nslots + 1 planes - frame t reads plane t mod (nslots + 1) and writes the next one, so what a frame read stays intact as
+  // long as its slot's planes do (debug plane "strsum")
+  int8_t *prev_ring; int nring;
   hipEvent_t last_strong; int have_last_strong;
   long next_enqueue, next_poll;
   int last_polled_slot;
@@ -532,6 +536,19 @@ static void frame_absorb_slow(rd_detector *d, Slot *s) {
   s->h_ctr[52] = 0;
 }
 
+// The whole frame-to-frame dependency chain in ONE launch (not captured: its planes change from frame to frame): this frame's strong mask
+// (what oclrect.c:307-313 derives from the strength sums) from the sums + the strong mask of the frame before (H1, oclrect.c:274-275: the
+// reference starts the sums from that mask; here the mask's element is added where a sum is read).  The same pass yields the edge mask at
+// 500 of oclrect.c:277-284 and filters the labels at 2500 (filtering once at 2500 equals filtering at 500 and then at 2500, and both
+// masks come from the unfiltered labels).
+static void frame_strong(rd_detector *d, Slot *s, hipStream_t st) {
+  const size_t N = (size_t)d->N;
+  const long t = s->seq;
+  s->prev_in = d->prev_ring + (size_t)(t % d->nring) * N;
+  int8_t *out = d->prev_ring + (size_t)((t + 1) % d->nring) * N;
+  rdk::strength_masks(st, s->strong, out, NULL, s->e8, s->label1, s->strsum, 500, 2500, d->iw, d->ih, s->prev_in);
+}
+
 static void frame_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t st_over = NULL) {
   const int iw = d->iw, ih = d->ih, N = d->N;
   hipStream_t st = st_over ? st_over : s->st;
@@ -551,16 +568,8 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t 
   // components (background included) of the tidied mask; the tidy itself runs inside the labelling's tile kernel (and clears the
   // strength sums for the H1 segment); the walk to the roots happens in the first kernel of the next segment
   rdk::label8_tidy(st, s->label1, s->mask0, s->tidy, s->nms, s->strsum, iw, ih, 1);
-  return;
-  }
-  if (seg == 1) {
-  // strength sums on top of last frame's strong mask (H1, oclrect.c:274-275) and - at once - this frame's strong mask
-  // (what oclrect.c:307-313 derives from the sums later): nothing else of a frame is needed by the next one, so this
-  // short segment is the whole frame-to-frame dependency chain
-  rdk::calc_strength(st, s->strsum, s->nms, s->label1, iw, ih, d->prev_strong, 1);
-  // (the same pass also yields the edge mask at 500 of oclrect.c:277-284 and filters the labels at 2500, oclrect.c:307-313:
-  //  filtering once at 2500 equals filtering at 500 and then at 2500, and both masks come from the unfiltered labels)
-  rdk::strength_masks(st, s->strong, d->prev_strong, NULL, s->e8, s->label1, s->strsum, 500, 2500, iw, ih);
+  // strength sums per component (oclrect.c:274-275) - without the strong mask of the frame before (H1), which frame_strong() adds
+  rdk::calc_strength(st, s->strsum, s->nms, s->label1, iw, ih, NULL, 1);
   return;
   }
   // Three chains leave this point and meet again before the region stage / the votes:
@@ -646,7 +655,7 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   rdk::bgr2plab_transposed(s->st, s->plab0, s->tr, s->src, d->iw, d->ih, ws);
   run_segment(d, s, ws, 0);
   if (d->have_last_strong) RD_HIP(hipStreamWaitEvent(s->st, d->last_strong, 0));
-  run_segment(d, s, ws, 1);
+  frame_strong(d, s, s->st);
   RD_HIP(hipEventRecord(s->ev_strong, s->st));
   d->last_strong = s->ev_strong; d->have_last_strong = 1;
   s->rounds = d->fixed_rounds ? d->fixed_rounds : __atomic_load_n(&d->rounds_budget, __ATOMIC_RELAXED);
@@ -681,6 +690,7 @@ static void group_segment(rd_detector *d, Slot *s, int nz, int seg, hipStream_t 
     rdk::edge_plab(st, s->strength, s->plab1, iw, ih, nz, zs);
     rdk::thinthres(st, s->nms, s->strength, s->vxy, iw, ih, nz, zs);
     rdk::label8_tidy(st, s->label1, s->mask0, s->tidy, s->nms, s->strsum, iw, ih, 1, nz, zs);
+    rdk::calc_strength(st, s->strsum, s->nms, s->label1, iw, ih, NULL, 1, nz, zs);
     return;
   }
   // seg 2: everything after the strong masks, in the order of a single frame on one stream (frame_segment, RD_NO_FORK)
@@ -758,7 +768,7 @@ static void group_launch(rd_detector *d, int g0) {
   for (int i = 0; i < zb; i++) {      // the strong masks, frame by frame (each on top of its predecessor's)
     Slot *s = &d->slots[g0 + i];
     if (d->have_last_strong) RD_HIP(hipStreamWaitEvent(st, d->last_strong, 0));
-    run_segment(d, s, ws, 1, st);
+    frame_strong(d, s, st);
     RD_HIP(hipEventRecord(s->ev_strong, st));
     d->last_strong = s->ev_strong; d->have_last_strong = 1;
   }
@@ -1009,8 +1019,9 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->maxrec_dev = d->N * 16 / 56;
   if (d->maxrec_dev > 65536) d->maxrec_dev = 65536;      // the slots' probe buffers; frames with more records are probed again into a buffer that grows (slot_rectangles)
   if (getenv("RD_MAXREC_DEV")) { const int m = atoi(getenv("RD_MAXREC_DEV")); if (m >= 16 && m < d->maxrec_dev) d->maxrec_dev = m; }      // (tests: exercise that path)
-  d->prev_strong = dnew<int8_t>((size_t)d->N);
-  RD_HIP(hipMemset(d->prev_strong, 0, (size_t)d->N));
+  d->nring = nslots + 1;
+  d->prev_ring = dnew<int8_t>((size_t)d->N * d->nring);
+  RD_HIP(hipMemset(d->prev_ring, 0, (size_t)d->N * d->nring));
   d->use_graph = getenv("RD_NO_GRAPH") ? 0 : 1;
   d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : (getenv("RD_POLY_COOP") ? 2 : 1);      // (RD_POLY_COOP: the cooperative launch for every frame - tests)
   d->force_redo = (getenv("RD_POLY_FORCE_REDO") ? 1 : 0) | (getenv("RD_ABSORB_FORCE_SLOW") ? 2 : 0);   // tests: every frame also takes the polyline / absorption fallback
@@ -1107,7 +1118,7 @@ void rd_detector_destroy(rd_detector *d) {
   free(d->slots);
   free(d->frames);
   if (d->sparse_st) RD_HIP(hipStreamDestroy(d->sparse_st));
-  dfree(d->prev_strong);
+  dfree(d->prev_ring);
   dfree(d->arena);
   free(d->last_segs);
   d->magic = 0;
@@ -1261,6 +1272,13 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
         return n * 4;
       }
       RD_HIP(hipMemcpy(dst, tab[i].p, b, hipMemcpyDeviceToHost));
+      if (!strcmp(name, "strsum") && s->prev_in) {      // the reference's plane holds the sums ON TOP of the previous frame's strong mask (H1): added here, where it is looked at
+        const size_t n = b / 4;
+        int8_t *tmp = (int8_t *)malloc(n ? n : 1);
+        RD_HIP(hipMemcpy(tmp, s->prev_in, n, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < n; k++) ((int *)dst)[k] += tmp[k];
+        free(tmp);
+      }
       return b;
     }
   return 0;

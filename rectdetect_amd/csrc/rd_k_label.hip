@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256) void k_label_flatten(int *label, int n, int *v
 #define CS_T 1024      // hash slots per block (64 x 16 pixels, a third of them contributing)
 // (flatten: the labels arrive as the trees the border kernel left - phase 3 of the labelling, k_label_flatten, is done here on the way:
 //  each pixel walks to its root and stores it; any interleaving only ever stores roots)
-__global__ __launch_bounds__(256) void k_calc_strength(int *out, const float *__restrict__ edge, int *label, int iw, int ih, const int8_t *__restrict__ add, int flatten) {
+__global__ __launch_bounds__(256) void k_calc_strength(int *out, const float *__restrict__ edge, int *label, int iw, int ih, const int8_t *__restrict__ add, int flatten, size_t zs) {
+  RD_ZSHIFT(zs, out, edge, label);      // (`add` belongs to no frame slot: group launches pass none)
   __shared__ int keys[CS_T], vals[CS_T];
   const int tid = threadIdx.y * 64 + threadIdx.x;
   for (int t = tid; t < CS_T; t += 256) { keys[t] = -1; vals[t] = 0; }
@@ -365,13 +366,15 @@ __global__ __launch_bounds__(256) void k_filter_strength(int *label, const int *
 // reaches t_strong, the frame ring is never filtered), the edge mask at t_edge as int and int8 (oclrect.c:277-284) - both from
 // the unfiltered labels - and the labels filtered at t_strong in place (filtering at t_edge first changes nothing).
 __global__ __launch_bounds__(256) void k_strength_masks(int *__restrict__ strong, int8_t *__restrict__ strong2, int *__restrict__ edge, int8_t *__restrict__ edge8,
-                                                         int *__restrict__ label, const int *__restrict__ str, int t_edge, int t_strong, int iw, int ih) {
+                                                         int *__restrict__ label, const int *__restrict__ str, int t_edge, int t_strong, int iw, int ih, const int8_t *__restrict__ prev) {
   const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
   if (x >= iw || y >= ih) return;
   const int p = y * iw + x;
   const int l = label[p];
   const bool interior = x > 0 && y > 0 && x < iw - 1 && y < ih - 1;
-  const int sum = (l > 0 && interior) ? str[l] : 0;
+  // (prev, optional: the strong mask of the frame before - quirk H1 - as a 0/1 byte plane that is added to the sums element by element:
+  //  sum of label l = str[l] + prev[l]; then `strong2` must be another plane, other threads still read this one)
+  const int sum = (l > 0 && interior) ? str[l] + (prev ? (int)prev[l] : 0) : 0;
   const int vs = (l > 0 && !(interior && sum < t_strong)) ? 1 : 0;
   const int ve = (l > 0 && !(interior && sum < t_edge)) ? 1 : 0;
   strong[p] = vs; strong2[p] = (int8_t)vs;       // (the copy for the next frame: a byte plane - it is read once, as an addend)
@@ -424,12 +427,12 @@ void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, i
   hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g, 1, nz), dim3(256), 0, s, label, n, vt_table, vt_claim, vt_list, zs);
 }
 
-void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int iw, int ih, const int8_t *add, int flatten) {
-  hipLaunchKernelGGL(k_calc_strength, dim3(cdiv(iw, 64), cdiv(ih, 4 * CS_ROWS)), block2, 0, s, out, edge, label, iw, ih, add, flatten);
+void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int iw, int ih, const int8_t *add, int flatten, int nz, size_t zs) {
+  hipLaunchKernelGGL(k_calc_strength, dim3(cdiv(iw, 64), cdiv(ih, 4 * CS_ROWS), nz), block2, 0, s, out, edge, label, iw, ih, add, flatten, zs);
 }
 
-void strength_masks(hipStream_t s, int *strong, int8_t *strong2, int *edge, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih) {
-  hipLaunchKernelGGL(k_strength_masks, grid2(iw, ih), block2, 0, s, strong, strong2, edge, edge8, label, str, t_edge, t_strong, iw, ih);
+void strength_masks(hipStream_t s, int *strong, int8_t *strong2, int *edge, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih, const int8_t *prev) {
+  hipLaunchKernelGGL(k_strength_masks, grid2(iw, ih), block2, 0, s, strong, strong2, edge, edge8, label, str, t_edge, t_strong, iw, ih, prev);
 }
 
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih) {

@@ -61,10 +61,11 @@ void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, 
 void label8_tidy(hipStream_t s, int *label, int *mask0, int *tidy, const float *nms, int *zero_plane, int iw, int ih, int skip_flatten = 0, int nz = 1, size_t zs = 0);   // rect_tidy + label8(tidy, background -1) in the same tile kernel
 void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih, int *vt_table = nullptr, int *vt_claim = nullptr, int *vt_list = nullptr, int nz = 1, size_t zs = 0);   // mark_boundary + label8(marks, background -1) with the marking fused into the tile kernel
 // add (optional): a plane whose non-zero elements are added to out element by element in the same launch (out = zeros + add + sums)
-void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int iw, int ih, const int8_t *add = nullptr, int flatten = 0);   // add (optional): a 0/1 byte plane added to the sums (H1)
+void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int iw, int ih, const int8_t *add = nullptr, int flatten = 0, int nz = 1, size_t zs = 0);   // add (optional): a 0/1 byte plane added to the sums (H1)
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih);
 // strong mask at t_strong (two copies) + edge mask at t_edge (int, int8), both from the unfiltered labels, + filter_strength at t_strong (label in place), one pass; t_edge <= t_strong
-void strength_masks(hipStream_t s, int *strong, int8_t *strong2, int *edge /* may be NULL */, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih);
+// prev (optional): a 0/1 byte plane added to the sums element by element (sum of label l = str[l] + prev[l]: quirk H1 without a pass of its own); strong2 != prev
+void strength_masks(hipStream_t s, int *strong, int8_t *strong2, int *edge /* may be NULL */, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih, const int8_t *prev = nullptr);
 
 // ---- rd_k_rect.hip: rect-path stages
 void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih, int *merge_mask_scratch = nullptr, int nz = 1, size_t zs = 0);   // merge_mask_scratch (optional): also leaves merge_mask's bit rows there (then call merge_mask with junction = nullptr)
