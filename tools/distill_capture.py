@@ -19,12 +19,12 @@ for src, dst in (("bench_default.json", "bench_default.json"), ("bench_slots1.js
 with open(os.path.join(P, pre + "_size_sweep.txt"), "w") as f:
     f.write("# tools/size_sweep.py, SLOTS=16\n" + open(os.path.join(C, "size_sweep.txt")).read())
 
-# kernel traces: frames = launches of the one kernel that every frame launches on its own, grouped or not (the strength sums: they
-# start from the previous frame's strong mask)
+# kernel traces: frames = launches of the one kernel that every frame launches on its own, grouped or not (the strong mask: it
+# starts from the previous frame's)
 for name, out in (("trace_default", "kernel_stats_1080p_default.txt"), ("trace_slots1", "kernel_stats_1080p_slots1.txt")):
     db = os.path.join(C, name, "t_results.db")
     con = sqlite3.connect(db)
-    frames = con.execute("select total_calls from top_kernels where name like '%k_calc_strength%'").fetchone()[0]
+    frames = con.execute("select total_calls from top_kernels where name like '%k_strength_masks%'").fetchone()[0]
     head = "# rocprofv3 --kernel-trace --stats -- python bench.py %s (%d frames)\n" % (
         "--steps 3 --warmup 1 --frames-per-step 64 --no-cpu-baseline --no-verify --no-configs" if name == "trace_default" else "--steps 1 --warmup 1 --slots 1 --frames-per-step 8 --no-cpu-baseline --no-verify --no-configs", frames)
     with open(os.path.join(P, pre + "_" + out), "w") as f:
@@ -46,7 +46,7 @@ def total(db, counter, like=None):
 
 
 def frames_in(db):
-    return sqlite3.connect(db).execute("select count(*) from counters_collection where kernel_name like '%k_calc_strength%'").fetchone()[0]
+    return sqlite3.connect(db).execute("select count(*) from counters_collection where kernel_name like '%k_strength_masks%'").fetchone()[0]
 
 
 TRAFFIC_CMD = "python bench.py --steps 2 --warmup 1 --frames-per-step 16 --no-cpu-baseline --no-verify --no-configs"
