@@ -161,7 +161,7 @@ def test_rect_outputs_match_reference_golden(name, device_post):
 
 @pytest.mark.parametrize("name,nslots", [("stream_1920x1080_s0", 8), ("stream_1920x1080_s0", 16), ("stream_1280x720_s1", 8), ("stream_1280x720_s1", 2), ("stream_3840x2160_s4", 3),
                                          ("stream_1280x720_s1_300", 16), ("stream_1920x1080_s0_100", 16), ("stream_3840x2160_s4_16", 16),
-                                         ("stream_1920x1080_s7_100", 16)])
+                                         ("stream_1920x1080_s7_100", 16), ("stream_1920x1080_s0_100", 32)])
 def test_long_streams_in_the_benchmarked_configuration_vs_reference(name, nslots):
     """16 consecutive 1920x1080 frames of the bench stream (BASELINE.json configs[4]), 30 frames of the 1280x720 stream
     (configs[2]) and 3 frames of the 3840x2160 stream (configs[3]; its frames overflow the single-launch polyline kernel) - and the

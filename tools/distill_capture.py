@@ -17,7 +17,7 @@ def run(*a):
 for src, dst in (("bench_default.json", "bench_default.json"), ("bench_slots1.json", "bench_slots1.json"), ("bench_slots2.json", "bench_slots2.json")):
     shutil.copy(os.path.join(C, src), os.path.join(P, pre + "_" + dst))
 with open(os.path.join(P, pre + "_size_sweep.txt"), "w") as f:
-    f.write("# tools/size_sweep.py, SLOTS=16\n" + open(os.path.join(C, "size_sweep.txt")).read())
+    f.write("# tools/size_sweep.py, SLOTS=32 (3840x2160: 16)\n" + open(os.path.join(C, "size_sweep.txt")).read())
 
 # kernel traces: frames = launches of the one kernel that every frame launches on its own, grouped or not (the strong mask: it
 # starts from the previous frame's)

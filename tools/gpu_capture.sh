@@ -8,7 +8,7 @@ cp tools/.capture_commit $O/commit.txt 2>/dev/null
 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 python bench.py --slots 1 --no-cpu-baseline --no-configs --frames-per-step 128 > $O/bench_slots1.json 2>> $O/bench_default.err
 python bench.py --slots 2 --no-cpu-baseline --no-configs --frames-per-step 128 > $O/bench_slots2.json 2>> $O/bench_default.err
-SLOTS=16 python tools/size_sweep.py > $O/size_sweep.txt 2>&1
+SLOTS=32 python tools/size_sweep.py > $O/size_sweep.txt 2>&1
 export TMPDIR=/tmp
 cd /tmp
 # kernel trace of the default command (fewer steps) and of one frame slot alone

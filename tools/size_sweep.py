@@ -9,6 +9,7 @@ L = ra.lib()
 TAN = float(np.tan(36.0 / 180 * np.pi))
 for iw, ih in [(640, 480), (1280, 720), (1920, 1080), (3840, 2160)]:
     slots = int(os.environ.get("SLOTS", "16"))
+    if iw * ih > 1920 * 1088: slots = min(slots, 16)
     det = ra.Detector(iw, ih, nslots=slots, nworkers=1)
     frames = []
     for t in range(16):
