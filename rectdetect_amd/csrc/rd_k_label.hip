@@ -44,6 +44,9 @@ __device__ __forceinline__ void lt_union(int *lab, int a, int b) {
 #ifndef LT_TY
 #define LT_TY 4
 #endif
+#ifndef LT_TY1
+#define LT_TY1 LT_TY      // thread rows of the boundary variant (the tidy variant's tile code is written for four waves)
+#endif
 // LT_TY: thread rows per block (16 is ~20% faster run alone, but costs 50% more wave-cycles: worse with frames in flight)
 #define LT_MP 68      // row pitch of the staged region tile of the boundary variant (64 + 2 x 2 cells of halo)
 // BOUNDARY = false: the pixel values are read from `pix`.  BOUNDARY = true: they are the region-boundary marks of oclrect.cl:373-390,
@@ -53,8 +56,8 @@ __device__ __forceinline__ void lt_union(int *lab, int a, int b) {
 // border kernel - one launch and one pass over the plane less than marking first and labelling then.
 // SRC == 2: the pixel values are the rect-variant edge tidy of the NMS response `nms` (rd_tidy_tile.h), computed here and written to
 // mask0 / pix_out (and zero_plane cleared) as k_rect_tidy would.
-template <int SRC>
-__global__ __launch_bounds__(64 * LT_TY) void k_label_tile(int *__restrict__ label, const int *__restrict__ pix, int bgc, int iw, int ih, int *__restrict__ pix_out,
+template <int SRC, int TY>
+__global__ __launch_bounds__(64 * TY) void k_label_tile(int *__restrict__ label, const int *__restrict__ pix, int bgc, int iw, int ih, int *__restrict__ pix_out,
                                                     const float *__restrict__ nms, int *__restrict__ mask0, int *__restrict__ zero_plane, size_t zs) {
   constexpr bool BOUNDARY = SRC == 1;
   RD_ZSHIFT(zs, label, pix, pix_out, nms, mask0, zero_plane);
@@ -64,19 +67,19 @@ __global__ __launch_bounds__(64 * LT_TY) void k_label_tile(int *__restrict__ lab
   const bool xin = x < iw;
   int v00;
   bool uniform = true;
-  int pv8[LT_H / LT_TY];            // this thread's pixels, requested together (one wait for memory instead of one per row)
-  if (SRC == 2) {
+  int pv8[LT_H / TY];            // this thread's pixels, requested together (one wait for memory instead of one per row)
+  if constexpr (SRC == 2) {
     __shared__ __align__(16) uint8_t A[(LT_H + 2 * TD_M) * TD_P], B[(LT_H + 2 * TD_M) * TD_P];
     rect_tidy_tile<LT_H>(A, B, blockIdx.x * LT_W, y0, threadIdx.y * 64 + tx, nms, mask0, pix_out, zero_plane, iw, ih, pv8);
     __shared__ int s_t00;            // the value of the tile's first pixel, for the uniform-tile test below
     if (threadIdx.y == 0 && tx == 0) s_t00 = pv8[0];
     __syncthreads();
     v00 = s_t00;
-  } else if (!BOUNDARY) {
+  } else if constexpr (!BOUNDARY) {
     v00 = pix[(size_t)y0 * iw + blockIdx.x * LT_W];   // the tile's first pixel is always inside the frame
 #pragma unroll
-    for (int k = 0; k < LT_H / LT_TY; k++) {
-      const int y = y0 + threadIdx.y + k * LT_TY;
+    for (int k = 0; k < LT_H / TY; k++) {
+      const int y = y0 + threadIdx.y + k * TY;
       pv8[k] = pix[(xin && y < ih) ? y * iw + x : 0];
     }
   } else {
@@ -85,27 +88,27 @@ __global__ __launch_bounds__(64 * LT_TY) void k_label_tile(int *__restrict__ lab
     const int x0 = blockIdx.x * LT_W, tid = threadIdx.y * 64 + tx;
     const int r00 = pix[(size_t)y0 * iw + x0];
     bool flat = true;
-    stage_cells<(LT_H + 4) * LT_MP, 256>(tid, pix,
+    stage_cells<(LT_H + 4) * LT_MP, 64 * TY>(tid, pix,
       [&](int c, int &a) { const int xx = x0 - 2 + c % LT_MP, yy = y0 - 2 + c / LT_MP; a = yy * iw + xx; return xx >= 0 && xx < iw && yy >= 0 && yy < ih; },
       [&](int c, bool inside, int v) { flat = flat && (!inside || v == r00); t[c] = inside ? v : 0; });
     if (__syncthreads_and(flat)) {
       // no differing cell anywhere in reach: nothing is a boundary pixel, nothing to label
 #pragma unroll
-      for (int k = 0; k < LT_H / LT_TY; k++) {
-        const int y = y0 + threadIdx.y + k * LT_TY;
+      for (int k = 0; k < LT_H / TY; k++) {
+        const int y = y0 + threadIdx.y + k * TY;
         if (xin && y < ih) { pix_out[y * iw + x] = -1; label[y * iw + x] = -1; }
       }
       return;
     }
-    for (int r = threadIdx.y; r < LT_H + 4; r += LT_TY) {
+    for (int r = threadIdx.y; r < LT_H + 4; r += TY) {
       const int *row = t + r * LT_MP + tx + 2;
       const int c = row[0];
       hu[r * 64 + tx] = (row[-2] == c && row[-1] == c && row[1] == c && row[2] == c) ? 1 : 0;
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < LT_H / LT_TY; k++) {
-      const int r = threadIdx.y + k * LT_TY;
+    for (int k = 0; k < LT_H / TY; k++) {
+      const int r = threadIdx.y + k * TY;
       const int y = y0 + r;
       int res = -1;
       if (xin && y < ih && x > 1 && y > 1 && x < iw - 2 && y < ih - 2) {
@@ -124,8 +127,8 @@ __global__ __launch_bounds__(64 * LT_TY) void k_label_tile(int *__restrict__ lab
     v00 = s_v00;
   }
 #pragma unroll
-  for (int k = 0; k < LT_H / LT_TY; k++) {
-    const int r = threadIdx.y + k * LT_TY;
+  for (int k = 0; k < LT_H / TY; k++) {
+    const int r = threadIdx.y + k * TY;
     const int y = y0 + r;
     const bool valid = xin && y < ih;
     const int v = valid ? pv8[k] : 0;
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(64 * LT_TY) void k_label_tile(int *__restrict__ lab
     if (__syncthreads_and(uniform)) {
       const int l = v00 == bgc ? -1 : y0 * iw + blockIdx.x * LT_W;
 #pragma unroll
-      for (int r = threadIdx.y; r < LT_H; r += LT_TY) {
+      for (int r = threadIdx.y; r < LT_H; r += TY) {
         const int y = y0 + r;
         if (xin && y < ih) label[y * iw + x] = l;
       }
@@ -154,7 +157,7 @@ __global__ __launch_bounds__(64 * LT_TY) void k_label_tile(int *__restrict__ lab
   // unions with the row above, inside the tile; a pixel only issues one when no pixel of its run is guaranteed to issue
   // an equivalent one (same case analysis as k_label_border below)
 #pragma unroll
-  for (int r = threadIdx.y; r < LT_H; r += LT_TY) {
+  for (int r = threadIdx.y; r < LT_H; r += TY) {
     if (r == 0) continue;
     const int q = r * LT_W + tx;
     if (lab[q] < 0) continue;
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(64 * LT_TY) void k_label_tile(int *__restrict__ lab
   }
   __syncthreads();
 #pragma unroll
-  for (int r = threadIdx.y; r < LT_H; r += LT_TY) {
+  for (int r = threadIdx.y; r < LT_H; r += TY) {
     const int y = y0 + r;
     if (!xin || y >= ih) continue;
     const int q = r * LT_W + tx;
@@ -389,7 +392,7 @@ namespace rdk {
 
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, int skip_flatten) {
   const size_t zs = 0;
-  hipLaunchKernelGGL(k_label_tile<0>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, pix, bgc, iw, ih, (int *)nullptr, (const float *)nullptr, (int *)nullptr, (int *)nullptr, zs);
+  hipLaunchKernelGGL((k_label_tile<0, LT_TY>), dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, pix, bgc, iw, ih, (int *)nullptr, (const float *)nullptr, (int *)nullptr, (int *)nullptr, zs);
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
   if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb), dim3(256), 0, s, label, pix, bgc, iw, ih, hb, zs);
@@ -401,7 +404,7 @@ void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, 
 
 // rect_tidy(mask0, tidy, nms, zero_plane) + label8(label, tidy, background -1, skip_flatten) with the tidy computed inside the tile kernel
 void label8_tidy(hipStream_t s, int *label, int *mask0, int *tidy, const float *nms, int *zero_plane, int iw, int ih, int skip_flatten, int nz, size_t zs) {
-  hipLaunchKernelGGL(k_label_tile<2>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H), nz), dim3(64, LT_TY), 0, s, label, (const int *)nullptr, -1, iw, ih, tidy, nms, mask0, zero_plane, zs);
+  hipLaunchKernelGGL((k_label_tile<2, 4>), dim3(cdiv(iw, LT_W), cdiv(ih, LT_H), nz), dim3(64, 4), 0, s, label, (const int *)nullptr, -1, iw, ih, tidy, nms, mask0, zero_plane, zs);
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
   // (this plane is labelled with its background, one component that spans the frame: uniting the tiles of a row first and the rows
@@ -418,7 +421,7 @@ void label8_tidy(hipStream_t s, int *label, int *mask0, int *tidy, const float *
 
 // region boundaries (oclrect.cl:373-390) marked into `marks` and their 8-connected components labelled into `label`
 void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih, int *vt_table, int *vt_claim, int *vt_list, int nz, size_t zs) {
-  hipLaunchKernelGGL(k_label_tile<1>, dim3(cdiv(iw, LT_W), cdiv(ih, LT_H), nz), dim3(64, LT_TY), 0, s, label, region, -1, iw, ih, marks, (const float *)nullptr, (int *)nullptr, (int *)nullptr, zs);
+  hipLaunchKernelGGL((k_label_tile<1, LT_TY1>), dim3(cdiv(iw, LT_W), cdiv(ih, LT_H), nz), dim3(64, LT_TY1), 0, s, label, region, -1, iw, ih, marks, (const float *)nullptr, (int *)nullptr, (int *)nullptr, zs);
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
   if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb, 1, nz), dim3(256), 0, s, label, (const int *)marks, -1, iw, ih, hb, zs);
