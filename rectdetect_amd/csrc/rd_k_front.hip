@@ -875,11 +875,14 @@ void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], 
 // (measured at 1080p, one wave per SIMD with 96 / 112 rows: 62 / 55 us; 32, 48, 64 rows: 48, 45, 50 us with transposed output,
 // 37, 38, 40 us without).  RD_IIR_ROWS
 // overrides (32, 48, 64, 96, 112, 128).
-static int if_pick_rows(int np, int W, int H, int transpose_out) {
+static int if_pick_rows(int np, int W, int H, int transpose_out, int nz) {
   (void)np; (void)W; (void)H;
   static const int forced = getenv("RD_IIR_ROWS") ? atoi(getenv("RD_IIR_ROWS")) : 0;
   if (forced == 32 || forced == 64 || forced == 96 || forced == 128) return forced;
   (void)transpose_out;
+  // (group launches: 128 rows - a quarter instead of half as much run-in, half as many borders to check; 2154-2167 against 2121-2151 frames/s
+  //  in four interleaved pairs of runs; single frames keep 64: more blocks for the same device)
+  if (nz > 1) return 128;
   return 64;     // 32 rows of run-in per 64 rows of output: with several frames in flight the instruction count matters more than the wave count (48 / 32 rows ran 5 % slower there, though faster alone)
 }
 
@@ -892,7 +895,7 @@ size_t iir_pass_scratch_floats(int np, int W, int H) { return (size_t)np * if_nc
 // src16 (only with transpose_out): the source planes hold 16-bit Lab fields (bgr2plab_transposed), plane 0 = L
 void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3], float *const fwd[3], float *const bwd[3], int np, int W, int H,
                    int transpose_out, float *tails, int *bad, int src16, int nz, size_t zs) {
-  const int rows = if_pick_rows(np, W, H, transpose_out);
+  const int rows = if_pick_rows(np, W, H, transpose_out, nz);
   const int nchunks = if_nchunks(H, rows);
   const dim3 grid(cdiv(W, 64), np * nz, nchunks);
 #define IF_LAUNCH(T, R, S16) hipLaunchKernelGGL((k_iir_fused<T, R, S16>), grid, dim3(128), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks, bad, np, zs)
