@@ -494,7 +494,9 @@ __device__ __forceinline__ float v5c(int i) {
 // (pack_out, optional: the packed Lab of the pixel's own blurred L, a, b - iu:28-34 - on the way: saves the frame path a launch)
 // Every thread handles EV_PX pixels below one another: their 5x5 windows overlap in all but one row each, so a column of four
 // costs 8 x 5 loads instead of 100 (same sums in the same order per pixel).
+#ifndef EV_PX
 #define EV_PX 4
+#endif
 __device__ __forceinline__ void ev_finish(float2 *__restrict__ dst, int p, float vx, float vy) {
   float len = vx * vx + vy * vy;
   if ((double)len > 1e-10) {
@@ -560,7 +562,9 @@ __global__ __launch_bounds__(256) void k_edgevec(float2 *__restrict__ dst, const
 // (blocks whose 3x3 windows stay inside the frame - all but the frame's rim - address their neighbours by constant offsets: the
 //  mirrored-index arithmetic of the general form costs as many instructions as the gradient itself)
 // (every thread handles EP_PX pixels below one another: a column of four unpacks 6 x 3 cells instead of 32)
+#ifndef EP_PX
 #define EP_PX 4
+#endif
 __device__ __forceinline__ float ep_strength(const float (&n)[3], const float (&s)[3], const float (&w)[3], const float (&e)[3],
                                              const float (&nw)[3], const float (&ne)[3], const float (&sw)[3], const float (&se)[3]) {
   float sum[3];
@@ -630,7 +634,9 @@ __device__ __forceinline__ float bicubic(const float *__restrict__ p, float x, f
 // (64+8) x (TT_ROWS+7) tile of the strength plane in LDS with the mirrored border already applied, so a bicubic is one
 // address computation and 16 ds_reads at constant offsets instead of 8 mirror clamps and 16 global gathers.  The outer
 // two samples are only evaluated for local maxima (they do not influence the comparison).
+#ifndef TT_ROWS
 #define TT_ROWS 8
+#endif
 #define TT_PITCH 72
 __device__ __forceinline__ float bicubic_lds(const float *t, float x, float y, int x0, int y0) {
   const int ix = (int)x, iy = (int)y;

@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) void k_rect_tidy(int *__restrict__ mask0, int 
 //       c > n-1, or (centre on an edge ? !E[c] : !E[c] & E[c+1]).
 // Cells outside the frame are staged as zero, which makes the reference's `c < n-1` and `has side cell` tests redundant.
 // A pixel then reads its five relevant stop bits per direction and counts the leading clear ones.
+#ifndef BE_ROWS
 #define BE_ROWS 32
+#endif
 #define BE_NR (BE_ROWS + 11)          // rows y0-5 .. y0+BE_ROWS+5
 __global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ ext, const int8_t *__restrict__ edge, int iw, int ih, size_t zs) {
   RD_ZSHIFT(zs, ext, edge);
@@ -324,7 +326,9 @@ __global__ void k_quant24_lut() {
 // One block per 64 x DS_ROWS tile: the tile and a 1-cell halo of both inputs are staged in LDS (colours already quantised,
 // the response reduced to flags) with all loads of a thread in flight together; the affected pixels - a few per cent, on thin
 // lines that cross a third of all waves - are collected in an LDS list and worked off with all lanes busy, from LDS only.
+#ifndef DS_ROWS
 #define DS_ROWS 16
+#endif
 #define DS_P 66
 // QN > 0: the input is quantised to QN levels per field on the fly (rc:207-216 fused in: no separate pass over the plane)
 template <int QN>
