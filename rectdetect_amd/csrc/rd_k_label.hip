@@ -368,22 +368,56 @@ __global__ __launch_bounds__(256) void k_filter_strength(int *label, const int *
 // the next frame - all the next frame needs from this one; interior pixels keep a label > 0 exactly when their sum
 // reaches t_strong, the frame ring is never filtered), the edge mask at t_edge as int and int8 (oclrect.c:277-284) - both from
 // the unfiltered labels - and the labels filtered at t_strong in place (filtering at t_edge first changes nothing).
+__device__ __forceinline__ void strength_mask_one(int l, int sum, bool interior, int t_edge, int t_strong, int &vs, int &ve, int &lnew) {
+  vs = (l > 0 && !(interior && sum < t_strong)) ? 1 : 0;
+  ve = (l > 0 && !(interior && sum < t_edge)) ? 1 : 0;
+  lnew = (interior && l != -1 && (l <= 0 || sum < t_strong)) ? -1 : l;
+}
+// (prev, optional: the strong mask of the frame before - quirk H1 - as a 0/1 byte plane that is added to the sums element by element:
+//  sum of label l = str[l] + prev[l]; then `strong2` must be another plane, other threads still read this one)
+// VEC: four consecutive pixels of a row per thread (rows are 16-byte aligned: iw % 4 == 0) - one 16-byte load of the labels, the eight
+// gathers of the sums in flight together, 16-byte / 4-byte stores instead of four 4-byte / 1-byte ones.  This kernel is the frame-to-frame
+// chain: it runs alone, once per frame.
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_strength_masks(int *__restrict__ strong, int8_t *__restrict__ strong2, int *__restrict__ edge, int8_t *__restrict__ edge8,
                                                          int *__restrict__ label, const int *__restrict__ str, int t_edge, int t_strong, int iw, int ih, const int8_t *__restrict__ prev) {
+  if (VEC) {
+    const int x = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
+    if (x >= iw || y >= ih) return;
+    const int p = y * iw + x;
+    const int4 lv = *(const int4 *)(label + p);
+    const int l[4] = { lv.x, lv.y, lv.z, lv.w };
+    const bool rowin = y > 0 && y < ih - 1;
+    bool interior[4]; int sa[4], sb[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      interior[k] = rowin && x + k > 0 && x + k < iw - 1;
+      const bool need = l[k] > 0 && interior[k];
+      sa[k] = str[need ? l[k] : 0];
+      sb[k] = prev ? (int)prev[need ? l[k] : 0] : 0;
+    }
+    int vs[4], ve[4], ln[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) strength_mask_one(l[k], (l[k] > 0 && interior[k]) ? sa[k] + sb[k] : 0, interior[k], t_edge, t_strong, vs[k], ve[k], ln[k]);
+    *(int4 *)(strong + p) = make_int4(vs[0], vs[1], vs[2], vs[3]);
+    *(uint32_t *)(strong2 + p) = (uint32_t)vs[0] | ((uint32_t)vs[1] << 8) | ((uint32_t)vs[2] << 16) | ((uint32_t)vs[3] << 24);
+    if (edge != nullptr) *(int4 *)(edge + p) = make_int4(ve[0], ve[1], ve[2], ve[3]);
+    *(uint32_t *)(edge8 + p) = (uint32_t)ve[0] | ((uint32_t)ve[1] << 8) | ((uint32_t)ve[2] << 16) | ((uint32_t)ve[3] << 24);
+    if (ln[0] != l[0] || ln[1] != l[1] || ln[2] != l[2] || ln[3] != l[3]) *(int4 *)(label + p) = make_int4(ln[0], ln[1], ln[2], ln[3]);
+    return;
+  }
   const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
   if (x >= iw || y >= ih) return;
   const int p = y * iw + x;
   const int l = label[p];
   const bool interior = x > 0 && y > 0 && x < iw - 1 && y < ih - 1;
-  // (prev, optional: the strong mask of the frame before - quirk H1 - as a 0/1 byte plane that is added to the sums element by element:
-  //  sum of label l = str[l] + prev[l]; then `strong2` must be another plane, other threads still read this one)
   const int sum = (l > 0 && interior) ? str[l] + (prev ? (int)prev[l] : 0) : 0;
-  const int vs = (l > 0 && !(interior && sum < t_strong)) ? 1 : 0;
-  const int ve = (l > 0 && !(interior && sum < t_edge)) ? 1 : 0;
+  int vs, ve, ln;
+  strength_mask_one(l, sum, interior, t_edge, t_strong, vs, ve, ln);
   strong[p] = vs; strong2[p] = (int8_t)vs;       // (the copy for the next frame: a byte plane - it is read once, as an addend)
   if (edge != nullptr) edge[p] = ve;             // (the int form of the edge mask is a test plane only: rd_detector_debug_plane widens the bytes)
   edge8[p] = (int8_t)ve;
-  if (interior && l != -1 && (l <= 0 || sum < t_strong)) label[p] = -1;
+  if (ln != l) label[p] = ln;
 }
 
 }  // namespace
@@ -435,7 +469,10 @@ void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int i
 }
 
 void strength_masks(hipStream_t s, int *strong, int8_t *strong2, int *edge, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih, const int8_t *prev) {
-  hipLaunchKernelGGL(k_strength_masks, grid2(iw, ih), block2, 0, s, strong, strong2, edge, edge8, label, str, t_edge, t_strong, iw, ih, prev);
+  // (16-byte accesses need 16-byte aligned rows and planes: the frame path's planes are; an operator call with odd pointers takes the plain form)
+  const bool vec = (iw & 3) == 0 && ((((uintptr_t)strong | (uintptr_t)label | (uintptr_t)edge) & 15) == 0) && ((((uintptr_t)strong2 | (uintptr_t)edge8) & 3) == 0);
+  if (vec) hipLaunchKernelGGL(k_strength_masks<true>, dim3(cdiv(iw, 256), cdiv(ih, 4)), block2, 0, s, strong, strong2, edge, edge8, label, str, t_edge, t_strong, iw, ih, prev);
+  else hipLaunchKernelGGL(k_strength_masks<false>, grid2(iw, ih), block2, 0, s, strong, strong2, edge, edge8, label, str, t_edge, t_strong, iw, ih, prev);
 }
 
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih) {
