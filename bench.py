@@ -100,6 +100,15 @@ def traffic_per_frame():
         return None, None
 
 
+def device_bus_id(L, dev):
+    import ctypes
+    buf = ctypes.create_string_buffer(64)
+    try:
+        return buf.value.decode().lower() if L.rd_device_pci_bus_id(dev, buf, 64) == 0 and buf.value else None
+    except AttributeError:
+        return None
+
+
 def pin_to_gpu_cores(L, dev):
     """One process per GPU runs the enqueue / poll loop plus one post-process worker thread per frame slot (9 threads); on the
     8-GPU node (256 host cores, several NUMA nodes) keep them on the cores next to this rank's GPU.  Best effort: returns the
@@ -123,6 +132,28 @@ def pin_to_gpu_cores(L, dev):
         return spec
     except (OSError, ValueError, AttributeError):
         return None
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher (N > 1): start N ranks of this script - one process per GPU - through
+    torch.distributed.run on 127.0.0.1, the way the driver's own multi-GPU command does, and hand their exit code back.  More ranks than
+    the node has devices is an error, never a silent N = 1 (a dry run needs no device)."""
+    import socket
+    import subprocess
+    if not args.dry_run:
+        import rectdetect_amd as ra
+        have = ra.lib().rd_device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but this node has %d HIP device(s); one rank per GPU, no oversubscription" % (args.gpus, have))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def side_config(ra, L, label, iw, ih, seed, nframes, slots, dev, min_seconds=1.5):
@@ -182,12 +213,19 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="profiling runs only: skip the sequential verification pass and the host-frames pass (the line then says outputs_verified: null)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercises sharding/aggregation only (CPU tests)")
     ap.add_argument("--no-configs", action="store_true", help="skip the side measurements of the 1280x720 and 3840x2160 configurations")
+    ap.add_argument("--share-gpus", action="store_true", help="tests on a one-GPU box only: ranks beyond the device count share devices (rank mod count); without it more ranks than devices is an error")
     ap.add_argument("--backend", default=None, help="torch.distributed backend of the control plane (default gloo: barrier + MAX-reduce of a double need no device)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))      # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE); refusing to label one as the other" % (args.gpus, world))
     dist = None
     if world > 1:
         import torch
@@ -215,8 +253,11 @@ def main():
             a = np.zeros((IH, IW, 3), np.uint8)
             L.rd_synth_frame(a.ctypes.data, IW, IH, IW * 3, synth.SEED0 + seed_stream, t, 1)
             frames.append(a)
-        dev = local % L.rd_device_count()     # identity on a full node; lets two ranks share the only GPU of a test box (gloo)
-        pinned = pin_to_gpu_cores(L, dev) if world > 1 else None
+        ndev = L.rd_device_count()
+        if local >= ndev and not args.share_gpus:
+            raise SystemExit("bench.py: rank %d has no GPU of its own (%d device(s) on this node); one rank per GPU" % (rank, ndev))
+        dev = local % ndev                    # identity on a full node (--share-gpus: two ranks on the only GPU of a test box)
+        pinned = pin_to_gpu_cores(L, dev)
         det = ra.Detector(IW, IH, device=dev, nslots=args.slots, nworkers=1)
         dframes = []
         for a in frames:
@@ -293,13 +334,17 @@ def main():
 
     # who did what: every rank reports its device, stream seed, frames and time (host-side gather of a few bytes, not a data-path collective)
     mine = {"rank": rank, "device": None if args.dry_run else dev, "stream_seed": seed_stream, "frames": args.steps * F, "frames_per_s": round(args.steps * F / own_elapsed, 2),
-            "rectangles": int(sum(len(r) for r in results[args.warmup * F:])), "own_elapsed_s": round(own_elapsed, 4), "pinned_cpus": None if args.dry_run else pinned}
+            "rectangles": int(sum(len(r) for r in results[args.warmup * F:])), "own_elapsed_s": round(own_elapsed, 4), "pinned_cpus": None if args.dry_run else pinned,
+            "pci_bus_id": None if args.dry_run else device_bus_id(ra.lib(), dev), "pid": os.getpid()}
     per_rank = [mine]
     if dist is not None:
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
 
     if rank == 0:
+        devs = [r["pci_bus_id"] or r["device"] for r in per_rank]
+        if not args.dry_run and not args.share_gpus and len(set(devs)) != world:
+            raise SystemExit("bench.py: %d ranks on %d distinct devices (%s) - not a %d-GPU measurement" % (world, len(set(devs)), devs, world))
         total_frames = world * args.steps * F
         fps = total_frames / elapsed
         N = IW * IH

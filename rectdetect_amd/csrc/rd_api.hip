@@ -300,6 +300,7 @@ struct Slot {
   hipEvent_t ev_dense;                    // batched mode: the frame's dense stages are done (the batch's sparse stages wait for it)
   int pending_sparse;                     // batched mode: dense stages enqueued, sparse stages not launched yet
   int pending_dense;                      // group mode (rd_detector::zb > 1): frame handed over, nothing launched yet
+  int group_n;                            // frames that ran between this frame's ev_begin and ev_done (1, or the group's size: the interval is shared)
   hipGraphExec_t gz0, gz2[3 * RD_NBUDGETS]; int gz_ws;      // group mode, first slot of a group: the group's launch sequences (dense stages up to the first labelling; everything after the strong masks)
   // rectangles on the device (RD_DEVICE_POST): scratch, result block in pinned host memory, whether this frame's block is valid and for which aperture
   int *post_scratch, *h_post, *h_post_dev;
@@ -479,11 +480,18 @@ static void frame_polyline(rd_detector *d, Slot *s, hipStream_t st, int mode) {
 // tables_are_clean: frame_regions() ran just before (its last kernel undoes the previous entries of the vote tables)
 // with_post: also the rectangles on the device, for the aperture the caller polled with last (the reference hands the aperture over with
 // the poll, after the frame: a frame polled with another one, or the first frames of a stream, are post-processed on the host)
-static void frames_votes(rd_detector *d, const rdk::PolyFrame *frames, int nb, hipStream_t st, int tables_are_clean, int with_post) {
+static void frames_votes(rd_detector *d, const rdk::PolyFrame *frames, int nb, hipStream_t st, int tables_are_clean, int with_post, double tan_aov = 0.0) {
   const int nentry = d->N * 4 / 5;
   rdk::reduce_ls(st, frames, nb, d->iw, d->ih, nentry, tables_are_clean);
   rdk::sample_segments(st, frames, nb, d->maxrec_dev, d->iw, d->ih, nentry, RD_MAXREC);
-  if (with_post) rdk::post_device(st, frames, nb, d->maxrec_dev, d->iw, d->ih, d->tan_aov);
+  if (with_post) rdk::post_device(st, frames, nb, d->maxrec_dev, d->iw, d->ih, tan_aov);      // (the caller's snapshot of the aperture: what the frames are labelled with)
+}
+// the aperture the device post-process of frames launched now runs with (set by polls and rd_detector_set_aperture, possibly on another thread)
+static int aperture_snapshot(rd_detector *d, double *tan_out) {
+  pthread_mutex_lock(&d->tan_mu);
+  const int have = d->have_tan; *tan_out = d->tan_aov;
+  pthread_mutex_unlock(&d->tan_mu);
+  return have;
 }
 static void frame_votes(rd_detector *d, Slot *s, int tables_are_clean) { frames_votes(d, s->frame, 1, s->st, tables_are_clean, 0); }
 
@@ -518,7 +526,7 @@ static void redo_votes(rd_detector *d, Slot *s, hipStream_t st) {
     with_post = d->have_tan; s->post_tan = d->tan_aov;
     pthread_mutex_unlock(&d->tan_mu);
   }
-  frames_votes(d, s->frame, 1, st, 1, with_post);
+  frames_votes(d, s->frame, 1, st, 1, with_post, s->post_tan);
   s->post_mode = with_post;
 }
 
@@ -652,6 +660,7 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
     s->graph_ws = ws;
   }
   RD_HIP(hipEventRecord(s->ev_begin, s->st));
+  s->group_n = 1;
   rdk::bgr2plab_transposed(s->st, s->plab0, s->tr, s->src, d->iw, d->ih, ws);
   run_segment(d, s, ws, 0);
   if (d->have_last_strong) RD_HIP(hipStreamWaitEvent(s->st, d->last_strong, 0));
@@ -661,12 +670,12 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
   s->rounds = d->fixed_rounds ? d->fixed_rounds : __atomic_load_n(&d->rounds_budget, __ATOMIC_RELAXED);
   if (d->budget_cycle) s->rounds = kRoundBudgets[2 + (int)((s->seq / d->budget_cycle) % (RD_NBUDGETS - 2))];      // (tests: a new graph every few frames)
   s->poly_mode = current_poly_mode(d);
-  if (d->batch == 1) { s->post_mode = d->device_post && d->have_tan; s->post_tan = d->tan_aov; }
+  if (d->batch == 1) { double tn = 0; const int have = aperture_snapshot(d, &tn); s->post_mode = d->device_post && have; s->post_tan = tn; }
   for (int k = 0; k < RD_NBUDGETS; k++) if (kRoundBudgets[k] == s->rounds) d->budget_count[k]++;
   run_segment(d, s, ws, 2);
   if (d->batch > 1) { RD_HIP(hipEventRecord(s->ev_dense, s->st)); s->pending_sparse = 1; }
   else {
-    if (s->post_mode) rdk::post_device(s->st, s->frame, 1, d->maxrec_dev, d->iw, d->ih, d->tan_aov);      // (outside the captured graphs: the aperture is a launch argument)
+    if (s->post_mode) rdk::post_device(s->st, s->frame, 1, d->maxrec_dev, d->iw, d->ih, s->post_tan);      // (outside the captured graphs: the aperture is a launch argument)
     RD_HIP(hipEventRecord(s->ev_done, s->st));
   }
   rdrt::check_launch("rect frame");
@@ -781,11 +790,12 @@ static void group_launch(rd_detector *d, int g0) {
     for (int k = 0; k < RD_NBUDGETS; k++) if (kRoundBudgets[k] == s->rounds) d->budget_count[k]++;
   }
   run_group_segment(d, lead, zb, 2, st);
-  const int with_post = d->device_post && d->have_tan;
-  if (with_post) rdk::post_device(st, lead->frame, zb, d->maxrec_dev, d->iw, d->ih, d->tan_aov);
+  double tn = 0;
+  const int with_post = aperture_snapshot(d, &tn) && d->device_post;
+  if (with_post) rdk::post_device(st, lead->frame, zb, d->maxrec_dev, d->iw, d->ih, tn);
   for (int i = 0; i < zb; i++) {
     Slot *s = &d->slots[g0 + i];
-    s->post_mode = with_post; s->post_tan = d->tan_aov;
+    s->post_mode = with_post; s->post_tan = tn; s->group_n = zb;
     RD_HIP(hipEventRecord(s->ev_done, st));
   }
   rdrt::check_launch("rect frames, group launch");
@@ -814,11 +824,12 @@ static void sparse_launch(rd_detector *d, int a, int b) {
   const int pm = current_poly_mode(d);
   const rdk::PolyFrame *frames = d->frames + a;
   if (!(d->diag_skip & 4)) rdk::polyline(st, frames, nb, d->N * 16, 1, 4.0f, 20, d->iw, d->ih, pm);
-  const int with_post = d->device_post && d->have_tan;
-  frames_votes(d, frames, nb, st, 1, with_post);
+  double tn = 0;
+  const int with_post = aperture_snapshot(d, &tn) && d->device_post;
+  frames_votes(d, frames, nb, st, 1, with_post, tn);
   for (int i = a; i <= b; i++) {
     Slot *s = &d->slots[i];
-    s->post_mode = with_post; s->post_tan = d->tan_aov;
+    s->post_mode = with_post; s->post_tan = tn;
     s->poly_mode = pm;
     RD_HIP(hipEventRecord(s->ev_done, st));
     s->pending_sparse = 0;
@@ -1139,7 +1150,9 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
   if (d->zb > 1) {      // group mode: launched together with the other frames of its group, once that is full (or a poll needs one of them)
     const int si = (int)(s - d->slots);
     s->pending_dense = 1;
-    if (si % d->zb == d->zb - 1) group_launch(d, si / d->zb * d->zb);
+    // (the last group of slots may be short - nslots need not be a multiple of zb - and is launched when ITS last slot is filled: every group
+    //  is launched the moment its last frame arrives, so frames reach the device in sequence order and at most one group is ever waiting)
+    if (si % d->zb == d->zb - 1 || si == d->nslots - 1) group_launch(d, si / d->zb * d->zb);
   } else {
   enqueue_frame(d, s, ws);
   }
@@ -1191,7 +1204,7 @@ void *rd_detector_poll(rd_detector *d, double tanAOV) {
     slot_finish_device(d, s);
     r = slot_rectangles(d, s, tanAOV, &segs, &ns);
   }
-  { float ms = 0.0f; if (hipEventElapsedTime(&ms, s->ev_begin, s->ev_done) == hipSuccess) { d->dev_us += (long)(ms * 1000.0f); d->dev_frames++; } }
+  { float ms = 0.0f; if (hipEventElapsedTime(&ms, s->ev_begin, s->ev_done) == hipSuccess) { d->dev_us += (long)(ms * 1000.0f) / (s->group_n > 0 ? s->group_n : 1); d->dev_frames++; } }      // (a group's interval is shared by its frames: counted once)
   free(d->last_segs);
   d->last_segs = segs; d->last_nsegs = ns;
   d->last_polled_slot = si;
@@ -1214,7 +1227,7 @@ void rd_detector_drain(rd_detector *d) {
   if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_drain: bad handle\n");
   RD_HIP(hipSetDevice(d->device));
   if (d->batch > 1) for (int i = 0; i < d->nslots; i += d->batch) sparse_flush(d, i);
-  if (d->zb > 1) for (int i = 0; i < d->nslots; i += d->zb) group_launch(d, i);
+  if (d->zb > 1) for (long q = d->next_poll; q < d->next_enqueue; q++) { const int si = (int)(q % d->nslots); if (d->slots[si].pending_dense) group_launch(d, si / d->zb * d->zb); }      // (sequence order)
   for (int i = 0; i < d->nslots; i++) RD_HIP(hipStreamSynchronize(d->slots[i].st));
   if (d->sparse_st) RD_HIP(hipStreamSynchronize(d->sparse_st));
 }
