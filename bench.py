@@ -143,7 +143,9 @@ def spawn_ranks(args):
     if not args.dry_run:
         import rectdetect_amd as ra
         have = ra.lib().rd_device_count()
-        if have < args.gpus:
+        if have < 1:
+            raise SystemExit("bench.py: no HIP device - the product has no CPU fallback")
+        if have < args.gpus and not args.share_gpus:      # (--share-gpus: tests on a one-GPU box, ranks share devices on purpose)
             raise SystemExit("bench.py: --gpus %d but this node has %d HIP device(s); one rank per GPU, no oversubscription" % (args.gpus, have))
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))

@@ -292,7 +292,7 @@ struct Slot {
   float *tr[3], *fw[3], *bw[3], *hz[3], *bl[3], *vxy, *strength, *nms;
   int *i0, *i1, *mask0, *tidy, *label1, *strsum, *strong, *junction, *mergemask, *region, *rsize, *scratch2, *d2s, *boundarysrc, *boundary, *lsid, *table, *claim, *probes, *region0, *tlist;
   int8_t *e8;
-  uint16_t *ext;
+  void *ext;                              // run-extent records of the edge-stopped blur
   float *tails; int *flags; int iir_chunked;
   void *lslist;
   rdk::PolyScratch *ps;
@@ -348,6 +348,7 @@ struct rd_detector {
   long next_enqueue, next_poll;
   int last_polled_slot;
   void *last_segs; int last_nsegs;
+  int front_split;        // RD_FRONT_SPLIT (measurements): gradient / strength / suppression as three launches instead of the tile kernel
   int use_graph, poly_mode, force_redo, diag_no_post, diag_skip, fork_poly, fixed_rounds, budget_cycle; long n_redo, n_redo_rounds, n_redo_absorb;
   int overflow_streak;
   int poly_overflows;                     // set once two frames in a row overflowed the single-launch polyline kernel: later frames go multi-launch
@@ -393,7 +394,7 @@ static void slot_planes(rd_detector *d, Slot *s, PlaneAlloc &A) {
   s->table = A.get<int>(N * 4); s->claim = A.get<int>(N); s->tlist = A.get<int>(N);
   if (A.real()) rdk::reduce_ls_init(s->st, s->table, s->claim, s->tlist, (int)(N * 4 / 5));
   s->e8 = A.get<int8_t>(N);
-  s->ext = A.get<uint16_t>(N);
+  s->ext = A.get<uint8_t>(rdk::blblur_ext_bytes(d->iw, d->ih));
   { size_t a = rdk::iir_pass_scratch_floats(3, d->ih, d->iw), b = rdk::iir_pass_scratch_floats(3, d->iw, d->ih); s->tails = A.get<float>(a > b ? a : b); }
   s->flags = A.get<int>(16); if (A.real()) { RD_HIP(hipMemset(s->flags, 0, 16 * sizeof(int))); RD_HIP(hipStreamSynchronize(0)); }
   s->iir_chunked = 1;
@@ -557,6 +558,22 @@ static void frame_strong(rd_detector *d, Slot *s, hipStream_t st) {
   rdk::strength_masks(st, s->strong, out, NULL, s->e8, s->label1, s->strsum, 500, 2500, d->iw, d->ih, s->prev_in);
 }
 
+// gradient direction, re-packed blurred Lab, strength, non-max suppression (oclrect.c:251-258) of nz frames: one tile kernel that keeps the three
+// intermediate planes on the chip (rd_k_front.hip: k_grad_nms); frame sizes its tiles do not cover take the three operators' kernels.
+// taps: the intermediate planes are written as well (debug planes "plab1", "vxy", "strength")
+static bool front_is_fused(const rd_detector *d) { return !d->front_split && rdk::grad_nms_fits(d->iw, d->ih); }
+static void frames_grad_nms(rd_detector *d, Slot *s, hipStream_t st, int nz, size_t zs, int taps = 0) {
+  const int iw = d->iw, ih = d->ih;
+  if (front_is_fused(d)) {
+    if (taps) rdk::grad_nms(st, s->nms, s->bl, iw, ih, nz, zs, s->plab1, s->vxy, s->strength);
+    else rdk::grad_nms(st, s->nms, s->bl, iw, ih, nz, zs);
+    return;
+  }
+  rdk::edgevec(st, s->vxy, s->bl[0], iw, ih, s->plab1, s->bl[1], s->bl[2], nz, zs);
+  rdk::edge_plab(st, s->strength, s->plab1, iw, ih, nz, zs);
+  rdk::thinthres(st, s->nms, s->strength, s->vxy, iw, ih, nz, zs);
+}
+
 static void frame_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t st_over = NULL) {
   const int iw = d->iw, ih = d->ih, N = d->N;
   hipStream_t st = st_over ? st_over : s->st;
@@ -568,9 +585,7 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t 
   { const float *c[3] = { s->tr[0], s->tr[1], s->tr[2] }; rdk::iir_blur_pass(st, s->hz, c, s->fw, s->bw, 3, ih, iw, 1, s->tails, s->flags, 1); }    // along x (source: 16-bit fields)
   { const float *c[3] = { s->hz[0], s->hz[1], s->hz[2] }; rdk::iir_blur_pass(st, s->bl, c, s->fw, s->bw, 3, iw, ih, 0, s->tails, s->flags + 1); }   // along y
   // gradient direction (+ the packing of the blurred Lab, oclrect.c:251, on the way), strength, non-max suppression (oclrect.c:253-258)
-  rdk::edgevec(st, s->vxy, s->bl[0], iw, ih, s->plab1, s->bl[1], s->bl[2]);
-  rdk::edge_plab(st, s->strength, s->plab1, iw, ih);
-  rdk::thinthres(st, s->nms, s->strength, s->vxy, iw, ih);
+  frames_grad_nms(d, s, st, 1, 0);
 
   // mask of positive responses and the rect-path tidy (oclrect.c:262-272)
   // components (background included) of the tidied mask; the tidy itself runs inside the labelling's tile kernel (and clears the
@@ -695,9 +710,7 @@ static void group_segment(rd_detector *d, Slot *s, int nz, int seg, hipStream_t 
   if (seg == 0) {
     { const float *c[3] = { s->tr[0], s->tr[1], s->tr[2] }; rdk::iir_blur_pass(st, s->hz, c, s->fw, s->bw, 3, ih, iw, 1, s->tails, s->flags, 1, nz, zs); }
     { const float *c[3] = { s->hz[0], s->hz[1], s->hz[2] }; rdk::iir_blur_pass(st, s->bl, c, s->fw, s->bw, 3, iw, ih, 0, s->tails, s->flags + 1, 0, nz, zs); }
-    rdk::edgevec(st, s->vxy, s->bl[0], iw, ih, s->plab1, s->bl[1], s->bl[2], nz, zs);
-    rdk::edge_plab(st, s->strength, s->plab1, iw, ih, nz, zs);
-    rdk::thinthres(st, s->nms, s->strength, s->vxy, iw, ih, nz, zs);
+    frames_grad_nms(d, s, st, nz, zs);
     rdk::label8_tidy(st, s->label1, s->mask0, s->tidy, s->nms, s->strsum, iw, ih, 1, nz, zs);
     rdk::calc_strength(st, s->strsum, s->nms, s->label1, iw, ih, NULL, 1, nz, zs);
     return;
@@ -1037,6 +1050,7 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : (getenv("RD_POLY_COOP") ? 2 : 1);      // (RD_POLY_COOP: the cooperative launch for every frame - tests)
   d->force_redo = (getenv("RD_POLY_FORCE_REDO") ? 1 : 0) | (getenv("RD_ABSORB_FORCE_SLOW") ? 2 : 0);   // tests: every frame also takes the polyline / absorption fallback
   d->diag_no_post = getenv("RD_DIAG_NO_POST") ? 1 : 0;
+  d->front_split = getenv("RD_FRONT_SPLIT") ? 1 : 0;
   // candidate funnel + pose estimation on the device (rd_k_post.hip) instead of on one worker thread per frame slot: RD_DEVICE_POST=0|1 decides;
   // otherwise the host path - 0.3 ms of CPU time per 1080p frame, i.e. 0.6 of a core at 2000 frames/s: measured 2050 frames/s on 8 cores
   // as on 256, against 1830 for the device path - unless this process may run on one or two cores only
@@ -1275,6 +1289,8 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
     if (!strcmp(tab[i].n, name)) {
       const size_t b = tab[i].bytes < max_bytes ? tab[i].bytes : max_bytes;
       if (!strcmp(name, "lsid")) rdk::polyline_ids(s->st, s->frame, 1, (int)N);   // not part of the frame path: built from the compact state
+      if ((!strcmp(name, "plab1") || !strcmp(name, "vxy") || !strcmp(name, "strength")) && front_is_fused(d))
+        frames_grad_nms(d, s, s->st, 1, 0, 1);      // these never leave the chip on the frame path: the same kernel again, writing them out (the blurred planes are intact)
       RD_HIP(hipStreamSynchronize(s->st));
       if (!strcmp(name, "edge500")) {       // kept as bytes on the device (the blur's mask); handed out as the int plane of oclrect.c:277-284
         const size_t n = N * 4 <= max_bytes ? N : max_bytes / 4;
