@@ -292,7 +292,7 @@ struct Slot {
   float *tr[3], *fw[3], *bw[3], *hz[3], *bl[3], *vxy, *strength, *nms;
   int *i0, *i1, *mask0, *tidy, *label1, *strsum, *strong, *junction, *mergemask, *region, *rsize, *scratch2, *d2s, *boundarysrc, *boundary, *lsid, *table, *claim, *probes, *region0, *tlist;
   int8_t *e8;
-  void *ext;                              // run-extent records of the edge-stopped blur
+  uint16_t *ext;
   float *tails; int *flags; int iir_chunked;
   void *lslist;
   rdk::PolyScratch *ps;
@@ -394,7 +394,7 @@ static void slot_planes(rd_detector *d, Slot *s, PlaneAlloc &A) {
   s->table = A.get<int>(N * 4); s->claim = A.get<int>(N); s->tlist = A.get<int>(N);
   if (A.real()) rdk::reduce_ls_init(s->st, s->table, s->claim, s->tlist, (int)(N * 4 / 5));
   s->e8 = A.get<int8_t>(N);
-  s->ext = A.get<uint8_t>(rdk::blblur_ext_bytes(d->iw, d->ih));
+  s->ext = A.get<uint16_t>(N);
   { size_t a = rdk::iir_pass_scratch_floats(3, d->ih, d->iw), b = rdk::iir_pass_scratch_floats(3, d->iw, d->ih); s->tails = A.get<float>(a > b ? a : b); }
   s->flags = A.get<int>(16); if (A.real()) { RD_HIP(hipMemset(s->flags, 0, 16 * sizeof(int))); RD_HIP(hipStreamSynchronize(0)); }
   s->iir_chunked = 1;

@@ -78,20 +78,12 @@ __global__ __launch_bounds__(256) void k_rect_tidy(int *__restrict__ mask0, int 
 #define BE_ROWS 32
 #endif
 #define BE_NR (BE_ROWS + 11)          // rows y0-5 .. y0+BE_ROWS+5
-// Output: a byte per pixel and axis, nl | nr << 3 (samples taken towards smaller / larger coordinates, centre included in both, 0..5 each),
-// stored as RECORDS of the eight pixels a thread of the blur handles in one go:
-//   extH[(x >> 3) * ih + y]  = the bytes of pixels (x & ~7) + 0..7 of row y     (byte j = pixel j; a wave of the blur's pass along x has a ROW per lane)
-//   extV[(y >> 3) * iw + x]  = the bytes of rows (y & ~7) + 0..7 of column x   (a COLUMN per lane in the pass along y)
-// so that either pass fetches what it needs about its eight pixels with one coalesced 8-byte load per lane.  Bytes of pixels outside the frame are 0.
-#define RD_EXT_FULL 0x2d2d2d2d2d2d2d2dull      // nl = nr = 5 for all eight pixels
-__global__ __launch_bounds__(256) void k_blblur_extents(unsigned long long *__restrict__ extH, unsigned long long *__restrict__ extV, const int8_t *__restrict__ edge, int iw, int ih, size_t zs) {
-  RD_ZSHIFT(zs, extH, extV, edge);
+__global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ ext, const int8_t *__restrict__ edge, int iw, int ih, size_t zs) {
+  RD_ZSHIFT(zs, ext, edge);
   typedef unsigned long long u64;
   __shared__ u64 EA[BE_NR + 1], EB[BE_NR + 1];   // mask != 0 for columns x0-8 .. x0+55 (A) and x0+56 .. x0+71 (B)
   __shared__ u64 HLa[BE_NR], HLb[BE_NR], HRa[BE_NR], HRb[BE_NR];   // along x: stop bits towards smaller / larger x (centre not on an edge)
   __shared__ u64 VL[BE_NR], VR[BE_NR], VE[BE_NR];                  // along y, tile columns only (bit = column - x0)
-  __shared__ __align__(8) uint8_t bH[BE_ROWS][64], bV[BE_ROWS][64];
-  static_assert(BE_ROWS % 8 == 0, "records hold eight rows");
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BE_ROWS;
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
   {
@@ -141,8 +133,10 @@ __global__ __launch_bounds__(256) void k_blblur_extents(unsigned long long *__re
   }
   __syncthreads();
   const int x = x0 + tx;
+  if (x >= iw) return;
   for (int rr = ty; rr < BE_ROWS; rr += 4) {
     const int y = y0 + rr;
+    if (y >= ih) break;
     const int r = rr + 5;
     // 64-bit windows starting at column x - 8: the pixel is bit 8
     const int sh = tx, rs = (64 - tx) & 63;
@@ -163,164 +157,151 @@ __global__ __launch_bounds__(256) void k_blblur_extents(unsigned long long *__re
       uv |= (unsigned)((w >> tx) & 1ull) << d;
     }
     const int nlv = __clz((int)tv) - 27, nrv = __ffs((int)uv) - 1;
-    const bool in = x < iw && y < ih;
-    bH[rr][tx] = in ? (uint8_t)(nl | (nr << 3)) : (uint8_t)0;
-    bV[rr][tx] = in ? (uint8_t)(nlv | (nrv << 3)) : (uint8_t)0;
-  }
-  __syncthreads();
-  // records along x: 8 strips of 8 columns x BE_ROWS rows; consecutive threads take consecutive rows (consecutive addresses)
-  for (int t = tid; t < 8 * BE_ROWS; t += 256) {
-    const int st = t / BE_ROWS, rr = t - st * BE_ROWS;
-    if (x0 + 8 * st < iw && y0 + rr < ih) extH[(size_t)((x0 >> 3) + st) * ih + y0 + rr] = *(const u64 *)&bH[rr][8 * st];
-  }
-  // records along y: BE_ROWS / 8 strips of 8 rows x 64 columns
-  for (int t = tid; t < (BE_ROWS / 8) * 64; t += 256) {
-    const int st = t >> 6, c = t & 63;
-    if (x0 + c < iw && y0 + 8 * st < ih) {
-      u64 v = 0;
-#pragma unroll
-      for (int j = 0; j < 8; j++) v |= (u64)bV[8 * st + j][c] << (8 * j);
-      extV[(size_t)((y0 >> 3) + st) * iw + x0 + c] = v;
-    }
+    ext[y * iw + x] = (uint16_t)((unsigned)(nl | (nr << 3)) | ((unsigned)(nlv | (nrv << 3)) << 6));
   }
 }
 
-// One (horizontal, vertical) pair of passes (rh:286-296) in a single launch, in STRIPS: a thread produces eight consecutive pixels along
-// the pass's axis from the sixteen it reads (its eight + four on either side), a wave 64 such strips side by side - one ROW per lane in the pass
-// along x, one COLUMN per lane in the pass along y.  The block stages a (64 + 8) x (BQ_R + 8) tile of the packed input in LDS, runs the pass along
-// x for the 64 x (BQ_R + 8) strip into a second LDS tile (4 extra rows above and below) and the pass along y from there: the intermediate plane
-// never travels through HBM.  Against one pixel per thread (10 LDS reads of 8 bytes per pixel and pass) a pixel costs 2 reads of 4 bytes, and
-// - what matters more, the passes are bound by vector instructions - where all 64 lanes have a full run on both sides (nl = nr = 5: everywhere but
-// within five pixels of a transition of the edge mask) the ten-sample sum is a sliding window (add the entering sample, subtract the leaving one)
-// and the division a multiplication by 52429 >> 19 (exact below 81920).  Other pixels sum their samples under per-lane masks (same result as the
-// reference's two loops: a sample beyond the run contributes zero) and divide by their count through div_small_f.  Which form a pixel takes is decided
-// per wave and pixel index (uniform branch), from the records k_blblur_extents leaves.
-#ifndef BQ_R
-#define BQ_R 120             // rows per tile: a multiple of 8; BQ_R + 8 a multiple of 64 keeps the pass along x's waves full
-#endif
-#define BQ_HR (BQ_R + 8)
-#define BQ_SP 73             // pitch of the staged input (72 used: columns x0 - 4 .. x0 + 67); odd: a wave reads a column of it (one row per lane)
-#define BQ_HP 65             // pitch of the intermediate tile (written a column per wave, read a row per wave)
-#define BQ_NT 512
+// One (horizontal, vertical) pair of passes (rh:286-296) in a single launch.  The block stages a (64+8) x (BP_ROWS+8)
+// tile of the input in LDS in EXPANDED form (uint2: L | a << 16, b - 16-bit fields, so that a sum of 10 samples is two
+// plain adds without carries between fields), runs the horizontal pass for the 64 x (BP_ROWS+8) strip into a second LDS
+// tile (4 extra rows above and below) and the vertical pass from there: the intermediate plane never travels through
+// HBM, every sample is one unconditional ds_read_b64 (samples beyond the run read a zero slot), and all reads of a pixel
+// are in flight together.
+#define BP_ROWS 64
+#define BP_SW 73              // row pitch of the staged input (72 used)
 // floor(s / w) for 0 <= s <= 40950, 1 <= w <= 10 (exhaustively checked: tools/check_div_small.py)
 // (one fused multiply-add: float(s) * (1/w) + 0.5 * (1/w), rounded once - the explicit fma is part of the checked formula, not a contraction)
 __device__ __forceinline__ unsigned div_small_f(unsigned s, float2 rw) { return (unsigned)__fmaf_rn((float)s, rw.x, rw.y); }
 
-// the eight outputs of a strip: q = the sixteen packed input words (output k's centre is q[k + 4]), rec = the strip's record, rwt = (1 / w, 0.5 / w) table in LDS
-template <typename Store>
-__device__ __forceinline__ void bq_strip(const uint32_t (&q)[16], unsigned long long rec, const float2 *rwt, Store store) {
-  // expanded form: lo = L | a << 16, hi = b (16-bit fields: a sum of 10 samples is two plain adds without carries between fields)
-  unsigned lo[16], hi[16];
-#pragma unroll
-  for (int j = 0; j < 16; j++) { lo[j] = (q[j] & 4095u) | ((q[j] << 4) & 0x3ff0000u); hi[j] = q[j] >> 22; }
-  unsigned wlo = 0, whi = 0;      // window sum of the nine samples around output k
-#pragma unroll
-  for (int j = 0; j < 9; j++) { wlo += lo[j]; whi += hi[j]; }
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    if (k > 0) { wlo += lo[k + 8] - lo[k - 1]; whi += hi[k + 8] - hi[k - 1]; }
-    const unsigned b = (unsigned)(rec >> (8 * k)) & 0xffu;
-    uint32_t o;
-    if (__ballot(b != 0x2du) == 0) {
-      const unsigned slo = wlo + lo[k + 4], shi = whi + hi[k + 4];
-      const unsigned L = ((slo & 0xffffu) * 52429u) >> 19, A = ((slo >> 16) * 52429u) >> 19, B = (shi * 52429u) >> 19;
-      o = L | (A << 12) | (B << 22);
-    } else {
-      const int nl = b & 7, nr = b >> 3;
-      unsigned slo = 0, shi = 0;
-#pragma unroll
-      for (int d = 0; d < 5; d++) {
-        const bool tl = d < nl, tr = d < nr;
-        slo += tl ? lo[k + 4 - d] : 0u; shi += tl ? hi[k + 4 - d] : 0u;
-        slo += tr ? lo[k + 4 + d] : 0u; shi += tr ? hi[k + 4 + d] : 0u;
-      }
-      const int w = nl + nr;
-      const float2 rw = rwt[w];
-      o = w > 0 ? (div_small_f(slo & 0xffffu, rw) | (div_small_f(slo >> 16, rw) << 12) | (div_small_f(shi, rw) << 22)) : q[k + 4];   // fields cannot exceed their range: no clamp needed
-    }
-    store(k, o);
-  }
-}
-
-__global__ __launch_bounds__(BQ_NT) void k_blblur_pair(uint32_t *__restrict__ out, const unsigned long long *__restrict__ extH, const unsigned long long *__restrict__ extV, const uint32_t *__restrict__ in, int iw, int ih, size_t zs) {
-  RD_ZSHIFT(zs, out, extH, extV, in);
-  typedef unsigned long long u64;
-  __shared__ uint32_t src[BQ_HR * BQ_SP];
-  __shared__ uint32_t hz[BQ_HR * BQ_HP];
+#define BP_TY 16         // thread rows per block (4 / 8 / 16 at full rate: 2003 / 2111 / 2126 frames/s)
+__global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih, size_t zs) {
+  RD_ZSHIFT(zs, out, ext, in);
+  // one array: the staged input, the horizontal result, and a REGION of zeros - the sample beyond a run is read at `zero region + the
+  // same constant offset as the sample inside the run`, so that a sample's address is one select between two registers and the offset
+  // travels in the load instruction (with single zero slots the compiler paid an add or a constant per sample)
+  constexpr int SRC_N = (BP_ROWS + 8) * BP_SW, HZ_N = (BP_ROWS + 8) * 64, ZR_N = 2048 / 8 + 8;
+  __shared__ uint2 lds[SRC_N + HZ_N + ZR_N];
+  uint2 *const src = lds, *const hz = lds + SRC_N;
   __shared__ float2 rwt[16];                                     // (1 / w correctly rounded, half of it)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int NW = BQ_NT / 64;
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BQ_R;
-  // tasks of the pass along x: (strip of 8 columns, group of 64 rows), of the pass along y: strip of 8 rows; a wave takes every NW-th
-  constexpr int NTH = 8 * ((BQ_HR + 63) / 64), NTV = BQ_R / 8, PH = (NTH + NW - 1) / NW, PV = (NTV + NW - 1) / NW;
-  // the records of this thread's strips are requested first: their latency overlaps the staging of the tile
-  u64 rh[PH], rv[PV];
+  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BP_ROWS;
+  const int x = x0 + tx;
+  // the run extents of this thread's pixels (3 rows of the horizontal strip, 2 rows of the output tile): requested first so
+  // that their latency overlaps the staging of the tile
+  // (every load below is unconditional - the address of a cell outside the frame is clamped, its value replaced afterwards -
+  //  so that all eight are in flight together: a block's critical path holds one trip to memory, not one per staging step)
+  constexpr int NT = 64 * BP_TY, NH = (BP_ROWS + 8 + BP_TY - 1) / BP_TY, NV = BP_ROWS / BP_TY, NQ = ((BP_ROWS + 8) * 72 + NT - 1) / NT;
+  unsigned eh[NH], ev[NV];
+  uint32_t q[NQ];
+  bool okh[NH], okv[NV], okq[NQ];
+  // (a block whose staged patch lies inside the frame - all but the frame's rim - needs no clamping and no validity flags: that
+  //  bookkeeping was an eighth of the kernel's vector instructions)
+  const bool interior = x0 >= 4 && y0 >= 4 && x0 + 68 <= iw && y0 + BP_ROWS + 4 <= ih;
+  // (element indices as unsigned 32-bit offsets from the planes' bases - atu() - keep the address arithmetic out of the vector unit)
+  if (interior) {
+    const unsigned eb = (unsigned)((y0 - 4 + ty) * iw + x);
 #pragma unroll
-  for (int i = 0; i < PH; i++) {
-    const int t = wave + NW * i, st = t & 7, r = (t >> 3) * 64 + lane, y = y0 - 4 + r;
-    const bool ok = t < NTH && r < BQ_HR && y >= 0 && y < ih && x0 + 8 * st < iw;
-    rh[i] = extH[ok ? (size_t)((x0 >> 3) + st) * ih + y : 0];
-    if (!ok) rh[i] = RD_EXT_FULL;      // (strips outside the frame: nobody reads their results; "full" keeps them from forcing their wave onto the masked form)
+    for (int k = 0; k < NH; k++) { okh[k] = ty + BP_TY * k < BP_ROWS + 8; eh[k] = okh[k] ? atu(ext, eb + (unsigned)(BP_TY * k * iw)) : (uint16_t)0; }
+#pragma unroll
+    for (int k = 0; k < NV; k++) { okv[k] = true; ev[k] = atu(ext, eb + (unsigned)((BP_TY * k + 4) * iw)); }
+    const unsigned ib = (unsigned)((y0 - 4) * iw + x0 - 4);
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+      const int t = tid + NT * i;
+      const int r = t / 72, c = t % 72;
+      okq[i] = t < (BP_ROWS + 8) * 72;
+      q[i] = okq[i] ? atu(in, ib + (unsigned)(r * iw + c)) : 0u;
+    }
+  } else {
+#pragma unroll
+  for (int k = 0; k < NH; k++) {
+    const int y = y0 - 4 + ty + BP_TY * k;
+    okh[k] = ty + BP_TY * k < BP_ROWS + 8 && x < iw && y >= 0 && y < ih;
+    eh[k] = atu(ext, okh[k] ? (unsigned)(y * iw + x) : 0u);
   }
 #pragma unroll
-  for (int i = 0; i < PV; i++) {
-    const int t = wave + NW * i, y = y0 + 8 * t;
-    const bool ok = t < NTV && y < ih && x0 + lane < iw;
-    rv[i] = extV[ok ? (size_t)((y0 >> 3) + t) * iw + x0 + lane : 0];
-    if (!ok) rv[i] = RD_EXT_FULL;
+  for (int k = 0; k < NV; k++) {
+    const int y = y0 + ty + BP_TY * k;
+    okv[k] = x < iw && y < ih;
+    ev[k] = atu(ext, okv[k] ? (unsigned)(y * iw + x) : 0u);
   }
-  // stage the tile: a wave takes every NW-th row (lanes = columns 0..63); the 8 columns left over are (BQ_HR * 8) cells shared out over all threads
-  {
-    constexpr int NR = (BQ_HR + NW - 1) / NW, NX = (BQ_HR * 8 + BQ_NT - 1) / BQ_NT;
-    uint32_t v[NR + NX];
-    const int xa = x0 - 4 + lane;
-    const bool xok = xa >= 0 && xa < iw;
 #pragma unroll
-    for (int i = 0; i < NR; i++) {
-      const int r = wave + NW * i, y = y0 - 4 + r;
-      const bool ok = r < BQ_HR && xok && y >= 0 && y < ih;
-      v[i] = in[ok ? y * iw + xa : 0];
-      if (!ok) v[i] = 0;
+  for (int i = 0; i < NQ; i++) {
+    const int t = tid + NT * i;
+    const int r = t / 72, c = t % 72;
+    const int xx = x0 - 4 + c, yy = y0 - 4 + r;
+    okq[i] = t < (BP_ROWS + 8) * 72 && xx >= 0 && xx < iw && yy >= 0 && yy < ih;
+    q[i] = atu(in, okq[i] ? (unsigned)(yy * iw + xx) : 0u);
+  }
+  }
+  for (int t = tid; t < ZR_N; t += 64 * BP_TY) lds[SRC_N + HZ_N + t] = make_uint2(0, 0);     // (whatever the block size)
+  unsigned zrs = (unsigned)(SRC_N + HZ_N) * 8u, zrh = (unsigned)ZR_N * 0u + (unsigned)HZ_N * 8u;      // the zero region's byte offset from `src` / from `hz`
+  asm volatile("" : "+v"(zrs), "+v"(zrh));      // (opaque to the optimiser: it would fold the per-sample constants into them again)
+  if (tid < 16) { const float r = tid >= 1 && tid <= 10 ? 1.0f / (float)tid : 0.0f; rwt[tid] = make_float2(r, 0.5f * r); }
+#pragma unroll
+  for (int i = 0; i < NQ; i++) {
+    const int t = tid + NT * i;
+    const uint32_t v = okq[i] ? q[i] : 0u;
+    if (t < (BP_ROWS + 8) * 72) src[(t / 72) * BP_SW + t % 72] = make_uint2((v & 4095u) | ((v << 4) & 0x3ff0000u), v >> 22);
+  }
+#pragma unroll
+  for (int k = 0; k < NH; k++) if (!okh[k]) eh[k] = 0u;
+#pragma unroll
+  for (int k = 0; k < NV; k++) if (!okv[k]) ev[k] = 0u;
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < NH; k++) {
+    const int r = ty + BP_TY * k;
+    if (r >= BP_ROWS + 8) break;
+    const unsigned e = eh[k];
+    const int nl = e & 7, nr = (e >> 3) & 7;
+    const int c = r * BP_SW + tx + 4;
+    uint2 v[10];
+    // (byte addresses: a sample's address is `selected base + constant`, so the constant travels in the instruction)
+    const unsigned cb = (unsigned)c * 8u, cbm = cb - 32u;
+#pragma unroll
+    for (int d = 0; d < 5; d++) {
+      v[d] = *(const uint2 *)((const char *)src + ((d < nl ? cbm : zrs) + (32u - 8u * d)));
+      v[5 + d] = *(const uint2 *)((const char *)src + ((d < nr ? cb : zrs) + 8u * d));
     }
+    unsigned lo = 0, hi = 0;
 #pragma unroll
-    for (int i = 0; i < NX; i++) {
-      const int t = tid + BQ_NT * i, r = t >> 3, c = 64 + (t & 7), y = y0 - 4 + r, xx = x0 - 4 + c;
-      const bool ok = r < BQ_HR && xx < iw && y >= 0 && y < ih;
-      v[NR + i] = in[ok ? y * iw + xx : 0];
-      if (!ok) v[NR + i] = 0;
+    for (int d = 0; d < 10; d++) { lo += v[d].x; hi += v[d].y; }
+    const int w = nl + nr;
+    uint2 o = src[c];
+    if (w > 0) {
+      const float2 rw = rwt[w];
+      o = make_uint2(div_small_f(lo & 0xffffu, rw) | (div_small_f(lo >> 16, rw) << 16), div_small_f(hi, rw));   // fields cannot exceed their range: no clamp needed
     }
-    if (tid < 16) { const float r = tid >= 1 && tid <= 10 ? 1.0f / (float)tid : 0.0f; rwt[tid] = make_float2(r, 0.5f * r); }
-#pragma unroll
-    for (int i = 0; i < NR; i++) { const int r = wave + NW * i; if (r < BQ_HR) src[r * BQ_SP + lane] = v[i]; }
-#pragma unroll
-    for (int i = 0; i < NX; i++) { const int t = tid + BQ_NT * i, r = t >> 3, c = 64 + (t & 7); if (r < BQ_HR) src[r * BQ_SP + c] = v[NR + i]; }
+    hz[r * 64 + tx] = o;
   }
   __syncthreads();
-  // pass along x: lane = row
+  if (x >= iw) return;
 #pragma unroll
-  for (int i = 0; i < PH; i++) {
-    const int t = wave + NW * i, st = t & 7, r = (t >> 3) * 64 + lane;
-    if (t >= NTH) break;
-    const int rr = r < BQ_HR ? r : BQ_HR - 1;
-    uint32_t q[16];
+  for (int k = 0; k < NV; k++) {
+    const int r = ty + BP_TY * k;
+    const int y = y0 + r;
+    if (y >= ih) break;
+    const unsigned e = ev[k] >> 6;
+    const int nl = e & 7, nr = (e >> 3) & 7;
+    const int c = (r + 4) * 64 + tx;
+    uint2 v[10];
+    const unsigned cb = (unsigned)c * 8u, cbm = cb - 2048u;
 #pragma unroll
-    for (int j = 0; j < 16; j++) q[j] = src[rr * BQ_SP + 8 * st + j];
-    uint32_t *h = hz + rr * BQ_HP + 8 * st;
-    const bool live = r < BQ_HR;
-    bq_strip(q, rh[i], rwt, [&](int k, uint32_t o) { if (live) h[k] = o; });
-  }
-  __syncthreads();
-  // pass along y: lane = column
-  const int x = x0 + lane;
+    for (int d = 0; d < 5; d++) {
+      v[d] = *(const uint2 *)((const char *)hz + ((d < nl ? cbm : zrh) + (2048u - 512u * d)));
+      v[5 + d] = *(const uint2 *)((const char *)hz + ((d < nr ? cb : zrh) + 512u * d));
+    }
+    unsigned lo = 0, hi = 0;
 #pragma unroll
-  for (int i = 0; i < PV; i++) {
-    const int t = wave + NW * i;
-    if (t >= NTV) break;
-    uint32_t q[16];
-#pragma unroll
-    for (int j = 0; j < 16; j++) q[j] = hz[(8 * t + j) * BQ_HP + lane];
-    const int y = y0 + 8 * t;
-    bq_strip(q, rv[i], rwt, [&](int k, uint32_t o) { if (x < iw && y + k < ih) atu(out, (unsigned)((y + k) * iw + x)) = o; });
+    for (int d = 0; d < 10; d++) { lo += v[d].x; hi += v[d].y; }
+    const int w = nl + nr;
+    uint2 o = hz[c];
+    if (w > 0) {
+      const float2 rw = rwt[w];
+      o = make_uint2(div_small_f(lo & 0xffffu, rw) | (div_small_f(lo >> 16, rw) << 16), div_small_f(hi, rw));
+    }
+    atu(out, (unsigned)(y * iw + x)) = (o.x & 0xffffu) | ((o.x >> 16) << 12) | (o.y << 22);
   }
 }
 
@@ -1796,15 +1777,11 @@ void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int i
 void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, int ih, int *zero_plane) {
   hipLaunchKernelGGL(k_rect_tidy, dim3(cdiv(iw, 64), cdiv(ih, TD_ROWS)), dim3(64, 4), 0, s, mask0, tidy, nms, iw, ih, zero_plane);
 }
-// ext: blblur_ext_bytes(iw, ih) bytes - the records along x, then the records along y
-size_t blblur_ext_bytes(int iw, int ih) { return ((size_t)cdiv(iw, 8) * ih + (size_t)cdiv(ih, 8) * iw) * 8; }
-void blblur_extents(hipStream_t s, void *ext, const int8_t *edge, int iw, int ih, int nz, size_t zs) {
-  unsigned long long *eh = (unsigned long long *)ext, *ev = eh + (size_t)cdiv(iw, 8) * ih;
-  hipLaunchKernelGGL(k_blblur_extents, dim3(cdiv(iw, 64), cdiv(ih, BE_ROWS), nz), dim3(64, 4), 0, s, eh, ev, edge, iw, ih, zs);
+void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih, int nz, size_t zs) {
+  hipLaunchKernelGGL(k_blblur_extents, dim3(cdiv(iw, 64), cdiv(ih, BE_ROWS), nz), dim3(64, 4), 0, s, ext, edge, iw, ih, zs);
 }
-void blblur_pair(hipStream_t s, uint32_t *out, const void *ext, const uint32_t *in, int iw, int ih, int nz, size_t zs) {
-  const unsigned long long *eh = (const unsigned long long *)ext, *ev = eh + (size_t)cdiv(iw, 8) * ih;
-  hipLaunchKernelGGL(k_blblur_pair, dim3(cdiv(iw, 64), cdiv(ih, BQ_R), nz), dim3(BQ_NT), 0, s, out, eh, ev, in, iw, ih, zs);
+void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih, int nz, size_t zs) {
+  hipLaunchKernelGGL(k_blblur_pair, dim3(cdiv(iw, 64), cdiv(ih, BP_ROWS), nz), dim3(64, BP_TY), 0, s, out, ext, in, iw, ih, zs);
 }
 // fills the quantisation tables of the current device (once per device, before its first frame; the caller synchronises)
 void quant_lut_init(hipStream_t s) { hipLaunchKernelGGL(k_quant24_lut, dim3(20), dim3(256), 0, s); }

@@ -75,12 +75,10 @@ void strength_masks(hipStream_t s, int *strong, int8_t *strong2, int *edge /* ma
 void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih, int *merge_mask_scratch = nullptr, int nz = 1, size_t zs = 0);   // merge_mask_scratch (optional): also leaves merge_mask's bit rows there (then call merge_mask with junction = nullptr)
 // mask0 = (nms > 0), tidy = thin(thin(close_gaps(junction(mask0)), parity 0), parity 1) in one launch (oclrect.cl:74-135)
 void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, int ih, int *zero_plane = nullptr);   // zero_plane (optional): cleared on the way
-// run extents of the edge-stopped blur (depend on the edge mask only), as records of eight pixels along either axis (rd_k_rect.hip: k_blblur_extents);
-// ext: blblur_ext_bytes() bytes
-size_t blblur_ext_bytes(int iw, int ih);
-void blblur_extents(hipStream_t s, void *ext, const int8_t *edge, int iw, int ih, int nz = 1, size_t zs = 0);
+// run extents of the edge-stopped blur (depend on the edge mask only): ext[p] = nl_h | nr_h<<3 | nl_v<<6 | nr_v<<9
+void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih, int nz = 1, size_t zs = 0);
 // one horizontal + vertical pass pair; out must not alias in
-void blblur_pair(hipStream_t s, uint32_t *out, const void *ext, const uint32_t *in, int iw, int ih, int nz = 1, size_t zs = 0);
+void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih, int nz = 1, size_t zs = 0);
 void quant_lut_init(hipStream_t s);   // once per device before the first despeckle(quantize24 = 1): builds the 24-level quantisation tables on the device
 void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih, int quantize24, int nz = 1, size_t zs = 0);   // quantize24: `in` is quantised to 24 levels per field on the fly
 void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih, int nz = 1, size_t zs = 0);   // scratch: >= ih*ceil(iw/64)*4 ints
