@@ -290,8 +290,9 @@ struct Slot {
   const uint8_t *src;                     // where the frame in flight is read from: bgr (uploaded) or the caller's device buffer
   uint32_t *plab0, *plab1, *smooth, *quant;
   float *tr[3], *fw[3], *bw[3], *hz[3], *bl[3], *vxy, *strength, *nms;
-  int *i0, *i1, *mask0, *tidy, *label1, *strsum, *strong, *junction, *mergemask, *region, *rsize, *scratch2, *d2s, *boundarysrc, *boundary, *lsid, *table, *claim, *probes, *region0, *tlist;
+  int *i0, *i1, *mask0, *tidy, *label1, *strsum, *junction, *mergemask, *region, *rsize, *scratch2, *d2s, *boundarysrc, *boundary, *lsid, *table, *claim, *probes, *region0, *tlist;
   int8_t *e8;
+  unsigned long long *strongbits;         // this frame's strong mask as a bit plane (ceil(iw / 64) words per row): what the polyline stage traces
   uint16_t *ext;
   float *tails; int *flags; int iir_chunked;
   void *lslist;
@@ -314,7 +315,7 @@ struct Slot {
   // captured launch sequences (three segments, see enqueue_frame) and the stride they were captured for
   hipGraphExec_t gexec[3]; int graph_ws;   // gexec[2] unused: the last segment has one graph per round budget (gexec2)
   hipGraphExec_t gexec2[3 * RD_NBUDGETS];  // [round budget index][polyline mode]
-  int poly_mode;                           // polyline mode of the frame in flight (1 = single block, 2 = one cooperative launch of several blocks, 0 = multi-launch)
+  int poly_mode;                           // polyline mode of the frame in flight (1 = single block, 0 = multi-launch)
   int rounds;                             // region-merge round budget of the frame in flight
   // post-process worker
   pthread_t th; pthread_mutex_t mu; pthread_cond_t cv;
@@ -386,7 +387,7 @@ static void slot_planes(rd_detector *d, Slot *s, PlaneAlloc &A) {
   s->plab0 = A.get<uint32_t>(N); s->plab1 = A.get<uint32_t>(N); s->smooth = A.get<uint32_t>(N); s->quant = A.get<uint32_t>(N);
   for (int k = 0; k < 3; k++) { s->tr[k] = A.get<float>(N); s->fw[k] = A.get<float>(N); s->bw[k] = A.get<float>(N); s->hz[k] = A.get<float>(N); s->bl[k] = A.get<float>(N); }
   s->vxy = A.get<float>(N * 2); s->strength = A.get<float>(N); s->nms = A.get<float>(N);
-  int **ip[] = { &s->i0, &s->i1, &s->mask0, &s->tidy, &s->label1, &s->strsum, &s->strong, &s->junction, &s->mergemask, &s->region, &s->rsize,
+  int **ip[] = { &s->i0, &s->i1, &s->mask0, &s->tidy, &s->label1, &s->strsum, &s->junction, &s->mergemask, &s->region, &s->rsize,
                  &s->boundarysrc, &s->boundary, &s->lsid, &s->region0 };
   for (size_t i = 0; i < sizeof(ip) / sizeof(ip[0]); i++) *ip[i] = A.get<int>(N);
   s->scratch2 = A.get<int>(N * 3 + 256);      // region_merge: the initial forest, flags + allow bytes, the second label plane of the rounds
@@ -394,6 +395,7 @@ static void slot_planes(rd_detector *d, Slot *s, PlaneAlloc &A) {
   s->table = A.get<int>(N * 4); s->claim = A.get<int>(N); s->tlist = A.get<int>(N);
   if (A.real()) rdk::reduce_ls_init(s->st, s->table, s->claim, s->tlist, (int)(N * 4 / 5));
   s->e8 = A.get<int8_t>(N);
+  s->strongbits = A.get<unsigned long long>((size_t)((d->iw + 63) / 64) * d->ih + 8);
   s->ext = A.get<uint16_t>(N);
   { size_t a = rdk::iir_pass_scratch_floats(3, d->ih, d->iw), b = rdk::iir_pass_scratch_floats(3, d->iw, d->ih); s->tails = A.get<float>(a > b ? a : b); }
   s->flags = A.get<int>(16); if (A.real()) { RD_HIP(hipMemset(s->flags, 0, 16 * sizeof(int))); RD_HIP(hipStreamSynchronize(0)); }
@@ -437,15 +439,15 @@ static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
   s->frame = d->frames + (s - d->slots);
   rdk::PolyFrame &f = *s->frame;
   memset(&f, 0, sizeof(f));
-  f.ps = *s->ps; f.in = s->strong; f.ring_src = NULL; f.lslist = s->lslist; f.ids = s->lsid;
+  f.ps = *s->ps; f.in = NULL; f.in_bits = s->strongbits; f.ring_src = NULL; f.lslist = s->lslist; f.ids = s->lsid;
   f.boundary = s->boundary; f.table = s->table; f.claim = s->claim; f.tlist = s->tlist; f.probes = s->probes; f.pack = s->h_pack_dev; f.rflags = s->scratch2 + N;
   f.post_scratch = s->post_scratch; f.post_out = s->h_post_dev;
 }
 
 static void slot_free(Slot *s) {
   RD_HIP(hipStreamSynchronize(s->st));
-  void *all[] = { s->bgr, s->plab0, s->plab1, s->smooth, s->quant, s->vxy, s->strength, s->nms, s->i0, s->i1, s->mask0, s->tidy, s->label1, s->strsum, s->strong,
-                  s->junction, s->mergemask, s->region, s->rsize, s->scratch2, s->d2s, s->boundarysrc, s->boundary, s->lsid, s->table, s->claim, s->tlist, s->region0, s->probes, s->e8, s->ext, s->tails, s->flags, s->lslist };
+  void *all[] = { s->bgr, s->plab0, s->plab1, s->smooth, s->quant, s->vxy, s->strength, s->nms, s->i0, s->i1, s->mask0, s->tidy, s->label1, s->strsum,
+                  s->junction, s->mergemask, s->region, s->rsize, s->scratch2, s->d2s, s->boundarysrc, s->boundary, s->lsid, s->table, s->claim, s->tlist, s->region0, s->probes, s->e8, s->strongbits, s->ext, s->tails, s->flags, s->lslist };
   if (!s->owner->arena) {
   for (void *p : all) dfree(p);
   for (int k = 0; k < 3; k++) { dfree(s->tr[k]); dfree(s->fw[k]); dfree(s->bw[k]); dfree(s->hz[k]); dfree(s->bl[k]); }
@@ -555,7 +557,7 @@ static void frame_strong(rd_detector *d, Slot *s, hipStream_t st) {
   const long t = s->seq;
   s->prev_in = d->prev_ring + (size_t)(t % d->nring) * N;
   int8_t *out = d->prev_ring + (size_t)((t + 1) % d->nring) * N;
-  rdk::strength_masks(st, s->strong, out, NULL, s->e8, s->label1, s->strsum, 500, 2500, d->iw, d->ih, s->prev_in);
+  rdk::strength_masks(st, NULL, out, NULL, s->e8, s->label1, s->strsum, 500, 2500, d->iw, d->ih, s->prev_in, s->strongbits);      // (the mask as bytes for the next frame, as bits for this frame's polylines; nobody reads it as ints)
 }
 
 // gradient direction, re-packed blurred Lab, strength, non-max suppression (oclrect.c:251-258) of nz frames: one tile kernel that keeps the three
@@ -639,12 +641,10 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t 
 // needed (+ margin).  A frame whose last launched round still changed something is repeated with the full budget
 // (slot_postprocess), so the result never depends on the budget.
 // how the polyline stage of the next frame is launched: the single-block kernel (1) until two frames in a row overflowed its on-chip tables
-// (e.g. 3840x2160), from then on the ~85-launch form (0), which is also what repeats a frame that another mode gave up on.  RD_POLY_COOP=1:
-// the same stage as ONE cooperative launch of several blocks per frame (2) for every frame - bit-identical, but measured SLOWER at full
-// rate than the 85 launches (3840x2160: 487 against 545 frames/s): its blocks hold their CUs while they wait at ~50 grid barriers, and every
-// barrier's device-scope fences write back and invalidate the L2s under the dense kernels of the other streams.
+// (e.g. 3840x2160), from then on the ~85-launch form (0), which is also what repeats a frame the single-block kernel gave up on.  (One
+// cooperative launch of several blocks per frame was built in round 3 and measured slower than the 85 launches: profiles/NOTES_r03.md.)
 static int current_poly_mode(const rd_detector *d) {
-  if (d->poly_mode == 0 || d->poly_mode == 2) return d->poly_mode;
+  if (d->poly_mode == 0) return 0;
   return __atomic_load_n(&d->poly_overflows, __ATOMIC_RELAXED) ? 0 : 1;
 }
 
@@ -1047,7 +1047,7 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->prev_ring = dnew<int8_t>((size_t)d->N * d->nring);
   RD_HIP(hipMemset(d->prev_ring, 0, (size_t)d->N * d->nring));
   d->use_graph = getenv("RD_NO_GRAPH") ? 0 : 1;
-  d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : (getenv("RD_POLY_COOP") ? 2 : 1);      // (RD_POLY_COOP: the cooperative launch for every frame - tests)
+  d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : 1;      // (tests: the ~85-launch form for every frame)
   d->force_redo = (getenv("RD_POLY_FORCE_REDO") ? 1 : 0) | (getenv("RD_ABSORB_FORCE_SLOW") ? 2 : 0);   // tests: every frame also takes the polyline / absorption fallback
   d->diag_no_post = getenv("RD_DIAG_NO_POST") ? 1 : 0;
   d->front_split = getenv("RD_FRONT_SPLIT") ? 1 : 0;
@@ -1281,7 +1281,7 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
   struct { const char *n; const void *p; size_t bytes; } tab[] = {
     { "plab0", s->plab0, N * 4 }, { "plab1", s->plab1, N * 4 }, { "lblur", s->bl[0], N * 4 }, { "vxy", s->vxy, N * 8 }, { "strength", s->strength, N * 4 },
     { "nms", s->nms, N * 4 }, { "mask0", s->mask0, N * 4 }, { "tidy", s->tidy, N * 4 }, { "label1", s->label1, N * 4 }, { "strsum", s->strsum, N * 4 },
-    { "edge500", s->e8, N }, { "smooth", s->smooth, N * 4 }, { "quant", s->quant, N * 4 }, { "strong", s->strong, N * 4 }, { "junction", s->junction, N * 4 },
+    { "edge500", s->e8, N }, { "smooth", s->smooth, N * 4 }, { "quant", s->quant, N * 4 }, { "strong", s->strongbits, N * 4 }, { "junction", s->junction, N * 4 },
     { "mergemask", s->mergemask, N * 4 }, { "region", s->region, N * 4 }, { "region0", s->region0, N * 4 }, { "rsize", s->rsize, N * 4 }, { "boundarysrc", s->boundarysrc, N * 4 },
     { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 }, { "polyctr", rdk::poly_scratch_counters(s->ps), 64 * 4 }, { "iirflags", s->flags, 16 * 4 }, { "d2work", s->d2s + N, 16 * 4 }, { "absorb", s->scratch2 + N + 64, 8 * 4 },
   };
@@ -1292,6 +1292,15 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
       if ((!strcmp(name, "plab1") || !strcmp(name, "vxy") || !strcmp(name, "strength")) && front_is_fused(d))
         frames_grad_nms(d, s, s->st, 1, 0, 1);      // these never leave the chip on the frame path: the same kernel again, writing them out (the blurred planes are intact)
       RD_HIP(hipStreamSynchronize(s->st));
+      if (!strcmp(name, "strong")) {        // kept as a bit plane on the device (what the polyline stage traces); handed out as the 0/1 int plane of oclrect.c:307-313
+        const size_t n = N * 4 <= max_bytes ? N : max_bytes / 4;
+        const int wpr = (d->iw + 63) / 64;
+        unsigned long long *tmp = (unsigned long long *)malloc((size_t)wpr * d->ih * 8 + 8);
+        RD_HIP(hipMemcpy(tmp, s->strongbits, (size_t)wpr * d->ih * 8, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < n; k++) { const size_t y = k / d->iw, x = k % d->iw; ((int *)dst)[k] = (int)((tmp[y * wpr + (x >> 6)] >> (x & 63)) & 1ull); }
+        free(tmp);
+        return n * 4;
+      }
       if (!strcmp(name, "edge500")) {       // kept as bytes on the device (the blur's mask); handed out as the int plane of oclrect.c:277-284
         const size_t n = N * 4 <= max_bytes ? N : max_bytes / 4;
         int8_t *tmp = (int8_t *)malloc(n ? n : 1);

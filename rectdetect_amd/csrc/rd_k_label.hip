@@ -378,12 +378,23 @@ __device__ __forceinline__ void strength_mask_one(int l, int sum, bool interior,
 // VEC: four consecutive pixels of a row per thread (rows are 16-byte aligned: iw % 4 == 0) - one 16-byte load of the labels, the eight
 // gathers of the sums in flight together, 16-byte / 4-byte stores instead of four 4-byte / 1-byte ones.  This kernel is the frame-to-frame
 // chain: it runs alone, once per frame.
+// bits (optional): the strong mask as a bit plane as well - ceil(iw / 64) words per row, bit b of word wx = pixel wx * 64 + b - which is what the
+// polyline stage traces (rd_k_poly.hip); strong (the int plane) may then be null
+// 16 bits -> every fourth bit of a 64-bit word
+__device__ __forceinline__ unsigned long long spread4(unsigned long long x) {
+  x = (x | (x << 24)) & 0x000000ff000000ffull;
+  x = (x | (x << 12)) & 0x000f000f000f000full;
+  x = (x | (x << 6)) & 0x0303030303030303ull;
+  x = (x | (x << 3)) & 0x1111111111111111ull;
+  return x;
+}
 template <bool VEC>
 __global__ __launch_bounds__(256) void k_strength_masks(int *__restrict__ strong, int8_t *__restrict__ strong2, int *__restrict__ edge, int8_t *__restrict__ edge8,
-                                                         int *__restrict__ label, const int *__restrict__ str, int t_edge, int t_strong, int iw, int ih, const int8_t *__restrict__ prev) {
+                                                         int *__restrict__ label, const int *__restrict__ str, int t_edge, int t_strong, int iw, int ih, const int8_t *__restrict__ prev,
+                                                         unsigned long long *__restrict__ bits) {
   if (VEC) {
     const int x = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
-    if (x >= iw || y >= ih) return;
+    if (x >= iw || y >= ih) return;      // (lanes beyond the row are simply missing from the ballots below: their bits are 0)
     const int p = y * iw + x;
     const int4 lv = *(const int4 *)(label + p);
     const int l[4] = { lv.x, lv.y, lv.z, lv.w };
@@ -399,8 +410,18 @@ __global__ __launch_bounds__(256) void k_strength_masks(int *__restrict__ strong
     int vs[4], ve[4], ln[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) strength_mask_one(l[k], (l[k] > 0 && interior[k]) ? sa[k] + sb[k] : 0, interior[k], t_edge, t_strong, vs[k], ve[k], ln[k]);
-    *(int4 *)(strong + p) = make_int4(vs[0], vs[1], vs[2], vs[3]);
+    if (strong != nullptr) *(int4 *)(strong + p) = make_int4(vs[0], vs[1], vs[2], vs[3]);
     *(uint32_t *)(strong2 + p) = (uint32_t)vs[0] | ((uint32_t)vs[1] << 8) | ((uint32_t)vs[2] << 16) | ((uint32_t)vs[3] << 24);
+    if (bits != nullptr) {
+      // the wave's 256 pixels = four words: ballot k holds pixel 4 L + k at bit L; lane j < 4 assembles word j from the j-th 16 lanes
+      const unsigned long long b0 = __ballot(vs[0] != 0), b1 = __ballot(vs[1] != 0), b2 = __ballot(vs[2] != 0), b3 = __ballot(vs[3] != 0);
+      const int j = threadIdx.x;
+      const int wx = blockIdx.x * 4 + j, wpr = (iw + 63) >> 6;
+      if (j < 4 && wx < wpr) {
+        const int sh = 16 * j;
+        bits[(size_t)y * wpr + wx] = spread4((b0 >> sh) & 0xffffull) | (spread4((b1 >> sh) & 0xffffull) << 1) | (spread4((b2 >> sh) & 0xffffull) << 2) | (spread4((b3 >> sh) & 0xffffull) << 3);
+      }
+    }
     if (edge != nullptr) *(int4 *)(edge + p) = make_int4(ve[0], ve[1], ve[2], ve[3]);
     *(uint32_t *)(edge8 + p) = (uint32_t)ve[0] | ((uint32_t)ve[1] << 8) | ((uint32_t)ve[2] << 16) | ((uint32_t)ve[3] << 24);
     if (ln[0] != l[0] || ln[1] != l[1] || ln[2] != l[2] || ln[3] != l[3]) *(int4 *)(label + p) = make_int4(ln[0], ln[1], ln[2], ln[3]);
@@ -414,7 +435,9 @@ __global__ __launch_bounds__(256) void k_strength_masks(int *__restrict__ strong
   const int sum = (l > 0 && interior) ? str[l] + (prev ? (int)prev[l] : 0) : 0;
   int vs, ve, ln;
   strength_mask_one(l, sum, interior, t_edge, t_strong, vs, ve, ln);
-  strong[p] = vs; strong2[p] = (int8_t)vs;       // (the copy for the next frame: a byte plane - it is read once, as an addend)
+  if (bits != nullptr) { const unsigned long long m = __ballot(vs != 0); if (threadIdx.x == 0) bits[(size_t)y * ((iw + 63) >> 6) + blockIdx.x] = m; }
+  if (strong != nullptr) strong[p] = vs;
+  strong2[p] = (int8_t)vs;       // (the copy for the next frame: a byte plane - it is read once, as an addend)
   if (edge != nullptr) edge[p] = ve;             // (the int form of the edge mask is a test plane only: rd_detector_debug_plane widens the bytes)
   edge8[p] = (int8_t)ve;
   if (ln != l) label[p] = ln;
@@ -468,11 +491,11 @@ void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int i
   hipLaunchKernelGGL(k_calc_strength, dim3(cdiv(iw, 64), cdiv(ih, 4 * CS_ROWS), nz), block2, 0, s, out, edge, label, iw, ih, add, flatten, zs);
 }
 
-void strength_masks(hipStream_t s, int *strong, int8_t *strong2, int *edge, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih, const int8_t *prev) {
+void strength_masks(hipStream_t s, int *strong, int8_t *strong2, int *edge, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih, const int8_t *prev, unsigned long long *bits) {
   // (16-byte accesses need 16-byte aligned rows and planes: the frame path's planes are; an operator call with odd pointers takes the plain form)
   const bool vec = (iw & 3) == 0 && ((((uintptr_t)strong | (uintptr_t)label | (uintptr_t)edge) & 15) == 0) && ((((uintptr_t)strong2 | (uintptr_t)edge8) & 3) == 0);
-  if (vec) hipLaunchKernelGGL(k_strength_masks<true>, dim3(cdiv(iw, 256), cdiv(ih, 4)), block2, 0, s, strong, strong2, edge, edge8, label, str, t_edge, t_strong, iw, ih, prev);
-  else hipLaunchKernelGGL(k_strength_masks<false>, grid2(iw, ih), block2, 0, s, strong, strong2, edge, edge8, label, str, t_edge, t_strong, iw, ih, prev);
+  if (vec) hipLaunchKernelGGL(k_strength_masks<true>, dim3(cdiv(iw, 256), cdiv(ih, 4)), block2, 0, s, strong, strong2, edge, edge8, label, str, t_edge, t_strong, iw, ih, prev, bits);
+  else hipLaunchKernelGGL(k_strength_masks<false>, grid2(iw, ih), block2, 0, s, strong, strong2, edge, edge8, label, str, t_edge, t_strong, iw, ih, prev, bits);
 }
 
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih) {

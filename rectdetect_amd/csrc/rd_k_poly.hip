@@ -30,117 +30,197 @@ inline dim3 grid2(int iw, int ih) { return dim3(cdiv(iw, 64), cdiv(ih, 4)); }
 struct ls_rec { float x0, y0, x1, y1; int startIndex, endIndex, leftPtr, rightPtr, startCount, endCount, maxDist, polyid, npix, level; };
 struct lsx_rec { long long mx00, mx01, mx11, my0, my1; short dx, dy, vx, vy; int d2, pad; };
 
-// ------------------------------------------------------------------------------------------------ dense tidy
-// Five stencils of the reference in one tile kernel:
+// ------------------------------------------------------------------------------------------------ tidy and compaction on bit planes
+// The mask whose curves are traced arrives as a BIT PLANE: wpr = ceil(iw / 64) words per row, bit b of word (y, wx) = pixel (wx * 64 + b, y),
+// bits beyond the frame 0 (the rect path's strong-mask kernel writes it directly - rd_k_label.hip: k_strength_masks -; a caller's int plane is
+// converted by k_mask_bits).  Everything up to the chain pixels' compact arrays then works on 1 bit per pixel:
+//   k_tidy_bits      the five stencils of the reference (below) on bit rows, a wave per 64-column x 52-row tile, one ROW per lane (the rows above
+//                    and below a lane's row come from its neighbour lanes); result: another bit plane
+//   k_row_prefix     per word: the number of chain pixels before it in its row; per row: their total
+//   k_chain_scatter  raster-order ranks = row base + word prefix + bits below: pos[rank] = pixel; the row bases are written on the way
+// and a pixel's compact index - what the reference's dense planes answer by position - is a lookup in those tables (px_rank).  Before: a dense
+// int plane out of the tidy, a dense compaction pass over it, a dense pixel -> rank plane: 16 bytes per pixel and 27 us per 1080p frame of
+// sweeps to find 4 % of the pixels.
+//
+// The five stencils:
 //   pl:66-87   junction counts (`!= 0`): on-pixels of the 3x3 block, isolated pixels -> 0, frame border 0
 //   pl:89-110  1-px gaps between two curve ends are bridged (8 strict patterns).  The kernel of the reference does not
 //              write the 2-px frame ring of its output plane, so the ring keeps the plane's previous content (SURVEY.md
 //              H3): here it is taken from ring_src (the caller's plane) or, when that is null, set to ring_const
 //   pl:112-124 checkerboard thinning, parity 0 then parity 1
 //   pl:126-147 keep on-pixels with at most two on-neighbours (cuts the curves at junctions)
-// one 64 x PT_ROWS tile per block, in LDS (6 cells of halo in total; after the bridging step only
-// "zero / non-zero" matters, so every intermediate is a byte)
-#define PT_ROWS 16
+// (6 cells of margin in total; after the bridging step only "zero / non-zero" matters, so every intermediate is a bit)
+typedef unsigned long long u64;
 #define PT_M 6
-__global__ __launch_bounds__(256) void k_poly_tidy(const rdk::PolyFrames FRS, int ring_const, int iw, int ih) {
+#define TB_OUT (64 - 2 * PT_M)          // rows a wave produces
+
+// int plane(s) -> bit planes (callers of oclpolyline_execute hand over int planes): one wave per row and word
+__global__ __launch_bounds__(256) void k_mask_bits(const rdk::PolyFrames FRS, int iw, int ih, int wpr) {
   RD_FRAME;
-  int *__restrict__ out = s.planeC;
-  const int *__restrict__ in = FRM.in;
-  const int *__restrict__ ring_src = FRM.ring_src;
-  int *gen = s.csync;
-  // On bit rows (rd_tidy_tile.h): a row of the tile with 6 cells of margin is 76 bits of a 128-bit word pair, bit b = column
-  // x0 - 6 + b; the five stencils are word operations on neighbouring rows, one thread per row.
-  constexpr int R = PT_ROWS + 2 * PT_M;
-  __shared__ bitrow M[R], NZ[R], E2[R], RG[R], O[R], T0[R], T1[R];
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * PT_ROWS;
-  const int tid = threadIdx.y * 64 + threadIdx.x;
-  const int lane = threadIdx.x, w = threadIdx.y;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) gen[0] = gen[0] + 1;      // generation of this frame's compaction state words (k_compact1)
-  {   // the mask (and, if the caller supplies one, the plane whose frame ring stands in for the bridging step's own) as bit rows:
-      // wave w takes rows w, w + 4, ...; lanes = columns -6..57, then lanes 0..11 = columns 58..69; all loads first
-    constexpr int RW = (R + 3) / 4;
-    int va[RW], vb[RW], ga[RW], gb[RW];
-    bool oka[RW], okb[RW];
-#pragma unroll
-    for (int k = 0; k < RW; k++) {
-      const int r = w + 4 * k, y = y0 - PT_M + r;
-      const int xa = x0 - PT_M + lane, xb = x0 - PT_M + 64 + lane;
-      const bool rowin = r < R && y >= 0 && y < ih;
-      oka[k] = rowin && xa >= 0 && xa < iw;
-      okb[k] = rowin && lane < 12 && xb < iw;
-      va[k] = in[oka[k] ? y * iw + xa : 0];
-      vb[k] = in[okb[k] ? y * iw + xb : 0];
-      // (the ring only: rows 0, 1, ih-2, ih-1 and columns 0, 1, iw-2, iw-1)
-      const bool yring = y <= 1 || y >= ih - 2;
-      const bool ra = ring_src != nullptr && oka[k] && (yring || xa <= 1 || xa >= iw - 2), rb = ring_src != nullptr && okb[k] && (yring || xb <= 1 || xb >= iw - 2);
-      ga[k] = ra ? ring_src[y * iw + xa] : 0;
-      gb[k] = rb ? ring_src[y * iw + xb] : 0;
-    }
-#pragma unroll
-    for (int k = 0; k < RW; k++) {
-      const int r = w + 4 * k;
-      const unsigned long long ma = __ballot(oka[k] && va[k] != 0), mb = __ballot(okb[k] && vb[k] != 0);
-      const unsigned long long qa = __ballot(ga[k] != 0), qb = __ballot(gb[k] != 0);
-      if (r < R && lane == 0) { M[r] = br(ma, mb); RG[r] = br(qa, qb); }
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  if (y >= ih) return;
+  const bool in = x < iw;
+  const int v = FRM.in[in ? y * iw + x : 0];
+  const u64 m = __ballot(in && v != 0);
+  u64 q = 0;
+  if (FRM.ring_src != nullptr) {      // (the ring only: rows 0, 1, ih-2, ih-1 and columns 0, 1, iw-2, iw-1)
+    const bool ring = in && (y <= 1 || y >= ih - 2 || x <= 1 || x >= iw - 2);
+    const int g = ring ? FRM.ring_src[y * iw + x] : 0;
+    q = __ballot(g != 0);
+  }
+  if (threadIdx.x == 0) { s.sb[y * wpr + blockIdx.x] = m; s.rb[y * wpr + blockIdx.x] = q; }
+}
+
+__device__ __forceinline__ bitrow br_lane(bitrow a, int src_lane) {
+  const unsigned a0 = (unsigned)a.lo, a1 = (unsigned)(a.lo >> 32), a2 = (unsigned)a.hi, a3 = (unsigned)(a.hi >> 32);
+  const unsigned b0 = __shfl(a0, src_lane), b1 = __shfl(a1, src_lane), b2 = __shfl(a2, src_lane), b3 = __shfl(a3, src_lane);
+  return br((u64)b0 | ((u64)b1 << 32), (u64)b2 | ((u64)b3 << 32));
+}
+
+__global__ __launch_bounds__(256) void k_tidy_bits(const rdk::PolyFrames FRS, int ring_const, int iw, int ih, int wpr) {
+  RD_FRAME;
+  const u64 *__restrict__ SB = FRM.in_bits != nullptr ? FRM.in_bits : s.sb;
+  const u64 *__restrict__ RB = (FRM.in_bits == nullptr && FRM.ring_src != nullptr) ? s.rb : nullptr;
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) s.csync[0] = s.csync[0] + 1;      // generation of this frame's compaction state words (k_compact1)
+  const int lane = threadIdx.x & 63, wx = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wx >= wpr) return;                               // (whole waves: the kernel has no block-wide barrier)
+  constexpr int R = 64;
+  const int x0 = wx * 64, y0 = blockIdx.y * TB_OUT;
+  const int r = lane, y = y0 - PT_M + r;
+  const bool yin = y >= 0 && y < ih;
+  // the lane's row with 6 cells of margin as 128 bits: bit b = column x0 - 6 + b
+  bitrow M = br(0, 0), RG = br(0, 0);
+  if (yin) {
+    const u64 *row = SB + (size_t)y * wpr + wx;
+    const u64 W = wx > 0 ? row[-1] : 0ull, C = row[0], E = wx + 1 < wpr ? row[1] : 0ull;
+    M = br((W >> 58) | (C << 6), (C >> 58) | (E << 6));
+    if (RB != nullptr) {
+      const u64 *rr = RB + (size_t)y * wpr + wx;
+      const u64 W2 = wx > 0 ? rr[-1] : 0ull, C2 = rr[0], E2w = wx + 1 < wpr ? rr[1] : 0ull;
+      RG = br((W2 >> 58) | (C2 << 6), (C2 >> 58) | (E2w << 6));
     }
   }
-  __syncthreads();
-  const int r = tid;                                   // one thread per row for the stencils (R = 28 rows)
-  const int y = y0 - PT_M + r;
   const int b0 = PT_M - x0;                            // bit of column 0
-  const bool yin = y >= 0 && y < ih;
   const bitrow inimg = yin ? br_range(b0, iw - 1 + b0) : br(0, 0);
   const bitrow in1 = (y >= 1 && y <= ih - 2) ? br_range(1 + b0, iw - 2 + b0) : br(0, 0);
   const bitrow core = (y >= 2 && y <= ih - 3) ? br_range(2 + b0, iw - 3 + b0) : br(0, 0);      // the frame without its 2-px ring
-  const unsigned long long even = (((x0 - PT_M + y) & 1) == 0) ? 0x5555555555555555ull : 0xaaaaaaaaaaaaaaaaull;
-  if (r >= 1 && r < R - 1) {   // pl:66-87: on-pixels with at least one on-neighbour keep a count (!= 0); count 2 = exactly one neighbour
-    bitrow ge1, ge2;
-    br_count8(M[r - 1], M[r], M[r + 1], ge1, ge2);
-    const bitrow on = M[r] & in1;
-    NZ[r] = on & ge1;
-    E2[r] = on & ge1 & ~ge2;
-  } else if (r < R) { NZ[r] = br(0, 0); E2[r] = br(0, 0); }
-  __syncthreads();
-  if (r >= 3 && r < R - 3) {   // pl:89-110: on-pixels stay, 1-px gaps between two curve ends are bridged (8 strict patterns); the ring keeps stale values (H3)
-    const bitrow z2n = NZ[r - 2], zm = NZ[r], zs = NZ[r + 1], z2s = NZ[r + 2], en = E2[r - 1], em = E2[r], es = E2[r + 1];
-    const bitrow wem = br_west(em), eem = br_east(em), w2zm = br_west(br_west(zm)), e2zm = br_east(br_east(zm));
-    const bitrow pat = (w2zm & wem & eem & e2zm) |
-                       (z2n & en & es & z2s) |
-                       (br_west(br_west(z2n)) & br_west(en) & br_east(es) & br_east(br_east(z2s))) |
-                       (br_east(br_east(z2n)) & br_east(en) & br_west(es) & br_west(br_west(z2s))) |
-                       (e2zm & eem & br_west(es) & br_west(br_west(zs))) |
-                       (w2zm & wem & br_east(es) & br_east(br_east(zs))) |
-                       (br_east(z2n) & br_east(en) & es & z2s) |
-                       (br_west(z2n) & br_west(en) & es & z2s);
-    const bitrow ring = inimg & ~core;
-    const bitrow ringval = ring_src != nullptr ? RG[r] : (ring_const != 0 ? br(~0ull, ~0ull) : br(0, 0));
-    O[r] = (ring & ringval) | (core & (zm | pat));
-  } else if (r < R) O[r] = br(0, 0);
-  __syncthreads();
-  if (r >= 4 && r < R - 4) {   // pl:112-124, parity 0
-    const bitrow o = O[r];
-    T0[r] = o & ~(in1 & br(even, even) & (O[r - 1] | O[r + 1]) & (br_west(o) | br_east(o)));
-  } else if (r < R) T0[r] = br(0, 0);
-  __syncthreads();
-  if (r >= 5 && r < R - 5) {   // parity 1
-    const bitrow o = T0[r];
-    T1[r] = o & ~(in1 & br(~even, ~even) & (T0[r - 1] | T0[r + 1]) & (br_west(o) | br_east(o)));
-  } else if (r < R) T1[r] = br(0, 0);
-  __syncthreads();
-  if (r >= PT_M && r < R - PT_M) {   // pl:126-147: keep on-pixels with at most two on-neighbours (cuts the curves at junctions)
-    const bitrow u = T1[r - 1], m = T1[r], d = T1[r + 1];
-    const bitrow nb[8] = { br_west(u), u, br_east(u), br_west(m), br_east(m), br_west(d), d, br_east(d) };
-    bitrow ge1 = br(0, 0), ge2 = br(0, 0), ge3 = br(0, 0);
+  const u64 even = (((x0 - PT_M + y) & 1) == 0) ? 0x5555555555555555ull : 0xaaaaaaaaaaaaaaaaull;
+  const int up = lane > 0 ? lane - 1 : 0, dn = lane < 63 ? lane + 1 : 63, up2 = lane > 1 ? lane - 2 : 0, dn2 = lane < 62 ? lane + 2 : 63;
+  // (a lane whose row lies outside a stencil's valid range holds zeros for it, like the rows of the tile kernel this replaces: what it
+  //  receives from beyond the wave's ends never matters)
+  bitrow NZ = br(0, 0), E2 = br(0, 0);
+  {   // pl:66-87: on-pixels with at least one on-neighbour keep a count (!= 0); count 2 = exactly one neighbour
+    const bitrow Mu = br_lane(M, up), Md = br_lane(M, dn);
+    if (r >= 1 && r < R - 1) {
+      bitrow ge1, ge2;
+      br_count8(Mu, M, Md, ge1, ge2);
+      const bitrow on = M & in1;
+      NZ = on & ge1;
+      E2 = on & ge1 & ~ge2;
+    }
+  }
+  bitrow O = br(0, 0);
+  {   // pl:89-110: on-pixels stay, 1-px gaps between two curve ends are bridged (8 strict patterns); the ring keeps stale values (H3)
+    const bitrow z2n = br_lane(NZ, up2), zm = NZ, zs = br_lane(NZ, dn), z2s = br_lane(NZ, dn2), en = br_lane(E2, up), em = E2, es = br_lane(E2, dn);
+    if (r >= 3 && r < R - 3) {
+      const bitrow wem = br_west(em), eem = br_east(em), w2zm = br_west(br_west(zm)), e2zm = br_east(br_east(zm));
+      const bitrow pat = (w2zm & wem & eem & e2zm) |
+                         (z2n & en & es & z2s) |
+                         (br_west(br_west(z2n)) & br_west(en) & br_east(es) & br_east(br_east(z2s))) |
+                         (br_east(br_east(z2n)) & br_east(en) & br_west(es) & br_west(br_west(z2s))) |
+                         (e2zm & eem & br_west(es) & br_west(br_west(zs))) |
+                         (w2zm & wem & br_east(es) & br_east(br_east(zs))) |
+                         (br_east(z2n) & br_east(en) & es & z2s) |
+                         (br_west(z2n) & br_west(en) & es & z2s);
+      const bitrow ring = inimg & ~core;
+      const bitrow ringval = RB != nullptr ? RG : (ring_const != 0 ? br(~0ull, ~0ull) : br(0, 0));
+      O = (ring & ringval) | (core & (zm | pat));
+    }
+  }
+  bitrow T0 = br(0, 0);
+  {   // pl:112-124, parity 0
+    const bitrow Ou = br_lane(O, up), Od = br_lane(O, dn);
+    if (r >= 4 && r < R - 4) T0 = O & ~(in1 & br(even, even) & (Ou | Od) & (br_west(O) | br_east(O)));
+  }
+  bitrow T1 = br(0, 0);
+  {   // parity 1
+    const bitrow Tu = br_lane(T0, up), Td = br_lane(T0, dn);
+    if (r >= 5 && r < R - 5) T1 = T0 & ~(in1 & br(~even, ~even) & (Tu | Td) & (br_west(T0) | br_east(T0)));
+  }
+  {   // pl:126-147: keep on-pixels with at most two on-neighbours (cuts the curves at junctions)
+    const bitrow u = br_lane(T1, up), m = T1, d = br_lane(T1, dn);
+    if (r >= PT_M && r < R - PT_M && y < ih) {
+      const bitrow nb[8] = { br_west(u), u, br_east(u), br_west(m), br_east(m), br_west(d), d, br_east(d) };
+      bitrow ge1 = br(0, 0), ge2 = br(0, 0), ge3 = br(0, 0);
 #pragma unroll
-    for (int k = 0; k < 8; k++) { ge3 = ge3 | (ge2 & nb[k]); ge2 = ge2 | (ge1 & nb[k]); ge1 = ge1 | nb[k]; }
-    M[r] = m & in1 & ~ge3;       // (the mask rows are free by now)
+      for (int k = 0; k < 8; k++) { ge3 = ge3 | (ge2 & nb[k]); ge2 = ge2 | (ge1 & nb[k]); ge1 = ge1 | nb[k]; }
+      const bitrow f = m & in1 & ~ge3;
+      s.tb[(size_t)y * wpr + wx] = (f.lo >> PT_M) | (f.hi << (64 - PT_M));
+    }
+  }
+}
+
+// chain pixels before each word in its row (pw), per row (rowsum): a wave per row
+__global__ __launch_bounds__(256) void k_row_prefix(const rdk::PolyFrames FRS, int ih, int wpr) {
+  RD_FRAME;
+  const int lane = threadIdx.x & 63, y = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (y >= ih) return;
+  int run = 0;
+  for (int w0 = 0; w0 < wpr; w0 += 64) {
+    const int i = w0 + lane;
+    const int c = i < wpr ? __popcll(s.tb[(size_t)y * wpr + i]) : 0;
+    int inc = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+    if (i < wpr) s.pw[(size_t)y * wpr + i] = run + inc - c;
+    run += __shfl(inc, 63);
+  }
+  if (lane == 0) s.rowsum[y] = run;
+}
+
+// compact index of pixel (qx, qy) - its rank among the chain pixels in raster order - or -1 (k_chain_scatter has written the row bases)
+__device__ __forceinline__ int px_rank(const PolyScratch &s, int wpr, int qx, int qy) {
+  const size_t wi = (size_t)qy * wpr + (qx >> 6);
+  const u64 w = s.tb[wi];
+  const int b = qx & 63;
+  if (!((w >> b) & 1ull)) return -1;
+  return s.rowbase[qy] + s.pw[wi] + __popcll(w & ((1ull << b) - 1ull));
+}
+
+// pos[rank] = pixel for every chain pixel (raster order), lab[rank] = rank, ends[rank] = 0; rowbase[y] = chain pixels in rows above y; ctr[0] = their number
+#define CS_ROWS_PER_BLOCK 8
+__global__ __launch_bounds__(256) void k_chain_scatter(const rdk::PolyFrames FRS, int iw, int ih, int wpr) {
+  RD_FRAME;
+  __shared__ int part[256];
+  __shared__ int base[CS_ROWS_PER_BLOCK + 1];
+  const int tid = threadIdx.x, ya = blockIdx.x * CS_ROWS_PER_BLOCK;
+  int acc = 0;
+  for (int i = tid; i < ya; i += 256) acc += s.rowsum[i];
+  part[tid] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) part[tid] += part[tid + o]; __syncthreads(); }
+  if (tid == 0) {
+    int run = part[0];
+    for (int j = 0; j < CS_ROWS_PER_BLOCK; j++) {
+      base[j] = run;
+      if (ya + j < ih) { s.rowbase[ya + j] = run; run += s.rowsum[ya + j]; }
+    }
+    base[CS_ROWS_PER_BLOCK] = run;
+    if (ya + CS_ROWS_PER_BLOCK >= ih) s.ctr[0] = run;      // the block with the frame's last rows
   }
   __syncthreads();
-  const int x = x0 + lane;
-#pragma unroll
-  for (int j = 0; j < PT_ROWS / 4; j++) {
-    const int tr = w + 4 * j, yy = y0 + tr;
-    if (x < iw && yy < ih) out[yy * iw + x] = br_bit(M[tr + PT_M], lane + PT_M);
+  for (int t = tid; t < CS_ROWS_PER_BLOCK * wpr; t += 256) {
+    const int j = t / wpr, wx = t - j * wpr, y = ya + j;
+    if (y >= ih) break;
+    u64 w = s.tb[(size_t)y * wpr + wx];
+    int rank = base[j] + s.pw[(size_t)y * wpr + wx];
+    const int p = y * iw + wx * 64;
+    while (w) {
+      const int b = __ffsll((long long)w) - 1;
+      w &= w - 1;
+      s.pos[rank] = p + b; s.lab[rank] = rank; s.ends[rank] = 0;
+      rank++;
+    }
   }
 }
 
@@ -152,11 +232,11 @@ __global__ __launch_bounds__(256) void k_poly_tidy(const rdk::PolyFrames FRS, in
 // launch has so few of them - CP_PER_BLOCK elements each - that the launches of all hardware queues together cannot fill a
 // die with waiting blocks: the blocks waited for get to run) and publishes its own running total; then it scatters.  Blocks beyond the element count -
 // which may live on the device (nptr) - leave at once.  The state words carry a generation number (*gen, advanced once per
-// frame by k_poly_tidy; every call site has its own state array), so nothing has to be cleared between launches.  Outputs (each
-// optional): pos[rank] = index, cidx[index] = rank or -1, rank1[index] = rank + 1 for non-zero elements; *cnt = their number.
+// frame by k_tidy_bits; every call site has its own state array), so nothing has to be cleared between launches.  Outputs (each
+// optional): pos[rank] = index, rank1[index] = rank + 1 for non-zero elements; *cnt = their number.
 #define CP_K (CP_PER_BLOCK / 256)
 __device__ __forceinline__ unsigned long long cp_word(unsigned gen, unsigned status, unsigned value) { return ((unsigned long long)(gen & 0xffffffu) << 40) | ((unsigned long long)status << 38) | value; }
-// MODE 0: the elements are `plane`.  MODE 1: element i is "chain pixel i is the root of a sub-chain of more than size_thre pixels"
+// (MODE 0 - the chain pixels themselves out of a dense plane - is gone: k_chain_scatter.)  MODE 1: element i is "chain pixel i is the root of a sub-chain of more than size_thre pixels"
 // (pl:380-420: surviving roots are numbered 1..K in raster order = compact order).  MODE 2: element i is the id of chain pixel i's
 // sub-chain (0 = dropped), computed and stored on the way; block 0 also resets what the single-launch stage expects cleared
 // (header record, counters ctr[2..23], ctr[25]) when ls != nullptr.
@@ -164,16 +244,14 @@ template <int MODE>
 __global__ __launch_bounds__(256) void k_compact1(const rdk::PolyFrames FRS, int n, int nblk, int size_thre, int init_ls) {
   RD_FRAME;
   // what the three call sites compact, and where the results go (each has its own state words)
-  int *__restrict__ pos = MODE == 0 ? s.pos : (MODE == 2 ? s.live : nullptr);
-  int *__restrict__ cidx = MODE == 0 ? s.cidx : nullptr;
+  static_assert(MODE == 1 || MODE == 2, "two call sites");
+  int *__restrict__ pos = MODE == 2 ? s.live : nullptr;
   int *__restrict__ rank1 = MODE == 1 ? s.rootid : nullptr;
-  const int *__restrict__ plane = MODE == 0 ? s.planeC : nullptr;
-  const int *nptr = MODE == 0 ? nullptr : s.ctr;
-  int *cnt = MODE == 0 ? s.ctr : (MODE == 1 ? s.ctr + 1 : s.ctr + 24);
+  const int *nptr = s.ctr;
+  int *cnt = MODE == 1 ? s.ctr + 1 : s.ctr + 24;
   unsigned long long *state = s.cstate + (size_t)MODE * nblk;
   const int *genp = s.csync;
   ls_rec *ls = (MODE == 2 && init_ls) ? (ls_rec *)FRM.lslist : nullptr;
-  if (MODE == 2 && blockIdx.x == 0 && threadIdx.x == 0) s.csync[2] = 0;      // (the grid barrier of k_poly_coop counts from zero)
   if (MODE == 2 && ls != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
     ls_rec z = {};
     ls[0] = z;
@@ -190,13 +268,7 @@ __global__ __launch_bounds__(256) void k_compact1(const rdk::PolyFrames FRS, int
   const unsigned gen = (unsigned)*genp;
   // flags of this thread's CP_K elements (all loads in flight together), wave counts per row of 256 elements
   unsigned on = 0;
-  if (MODE == 0) {
-    int v[CP_K];
-#pragma unroll
-    for (int k = 0; k < CP_K; k++) { const int i = b * CP_PER_BLOCK + k * 256 + tid; v[k] = plane[i < n ? i : 0]; }
-#pragma unroll
-    for (int k = 0; k < CP_K; k++) { const int i = b * CP_PER_BLOCK + k * 256 + tid; if (i < n && v[k] != 0) on |= 1u << k; }
-  } else if (MODE == 1) {
+  if (MODE == 1) {
     int l[CP_K], sz[CP_K];
 #pragma unroll
     for (int k = 0; k < CP_K; k++) { const int i = b * CP_PER_BLOCK + k * 256 + tid; const int q = i < n ? i : 0; l[k] = s.lab2[q]; sz[k] = s.size[q]; }
@@ -263,23 +335,23 @@ __global__ __launch_bounds__(256) void k_compact1(const rdk::PolyFrames FRS, int
     const unsigned long long m = __ballot(o);
     if (i >= n) continue;
     const int rank = excl + wcount[k * 4 + w] + __popcll(m & ((1ull << lane) - 1ull));
-    if (o) { if (pos) pos[rank] = i; if (rank1) rank1[i] = rank + 1; if (MODE == 0 && s.lab != nullptr) { s.lab[rank] = rank; s.ends[rank] = 0; } }
-    if (cidx) cidx[i] = o ? rank : -1;
+    if (o) { if (pos) pos[rank] = i; if (rank1) rank1[i] = rank + 1; }
   }
 }
 
 // ------------------------------------------------------------------------------------------------ chain graph
 // The 8 neighbour compact indices of every chain pixel (E,NE,N,NW,W,SW,S,SE; -1 = none), its degree, and - in the same launch -
 // the 8-connected components of the chain mask (pl:811-854 to convergence): union with every neighbour of smaller index.
-// (lab[i] = i and ends[i] = 0 were set for all chain pixels by the compaction that produced them: k_compact1<0>)
-__global__ void k_chain_union(const rdk::PolyFrames FRS, int iw) {
+// (lab[i] = i and ends[i] = 0 were set for all chain pixels by k_chain_scatter)
+__global__ void k_chain_union(const rdk::PolyFrames FRS, int iw, int wpr) {
   RD_FRAME;
   const int cnt = s.ctr[0];
   SPARSE_LOOP(i, cnt) {
     const int p = s.pos[i];
+    const int py = p / iw, px = p - py * iw;
     int nb[8], deg = 0;
 #pragma unroll
-    for (int k = 0; k < 8; k++) nb[k] = s.cidx[p + nbr_dx(k) + nbr_dy(k) * iw];   // chain pixels are interior: no bounds check needed
+    for (int k = 0; k < 8; k++) nb[k] = px_rank(s, wpr, px + nbr_dx(k), py + nbr_dy(k));   // chain pixels are interior: no bounds check needed
 #pragma unroll
     for (int k = 0; k < 8; k++) { s.nbr[i * 8 + k] = nb[k]; deg += nb[k] >= 0; }
     s.flag2[i] = deg;     // degree, used for the end-point count
@@ -757,58 +829,6 @@ __device__ __forceinline__ void d_refine3(const rdk::PolyFrames &FRS, int maxrec
 }
 __global__ __launch_bounds__(1024) void k_refine3(const rdk::PolyFrames FRS, int maxrec) { d_refine3(FRS, maxrec); }
 
-// ------------------------------------------------------------------------------------------------ cooperative variant
-// The same launches as the multi-launch path - initial segments, up to 15 split rounds, refinement, end-point joining - as ONE launch of
-// PC_NB blocks per frame with grid barriers in between (every phase is the body of the kernel above, unchanged): for frames whose live
-// pixels or records do not fit the single block of k_poly_persistent (3840x2160: ~35 k live pixels).  About 50 barriers instead of 85
-// launches.  The barrier: a counter per frame (csync[2], zeroed by k_compact1<2>), release / acquire fences at device scope around it; the
-// blocks of a launch are far fewer than the chip holds, so all of them are resident.  A barrier that does not complete within ~10 ms
-// (never seen; it would mean that the blocks are not co-resident) makes the launch give up: ctr[25] <- 1, and the caller repeats the stage
-// with the multi-launch path, like an overflow of the single-block kernel.
-#define PC_NB 8
-#define PC_T 1024
-__device__ __forceinline__ bool pc_barrier(int *ctr, int &phase) {
-  __threadfence();
-  __syncthreads();
-  bool ok = true;
-  if (threadIdx.x == 0) {
-    phase++;
-    atomicAdd(ctr, 1);
-    const int target = phase * PC_NB;
-    int spins = 0;
-    while (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-      if (++spins > (1 << 21)) { ok = false; break; }
-      __builtin_amdgcn_s_sleep(8);
-    }
-  }
-  ok = __syncthreads_and(ok) != 0;
-  __threadfence();
-  return ok;
-}
-#define PC_BAR do { if (!pc_barrier(bar, phase)) { if (threadIdx.x == 0) s.ctr[25] = 1; return; } } while (0)
-__global__ __launch_bounds__(PC_T) void k_poly_coop(const rdk::PolyFrames FRS, int lsbytes, float minerror, int iw, int maxrec) {
-  RD_FRAME;
-  int *bar = s.csync + 2;
-  int phase = 0;
-  d_seg_clear(FRS, lsbytes); PC_BAR;
-  d_seg_pass0a(FRS, lsbytes); PC_BAR;
-  d_seg_pass0b(FRS, lsbytes); PC_BAR;
-  d_seg_finish(FRS, lsbytes, iw); PC_BAR;
-  for (int r = 0; r < 15; r++) {
-    d_split_move_dist(FRS, lsbytes, iw, 1); PC_BAR;
-    d_split_detect(FRS, lsbytes, minerror, iw, r); PC_BAR;
-    const int C = __hip_atomic_load(&s.ctr[2 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (C == 0) break;                       // (no candidate in this round: every later round would find the same; uniform over the blocks)
-    d_split_apply(FRS, lsbytes, iw, r); PC_BAR;
-    d_split_commit(FRS, r); PC_BAR;
-  }
-  d_split_move_dist(FRS, lsbytes, iw, 0); PC_BAR;
-  d_refine0(FRS, maxrec); PC_BAR;
-  d_refine1(FRS, maxrec, iw); PC_BAR;
-  d_refine2(FRS, maxrec); PC_BAR;
-  if (blockIdx.x == 0) d_refine3(FRS, maxrec);
-}
-
 // ------------------------------------------------------------------------------------------------ persistent variant
 // Everything from the initial segments to the end-point joining (pl:439-809: about 85 tiny launches above) in ONE
 // single-block launch: per-pixel state lives in registers (PP_PX live pixels per thread), segment records and moment
@@ -1122,8 +1142,9 @@ PolyScratch *poly_scratch_create(int iw, int ih) {
   PolyScratch *ps = new PolyScratch();
   const size_t N = (size_t)iw * ih;
   ps->cap = (int)N;
-  ps->planeA = dalloc<int>(N); ps->planeB = dalloc<int>(N); ps->planeC = dalloc<int>(N);
-  ps->cidx = dalloc<int>(N);
+  const size_t NWORDS = (size_t)cdiv(iw, 64) * ih + 8;
+  ps->sb = dalloc<unsigned long long>(NWORDS); ps->rb = dalloc<unsigned long long>(NWORDS); ps->tb = dalloc<unsigned long long>(NWORDS);
+  ps->pw = dalloc<int>(NWORDS); ps->rowsum = dalloc<int>(ih + 8); ps->rowbase = dalloc<int>(ih + 8);
   ps->cstate = dalloc<unsigned long long>(3 * (N / CP_PER_BLOCK + 2)); ps->csync = dalloc<int>(4);
   ps->pos = dalloc<int>(N); ps->nbr = dalloc<int>(N * 8);
   ps->lab = dalloc<int>(N); ps->alive = dalloc<int>(N); ps->ends = dalloc<int>(N);
@@ -1137,7 +1158,7 @@ PolyScratch *poly_scratch_create(int iw, int ih) {
   ps->live = dalloc<int>(N);
   (void)hipMemset(ps->ctr, 0, 64 * sizeof(int));
   (void)hipMemset(ps->cstate, 0, 3 * (N / CP_PER_BLOCK + 2) * sizeof(unsigned long long));
-  (void)hipMemset(ps->csync, 0, 4 * sizeof(int));      // [0]: generation of the compaction state words (k_poly_tidy advances it before use)
+  (void)hipMemset(ps->csync, 0, 4 * sizeof(int));      // [0]: generation of the compaction state words (k_tidy_bits advances it before use)
   (void)hipStreamSynchronize(0);   // the fill is asynchronous and the callers' streams do not wait for the null stream
   return ps;
 }
@@ -1146,7 +1167,7 @@ const int *poly_scratch_counters(const PolyScratch *ps) { return ps->ctr; }
 
 void poly_scratch_destroy(PolyScratch *ps) {
   if (!ps) return;
-  void *all[] = { ps->planeA, ps->planeB, ps->planeC, ps->cidx, ps->cstate, ps->csync, ps->pos, ps->nbr, ps->lab, ps->alive, ps->ends, ps->nx[0], ps->nx[1], ps->pv[0], ps->pv[1],
+  void *all[] = { ps->sb, ps->rb, ps->tb, ps->pw, ps->rowsum, ps->rowbase, ps->cstate, ps->csync, ps->pos, ps->nbr, ps->lab, ps->alive, ps->ends, ps->nx[0], ps->nx[1], ps->pv[0], ps->pv[1],
                   ps->num[0], ps->num[1], ps->link[0], ps->link[1], ps->flag, ps->flag2, ps->lab2, ps->size, ps->rootid, ps->id, ps->dist, ps->cand, ps->ctr, ps->lsx, ps->segaux, ps->live };
   for (void *p : all) if (p) (void)hipFree(p);
   delete ps;
@@ -1159,16 +1180,17 @@ void polyline(hipStream_t st, const PolyFrame *frames_host, int nb, int lslist_b
   const int maxrec = lslist_bytes / 56;
   const dim3 sg(SPARSE_GRID, 1, nb), sb(256);
 
-  // tidy (oclpolyline.c:222-235)
-  hipLaunchKernelGGL(k_poly_tidy, dim3(cdiv(iw, 64), cdiv(ih, PT_ROWS), nb), dim3(64, 4), 0, st, frames, ring_const, iw, ih);
-
-  // compaction of the chain pixels in raster order
+  // tidy (oclpolyline.c:222-235) and compaction of the chain pixels in raster order, on bit planes
+  const int wpr = cdiv(iw, 64);
+  if (frames_host[0].in_bits == nullptr) hipLaunchKernelGGL(k_mask_bits, dim3(wpr, cdiv(ih, 4), nb), dim3(64, 4), 0, st, frames, iw, ih, wpr);      // (all frames of a launch come from one caller)
+  hipLaunchKernelGGL(k_tidy_bits, dim3(cdiv(wpr, 4), cdiv(ih, TB_OUT), nb), dim3(256), 0, st, frames, ring_const, iw, ih, wpr);
+  hipLaunchKernelGGL(k_row_prefix, dim3(cdiv(ih, 4), 1, nb), dim3(256), 0, st, frames, ih, wpr);
+  hipLaunchKernelGGL(k_chain_scatter, dim3(cdiv(ih, CS_ROWS_PER_BLOCK), 1, nb), dim3(256), 0, st, frames, iw, ih, wpr);
   const int nblk = cdiv(N, CP_PER_BLOCK);
   const dim3 cg(nblk, 1, nb);
-  hipLaunchKernelGGL(k_compact1<0>, cg, dim3(256), 0, st, frames, N, nblk, 0, 0);
 
   // chains, loops, ends (oclpolyline.c:237-266)
-  hipLaunchKernelGGL(k_chain_union, sg, sb, 0, st, frames, iw);
+  hipLaunchKernelGGL(k_chain_union, sg, sb, 0, st, frames, iw, wpr);
   hipLaunchKernelGGL(k_flatten, sg, sb, 0, st, frames, 0);      // + ends per chain
   hipLaunchKernelGGL(k_find_ends0, sg, sb, 0, st, frames);
   hipLaunchKernelGGL(k_find_ends0_flags, sg, sb, 0, st, frames);
@@ -1183,11 +1205,6 @@ void polyline(hipStream_t st, const PolyFrame *frames_host, int nb, int lslist_b
   hipLaunchKernelGGL(k_compact1<1>, cg, dim3(256), 0, st, frames, N, nblk, sizeThre, 0);
   hipLaunchKernelGGL(k_compact1<2>, cg, dim3(256), 0, st, frames, N, nblk, 0, mode == 1 ? 1 : 0);
 
-  if (mode == 2) {
-    // frames too large for the single block below: the multi-launch stage as one cooperative launch (failure -> ctr[25])
-    hipLaunchKernelGGL(k_poly_coop, dim3(PC_NB, 1, nb), dim3(PC_T), 0, st, frames, lslist_bytes, minerror, iw, maxrec);
-    return;
-  }
   if (mode == 1) {
     // fast path: initial segments, 15 subdivision rounds and the refinement in one persistent launch, one block per frame (overflow -> ctr[25])
     static std::atomic<unsigned> lds_set{0};

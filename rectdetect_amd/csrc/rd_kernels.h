@@ -69,7 +69,7 @@ void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int i
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih);
 // strong mask at t_strong (two copies) + edge mask at t_edge (int, int8), both from the unfiltered labels, + filter_strength at t_strong (label in place), one pass; t_edge <= t_strong
 // prev (optional): a 0/1 byte plane added to the sums element by element (sum of label l = str[l] + prev[l]: quirk H1 without a pass of its own); strong2 != prev
-void strength_masks(hipStream_t s, int *strong, int8_t *strong2, int *edge /* may be NULL */, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih, const int8_t *prev = nullptr);
+void strength_masks(hipStream_t s, int *strong, int8_t *strong2, int *edge /* may be NULL */, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih, const int8_t *prev = nullptr, unsigned long long *bits = nullptr);   // bits (optional): the strong mask as a bit plane too (ceil(iw / 64) words per row); strong may then be null
 
 // ---- rd_k_rect.hip: rect-path stages
 void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih, int *merge_mask_scratch = nullptr, int nz = 1, size_t zs = 0);   // merge_mask_scratch (optional): also leaves merge_mask's bit rows there (then call merge_mask with junction = nullptr)

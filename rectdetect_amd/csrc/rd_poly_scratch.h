@@ -5,8 +5,9 @@ namespace rdk {
 
 struct PolyScratch {
   int cap;            // = iw*ih, capacity of every per-pixel array
-  int *planeA, *planeB, *planeC;   // dense int planes
-  int *cidx;          // dense: pixel -> compact index or -1
+  unsigned long long *sb, *rb;     // bit planes (ceil(iw / 64) words per row) of a caller's int planes: the mask, the plane that supplies the frame ring (k_mask_bits)
+  unsigned long long *tb;          // bit plane of the chain pixels (k_tidy_bits)
+  int *pw, *rowsum, *rowbase;      // chain pixels before each word in its row, per row, in the rows above (k_row_prefix, k_chain_scatter): pixel -> compact index = px_rank()
   unsigned long long *cstate;   // compaction: one state word per block and call site (generation | status | count or running total)
   int *csync;         // compaction: [0] generation, advanced once per frame
   int *pos;           // compact: pixel index, ascending
@@ -28,7 +29,8 @@ struct PolyScratch {
 // batch instead of once per frame.
 struct PolyFrame {
   PolyScratch ps;
-  const int *in;           // the mask whose curves are traced (dense int plane)
+  const int *in;           // the mask whose curves are traced: a dense int plane ...
+  const unsigned long long *in_bits;   // ... or (if not null) a bit plane, ceil(iw / 64) words per row, bit b of word wx = pixel wx * 64 + b
   const int *ring_src;     // plane supplying the stale 2-px ring of the bridging step; null: a constant is used
   void *lslist;            // linesegment_t list, record 0 = header
   int *ids;                // dense per-pixel segment ids (only written by polyline_ids)

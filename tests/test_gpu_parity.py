@@ -801,11 +801,10 @@ def test_polyline_single_launch_equals_multilaunch(iw, ih, seed):
     fast, n0 = _run_with_env({}, iw, ih, frames)
     slow, n1 = _run_with_env({"RD_POLY_MULTILAUNCH": "1"}, iw, ih, frames)
     redo, n2 = _run_with_env({"RD_POLY_FORCE_REDO": "1"}, iw, ih, frames)
-    coop, n3 = _run_with_env({"RD_POLY_COOP": "1"}, iw, ih, frames)       # the multi-launch stage as one cooperative launch of 8 blocks per frame (an option: slower at full rate than the 85 launches)
-    assert n0 == 0 and n1 == 0 and n2 == len(frames) and n3 == 0
-    for (r0, s0), (r1, s1), (r2, s2), (r3, s3) in zip(fast, slow, redo, coop):
-        assert helpers.segments_equal(s0, s1) and helpers.segments_equal(s0, s2) and helpers.segments_equal(s0, s3)
-        assert helpers.rects_equal(r0, r1) and helpers.rects_equal(r0, r2) and helpers.rects_equal(r0, r3)
+    assert n0 == 0 and n1 == 0 and n2 == len(frames)
+    for (r0, s0), (r1, s1), (r2, s2) in zip(fast, slow, redo):
+        assert helpers.segments_equal(s0, s1) and helpers.segments_equal(s0, s2)
+        assert helpers.rects_equal(r0, r1) and helpers.rects_equal(r0, r2)
 
 
 def test_polyline_overflow_takes_fallback_and_matches_oracle():
