@@ -290,8 +290,9 @@ struct Slot {
   const uint8_t *src;                     // where the frame in flight is read from: bgr (uploaded) or the caller's device buffer
   uint32_t *plab0, *plab1, *smooth, *quant;
   float *tr[3], *fw[3], *bw[3], *hz[3], *bl[3], *vxy, *strength, *nms;
-  int *i0, *i1, *mask0, *tidy, *label1, *strsum, *junction, *mergemask, *region, *rsize, *scratch2, *d2s, *boundarysrc, *boundary, *lsid, *table, *claim, *probes, *region0, *tlist;
+  int *i0, *i1, *mask0, *tidy, *label1, *strsum, *region, *rsize, *scratch2, *d2s, *boundarysrc, *boundary, *lsid, *table, *claim, *probes, *region0, *tlist;
   int8_t *e8;
+  unsigned long long *mmbits;             // the merge mask (oclrect.c:315-321) as a bit plane
   unsigned long long *strongbits;         // this frame's strong mask as a bit plane (ceil(iw / 64) words per row): what the polyline stage traces
   uint16_t *ext;
   float *tails; int *flags; int iir_chunked;
@@ -387,7 +388,7 @@ static void slot_planes(rd_detector *d, Slot *s, PlaneAlloc &A) {
   s->plab0 = A.get<uint32_t>(N); s->plab1 = A.get<uint32_t>(N); s->smooth = A.get<uint32_t>(N); s->quant = A.get<uint32_t>(N);
   for (int k = 0; k < 3; k++) { s->tr[k] = A.get<float>(N); s->fw[k] = A.get<float>(N); s->bw[k] = A.get<float>(N); s->hz[k] = A.get<float>(N); s->bl[k] = A.get<float>(N); }
   s->vxy = A.get<float>(N * 2); s->strength = A.get<float>(N); s->nms = A.get<float>(N);
-  int **ip[] = { &s->i0, &s->i1, &s->mask0, &s->tidy, &s->label1, &s->strsum, &s->junction, &s->mergemask, &s->region, &s->rsize,
+  int **ip[] = { &s->i0, &s->i1, &s->mask0, &s->tidy, &s->label1, &s->strsum, &s->region, &s->rsize,
                  &s->boundarysrc, &s->boundary, &s->lsid, &s->region0 };
   for (size_t i = 0; i < sizeof(ip) / sizeof(ip[0]); i++) *ip[i] = A.get<int>(N);
   s->scratch2 = A.get<int>(N * 3 + 256);      // region_merge: the initial forest, flags + allow bytes, the second label plane of the rounds
@@ -396,6 +397,7 @@ static void slot_planes(rd_detector *d, Slot *s, PlaneAlloc &A) {
   if (A.real()) rdk::reduce_ls_init(s->st, s->table, s->claim, s->tlist, (int)(N * 4 / 5));
   s->e8 = A.get<int8_t>(N);
   s->strongbits = A.get<unsigned long long>((size_t)((d->iw + 63) / 64) * d->ih + 8);
+  s->mmbits = A.get<unsigned long long>((size_t)((d->iw + 63) / 64) * d->ih + 8);
   s->ext = A.get<uint16_t>(N);
   { size_t a = rdk::iir_pass_scratch_floats(3, d->ih, d->iw), b = rdk::iir_pass_scratch_floats(3, d->iw, d->ih); s->tails = A.get<float>(a > b ? a : b); }
   s->flags = A.get<int>(16); if (A.real()) { RD_HIP(hipMemset(s->flags, 0, 16 * sizeof(int))); RD_HIP(hipStreamSynchronize(0)); }
@@ -447,7 +449,7 @@ static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
 static void slot_free(Slot *s) {
   RD_HIP(hipStreamSynchronize(s->st));
   void *all[] = { s->bgr, s->plab0, s->plab1, s->smooth, s->quant, s->vxy, s->strength, s->nms, s->i0, s->i1, s->mask0, s->tidy, s->label1, s->strsum,
-                  s->junction, s->mergemask, s->region, s->rsize, s->scratch2, s->d2s, s->boundarysrc, s->boundary, s->lsid, s->table, s->claim, s->tlist, s->region0, s->probes, s->e8, s->strongbits, s->ext, s->tails, s->flags, s->lslist };
+                  s->region, s->rsize, s->scratch2, s->d2s, s->boundarysrc, s->boundary, s->lsid, s->table, s->claim, s->tlist, s->region0, s->probes, s->e8, s->strongbits, s->mmbits, s->ext, s->tails, s->flags, s->lslist };
   if (!s->owner->arena) {
   for (void *p : all) dfree(p);
   for (int k = 0; k < 3; k++) { dfree(s->tr[k]); dfree(s->fw[k]); dfree(s->bw[k]); dfree(s->hz[k]); dfree(s->bl[k]); }
@@ -511,8 +513,8 @@ static void frame_regions(rd_detector *d, Slot *s) {
   // regions (oclrect.c:325-336)
   int *d2scratch = s->d2s;
   int marked = 0;
-  rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih, (d->diag_skip & 2) ? 2 : s->rounds,
-                    s->rsize, s->junction, &marked);   // H2: the sizes start from the junction counts (copied by the first kernel)
+  rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mmbits, s->strongbits, iw, ih, (d->diag_skip & 2) ? 2 : s->rounds,
+                    s->rsize, &marked);   // H2: the sizes start from the junction counts (evaluated by the first kernel)
   rdk::region_size(st, s->rsize, s->region0, N, d2scratch + N, marked);      // (also strips the rounds' marks from the labels)
   rdk::despeckle2(st, s->region, s->region0, d2scratch, s->rsize, 16, iw, ih, 1, s->scratch2 + N + 64);   // (status words: they travel to the host with the round flags)
 
@@ -605,8 +607,8 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t 
   if (d->fork_poly) {      // (RD_NO_FORK: everything on the main stream, blur chain first)
     RD_HIP(hipEventRecord(s->ev_fork, st));
     RD_HIP(hipStreamWaitEvent(s->st2, s->ev_fork, 0));
-    rdk::junction(s->st2, s->junction, s->label1, 0, iw, ih, s->scratch2);
-    rdk::merge_mask(s->st2, s->mergemask, s->scratch2, NULL, iw, ih);
+    rdk::junction_bits(s->st2, (unsigned long long *)s->scratch2, s->strongbits, iw, ih);
+    rdk::merge_mask(s->st2, s->mmbits, (const unsigned long long *)s->scratch2, iw, ih);
     RD_HIP(hipEventRecord(s->ev_mm, s->st2));
     if (!(d->diag_skip & 4)) frame_polyline(d, s, s->st2, s->poly_mode);
     RD_HIP(hipEventRecord(s->ev_join, s->st2));
@@ -623,8 +625,8 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t 
 
   if (d->fork_poly) RD_HIP(hipStreamWaitEvent(st, s->ev_mm, 0));
   else {
-    rdk::junction(st, s->junction, s->label1, 0, iw, ih, s->scratch2);
-    rdk::merge_mask(st, s->mergemask, s->scratch2, NULL, iw, ih);
+    rdk::junction_bits(st, (unsigned long long *)s->scratch2, s->strongbits, iw, ih);
+    rdk::merge_mask(st, s->mmbits, (const unsigned long long *)s->scratch2, iw, ih);
   }
 
   frame_regions(d, s);
@@ -720,10 +722,10 @@ static void group_segment(rd_detector *d, Slot *s, int nz, int seg, hipStream_t 
   { const uint32_t *src = s->plab0;
     for (int i = 0; i < 10; i++) { uint32_t *dst = (i & 1) ? s->smooth : (uint32_t *)s->i0; rdk::blblur_pair(st, dst, s->ext, src, iw, ih, nz, zs); src = dst; } }
   rdk::despeckle(st, s->quant, s->smooth, s->nms, iw, ih, 1, nz, zs);
-  rdk::junction(st, s->junction, s->label1, 0, iw, ih, s->scratch2, nz, zs);
-  rdk::merge_mask(st, s->mergemask, s->scratch2, NULL, iw, ih, nz, zs);
+  rdk::junction_bits(st, (unsigned long long *)s->scratch2, s->strongbits, iw, ih, nz, zs);
+  rdk::merge_mask(st, s->mmbits, (const unsigned long long *)s->scratch2, iw, ih, nz, zs);
   int marked = 0;
-  rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mergemask, s->label1, iw, ih, s->rounds, s->rsize, s->junction, &marked, nz, zs);
+  rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mmbits, s->strongbits, iw, ih, s->rounds, s->rsize, &marked, nz, zs);
   rdk::region_size(st, s->rsize, s->region0, N, s->d2s + N, marked, nz, zs);
   rdk::despeckle2(st, s->region, s->region0, s->d2s, s->rsize, 16, iw, ih, 1, s->scratch2 + N + 64, nz, zs);
   rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, iw, ih, s->table, s->claim, s->tlist, nz, zs);
@@ -1281,8 +1283,8 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
   struct { const char *n; const void *p; size_t bytes; } tab[] = {
     { "plab0", s->plab0, N * 4 }, { "plab1", s->plab1, N * 4 }, { "lblur", s->bl[0], N * 4 }, { "vxy", s->vxy, N * 8 }, { "strength", s->strength, N * 4 },
     { "nms", s->nms, N * 4 }, { "mask0", s->mask0, N * 4 }, { "tidy", s->tidy, N * 4 }, { "label1", s->label1, N * 4 }, { "strsum", s->strsum, N * 4 },
-    { "edge500", s->e8, N }, { "smooth", s->smooth, N * 4 }, { "quant", s->quant, N * 4 }, { "strong", s->strongbits, N * 4 }, { "junction", s->junction, N * 4 },
-    { "mergemask", s->mergemask, N * 4 }, { "region", s->region, N * 4 }, { "region0", s->region0, N * 4 }, { "rsize", s->rsize, N * 4 }, { "boundarysrc", s->boundarysrc, N * 4 },
+    { "edge500", s->e8, N }, { "smooth", s->smooth, N * 4 }, { "quant", s->quant, N * 4 }, { "strong", s->strongbits, N * 4 }, { "junction", s->strongbits, N * 4 },
+    { "mergemask", s->mmbits, N * 4 }, { "region", s->region, N * 4 }, { "region0", s->region0, N * 4 }, { "rsize", s->rsize, N * 4 }, { "boundarysrc", s->boundarysrc, N * 4 },
     { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 }, { "polyctr", rdk::poly_scratch_counters(s->ps), 64 * 4 }, { "iirflags", s->flags, 16 * 4 }, { "d2work", s->d2s + N, 16 * 4 }, { "absorb", s->scratch2 + N + 64, 8 * 4 },
   };
   for (size_t i = 0; i < sizeof(tab) / sizeof(tab[0]); i++)
@@ -1292,12 +1294,23 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
       if ((!strcmp(name, "plab1") || !strcmp(name, "vxy") || !strcmp(name, "strength")) && front_is_fused(d))
         frames_grad_nms(d, s, s->st, 1, 0, 1);      // these never leave the chip on the frame path: the same kernel again, writing them out (the blurred planes are intact)
       RD_HIP(hipStreamSynchronize(s->st));
-      if (!strcmp(name, "strong")) {        // kept as a bit plane on the device (what the polyline stage traces); handed out as the 0/1 int plane of oclrect.c:307-313
+      if (!strcmp(name, "strong") || !strcmp(name, "mergemask") || !strcmp(name, "junction")) {
+        // kept as bit planes on the device (what the polyline stage traces / what the region stage reads); handed out as the int planes of
+        // oclrect.c:307-321 - the junction counts (oclrect.cl:74-95: on-pixels of the 3x3 block, 1 -> 0, frame border 0) evaluated here from the strong mask
         const size_t n = N * 4 <= max_bytes ? N : max_bytes / 4;
-        const int wpr = (d->iw + 63) / 64;
-        unsigned long long *tmp = (unsigned long long *)malloc((size_t)wpr * d->ih * 8 + 8);
-        RD_HIP(hipMemcpy(tmp, s->strongbits, (size_t)wpr * d->ih * 8, hipMemcpyDeviceToHost));
-        for (size_t k = 0; k < n; k++) { const size_t y = k / d->iw, x = k % d->iw; ((int *)dst)[k] = (int)((tmp[y * wpr + (x >> 6)] >> (x & 63)) & 1ull); }
+        const int wpr = (d->iw + 63) / 64, iw = d->iw, ih = d->ih;
+        unsigned long long *tmp = (unsigned long long *)malloc((size_t)wpr * ih * 8 + 8);
+        RD_HIP(hipMemcpy(tmp, tab[i].p, (size_t)wpr * ih * 8, hipMemcpyDeviceToHost));
+        auto bit = [&](int x, int y) { return (int)((tmp[(size_t)y * wpr + (x >> 6)] >> (x & 63)) & 1ull); };
+        for (size_t k = 0; k < n; k++) {
+          const int y = (int)(k / iw), x = (int)(k % iw);
+          int v = bit(x, y);
+          if (!strcmp(name, "junction")) {
+            if (v && x > 0 && y > 0 && x < iw - 1 && y < ih - 1) { int c = 0; for (int dy = -1; dy <= 1; dy++) for (int dx = -1; dx <= 1; dx++) c += bit(x + dx, y + dy); v = c == 1 ? 0 : c; }
+            else v = 0;
+          }
+          ((int *)dst)[k] = v;
+        }
         free(tmp);
         return n * 4;
       }

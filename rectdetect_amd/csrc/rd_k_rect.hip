@@ -21,42 +21,30 @@ inline int ew_grid(int n) { int g = cdiv(n, 256 * 4); return g < 1 ? 1 : (g > 40
 #define RD_XY const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y
 
 // ------------------------------------------------------------------------------------------------ edge tidy
-// rc:74-95 (`> 0`) and pl:66-87 (`!= 0`): 3x3 population count of on-pixels, 1 -> 0, frame border 0
-// (bits, optional: the two bit rows per 64 pixels that k_mm_gather reads - "counted pixel", "curve end" - see k_mm_bits)
-__global__ __launch_bounds__(256) void k_junction(int *__restrict__ out, const int *__restrict__ in, int nz, int iw, int ih, unsigned long long *__restrict__ bits, int wpr, size_t zs) {
-  RD_ZSHIFT(zs, out, in, bits);
-  RD_XY;
-  const bool inside = x < iw && y < ih;
-  const int p = inside ? y * iw + x : 0;
-  int r = 0;
-  if (inside && x > 0 && y > 0 && x < iw - 1 && y < ih - 1) {
-    const int c = in[p];
-    if (nz ? c != 0 : c > 0) {
-      int count = 1;
-#pragma unroll
-      for (int i = 0; i < 8; i++) {
-        const int q = in[p + nbr_dx(i) + nbr_dy(i) * iw];
-        if (nz ? q != 0 : q > 0) count++;
-      }
-      r = count == 1 ? 0 : count;
-    }
-  }
-  if (inside) out[p] = r;
-  if (bits != nullptr) {
-    const unsigned long long any = __ballot(inside && r != 0), end = __ballot(inside && r == 2);
-    if (threadIdx.x == 0 && y < ih) {
-      unsigned long long *o = bits + ((size_t)y * wpr + blockIdx.x) * 2;
-      o[0] = any; o[1] = end;
-    }
-  }
+typedef unsigned long long u64;
+// A row of a bit plane (ceil(iw / 64) words per row, bit b of word k = pixel 64 k + b) around word k with one cell of margin: bit b = column 64 k - 1 + b
+__device__ __forceinline__ bitrow row_m1(const u64 *__restrict__ plane, int wpr, int y, int k, int ih) {
+  if (y < 0 || y >= ih) return br(0, 0);
+  const u64 *r = plane + (size_t)y * wpr + k;
+  const u64 W = k > 0 ? r[-1] : 0ull, C = r[0], E = k + 1 < wpr ? r[1] : 0ull;
+  return br((W >> 63) | (C << 1), (C >> 63) | (E << 1));
 }
-
-// the rect-variant edge tidy (rd_tidy_tile.h) as a kernel of its own; the frame path runs it inside the labelling tile kernel
-#define TD_ROWS 16
-__global__ __launch_bounds__(256) void k_rect_tidy(int *__restrict__ mask0, int *__restrict__ tidy, const float *__restrict__ nms, int iw, int ih, int *__restrict__ zero_plane) {
-  __shared__ __align__(16) uint8_t A[(TD_ROWS + 2 * TD_M) * TD_P], B[(TD_ROWS + 2 * TD_M) * TD_P];
-  int v[TD_ROWS / 4];
-  rect_tidy_tile<TD_ROWS>(A, B, blockIdx.x * 64, blockIdx.y * TD_ROWS, threadIdx.y * 64 + threadIdx.x, nms, mask0, tidy, zero_plane, iw, ih, v);
+// rc:74-95 on the strong mask's bit plane: a pixel's count is the number of on-pixels of its 3x3 block (1 -> 0; frame border 0).  All the merge mask
+// asks of the counts is "counted" (count != 0: on, with an on-neighbour) and "curve end" (count == 2: exactly one on-neighbour): two bit rows per
+// 64 pixels, words [0] and [1] of bits[(y * wpr + k) * 2].  One thread per word.  (The counts themselves - what the region sizes start from, quirk
+// H2 - are evaluated from the same bit plane where they are used: k_region_init.)
+__global__ __launch_bounds__(256) void k_junction_bits(u64 *__restrict__ bits, const u64 *__restrict__ strong, int iw, int ih, int wpr, size_t zs) {
+  RD_ZSHIFT(zs, bits, strong);
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= wpr * ih) return;
+  const int y = t / wpr, k = t - y * wpr;
+  const bitrow u = row_m1(strong, wpr, y - 1, k, ih), m = row_m1(strong, wpr, y, k, ih), d = row_m1(strong, wpr, y + 1, k, ih);
+  bitrow ge1, ge2;
+  br_count8(u, m, d, ge1, ge2);
+  const bitrow in1 = (y >= 1 && y <= ih - 2) ? br_range(1 - 64 * k + 1, iw - 2 - 64 * k + 1) : br(0, 0);
+  const bitrow any = m & in1 & ge1, end = any & ~ge2;
+  bits[(size_t)t * 2] = (any.lo >> 1) | (any.hi << 63);
+  bits[(size_t)t * 2 + 1] = (end.lo >> 1) | (end.hi << 63);
 }
 
 // ------------------------------------------------------------------------------------------------ edge-stopped box blur
@@ -421,19 +409,8 @@ __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, c
 // rc:246-287.  The reference scatters: every pixel with a non-zero junction count sets the ring 16 <= d^2 < 36 around
 // itself, then curve ends (count 2) erase the disc d^2 < 64 and all other counted pixels the disc d^2 < 16.  Equivalent
 // gather: mask(p) = A & ~B & ~C with A = "a counted pixel lies on the ring around p", B = "a curve end within d^2 < 64",
-// C = "another counted pixel within d^2 < 16".  The three pixel classes are turned into bit rows (one 64-bit word per
-// wave-row, by ballot) and each output pixel tests, per row offset dy, a 17-bit window against a precomputed dx mask.
-__global__ __launch_bounds__(256) void k_mm_bits(unsigned long long *__restrict__ bits, const int *__restrict__ junction, int iw, int ih, int wpr) {
-  RD_XY;
-  if (y >= ih) return;
-  const int j = x < iw ? junction[y * iw + x] : 0;
-  const unsigned long long any = __ballot(j != 0), end = __ballot(j == 2);
-  if (threadIdx.x == 0) {
-    unsigned long long *o = bits + ((size_t)y * wpr + blockIdx.x) * 2;
-    o[0] = any; o[1] = end;
-  }
-}
-
+// C = "another counted pixel within d^2 < 16".  The pixel classes arrive as bit rows (k_junction_bits) and the mask leaves as a bit plane
+// (ceil(iw / 64) words per row): its only reader, k_region_init, wants one bit per pixel.
 // The 64 cells of a word seeing the cell DX columns to their right (DX < 0: to their left): w0 w1 w2 = the words left of, at and
 // right of the output word in the source row.
 template <int DX>
@@ -463,13 +440,11 @@ __device__ __forceinline__ void mm_rows(const unsigned long long *sb, int r, uns
 
 // block: 64 columns x MM_ROWS rows.  The (MM_ROWS + 16) x 3 words x 2 classes of bit rows it needs are staged in LDS; ONE thread per
 // output row then evaluates the three tests for all 64 columns of its row at once - every (dy, dx) of a test is one shifted OR of
-// a 64-bit word instead of a 17-bit window test per pixel and row offset (262 -> 45 vector instructions per pixel) - and all
-// threads expand the result bits into the int plane.
+// a 64-bit word instead of a 17-bit window test per pixel and row offset (262 -> 45 vector instructions per pixel).
 #define MM_ROWS 64
-__global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const unsigned long long *__restrict__ bits, int iw, int ih, int wpr, size_t zs) {
+__global__ __launch_bounds__(256) void k_mm_gather(unsigned long long *__restrict__ out, const unsigned long long *__restrict__ bits, int iw, int ih, int wpr, size_t zs) {
   RD_ZSHIFT(zs, out, bits);
   __shared__ unsigned long long sb[(MM_ROWS + 16) * 6];
-  __shared__ unsigned long long res[MM_ROWS];
   const int k = blockIdx.x;                 // word holding this block's own 64 columns
   const int y0 = blockIdx.y * MM_ROWS;
   const int tid = threadIdx.y * 64 + threadIdx.x;
@@ -481,18 +456,11 @@ __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const 
     sb[t] = v;
   }
   __syncthreads();
-  if (tid < MM_ROWS) {
+  if (tid < MM_ROWS && y0 + tid < ih) {
     unsigned long long A = 0, B = 0, C = 0;
     mm_rows<-8>(sb, tid, A, B, C);
-    res[tid] = A & ~B & ~C;
-  }
-  __syncthreads();
-  const int x = k * 64 + threadIdx.x;
-  if (x >= iw) return;
-  for (int r = threadIdx.y; r < MM_ROWS; r += 4) {
-    const int y = y0 + r;
-    if (y >= ih) break;
-    out[y * iw + x] = (int)((res[r] >> threadIdx.x) & 1ull);
+    const int left = iw - 64 * k;           // columns of this word inside the frame
+    out[(size_t)(y0 + tid) * wpr + k] = A & ~B & ~C & (left >= 64 ? ~0ull : ((1ull << left) - 1ull));
   }
 }
 
@@ -516,9 +484,13 @@ __global__ __launch_bounds__(256) void k_mm_gather(int *__restrict__ out, const 
 #define RI_RW (64 + RI_H + 2)
 #define RI_RH (RI_ROWS + RI_H + 2)
 #define RI_NC (RI_RW * RI_RH)
-__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *__restrict__ B, uint8_t *__restrict__ allow, const int *__restrict__ pix, const int *__restrict__ mask,
-                                                     const int *__restrict__ edge, int iw, int ih, int *__restrict__ flags, int *__restrict__ size_out, const int *__restrict__ size_init, size_t zs) {
-  RD_ZSHIFT(zs, A, B, allow, pix, mask, edge, flags, size_out, size_init);
+// mask / edge: the merge mask and the strong mask as bit planes (wpr words per row); size_out (optional) <- the junction counts of the strong mask
+// (rc:74-95), which the region sizes start from (quirk H2: the reference counts into the plane that still holds them)
+__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *__restrict__ B, uint8_t *__restrict__ allow, const int *__restrict__ pix, const u64 *__restrict__ mask,
+                                                     const u64 *__restrict__ edge, int iw, int ih, int wpr, int *__restrict__ flags, int *__restrict__ size_out, size_t zs) {
+  RD_ZSHIFT(zs, A, B, allow, pix, mask, edge, flags, size_out);
+  __shared__ u64 sm[(RI_ROWS + 2) * 2];        // merge mask: rows y0 .. y0 + RI_ROWS + 1, words k and k + 1
+  __shared__ u64 se[(RI_ROWS + 3) * 3];        // strong mask: rows y0 - 1 .. y0 + RI_ROWS + 1, words k - 1, k, k + 1
   __shared__ int col[RI_NC];                  // colours, then (in place) nothing: kept for the allow bits
   __shared__ short lnk[RI_NC];                // raw link as a cell index of this tile's region (-1: cell outside the frame)
   __shared__ short prop[RI_NC];               // G as a cell index, or 0x7fff
@@ -535,24 +507,17 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
     [&](int t, bool ok, int v) { col[t] = v; lnk[t] = ok ? 0 : -1; });
   constexpr int MW = 64 + 2, MH = RI_ROWS + 2, MN = MW * MH;       // cells (RI_H .. RI_H + 65, RI_H .. RI_H + RI_ROWS + 1)
   {
-    constexpr int IT = (MN + 255) / 256;
-    int mv[IT], ev[IT];
-    bool ok[IT];
-#pragma unroll
-    for (int i = 0; i < IT; i++) {
-      const int t = tid + i * 256;
-      const int gx = gx0 + RI_H + t % MW, gy = gy0 + RI_H + t / MW;
-      ok[i] = t < MN && gx < iw && gy < ih;
-      const unsigned a = ok[i] ? (unsigned)(gy * iw + gx) : 0u;
-      mv[i] = at32(mask, a); ev[i] = at32(edge, a);
-    }
-#pragma unroll
-    for (int i = 0; i < IT; i++) {
-      const int t = tid + i * 256;
-      if (t < MN) alw[(RI_H + t / MW) * RI_RW + RI_H + t % MW] = (unsigned char)(ok[i] ? ((mv[i] != 0 ? 1 : 0) | (ev[i] <= 0 ? 2 : 0)) : 0);      // bit 0: mask set, bit 1: NOT a strong edge
-    }
+    const int k = blockIdx.x, y0 = blockIdx.y * RI_ROWS;
+    if (tid < (RI_ROWS + 2) * 2) { const int r = tid >> 1, kk = k + (tid & 1), yy = y0 + r; sm[tid] = (yy < ih && kk < wpr) ? mask[(size_t)yy * wpr + kk] : 0ull; }
+    if (tid < (RI_ROWS + 3) * 3) { const int r = tid / 3, kk = k - 1 + tid % 3, yy = y0 - 1 + r; se[tid] = (yy >= 0 && yy < ih && kk >= 0 && kk < wpr) ? edge[(size_t)yy * wpr + kk] : 0ull; }
   }
   __syncthreads();
+  for (int t = tid; t < MN; t += 256) {
+    const int cx = t % MW, cy = t / MW;
+    const int gx = gx0 + RI_H + cx, gy = gy0 + RI_H + cy;
+    const unsigned mbit = (unsigned)(sm[cy * 2 + (cx >> 6)] >> (cx & 63)) & 1u, ebit = (unsigned)(se[(cy + 1) * 3 + 1 + (cx >> 6)] >> (cx & 63)) & 1u;
+    alw[(RI_H + cy) * RI_RW + RI_H + cx] = (unsigned char)((gx < iw && gy < ih) ? (mbit | (ebit ? 0u : 2u)) : 0u);      // bit 0: mask set, bit 1: NOT a strong edge
+  }
   // raw links (cells of the first row / column of the region cannot know theirs: nothing reads them, see RI_H)
   for (int t = tid; t < RI_NC; t += 256) {
     if (lnk[t] < 0) continue;
@@ -639,7 +604,22 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
     A[p] = w;
     B[p] = w;
     allow[p] = alw[c];
-    if (size_out) size_out[p] = size_init[p];
+    if (size_out) {
+      // rc:74-95: on-pixels of the 3x3 block, the pixel's own included; 1 -> 0; the frame's border and off-pixels 0
+      int j = 0;
+      const int b = threadIdx.x;
+      if (x > 0 && y > 0 && x < iw - 1 && y < ih - 1 && ((se[(r + 1) * 3 + 1] >> b) & 1ull)) {
+        int cnt = 0;
+#pragma unroll
+        for (int dr = 0; dr < 3; dr++) {
+          const u64 *w = &se[(r + dr) * 3];
+          const unsigned v = b == 0 ? (((unsigned)w[1] & 3u) << 1) | (unsigned)(w[0] >> 63) : (b == 63 ? ((unsigned)(w[1] >> 62) & 3u) | (((unsigned)w[2] & 1u) << 2) : (unsigned)(w[1] >> (b - 1)) & 7u);
+          cnt += __popc(v);
+        }
+        j = cnt == 1 ? 0 : cnt;
+      }
+      size_out[p] = j;
+    }
   }
 }
 
@@ -1771,11 +1751,10 @@ __global__ void k_sample_segments(const rdk::PolyFrames FRS, int max_records, in
 
 namespace rdk {
 
-void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih, int *merge_mask_scratch, int nzf, size_t zs) {
-  hipLaunchKernelGGL(k_junction, dim3(cdiv(iw, 64), cdiv(ih, 4), nzf), block2, 0, s, out, in, nonzero_variant, iw, ih, (unsigned long long *)merge_mask_scratch, cdiv(iw, 64), zs);
-}
-void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, int ih, int *zero_plane) {
-  hipLaunchKernelGGL(k_rect_tidy, dim3(cdiv(iw, 64), cdiv(ih, TD_ROWS)), dim3(64, 4), 0, s, mask0, tidy, nms, iw, ih, zero_plane);
+// bits: ih * ceil(iw / 64) * 2 words ("counted", "curve end" per 64 pixels), from the strong mask's bit plane
+void junction_bits(hipStream_t s, unsigned long long *bits, const unsigned long long *strong, int iw, int ih, int nz, size_t zs) {
+  const int wpr = cdiv(iw, 64);
+  hipLaunchKernelGGL(k_junction_bits, dim3(cdiv(wpr * ih, 256), 1, nz), dim3(256), 0, s, bits, strong, iw, ih, wpr, zs);
 }
 void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih, int nz, size_t zs) {
   hipLaunchKernelGGL(k_blblur_extents, dim3(cdiv(iw, 64), cdiv(ih, BE_ROWS), nz), dim3(64, 4), 0, s, ext, edge, iw, ih, zs);
@@ -1789,23 +1768,22 @@ void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *ed
   if (quantize24) hipLaunchKernelGGL(k_despeckle<24>, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS), nz), dim3(64, 4), 0, s, out, in, edge, iw, ih, zs);
   else hipLaunchKernelGGL(k_despeckle<0>, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS), nz), dim3(64, 4), 0, s, out, in, edge, iw, ih, zs);
 }
-// scratch: ih * ceil(iw/64) * 2 64-bit words
-void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih, int nz, size_t zs) {
+// out: the merge mask as a bit plane (ih * ceil(iw / 64) words); bits: what junction_bits() left
+void merge_mask(hipStream_t s, unsigned long long *out, const unsigned long long *bits, int iw, int ih, int nz, size_t zs) {
   const int wpr = cdiv(iw, 64);
-  if (junction != nullptr) hipLaunchKernelGGL(k_mm_bits, grid2(iw, ih), block2, 0, s, (unsigned long long *)scratch, junction, iw, ih, wpr);   // (nullptr: rdk::junction has left the bit rows in scratch)
-  hipLaunchKernelGGL(k_mm_gather, dim3(wpr, cdiv(ih, MM_ROWS), nz), dim3(64, 4), 0, s, out, (const unsigned long long *)scratch, iw, ih, wpr, zs);
+  hipLaunchKernelGGL(k_mm_gather, dim3(wpr, cdiv(ih, MM_ROWS), nz), dim3(64, 4), 0, s, out, bits, iw, ih, wpr, zs);
 }
 
 // scratch: 3*N + 256 ints ([N, N + 96): a flag per launch and the absorption's status words, then the allowed-direction bytes; [2N, 3N): the second label plane of the rounds).
 // ROUNDS: the number of launches, even (the last one writes `label`); launches after one that changed nothing return at once.
 // *marked <- 1: `label` holds the rounds' words (label << 3 | mark), which region_size turns into plain labels.
-void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int ROUNDS, int *size_out, const int *size_init, int *marked, int nz, size_t zs) {
+void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const unsigned long long *mask, const unsigned long long *edge, int iw, int ih, int ROUNDS, int *size_out, int *marked, int nz, size_t zs) {
   const int n = iw * ih;
   if (ROUNDS < 2 || (ROUNDS & 1) || ROUNDS > 64) { fprintf(stderr, "region_merge: the number of launches must be even, 2..64 (got %d)\n", ROUNDS); abort(); }
   int *flags = scratch + n;
   uint8_t *allow = (uint8_t *)(flags + RR_NFLAGS);
   int *A = label, *B = scratch + 2 * (size_t)n;   // the two planes of the rounds; the result is in A
-  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS), nz), dim3(64, 4), 0, s, A, B, allow, pix, mask, edge, iw, ih, flags, size_out, size_init, zs);
+  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS), nz), dim3(64, 4), 0, s, A, B, allow, pix, mask, edge, iw, ih, cdiv(iw, 64), flags, size_out, zs);
   const dim3 grid(cdiv(iw, 64), cdiv(ih, RR_TY * RR_PX), nz);
   for (int r = 1; r < ROUNDS; r++) {       // (launch 0 was evaluated by k_region_init)
     if (r & 1) hipLaunchKernelGGL(k_region_round, grid, dim3(64, RR_TY), 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r, zs);

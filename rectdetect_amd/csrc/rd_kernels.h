@@ -72,22 +72,22 @@ void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw
 void strength_masks(hipStream_t s, int *strong, int8_t *strong2, int *edge /* may be NULL */, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih, const int8_t *prev = nullptr, unsigned long long *bits = nullptr);   // bits (optional): the strong mask as a bit plane too (ceil(iw / 64) words per row); strong may then be null
 
 // ---- rd_k_rect.hip: rect-path stages
-void junction(hipStream_t s, int *out, const int *in, int nonzero_variant, int iw, int ih, int *merge_mask_scratch = nullptr, int nz = 1, size_t zs = 0);   // merge_mask_scratch (optional): also leaves merge_mask's bit rows there (then call merge_mask with junction = nullptr)
-// mask0 = (nms > 0), tidy = thin(thin(close_gaps(junction(mask0)), parity 0), parity 1) in one launch (oclrect.cl:74-135)
-void rect_tidy(hipStream_t s, int *mask0, int *tidy, const float *nms, int iw, int ih, int *zero_plane = nullptr);   // zero_plane (optional): cleared on the way
+// "counted" / "curve end" bit rows of the strong mask's junction counts (oclrect.cl:74-95), 2 words per 64 pixels: what merge_mask() reads
+void junction_bits(hipStream_t s, unsigned long long *bits, const unsigned long long *strong, int iw, int ih, int nz = 1, size_t zs = 0);
 // run extents of the edge-stopped blur (depend on the edge mask only): ext[p] = nl_h | nr_h<<3 | nl_v<<6 | nr_v<<9
 void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, int ih, int nz = 1, size_t zs = 0);
 // one horizontal + vertical pass pair; out must not alias in
 void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih, int nz = 1, size_t zs = 0);
 void quant_lut_init(hipStream_t s);   // once per device before the first despeckle(quantize24 = 1): builds the 24-level quantisation tables on the device
 void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih, int quantize24, int nz = 1, size_t zs = 0);   // quantize24: `in` is quantised to 24 levels per field on the fly
-void merge_mask(hipStream_t s, int *out, int *scratch, const int *junction, int iw, int ih, int nz = 1, size_t zs = 0);   // scratch: >= ih*ceil(iw/64)*4 ints
+void merge_mask(hipStream_t s, unsigned long long *out, const unsigned long long *bits, int iw, int ih, int nz = 1, size_t zs = 0);   // out: bit plane, ceil(iw / 64) words per row
 // oclrect.cl:289-334 with the work-items of a launch concurrent (rd_k_rect.hip: k_region_init = the links and launch 0, k_region_round = the others).
+// mask / edge: the merge mask and the strong mask as bit planes.
 // launches: even, 2..64 (launches after one that changed nothing return at once; flag r of scratch[N + r] = launch r changed something);
-// size_out (optional) <- size_init, for region_size; scratch: 3N + 256 ints; *marked <- 1: `label` is left as label << 3 | mark words,
-// which region_size(…, marked) turns into plain labels
-void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const int *mask, const int *edge, int iw, int ih, int launches,
-                  int *size_out, const int *size_init, int *marked, int nz = 1, size_t zs = 0);
+// size_out (optional) <- the junction counts of the strong mask (what the reference's size plane holds when the counting starts: quirk H2), for region_size;
+// scratch: 3N + 256 ints; *marked <- 1: `label` is left as label << 3 | mark words, which region_size(…, marked) turns into plain labels
+void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const unsigned long long *mask, const unsigned long long *edge, int iw, int ih, int launches,
+                  int *size_out, int *marked, int nz = 1, size_t zs = 0);
 void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, int marked = 0, int nz = 1, size_t zs = 0);   // accumulates into out; zero_me (optional): an int to clear on the way
 #define RD_D2_SCRATCH_INTS(N) (5 * (size_t)(N) + 64)
 // absorption of small regions (oclrect.cl:348-371) exactly as the reference's serial raster order gives it.  out != in; scratch: RD_D2_SCRATCH_INTS(N) ints
