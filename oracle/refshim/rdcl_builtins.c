@@ -13,7 +13,18 @@
  *   - sqrt: correctly rounded; rsqrt(x) = 1.0f / sqrtf(x); hypot via double
  *   - distance: sqrtf of the left-to-right sum of squares (no FMA: -ffp-contract=off)
  * The HIP kernels and the C restatement (oracle/rd_oracle.c) use the same definitions.
+ *
+ * RDCL_VARIANT (build-time bit mask, default 0 = the definitions above): OTHER choices an OpenCL device may legally make for the builtins whose
+ * accuracy the standard leaves loose, so that it can be MEASURED how much of "the reference's output" hangs on ours
+ * (tools/make_golden_builtins.py -> tests/golden/builtin_sensitivity.npz):
+ *   1  rsqrt correctly rounded in one step ((float)(1 / sqrt((double)x))) instead of two correctly rounded operations
+ *   2  hypot evaluated in float (sqrtf(a * a + b * b)) instead of through double
+ *   4  distance through double (one rounding) instead of float operations left to right
+ * (FMA contraction - OpenCL C's default, H11 - is a compiler flag of the kernel objects, not a builtin: oracle/Makefile, variant "fma".)
  */
+#ifndef RDCL_VARIANT
+#define RDCL_VARIANT 0
+#endif
 #include <math.h>
 #include <stddef.h>
 #include <stdint.h>
@@ -132,10 +143,18 @@ float b_sqrt(float x) __asm__("_Z4sqrtf");
 float b_sqrt(float x) { return sqrtf(x); }
 
 float b_rsqrt(float x) __asm__("_Z5rsqrtf");
+#if RDCL_VARIANT & 1
+float b_rsqrt(float x) { return (float)(1.0 / sqrt((double)x)); }
+#else
 float b_rsqrt(float x) { return 1.0f / sqrtf(x); }
+#endif
 
 float b_hypot(float a, float b) __asm__("_Z5hypotff");
+#if RDCL_VARIANT & 2
+float b_hypot(float a, float b) { return sqrtf(a * a + b * b); }
+#else
 float b_hypot(float a, float b) { return (float)sqrt((double)a * (double)a + (double)b * (double)b); }
+#endif
 
 float b_fabs(float x) __asm__("_Z4fabsf");
 float b_fabs(float x) { return fabsf(x); }
@@ -146,11 +165,19 @@ float b_round(float x) { return roundf(x); }
 float b_distance2(float2 a, float2 b) __asm__("_Z8distanceDv2_fS_");
 float b_distance2(float2 a, float2 b) {
   float dx = a.x - b.x, dy = a.y - b.y;
+#if RDCL_VARIANT & 4
+  return (float)sqrt((double)dx * dx + (double)dy * dy);
+#else
   return sqrtf(dx * dx + dy * dy);
+#endif
 }
 
 float b_distance3(float3 a, float3 b) __asm__("_Z8distanceDv3_fS_");
 float b_distance3(float3 a, float3 b) {
   float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+#if RDCL_VARIANT & 4
+  return (float)sqrt((double)dx * dx + (double)dy * dy + (double)dz * dz);
+#else
   return sqrtf(dx * dx + dy * dy + dz * dz);
+#endif
 }

@@ -207,7 +207,9 @@ cl_int clBuildProgram(cl_program p, cl_uint n, const cl_device_id *d, const char
   (void)n; (void)d; (void)opts; (void)cb; (void)ud;
   if (!prog_dl[p->which]) {
     char path[4096];
-    self_dir(path, sizeof(path) - 64);
+    const char *vd = getenv("RDCL_KERNEL_DIR");      /* kernel objects of a builtin variant (oracle/Makefile: ref_variants), e.g. <this directory>/var_fma */
+    if (vd && *vd && strlen(vd) < sizeof(path) - 80) { strcpy(path, vd); strcat(path, "/"); }
+    else self_dir(path, sizeof(path) - 64);
     strcat(path, prog_so[p->which]);
     prog_dl[p->which] = dlopen(path, RTLD_NOW | RTLD_LOCAL);
     if (!prog_dl[p->which]) {

@@ -319,3 +319,24 @@ def test_concurrent_merge_restatement_equals_the_references_own_kernel(iw, ih, s
         R.rdcl_set_order(b"", 0, 0, 0, 0)
         r.close()
         orc.close()
+
+
+def test_builtin_sensitivity_fixture_is_consistent_with_the_other_goldens():
+    """tests/golden/builtin_sensitivity.npz (tools/make_golden_builtins.py: the reference under other legal OpenCL builtin choices): variant 0 is the
+    baseline every other fixture was made with - its rectangle lists must be the ones of the still fixtures of the same frames - and the recorded
+    differences of the baseline against itself are zero."""
+    g = golden("builtin_sensitivity")
+    variants = [str(v) for v in g["variants"]]
+    assert variants[0] == "baseline" and len(variants) >= 5
+    key = lambda r: r["c2"].tobytes() + r["c3"].tobytes() + r["value"].tobytes() + r["status"].tobytes()
+    stills = {(0, 640, 480, 0): "rect_640x480_s0", (5, 640, 480, 0): "rect_640x480_s5", (1, 1280, 720, 0): "rect_1280x720_s1", (0, 1920, 1080, 0): "rect_1920x1080_s0"}
+    checked = 0
+    for fi, fr in enumerate(g["frames"].tolist()):
+        member, union = g[f"f{fi}_member"], g[f"f{fi}_union"]
+        assert member.shape == (len(variants), len(union)) and not g[f"f{fi}_planes"][0].any() and g[f"f{fi}_segs"][0, 1] == 0
+        name = stills.get(tuple(fr))
+        if name and float(golden(name)["tan_aov"]) == float(np.tan(36.0 / 180.0 * np.pi)):
+            ref = golden(name)["f0_rects"]
+            assert sorted(key(r) for r, m in zip(union, member[0]) if m) == sorted(key(r) for r in ref), name
+            checked += 1
+    assert checked >= 2

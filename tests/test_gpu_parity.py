@@ -230,6 +230,9 @@ def test_long_streams_in_the_benchmarked_configuration_vs_reference(name, nslots
         within.append((t, float(np.abs(rects["c2"] - ref["c2"]).max(initial=0)), float(np.abs(rects["c3"] - ref["c3"]).max(initial=0))))
     print(name, "slots", nslots, ": rectangle sets bit-identical to the reference's (raster order) on %d of %d frames (%d in the same list order); inside the reference's own order-dependence on frames %s; same rectangles within tolerance (frame, max |dc2|, max |dc3|): %s; round budget, repeats:" %
           (exact, nframes, same_order, by_order, within), det.region_round_budget())
+    helpers.parity_report("rectangle lists vs the reference's raster-order goldens (frames)", f"{name} / {nslots} in flight",
+                          {"frames": nframes, "bit_identical_sets": exact, "same_list_order": same_order, "inside_reference_order_dependence": by_order, "within_tolerance_only": [w[0] for w in within],
+                           "segment_lists_bit_identical": nframes})
     assert exact + len(by_order) + len(within) == nframes
     assert within == [], "every frame must equal the reference's list or lie inside the reference's own order dependence"
     assert exact >= EXACT_FRAMES_MIN[name], (exact, "frames bit-identical to the raster-order reference: fewer than recorded")
@@ -274,6 +277,10 @@ def test_order_dependent_stream_frames_equal_the_spec(name):
             print(f"{name} frame {t}: reference order-independent here: {independent}; pixels whose region label differs from the reference-mode oracle: {int((gr != rr).sum())}; "
                   f"pixels on a region boundary in one and not in the other: {int(((gb > 0) != (rb > 0)).sum())} of {int((rb > 0).sum())}; "
                   f"rectangle list == reference golden (raster order): {helpers.rects_equal(rects, g[f'f{t}_rects'])}")
+            helpers.parity_report("order-dependent frames vs the reference-mode oracle (pixels)", f"{name} frame {t}",
+                                  {"reference_order_independent": independent, "region_label_differs": int((gr != rr).sum()), "boundary_membership_differs": int(((gb > 0) != (rb > 0)).sum()),
+                                   "boundary_pixels": int((rb > 0).sum()), "pixels": iw * ih, "rect_list_equals_raster_golden": bool(helpers.rects_equal(rects, g[f"f{t}_rects"])),
+                                   "region_planes_equal_spec": True})
             if independent:
                 assert helpers.rects_equal(rects, g[f"f{t}_rects"]), "where the reference does not depend on the order, the list must be the reference's in every bit"
         if t + 1 in frames:
@@ -1284,3 +1291,28 @@ def test_graphs_recorded_in_the_middle_of_a_run_while_workers_wait(monkeypatch):
     par.close()
     for (r1, s1), (r2, s2) in zip(want, got):
         assert helpers.rects_equal(r1, r2) and helpers.segments_equal(s1, s2)
+
+
+def test_builtin_sensitivity_report():
+    """REPORT, not a gate: the reference runs in this image on OUR OpenCL stand-in, whose loosely specified builtins (rsqrt, hypot, distance; FMA
+    contraction) are choices of ours.  tests/golden/builtin_sensitivity.npz (tools/make_golden_builtins.py) holds what THE
+    REFERENCE returns for seven fixture frames under the other legal choices.  Here: which of those variants' rectangle lists the HIP path's list
+    equals - it must equal the baseline's, the definitions the HIP kernels share - and how far the other variants move the reference itself;
+    written to tests/parity_report.json so that it shows in the driver's record."""
+    g = golden("builtin_sensitivity")
+    variants = [str(v) for v in g["variants"]]
+    key = lambda r: r["c2"].tobytes() + r["c3"].tobytes() + r["value"].tobytes() + r["status"].tobytes()
+    for fi, (seed, iw, ih, t) in enumerate(g["frames"].tolist()):
+        det = ra.Detector(iw, ih, nslots=1)
+        det.enqueue(synth.frame(synth.SEED0 + seed, iw, ih, t))
+        rects = det.poll(TAN36)
+        det.close()
+        union, member = g[f"f{fi}_union"], g[f"f{fi}_member"]
+        ukeys = [key(r) for r in union]
+        here = set(key(r) for r in rects)
+        same = [variants[vi] for vi in range(len(variants)) if set(k for k, m in zip(ukeys, member[vi]) if m) == here]
+        moved = [variants[vi] for vi in range(1, len(variants)) if not np.array_equal(member[vi], member[0])]
+        helpers.parity_report("builtin sensitivity of the reference (rectangle lists)", f"frame {fi}: {iw}x{ih} seed {seed} t {t}",
+                              {"hip_list_equals_reference_under": same, "reference_list_moves_under": moved, "rectangles_baseline": int(member[0].sum()),
+                               "distinct_rectangles_over_variants": len(union), "segment_records_differing_per_variant": {variants[vi]: int(g[f"f{fi}_segs"][vi, 1]) for vi in range(1, len(variants))}})
+        assert "baseline" in same, f"frame {fi}: the HIP path shares the baseline's builtin definitions and must return its list"
