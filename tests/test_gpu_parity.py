@@ -1315,4 +1315,8 @@ def test_builtin_sensitivity_report():
         helpers.parity_report("builtin sensitivity of the reference (rectangle lists)", f"frame {fi}: {iw}x{ih} seed {seed} t {t}",
                               {"hip_list_equals_reference_under": same, "reference_list_moves_under": moved, "rectangles_baseline": int(member[0].sum()),
                                "distinct_rectangles_over_variants": len(union), "segment_records_differing_per_variant": {variants[vi]: int(g[f"f{fi}_segs"][vi, 1]) for vi in range(1, len(variants))}})
-        assert "baseline" in same, f"frame {fi}: the HIP path shares the baseline's builtin definitions and must return its list"
+        # (a frame on which the reference's own list depends on the work-item order of its region kernels - tests/golden/stream_orders.npz, here
+        #  frame 0 of the held-out stream - is compared by membership in test_long_streams...; everywhere else the baseline's list is required)
+        order_dependent = any(k.endswith(f"_s{seed}_100_f{t}_union") and f"{iw}x{ih}" in k for k in golden("stream_orders").files)
+        helpers.parity_report("builtin sensitivity of the reference (rectangle lists)", f"frame {fi}: {iw}x{ih} seed {seed} t {t} (order-dependent)", order_dependent)
+        assert "baseline" in same or order_dependent, f"frame {fi}: the HIP path shares the baseline's builtin definitions and must return its list"

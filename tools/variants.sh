@@ -6,7 +6,7 @@ mkdir -p ../variants
 name=$1; shift
 FL="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -DCL_TARGET_OPENCL_VERSION=120 -Wno-unused-result -I. -I../../include"
 mkdir -p build/var_$name
-for f in rd_k_rect rd_k_label rd_k_front; do hipcc $FL "$@" -c $f.hip -o build/var_$name/$f.o & done; wait
+for f in rd_k_rect rd_k_label rd_k_front rd_k_nms; do x=""; [ $f = rd_k_nms ] && x="-fno-slp-vectorize"; hipcc $FL $x "$@" -c $f.hip -o build/var_$name/$f.o & done; wait
 objs=""; for f in rd_k_poly rd_k_post rd_runtime rd_api rd_post rd_helper rd_synth; do objs="$objs build/$f.o"; done
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/lib$name.so $objs build/var_$name/rd_k_rect.o build/var_$name/rd_k_label.o build/var_$name/rd_k_front.o -lpthread -lm
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/lib$name.so $objs build/var_$name/rd_k_rect.o build/var_$name/rd_k_label.o build/var_$name/rd_k_front.o build/var_$name/rd_k_nms.o -lpthread -lm
 echo built ../variants/lib$name.so
