@@ -85,7 +85,7 @@ def cpu_baseline():
                       "the reference's kernels run one work-item at a time on the serial OpenCL shim" % (P, wall)}
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r03_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r04_traffic.json")
 
 
 def traffic_per_frame():
@@ -250,11 +250,20 @@ def main():
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercises sharding/aggregation only (CPU tests)")
     ap.add_argument("--no-configs", action="store_true", help="skip the side measurements of the 1280x720 and 3840x2160 configurations")
     ap.add_argument("--share-gpus", action="store_true", help="tests on a one-GPU box only: ranks beyond the device count share devices (rank mod count); without it more ranks than devices is an error")
+    ap.add_argument("--frame", default=None, help="profiling runs only: another frame size than the headline's, e.g. 1280x720 or 3840x2160 (the line's metric then names that size); "
+                                                  "the driver's line is always 1920x1080")
+    ap.add_argument("--stream-seed", type=int, default=None, help="with --frame: seed offset of the synthetic stream (BASELINE.json configs[2]: 1, configs[3]: 4)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend of the control plane (default gloo: barrier + MAX-reduce of a double need no device)")
     args = ap.parse_args()
 
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.frame:
+        global IW, IH
+        IW, IH = (int(v) for v in args.frame.lower().split("x"))
+        args.no_configs = True
+        if IW * IH > 1920 * 1088:
+            args.slots = min(args.slots, 16)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args))      # plain `python bench.py --gpus N`: this process becomes the launcher of N ranks
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -273,7 +282,7 @@ def main():
         dist.init_process_group(backend=backend)
 
     F = args.frames_per_step
-    seed_stream = rank          # stream id = rank: independent 1080p streams, one per GPU (BASELINE.json configs[4])
+    seed_stream = rank + (args.stream_seed or 0)      # stream id = rank: independent 1080p streams, one per GPU (BASELINE.json configs[4])
 
     import rectdetect_amd as ra
     from rectdetect_amd import synth
@@ -416,10 +425,10 @@ def main():
                 host_rate = round(args.steps * F / th, 2)
         traffic, traffic_src = traffic_per_frame()
         out = {
-            "metric": "1920x1080 frames/sec", "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "%dx%d frames/sec" % (IW, IH), "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8/i32/f32 (bit-exact integer + IEEE f32 stencil path)", "data": "synthetic",
-            "config": {"workload": "vidrect 1920x1080 synthetic stream per GPU (BASELINE.json configs[4]; configs[1] is one frame of it)",
+            "config": {"workload": "vidrect 1920x1080 synthetic stream per GPU (BASELINE.json configs[4]; configs[1] is one frame of it)" if not args.frame else "vidrect %dx%d synthetic stream (profiling run, --frame)" % (IW, IH),
                        "frames_per_step": F, "frames_in_flight": args.slots, "frames_per_launch": None if args.dry_run else det.frames_per_launch(), "input": "BGR u8 host buffers (PCIe upload timed)" if args.host_frames else "BGR u8 frames resident in HBM", "parallelism": "independent streams, one per GPU, no collective"},
             "ranks": per_rank,
             "value_definition": "frames resident in HBM when the timed region starts (bench contract); value_host_frames = the same work with host BGR buffers handed over, "

@@ -1074,6 +1074,10 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->fixed_rounds = 0;
   if (getenv("RD_REGION_ROUNDS_FIXED")) { const int r = atoi(getenv("RD_REGION_ROUNDS_FIXED")); d->fixed_rounds = (r >= 8 && r <= 20 && !(r & 1)) ? r : 20; }
   d->rounds_budget = 20;
+  // The single-block polyline kernel holds 16 384 live chain pixels; a 1920x1080 frame of the synthetic streams has ~11 000, frames of 3 megapixels and
+  // more are beyond it as a rule: their streams start on the multi-launch form instead of overflowing - and being repeated - until the two-overflow rule
+  // below finds that out (3840x2160: 12 of the first 16 frames).  Smaller frames that overflow anyway are still caught by that rule.
+  d->poly_overflows = (long)iw * ih > 3000000L && !getenv("RD_POLY_TRY_SINGLE") ? 1 : 0;
   d->budget_cycle = getenv("RD_BUDGET_CYCLE") ? atoi(getenv("RD_BUDGET_CYCLE")) : 0;      // tests: the launch budget changes every so many frames (12, 14, .. 20, 12, ..)
   d->diag_skip = getenv("RD_DIAG_SKIP") ? atoi(getenv("RD_DIAG_SKIP")) : 0;   // timing diagnostics only: leaves stages out (wrong results)
   pthread_mutex_init(&d->tan_mu, NULL); pthread_cond_init(&d->tan_cv, NULL);

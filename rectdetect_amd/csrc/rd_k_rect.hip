@@ -2,6 +2,7 @@
 // region labelling, boundary marking, segment/boundary voting and result sampling.
 //
 // Reference behaviour being reproduced: oclrect.cl ("rc"), oclrect.c ("rh").  See rd_device.h for arithmetic rules.
+#include <stdlib.h>
 #include "rd_device.h"
 #include "rd_kernels.h"
 #include "rd_tidy_tile.h"

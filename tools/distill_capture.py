@@ -30,6 +30,15 @@ for name, out in (("trace_default", "kernel_stats_1080p_default.txt"), ("trace_s
     with open(os.path.join(P, pre + "_" + out), "w") as f:
         f.write(head + run(os.path.join(R, "tools", "prof_summary.py"), db, str(frames)))
 
+for name, out, cmd in (("trace_720p", "kernel_stats_720p_default.txt", "--frame 1280x720 --stream-seed 1 --steps 3 --warmup 1 --frames-per-step 64 --no-cpu-baseline --no-verify"),
+                       ("trace_4k", "kernel_stats_4k_default.txt", "--frame 3840x2160 --stream-seed 4 --steps 3 --warmup 1 --frames-per-step 16 --no-cpu-baseline --no-verify")):
+    db = os.path.join(C, name, "t_results.db")
+    if not os.path.exists(db):
+        continue
+    frames = sqlite3.connect(db).execute("select total_calls from top_kernels where name like '%k_strength_masks%'").fetchone()[0]
+    with open(os.path.join(P, pre + "_" + out), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py %s (%d frames)\n" % (cmd, frames) + run(os.path.join(R, "tools", "prof_summary.py"), db, str(frames)))
+
 # counters (RD_NO_GRAPH=1, --slots 1 --frames-per-step 4: 8 frames)
 sq = run(os.path.join(R, "tools", "pmc_summary.py"), os.path.join(C, "pmc_sq", "results.db"), "8", "40")
 with open(os.path.join(P, pre + "_pmc_sq_1080p.txt"), "w") as f:
@@ -73,8 +82,20 @@ MEASURED = ["rectdetect_amd", "include", "bench.py", "tools/gpu_capture.sh", "to
 moved = captured is None or subprocess.run(["git", "-C", R, "diff", "--quiet", captured, "HEAD", "--"] + MEASURED).returncode != 0
 if moved or dirty:
     sys.exit("distill_capture: the capture ran at %s, HEAD is %s%s - profiles must describe the code that is benchmarked: capture again (tools/capture_round.sh)" % (captured, commit, " with uncommitted changes" if dirty else ""))
+other = {}
+for key, label, npix in (("720p", "1280x720 (BASELINE.json configs[2])", 1280 * 720), ("4k", "3840x2160 (BASELINE.json configs[3])", 3840 * 2160)):
+    dr, dw = os.path.join(C, "pmc_rd_" + key, "results.db"), os.path.join(C, "pmc_wr_" + key, "results.db")
+    if os.path.exists(dr) and os.path.exists(dw) and frames_in(dr) and frames_in(dw):
+        r2, w2 = total(dr, "FETCH_SIZE") / frames_in(dr), total(dw, "WRITE_SIZE") / frames_in(dw)
+        b = int((r2 * corr_rd + w2 * corr_wr) * 1024)
+        other[label] = {"frames": frames_in(dr), "fetch_size_kib_per_frame": int(r2), "write_size_kib_per_frame": int(w2), "hbm_bytes_per_frame": b,
+                        "hbm_bytes_per_pixel": round(b / npix, 1), "algorithmic_bytes_per_frame": 829 * npix}
+        with open(os.path.join(P, pre + "_pmc_traffic_%s.txt" % key), "w") as f:
+            f.write("# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (KiB per frame; python bench.py --frame ... --steps 2 --warmup 1; %d frames); corrections as for 1080p: fetch x %.3f, write x %.3f\n" % (frames_in(dr), corr_rd, corr_wr))
+            f.write(run(os.path.join(R, "tools", "pmc_summary.py"), dr, str(frames_in(dr)), "40"))
+            f.write(run(os.path.join(R, "tools", "pmc_summary.py"), dw, str(frames_in(dw)), "40"))
 with open(os.path.join(P, ROUND + "_traffic.json"), "w") as f:
-    json.dump({"commit": captured, "command": TRAFFIC_CMD, "frames": nf_rd,
+    json.dump({"commit": captured, "command": TRAFFIC_CMD, "frames": nf_rd, "other_configurations": other,
                "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over the benchmarked configuration (default slots, graphs on; profiles/%s_pmc_traffic_1080p.txt); "
                "each corrected by the factor the calibration copy of 3 x 1 GiB (4 B/lane coalesced, tools/pmc_calibrate.py) yields in the same capture "
                "(FETCH_SIZE reports half of the bytes read on gfx950, as MI355X_MICROARCH.md describes)" % pre,

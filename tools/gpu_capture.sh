@@ -14,7 +14,10 @@ cd /tmp
 # kernel trace of the default command (fewer steps) and of one frame slot alone
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_default -o t -- python $R/bench.py --steps 3 --warmup 1 --frames-per-step 64 --no-cpu-baseline --no-verify --no-configs > $O/trace_default.log 2>&1
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_slots1 -o t -- python $R/bench.py --steps 1 --warmup 1 --slots 1 --frames-per-step 8 --no-cpu-baseline --no-verify --no-configs > $O/trace_slots1.log 2>&1
+# the other two video configurations of BASELINE.json (configs[2], configs[3]): kernel traces of the same command at their frame sizes
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_720p -o t -- python $R/bench.py --frame 1280x720 --stream-seed 1 --steps 3 --warmup 1 --frames-per-step 64 --no-cpu-baseline --no-verify > $O/trace_720p.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_4k -o t -- python $R/bench.py --frame 3840x2160 --stream-seed 4 --steps 3 --warmup 1 --frames-per-step 16 --no-cpu-baseline --no-verify > $O/trace_4k.log 2>&1
 cd $R
 bash tools/gpu_pmc.sh cap$tag > $O/pmc.log 2>&1
-for d in sq rd wr calrd calwr; do mkdir -p $O/pmc_$d; cp $(find gpurun_out/pmccap${tag}_$d -name "*.db" | head -1) $O/pmc_$d/results.db; done
+for d in sq rd wr calrd calwr rd_720p wr_720p rd_4k wr_4k; do mkdir -p $O/pmc_$d; cp $(find gpurun_out/pmccap${tag}_$d -name "*.db" | head -1) $O/pmc_$d/results.db; done
 ls -la $O
