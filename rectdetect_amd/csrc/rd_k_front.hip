@@ -387,7 +387,9 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
 // IIR_WARM rows of run-in) by the lane that found it, through the `fwd` scratch plane (two chunks of one column may both do
 // that: they write the same values).  `force` (diagnostics) treats every column of chunk 0 as different.
 #define IC_CH 4
-template <int TOUT, int SRC16>
+// EAGER: all 28 values of a lane are requested before the first comparison (one trip to memory instead of up to fourteen dependent ones: a single frame's
+// launch is nothing but that latency - 35 -> 8 us at 1920x1080; in group launches, eight frames' worth of bytes, the short-circuit form is faster)
+template <int TOUT, int SRC16, int EAGER>
 __global__ __launch_bounds__(64 * IC_CH) void k_iir_check_fix(P3 dst, P3c src, P3 fwd, const float *__restrict__ tails, int *bad, int W, int H, int nchunks, int IF_ROWS, int force, int np, size_t zs) {
   const int x = blockIdx.x * 64 + threadIdx.x;
   const int k = blockIdx.y % np, c = blockIdx.z * IC_CH + threadIdx.y;      // (one wave per chunk, IC_CH chunks per block: a block per wave was 6000 dispatches per plane set)
@@ -397,15 +399,30 @@ __global__ __launch_bounds__(64 * IC_CH) void k_iir_check_fix(P3 dst, P3c src, P
   const int s0 = c * IF_ROWS, s1 = (c == nchunks - 1) ? H : s0 + IF_ROWS;
   const float *me = tails + ((size_t)(k * nchunks + c) * 4 * 7) * W + x;
   bool differ = force != 0 && c == 0;
-  if (c > 0 && s0 - IF_WU > -IIR_WARM) {                 // causal: my warm rows s0-7..s0-1 against the previous block's last rows
-    const float *pv = tails + ((size_t)(k * nchunks + c - 1) * 4 * 7) * W + x;
+  const bool chk_f = c > 0 && s0 - IF_WU > -IIR_WARM;                 // causal: my warm rows s0-7..s0-1 against the previous block's last rows
+  const bool chk_b = c < nchunks - 1 && s1 - 1 + IF_WU < H + IIR_WARM;   // anti-causal: my warm rows s1..s1+6 against the next block's first rows
+  const float *pv = tails + ((size_t)(k * nchunks + (chk_f ? c - 1 : c)) * 4 * 7) * W + x;
+  const float *nx = tails + ((size_t)(k * nchunks + (chk_b ? c + 1 : c)) * 4 * 7) * W + x;
+  if (EAGER) {
+    unsigned a[14], b[14];
 #pragma unroll
-    for (int j = 0; j < 7; j++) differ = differ || (__float_as_uint(me[(size_t)(0 * 7 + j) * W]) != __float_as_uint(pv[(size_t)(1 * 7 + j) * W]));
-  }
-  if (c < nchunks - 1 && s1 - 1 + IF_WU < H + IIR_WARM) {   // anti-causal: my warm rows s1..s1+6 against the next block's first rows
-    const float *nx = tails + ((size_t)(k * nchunks + c + 1) * 4 * 7) * W + x;
+    for (int j = 0; j < 7; j++) {
+      a[j] = __float_as_uint(me[(size_t)(0 * 7 + j) * W]); b[j] = __float_as_uint(pv[(size_t)(1 * 7 + j) * W]);
+      a[7 + j] = __float_as_uint(me[(size_t)(2 * 7 + j) * W]); b[7 + j] = __float_as_uint(nx[(size_t)(3 * 7 + j) * W]);
+    }
+    unsigned df = 0, db = 0;
 #pragma unroll
-    for (int j = 0; j < 7; j++) differ = differ || (__float_as_uint(me[(size_t)(2 * 7 + j) * W]) != __float_as_uint(nx[(size_t)(3 * 7 + j) * W]));
+    for (int j = 0; j < 7; j++) { df |= a[j] ^ b[j]; db |= a[7 + j] ^ b[7 + j]; }
+    differ = differ || (chk_f && df != 0) || (chk_b && db != 0);
+  } else {
+    if (chk_f) {
+#pragma unroll
+      for (int j = 0; j < 7; j++) differ = differ || (__float_as_uint(me[(size_t)(0 * 7 + j) * W]) != __float_as_uint(pv[(size_t)(1 * 7 + j) * W]));
+    }
+    if (chk_b) {
+#pragma unroll
+      for (int j = 0; j < 7; j++) differ = differ || (__float_as_uint(me[(size_t)(2 * 7 + j) * W]) != __float_as_uint(nx[(size_t)(3 * 7 + j) * W]));
+    }
   }
   if (!differ) return;
   atomicOr(bad, 1);
@@ -882,9 +899,10 @@ void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3]
   if (nchunks > 1) {
     const dim3 cgrid(grid.x, grid.y, cdiv(nchunks, IC_CH)), cblock(64, IC_CH);
     const int force = getenv("RD_IIR_FORCE_FIX") ? 1 : 0;             // diagnostics: every column takes the full-length path
-    if (transpose_out && src16) hipLaunchKernelGGL((k_iir_check_fix<1, 1>), cgrid, cblock, 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force, np, zs);
-    else if (transpose_out) hipLaunchKernelGGL((k_iir_check_fix<1, 0>), cgrid, cblock, 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force, np, zs);
-    else hipLaunchKernelGGL((k_iir_check_fix<0, 0>), cgrid, cblock, 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force, np, zs);
+#define IC_LAUNCH(T, S16, E) hipLaunchKernelGGL((k_iir_check_fix<T, S16, E>), cgrid, cblock, 0, s, mk3(dst, np), mk3c(src, np), mk3(fwd, np), (const float *)tails, bad, W, H, nchunks, rows, force, np, zs)
+    if (nz > 1) { if (transpose_out && src16) IC_LAUNCH(1, 1, 0); else if (transpose_out) IC_LAUNCH(1, 0, 0); else IC_LAUNCH(0, 0, 0); }
+    else { if (transpose_out && src16) IC_LAUNCH(1, 1, 1); else if (transpose_out) IC_LAUNCH(1, 0, 1); else IC_LAUNCH(0, 0, 1); }
+#undef IC_LAUNCH
   }
   (void)bwd;
 }
