@@ -333,7 +333,6 @@ struct rd_detector {
   // are a chain of 20-odd latency-bound launches that keeps a hardware queue busy for ~0.4 ms without filling the chip, per
   // batch instead of per frame.  Slots [g * batch, (g + 1) * batch) form group g; 1 = every frame on its own (shortest latency).
   int batch; unsigned sparse_rot;
-  hipStream_t sparse_st;                  // (experiment RD_SPARSE_STREAM: the batched sparse stages on a stream of their own)
   int device_post;                        // candidate funnel + pose estimation on the device (rd_k_post.hip) instead of the host worker threads
   long n_post_device, n_post_host, host_post_ns;
   int defer, deferred_slot;               // batched mode: a complete group's sparse stages are launched only once the NEXT group's dense stages are enqueued (deferred_slot: a slot of the waiting group or -1)
@@ -350,8 +349,7 @@ struct rd_detector {
   long next_enqueue, next_poll;
   int last_polled_slot;
   void *last_segs; int last_nsegs;
-  int front_split;        // RD_FRONT_SPLIT (measurements): gradient / strength / suppression as three launches instead of the tile kernel
-  int use_graph, poly_mode, force_redo, diag_no_post, diag_skip, fork_poly, fixed_rounds, budget_cycle; long n_redo, n_redo_rounds, n_redo_absorb;
+  int use_graph, poly_mode, force_redo, fork_poly, fixed_rounds, budget_cycle; long n_redo, n_redo_rounds, n_redo_absorb;
   int overflow_streak;
   int poly_overflows;                     // set once two frames in a row overflowed the single-launch polyline kernel: later frames go multi-launch
   int rounds_budget, need_hist[64]; unsigned need_pos; long budget_count[RD_NBUDGETS], need_count[21];
@@ -513,7 +511,7 @@ static void frame_regions(rd_detector *d, Slot *s) {
   // regions (oclrect.c:325-336)
   int *d2scratch = s->d2s;
   int marked = 0;
-  rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mmbits, s->strongbits, iw, ih, (d->diag_skip & 2) ? 2 : s->rounds,
+  rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mmbits, s->strongbits, iw, ih, s->rounds,
                     s->rsize, &marked);   // H2: the sizes start from the junction counts (evaluated by the first kernel)
   rdk::region_size(st, s->rsize, s->region0, N, d2scratch + N, marked);      // (also strips the rounds' marks from the labels)
   rdk::despeckle2(st, s->region, s->region0, d2scratch, s->rsize, 16, iw, ih, 1, s->scratch2 + N + 64);   // (status words: they travel to the host with the round flags)
@@ -565,7 +563,7 @@ static void frame_strong(rd_detector *d, Slot *s, hipStream_t st) {
 // gradient direction, re-packed blurred Lab, strength, non-max suppression (oclrect.c:251-258) of nz frames: one tile kernel that keeps the three
 // intermediate planes on the chip (rd_k_front.hip: k_grad_nms); frame sizes its tiles do not cover take the three operators' kernels.
 // taps: the intermediate planes are written as well (debug planes "plab1", "vxy", "strength")
-static bool front_is_fused(const rd_detector *d) { return !d->front_split && rdk::grad_nms_fits(d->iw, d->ih); }
+static bool front_is_fused(const rd_detector *d) { return rdk::grad_nms_fits(d->iw, d->ih) != 0; }
 static void frames_grad_nms(rd_detector *d, Slot *s, hipStream_t st, int nz, size_t zs, int taps = 0) {
   const int iw = d->iw, ih = d->ih;
   if (front_is_fused(d)) {
@@ -604,13 +602,13 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t 
   //   2nd stream : junction counts of the filtered labels -> merge mask                      (oclrect.c:315-321)
   //                then the polyline stage, which needs nothing but the strong mask          (oclrect.c:361)
   // Inside a captured graph the streams become parallel branches.
-  if (d->fork_poly) {      // (RD_NO_FORK: everything on the main stream, blur chain first)
+  if (d->fork_poly) {      // (else: everything on the main stream, blur chain first)
     RD_HIP(hipEventRecord(s->ev_fork, st));
     RD_HIP(hipStreamWaitEvent(s->st2, s->ev_fork, 0));
     rdk::junction_bits(s->st2, (unsigned long long *)s->scratch2, s->strongbits, iw, ih);
     rdk::merge_mask(s->st2, s->mmbits, (const unsigned long long *)s->scratch2, iw, ih);
     RD_HIP(hipEventRecord(s->ev_mm, s->st2));
-    if (!(d->diag_skip & 4)) frame_polyline(d, s, s->st2, s->poly_mode);
+    frame_polyline(d, s, s->st2, s->poly_mode);
     RD_HIP(hipEventRecord(s->ev_join, s->st2));
   }
 
@@ -620,7 +618,7 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t 
   //  the HBM traffic of this stage and were measured 6 % SLOWER at full rate: 100 KB of LDS leave one 1024-thread block per CU and the
   //  extra barriers cost more than the saved traffic; the stage is bound by vector instructions, not by memory.  DESIGN.md.)
   { const uint32_t *src = s->plab0;     // ping-pong between i0 and smooth; the 10th pair lands in smooth
-    for (int i = 0; i < ((d->diag_skip & 1) ? 2 : 10); i++) { uint32_t *dst = (i & 1) ? s->smooth : (uint32_t *)s->i0; rdk::blblur_pair(st, dst, s->ext, src, iw, ih); src = dst; } }
+    for (int i = 0; i < 10; i++) { uint32_t *dst = (i & 1) ? s->smooth : (uint32_t *)s->i0; rdk::blblur_pair(st, dst, s->ext, src, iw, ih); src = dst; } }
   rdk::despeckle(st, s->quant, s->smooth, s->nms, iw, ih, 1);      // quantisation to 24 levels per field (oclrect.c:298) happens on the fly
 
   if (d->fork_poly) RD_HIP(hipStreamWaitEvent(st, s->ev_mm, 0));
@@ -631,10 +629,9 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t 
 
   frame_regions(d, s);
 
-  if (d->diag_skip & 64) for (int i = 0; i < 100; i++) rdk::clear_i(st, s->i1, 64);   // diagnostics: what does a launch cost?
   if (d->batch > 1) return;      // the sparse stages of the group's frames follow in one set of launches (sparse_launch)
   if (d->fork_poly) RD_HIP(hipStreamWaitEvent(st, s->ev_join, 0));
-  else if (!(d->diag_skip & 4)) frame_polyline(d, s, st, s->poly_mode);
+  else frame_polyline(d, s, st, s->poly_mode);
   frame_votes(d, s, 1);
 }
 
@@ -717,7 +714,7 @@ static void group_segment(rd_detector *d, Slot *s, int nz, int seg, hipStream_t 
     rdk::calc_strength(st, s->strsum, s->nms, s->label1, iw, ih, NULL, 1, nz, zs);
     return;
   }
-  // seg 2: everything after the strong masks, in the order of a single frame on one stream (frame_segment, RD_NO_FORK)
+  // seg 2: everything after the strong masks, in the order of a single frame on one stream (frame_segment without its fork)
   rdk::blblur_extents(st, s->ext, s->e8, iw, ih, nz, zs);
   { const uint32_t *src = s->plab0;
     for (int i = 0; i < 10; i++) { uint32_t *dst = (i & 1) ? s->smooth : (uint32_t *)s->i0; rdk::blblur_pair(st, dst, s->ext, src, iw, ih, nz, zs); src = dst; } }
@@ -834,11 +831,11 @@ static void slot_submitted(rd_detector *d, Slot *s) {
 static void sparse_launch(rd_detector *d, int a, int b) {
   const int nb = b - a + 1;
   Slot *host = &d->slots[a + (int)(d->sparse_rot++ % (unsigned)nb)];
-  hipStream_t st = d->sparse_st ? d->sparse_st : host->st;
+  hipStream_t st = host->st;
   for (int i = a; i <= b; i++) if (d->slots[i].st != st) RD_HIP(hipStreamWaitEvent(st, d->slots[i].ev_dense, 0));
   const int pm = current_poly_mode(d);
   const rdk::PolyFrame *frames = d->frames + a;
-  if (!(d->diag_skip & 4)) rdk::polyline(st, frames, nb, d->N * 16, 1, 4.0f, 20, d->iw, d->ih, pm);
+  rdk::polyline(st, frames, nb, d->N * 16, 1, 4.0f, 20, d->iw, d->ih, pm);
   double tn = 0;
   const int with_post = aperture_snapshot(d, &tn) && d->device_post;
   frames_votes(d, frames, nb, st, 1, with_post, tn);
@@ -950,7 +947,7 @@ static void *slot_rectangles(rd_detector *d, Slot *s, double tanAOV, void **segs
   int n = ((int *)s->h_segs)[0];
   // the rectangles the device computed (rd_k_post.hip), if this frame has them for this aperture and nothing overflowed there:
   // the valid candidates' records in candidate order (= the reference's list order)
-  if (s->post_mode && s->post_tan == tanAOV && s->h_post[1] == 0 && n + 1 <= d->maxrec_dev && !d->diag_no_post) {
+  if (s->post_mode && s->post_tan == tanAOV && s->h_post[1] == 0 && n + 1 <= d->maxrec_dev) {
     const int nc = s->h_post[0];
     const char *recs = (const char *)(s->h_post + 8 + RD_POST_MAXC);
     int nv = 0;
@@ -994,7 +991,7 @@ static void *slot_rectangles(rd_detector *d, Slot *s, double tanAOV, void **segs
   // RD_DIAG_NO_POST (diagnostics only): an empty rectangle list instead of the host post-process, to see whether a run is host-bound
   struct timespec tp0, tp1;
   clock_gettime(CLOCK_MONOTONIC, &tp0);
-  void *r = d->diag_no_post ? calloc(1, 176) : rd_post_run(segs, maxrec, probes, d->iw, d->ih, tanAOV);
+  void *r = rd_post_run(segs, maxrec, probes, d->iw, d->ih, tanAOV);
   clock_gettime(CLOCK_MONOTONIC, &tp1);
   __atomic_add_fetch(&d->host_post_ns, (tp1.tv_sec - tp0.tv_sec) * 1000000000L + (tp1.tv_nsec - tp0.tv_nsec), __ATOMIC_RELAXED);
   const int ns = n < maxrec ? n : maxrec - 1;
@@ -1051,8 +1048,6 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->use_graph = getenv("RD_NO_GRAPH") ? 0 : 1;
   d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : 1;      // (tests: the ~85-launch form for every frame)
   d->force_redo = (getenv("RD_POLY_FORCE_REDO") ? 1 : 0) | (getenv("RD_ABSORB_FORCE_SLOW") ? 2 : 0);   // tests: every frame also takes the polyline / absorption fallback
-  d->diag_no_post = getenv("RD_DIAG_NO_POST") ? 1 : 0;
-  d->front_split = getenv("RD_FRONT_SPLIT") ? 1 : 0;
   // candidate funnel + pose estimation on the device (rd_k_post.hip) instead of on one worker thread per frame slot: RD_DEVICE_POST=0|1 decides;
   // otherwise the host path - 0.3 ms of CPU time per 1080p frame, i.e. 0.6 of a core at 2000 frames/s: measured 2050 frames/s on 8 cores
   // as on 256, against 1830 for the device path - unless this process may run on one or two cores only
@@ -1066,8 +1061,6 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   // frames in flight a frame spreads over two streams (polyline chain beside the blur chain: shortest latency); from three
   // frames on every frame keeps to one stream, so that four frames occupy the four queues (highest throughput).
   d->fork_poly = nslots <= 2 ? 1 : 0;
-  if (getenv("RD_NO_FORK")) d->fork_poly = 0;
-  if (getenv("RD_FORK")) d->fork_poly = 1;
   // round budget of the region merge: what the last 64 frames needed + margin (8 / 12 / 16 / 20 launched rounds; the rounds after
   // the merge has settled are no-ops, but each still costs two launches of a thousand blocks), frames that turn out to need more
   // are repeated with all 20; RD_REGION_ROUNDS_FIXED=8|12|16|20 pins the budget (20: never repeat anything).
@@ -1077,9 +1070,8 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   // The single-block polyline kernel holds 16 384 live chain pixels; a 1920x1080 frame of the synthetic streams has ~11 000, frames of 3 megapixels and
   // more are beyond it as a rule: their streams start on the multi-launch form instead of overflowing - and being repeated - until the two-overflow rule
   // below finds that out (3840x2160: 12 of the first 16 frames).  Smaller frames that overflow anyway are still caught by that rule.
-  d->poly_overflows = (long)iw * ih > 3000000L && !getenv("RD_POLY_TRY_SINGLE") ? 1 : 0;
+  d->poly_overflows = (long)iw * ih > 3000000L ? 1 : 0;
   d->budget_cycle = getenv("RD_BUDGET_CYCLE") ? atoi(getenv("RD_BUDGET_CYCLE")) : 0;      // tests: the launch budget changes every so many frames (12, 14, .. 20, 12, ..)
-  d->diag_skip = getenv("RD_DIAG_SKIP") ? atoi(getenv("RD_DIAG_SKIP")) : 0;   // timing diagnostics only: leaves stages out (wrong results)
   pthread_mutex_init(&d->tan_mu, NULL); pthread_cond_init(&d->tan_cv, NULL);
   pthread_mutex_init(&d->launch_mu, NULL);
   d->slots = (Slot *)calloc((size_t)nslots, sizeof(Slot));
@@ -1092,13 +1084,11 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->frames = (rdk::PolyFrame *)calloc((size_t)nslots, sizeof(rdk::PolyFrame));
   d->deferred_slot = -1;
   d->defer = (d->batch > 1 && nslots >= 3 * d->batch) ? 1 : 0;       // needs a third group of slots to keep the streams fed meanwhile
-  if (getenv("RD_DEFER")) d->defer = atoi(getenv("RD_DEFER")) != 0 && d->batch > 1;
-  if (getenv("RD_SPARSE_STREAM") && d->batch > 1) RD_HIP(hipStreamCreateWithFlags(&d->sparse_st, hipStreamNonBlocking));
   // One stream per frame: the frames beyond the fourth queue up behind earlier ones on the same four streams (slot i uses the
   // streams of slot i mod 4) - a stream of its own would be time-sliced onto the same four hardware queues and stall frames
   // that have nothing to do with each other, while a queued frame keeps its queue busy as soon as its predecessor is done
   // (the host's turn-around between "frame polled" and "next frame enqueued" otherwise idles a quarter of the device).
-  const int nstreams = getenv("RD_STREAMS") ? atoi(getenv("RD_STREAMS")) : 4;
+  const int nstreams = 4;
   d->nstreams = nstreams < nslots ? nstreams : nslots;
   // Group mode: four frames per launch from twelve frame slots on (three groups: one being filled, two in flight), two from six on, eight from 32 on
   // (640x480: 9100 frames/s with 16 slots in groups of four, 11700 with 32 in groups of eight; 1080p: no difference);
@@ -1148,7 +1138,6 @@ void rd_detector_destroy(rd_detector *d) {
   }
   free(d->slots);
   free(d->frames);
-  if (d->sparse_st) RD_HIP(hipStreamDestroy(d->sparse_st));
   dfree(d->prev_ring);
   dfree(d->arena);
   free(d->last_segs);
@@ -1249,7 +1238,6 @@ void rd_detector_drain(rd_detector *d) {
   if (d->batch > 1) for (int i = 0; i < d->nslots; i += d->batch) sparse_flush(d, i);
   if (d->zb > 1) for (long q = d->next_poll; q < d->next_enqueue; q++) { const int si = (int)(q % d->nslots); if (d->slots[si].pending_dense) group_launch(d, si / d->zb * d->zb); }      // (sequence order)
   for (int i = 0; i < d->nslots; i++) RD_HIP(hipStreamSynchronize(d->slots[i].st));
-  if (d->sparse_st) RD_HIP(hipStreamSynchronize(d->sparse_st));
 }
 
 long rd_detector_counter(rd_detector *d, int which) {

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void k_transpose(P3 dst, P3c src, P3c fwd, P3c
 // sweep BIT FOR BIT is checked on the device: each block records the 7 outputs it computed just before entering its rows
 // ("warm") and its own last 7 outputs ("true"), k_iir_check_fix compares neighbours and evaluates a column with any
 // difference again by full-length sweeps (rdk::iir_blur_pass).  TOUT = 1 writes the result transposed (through the LDS tile).
-#define IF_ROWS_MIN 32         // rows per block: 32 ... 128, chosen per launch (if_pick_rows)
+#define IF_ROWS_MIN 64         // rows per block: 64 or 128, chosen per launch (if_pick_rows)
                               // (a remainder of fewer than 8 rows is merged into the last block: LDS tile = rows + 8)
 #define IF_WU 32              // warm-up rows (24 sufficed on every plane tried on the CPU; the on-device check is what guarantees the result)
 #define IF_PITCH 65
@@ -861,12 +861,9 @@ void transpose_f(hipStream_t s, float *const dst[3], const float *const src[3], 
 // Block height per launch.  One wave per block, each a serial recurrence of 2 x (rows + IF_WU) steps whose dependent chain is
 // longer than its issue time: several waves per SIMD hide that, so short blocks win although they repeat the run-in more often
 // (measured at 1080p, one wave per SIMD with 96 / 112 rows: 62 / 55 us; 32, 48, 64 rows: 48, 45, 50 us with transposed output,
-// 37, 38, 40 us without).  RD_IIR_ROWS
-// overrides (32, 48, 64, 96, 112, 128).
+// 37, 38, 40 us without).
 static int if_pick_rows(int np, int W, int H, int transpose_out, int nz) {
   (void)np; (void)W; (void)H;
-  static const int forced = getenv("RD_IIR_ROWS") ? atoi(getenv("RD_IIR_ROWS")) : 0;
-  if (forced == 32 || forced == 64 || forced == 96 || forced == 128) return forced;
   (void)transpose_out;
   // (group launches: 128 rows - a quarter instead of half as much run-in, half as many borders to check; 2154-2167 against 2121-2151 frames/s
   //  in four interleaved pairs of runs; single frames keep 64: more blocks for the same device)
@@ -889,9 +886,7 @@ void iir_blur_pass(hipStream_t s, float *const dst[3], const float *const src[3]
 #define IF_LAUNCH(T, R, S16) hipLaunchKernelGGL((k_iir_fused<T, R, S16>), grid, dim3(128), 0, s, mk3(dst, np), mk3c(src, np), tails, W, H, nchunks, bad, np, zs)
 #define IF_LAUNCH_R(R) { if (transpose_out && src16) IF_LAUNCH(1, R, 1); else if (transpose_out) IF_LAUNCH(1, R, 0); else IF_LAUNCH(0, R, 0); }
   switch (rows) {
-    case 32: IF_LAUNCH_R(32); break;
     case 64: IF_LAUNCH_R(64); break;
-    case 96: IF_LAUNCH_R(96); break;
     default: IF_LAUNCH_R(128); break;
   }
 #undef IF_LAUNCH_R
