@@ -76,6 +76,9 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
  * check the post-process against the reference with identical inputs.  `boundary` is the boundary-label plane,
  * `table` the reduceLS table (iw*ih*4/5 entries of 5 ints), `segs` the linesegment_t list with header. */
 void *rd_postprocess_planes(const void *segs, const int32_t *boundary, const int32_t *table, int iw, int ih, double tanAOV);
+/* test tap: the 15 probe pixels of a segment as the sampling kernel computes them (x, y pairs; (-1, -1): outside the frame) - compared with the oracle's
+ * independent restatement of oclrect.c:1066-1083 */
+void rd_probe_pixels(float x0, float y0, float x1, float y1, int iw, int ih, int32_t *out);
 
 /* ---- synthetic frames (csrc/rd_synth.c) */
 int rd_synth_num_quads(int iw, int ih);

@@ -978,3 +978,24 @@ void rdo_thincubic(float *out, const float *in, const float *vxy, int iw, int ih
       out[p0] = (am2 * C <= a0 && am1 * C <= a0 && a0 >= ap1 * C && a0 >= ap2 * C) ? (am2 + am1 + a0 + ap1 + ap2) : 0;
     }
 }
+
+
+/* oclrect.c:1066-1083 (see rd_oracle.h).  vec234.h:37-42: a vector is normalised by multiplying with 1 / (sqrt(sum of squares) + 1e-20). */
+void rdo_probe_pixels(float fx0, float fy0, float fx1, float fy1, int iw, int ih, int *out) {
+  const double ax = rint((double)fx0), ay = rint((double)fy0), bx = rint((double)fx1), by = rint((double)fy1);
+  const double ex = bx - ax, ey = by - ay;
+  const double inv = 1.0 / (sqrt(ex * ex + ey * ey) + 1e-20);
+  const double dx = ex * inv, dy = ey * inv;
+  const double nx = -dy, ny = dx;                        /* the segment's normal */
+  for (int j = 0; j < 3; j++) {
+    const double t = (j + 0.5) / 3;
+    const double px = ax + ex * t, py = ay + ey * t;
+    for (int dist = -2; dist <= 2; dist++) {
+      const double cx = px + nx * dist, cy = py + ny * dist;
+      const int x = (int)(cx + 0.5), y = (int)(cy + 0.5);
+      int *o = out + 2 * (j * 5 + dist + 2);
+      if (x < 0 || x >= iw || y < 0 || y >= ih) { o[0] = -1; o[1] = -1; }
+      else { o[0] = x; o[1] = y; }
+    }
+  }
+}

@@ -86,6 +86,11 @@ void rdo_rect_frame(rdo_rect_t *c, const uint8_t *bgr, int ws);
 void rdo_rect_set_region_mode(rdo_rect_t *c, int mode);
 int rdo_rect_info(const rdo_rect_t *c, int which);   /* 0: region_mode, 1: region_rounds, 2: absorb_rounds */
 
+/* oclrect.c:1066-1083: where the host looks for the boundary component next to a segment - 3 points along the segment (its end points rounded to
+ * integers first) x 5 offsets of -2..2 pixels along its normal.  out: 15 (x, y) pairs in the reference's loop order (point j outer, offset inner);
+ * a probe outside the frame is (-1, -1).  An independent restatement: the product's sampling kernel and its test tap share one helper of their own. */
+void rdo_probe_pixels(float x0, float y0, float x1, float y1, int iw, int ih, int *out);
+
 /* poly.cpp:104-123 device part: ids (N ints) and lslist (16N bytes) */
 void rdo_poly_frame(void *lslist, int *ids, const uint8_t *bgr, int iw, int ih, int ws, int strengthThre, float minerror, int sizeThre);
 

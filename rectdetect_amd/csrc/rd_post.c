@@ -238,3 +238,12 @@ void *rd_postprocess_planes(const void *segs, const int32_t *boundary, const int
   free(probes);
   return r;
 }
+
+
+void rd_probe_pixels(float x0, float y0, float x1, float y1, int iw, int ih, int32_t *out) {
+  for (int k = 0; k < 15; k++) {
+    int sx, sy;
+    if (rdp_probe_pixel(x0, y0, x1, y1, k, iw, ih, &sx, &sy)) { out[2 * k] = sx; out[2 * k + 1] = sy; }
+    else { out[2 * k] = -1; out[2 * k + 1] = -1; }
+  }
+}

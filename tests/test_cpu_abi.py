@@ -130,3 +130,28 @@ def test_reference_applications_compile_and_link_unchanged(app, tmp_path):
     subprocess.check_call(["g++", str(obj), "-o", str(exe), "-L", os.path.dirname(ra.LIB_PATH), "-lrectdetect_hip", "-Wl,-rpath," + os.path.dirname(ra.LIB_PATH), "-lm"])
     p = subprocess.run([str(exe)], capture_output=True, text=True, timeout=60)
     assert "Usage" in (p.stdout + p.stderr) or "usage" in (p.stdout + p.stderr), (p.returncode, p.stdout[-500:], p.stderr[-500:])
+
+
+def test_probe_geometry_against_the_oracles_independent_restatement():
+    """oclrect.c:1066-1083: the 15 probe pixels per segment.  The product's sampling kernel and its test tap share ONE helper (rd_post_core.h:
+    rdp_probe_pixel); the oracle restates the reference's loop on its own (rd_oracle.c: rdo_probe_pixels).  Random segments, segments on and across
+    the frame's border, degenerate ones: every pixel must agree."""
+    import ctypes
+    import numpy as np
+    L = ra.lib()
+    O = helpers.oracle()
+    f, i, p = ctypes.c_float, ctypes.c_int, ctypes.c_void_p
+    L.rd_probe_pixels.argtypes = [f, f, f, f, i, i, p]
+    L.rd_probe_pixels.restype = None
+    O.rdo_probe_pixels.argtypes = [f, f, f, f, i, i, p]
+    O.rdo_probe_pixels.restype = None
+    rng = np.random.default_rng(11)
+    iw, ih = 1920, 1080
+    cases = [(0.0, 0.0, 0.0, 0.0), (5.5, 5.5, 5.5, 5.5), (0.4, 0.4, 1919.6, 1079.6), (-3.0, 10.0, 30.0, -2.0), (1918.5, 0.0, 1919.49, 1079.0), (100.5, 200.5, 100.5, 900.5), (2.5, 3.5, 4.5, 3.5)]
+    cases += [tuple(float(v) for v in (rng.uniform(-4, iw + 4), rng.uniform(-4, ih + 4), rng.uniform(-4, iw + 4), rng.uniform(-4, ih + 4))) for _ in range(20000)]
+    cases += [tuple(float(np.float32(v)) for v in (x, y, x + rng.uniform(-3, 3), y + rng.uniform(-3, 3))) for x, y in zip(rng.uniform(0, iw, 5000), rng.uniform(0, ih, 5000))]
+    a, b = np.zeros(30, np.int32), np.zeros(30, np.int32)
+    for c in cases:
+        L.rd_probe_pixels(*c, iw, ih, a.ctypes.data)
+        O.rdo_probe_pixels(*c, iw, ih, b.ctypes.data)
+        assert np.array_equal(a, b), (c, a.tolist(), b.tolist())
