@@ -158,9 +158,10 @@ __global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ e
 // are in flight together.
 #define BP_ROWS 64
 #define BP_SW 73              // row pitch of the staged input (72 used)
-// floor(s / w) for 0 <= s <= 40950, 1 <= w <= 10 (exhaustively checked: tools/check_div_small.py)
-// (one fused multiply-add: float(s) * (1/w) + 0.5 * (1/w), rounded once - the explicit fma is part of the checked formula, not a contraction)
-__device__ __forceinline__ unsigned div_small_f(unsigned s, float2 rw) { return (unsigned)__fmaf_rn((float)s, rw.x, rw.y); }
+// floor(s / w) for a sum s of w samples of a field (s <= 4095 w, 1 <= w <= 10) as one 24-bit multiplication and a shift: s * ceil(2^19 / w) >> 19
+// (exhaustively checked: tools/check_div_small.py; the product stays below 2^32.  Before: float(s) * (1/w) + 0.5 * (1/w) through a conversion, an
+// fma and a conversion back - three operations per field instead of two)
+__device__ __forceinline__ unsigned div_small_m(unsigned s, unsigned m) { return __umul24(s, m) >> 19; }
 
 #define BP_TY 16         // thread rows per block (4 / 8 / 16 at full rate: 2003 / 2111 / 2126 frames/s)
 __global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih, size_t zs) {
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict
   constexpr int SRC_N = (BP_ROWS + 8) * BP_SW, HZ_N = (BP_ROWS + 8) * 64, ZR_N = 2048 / 8 + 8;
   __shared__ uint2 lds[SRC_N + HZ_N + ZR_N];
   uint2 *const src = lds, *const hz = lds + SRC_N;
-  __shared__ float2 rwt[16];                                     // (1 / w correctly rounded, half of it)
+  __shared__ unsigned rwt[16];                                   // ceil(2^19 / w)
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BP_ROWS;
   const int x = x0 + tx;
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict
   for (int t = tid; t < ZR_N; t += 64 * BP_TY) lds[SRC_N + HZ_N + t] = make_uint2(0, 0);     // (whatever the block size)
   unsigned zrs = (unsigned)(SRC_N + HZ_N) * 8u, zrh = (unsigned)ZR_N * 0u + (unsigned)HZ_N * 8u;      // the zero region's byte offset from `src` / from `hz`
   asm volatile("" : "+v"(zrs), "+v"(zrh));      // (opaque to the optimiser: it would fold the per-sample constants into them again)
-  if (tid < 16) { const float r = tid >= 1 && tid <= 10 ? 1.0f / (float)tid : 0.0f; rwt[tid] = make_float2(r, 0.5f * r); }
+  if (tid < 16) rwt[tid] = tid >= 1 && tid <= 10 ? ((1u << 19) + (unsigned)tid - 1u) / (unsigned)tid : 0u;
 #pragma unroll
   for (int i = 0; i < NQ; i++) {
     const int t = tid + NT * i;
@@ -259,8 +260,8 @@ __global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict
     const int w = nl + nr;
     uint2 o = src[c];
     if (w > 0) {
-      const float2 rw = rwt[w];
-      o = make_uint2(div_small_f(lo & 0xffffu, rw) | (div_small_f(lo >> 16, rw) << 16), div_small_f(hi, rw));   // fields cannot exceed their range: no clamp needed
+      const unsigned rw = rwt[w];
+      o = make_uint2(div_small_m(lo & 0xffffu, rw) | (div_small_m(lo >> 16, rw) << 16), div_small_m(hi, rw));   // fields cannot exceed their range: no clamp needed
     }
     hz[r * 64 + tx] = o;
   }
@@ -287,8 +288,8 @@ __global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict
     const int w = nl + nr;
     uint2 o = hz[c];
     if (w > 0) {
-      const float2 rw = rwt[w];
-      o = make_uint2(div_small_f(lo & 0xffffu, rw) | (div_small_f(lo >> 16, rw) << 16), div_small_f(hi, rw));
+      const unsigned rw = rwt[w];
+      o = make_uint2(div_small_m(lo & 0xffffu, rw) | (div_small_m(lo >> 16, rw) << 16), div_small_m(hi, rw));
     }
     atu(out, (unsigned)(y * iw + x)) = (o.x & 0xffffu) | ((o.x >> 16) << 12) | (o.y << 22);
   }
