@@ -31,11 +31,15 @@ const dim3 block2(64, 4);
 #define GN_LH (GN_ROWS + 9)
 #define GN_SW 71                       // strength tile: columns x0 - 3 .. x0 + 67 (pitch TT_PITCH)
 #define GN_SH (GN_ROWS + 7)
-#define GN_K (GN_ROWS / 4)             // pixels per thread: a column of GN_K rows
+#ifndef GN_TY
+#define GN_TY 4                       // thread rows (waves) per block
+#endif
+#define GN_NT (64 * GN_TY)
+#define GN_K (GN_ROWS / GN_TY)         // pixels per thread: a column of GN_K rows
 struct GnTaps { uint32_t *plab1; float2 *vxy; float *strength; };
 
 template <int TAPS>
-__global__ __launch_bounds__(256) void k_grad_nms(float *__restrict__ out, P3c bl, int iw, int ih, size_t zs, GnTaps taps) {
+__global__ __launch_bounds__(GN_NT) void k_grad_nms(float *__restrict__ out, P3c bl, int iw, int ih, size_t zs, GnTaps taps) {
   RD_ZSHIFT(zs, out, bl.p[0], bl.p[1], bl.p[2], taps.plab1, taps.vxy, taps.strength);
   // [0] raw L, [1..3] the re-packed fields as floats; after the strength is known the same memory holds the list of local maxima
   __shared__ float lab[4][GN_LH * GN_LW];
@@ -48,13 +52,13 @@ __global__ __launch_bounds__(256) void k_grad_nms(float *__restrict__ out, P3c b
   // ---- stage L, a, b (+ halo): a wave takes every fourth row of the tile, its lanes columns 0..63 (row address uniform, column address fixed per
   // lane); the 9 columns left over are a cell per thread.  All loads of a thread are in flight before the first is used.
   {
-    constexpr int NR = (GN_LH + 3) / 4;        // rows per wave
+    constexpr int NR = (GN_LH + GN_TY - 1) / GN_TY;        // rows per wave
     const int mcol = mirror1(x0 - 4 + tx, iw);                                   // (x0 - 4 + tx <= iw + 4 for every lane that matters: see below)
     const int sc = tid < 9 * GN_LH ? tid : 0, scy = sc / 9, scx = 64 + sc - scy * 9;      // the thread's cell of the side strip
     float vl[NR + 1], va[NR + 1], vb[NR + 1];
 #pragma unroll
     for (int i = 0; i <= NR; i++) {
-      const int cy = i < NR ? ty + 4 * i : scy, cx = i < NR ? tx : scx;
+      const int cy = i < NR ? ty + GN_TY * i : scy, cx = i < NR ? tx : scx;
       const int fx = x0 - 4 + cx, fy = y0 - 4 + cy;
       const bool ok = cy < GN_LH && fx <= iw + 4 && fy <= ih + 4;      // (cells further out are read by no pixel of the frame)
       const int a = ok ? mirror1(fy, ih) * iw + (i < NR ? mcol : mirror1(fx, iw)) : 0;
@@ -62,7 +66,7 @@ __global__ __launch_bounds__(256) void k_grad_nms(float *__restrict__ out, P3c b
     }
 #pragma unroll
     for (int i = 0; i <= NR; i++) {
-      const int cy = i < NR ? ty + 4 * i : scy, cx = i < NR ? tx : scx;
+      const int cy = i < NR ? ty + GN_TY * i : scy, cx = i < NR ? tx : scx;
       if (cy >= GN_LH || (i == NR && tid >= 9 * GN_LH)) continue;
       // pack_lab + unpack_lab (iu:28-39) with the integer fields kept: floor, clamp (NaN and negatives -> 0, large -> the field's maximum), then
       // field * 2^-k + half an LSB
@@ -121,7 +125,7 @@ __global__ __launch_bounds__(256) void k_grad_nms(float *__restrict__ out, P3c b
   };
   if (interior) {
     // columns 0..63 of the strength tile: a wave takes a band of rows, each lane a column of it (the three rows of a cell serve its neighbours too)
-    constexpr int BAND = (GN_SH + 3) / 4;
+    constexpr int BAND = (GN_SH + GN_TY - 1) / GN_TY;
     const int r0 = ty * BAND, r1 = r0 + BAND < GN_SH ? r0 + BAND : GN_SH;
     {
       float u[BAND + 2][3][3];     // [row][column][channel]
@@ -142,14 +146,14 @@ __global__ __launch_bounds__(256) void k_grad_nms(float *__restrict__ out, P3c b
         }
     }
     // columns 64..70: a cell per thread
-    for (int t = tid; t < 7 * GN_SH; t += 256) {
+    for (int t = tid; t < 7 * GN_SH; t += GN_NT) {
       const int sy = t / 7, sx = 64 + t - sy * 7;
       const float v = strength_at(sx + 1, sy + 1);
       str[sy * TT_PITCH + sx] = v;
       if (TAPS) { if (sy >= 3 && sy < 3 + GN_ROWS && sx < 67) taps.strength[(y0 - 3 + sy) * iw + x0 - 3 + sx] = v; }
     }
   } else {
-    for (int t = tid; t < GN_SW * GN_SH; t += 256) {
+    for (int t = tid; t < GN_SW * GN_SH; t += GN_NT) {
       const int sy = t / GN_SW, sx = t - sy * GN_SW;
       const int fx = x0 - 3 + sx, fy = y0 - 3 + sy;
       if (fx > iw + 3 || fy > ih + 3) continue;          // no pixel of the frame reads this cell
@@ -190,7 +194,7 @@ __global__ __launch_bounds__(256) void k_grad_nms(float *__restrict__ out, P3c b
   }
   __syncthreads();
   const int n = nlst;
-  for (int i = tid; i < n; i += 256) {
+  for (int i = tid; i < n; i += GN_NT) {
     const float4 e = lst[i];
     const int c = lpix[i], r = c >> 6, cx = c & 63;
     const int xx = x0 + cx, yy = y0 + r;
@@ -214,7 +218,7 @@ void grad_nms(hipStream_t s, float *nms, float *const bl[3], int iw, int ih, int
   P3c b = { { bl[0], bl[1], bl[2] } };
   GnTaps t = { tap_plab1, (float2 *)tap_vxy, tap_strength };
   const dim3 grid(cdiv(iw, 64), cdiv(ih, GN_ROWS), nz);
-  if (tap_plab1) hipLaunchKernelGGL(k_grad_nms<1>, grid, block2, 0, s, nms, b, iw, ih, zs, t);
-  else hipLaunchKernelGGL(k_grad_nms<0>, grid, block2, 0, s, nms, b, iw, ih, zs, t);
+  if (tap_plab1) hipLaunchKernelGGL(k_grad_nms<1>, grid, dim3(64, GN_TY), 0, s, nms, b, iw, ih, zs, t);
+  else hipLaunchKernelGGL(k_grad_nms<0>, grid, dim3(64, GN_TY), 0, s, nms, b, iw, ih, zs, t);
 }
 }  // namespace rdk
