@@ -665,8 +665,29 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
 #define RR_DEEP 3          // rounds in which the trees are still the chains of the initial links (a pixel's parent is 1, 10, 91 rows above it)
 #endif
 __device__ __forceinline__ int rr_label(const int *X, unsigned q) { return at32(X, q) >> RR_MBITS; }
-__global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round, size_t zs) {
-  RD_ZSHIFT(zs, X, Y, allow, flags);
+// Block -> (tile, frame): the launch is one-dimensional and the hardware hands consecutive blocks to the 8 XCDs in turn, each with an L2 of its own.  A group launch
+// of 8 frames gives every XCD ONE frame (frame = block mod 8): a tile's neighbours and the pixels its labels name - the rows above it - are then served by the L2
+// that fetched them for the neighbouring tiles, instead of eight L2s each fetching a copy from memory (64 % of this kernel's L2 requests missed).  Other launches
+// give every XCD a band of tile columns.  Speed only: nothing depends on where a block runs.
+#ifndef RR_XCD
+#define RR_XCD 1
+#endif
+__device__ __forceinline__ void rr_block_to_tile(int gx, int gy, int gz, int &bx, int &by, int &bz) {
+  const int b = blockIdx.x;
+  if (!RR_XCD) { bx = b % gx; by = (b / gx) % gy; bz = b / (gx * gy); return; }
+  if (gz == 8) { bz = b & 7; const int t = b >> 3; by = t / gx; bx = t - by * gx; return; }
+  // bands of columns: XCD k takes tile columns [k * cw, (k + 1) * cw) of every frame, walking down its band row by row
+  const int cw = (gx + 7) / 8, per = cw * gy * gz, k = b & 7, t = b >> 3;      // (the grid is padded to 8 * per blocks: the launcher)
+  bz = t / (cw * gy);
+  const int r = t - bz * (cw * gy);
+  by = r / cw; bx = k * cw + (r - by * cw);
+  if (t >= per || bx >= gx) { bx = -1; }
+}
+__global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round, size_t zs, int gx, int gy, int gz) {
+  int bx, by, bz;
+  rr_block_to_tile(gx, gy, gz, bx, by, bz);
+  if (bx < 0) return;
+  { const size_t rd_zoff_ = (size_t)bz * zs; RD_ZS1(X); RD_ZS1(Y); RD_ZS1(allow); RD_ZS1(flags); }
   if (round > 0 && flags[round - 1] == 0) return;
   __shared__ int hk[512], hv[512];
   __shared__ int tmin[64 * RR_TY * RR_PX];      // launch 1 only: the smallest proposal for each pixel of the block's tile (see below)
@@ -676,8 +697,8 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
   if (near) for (int t = tid; t < 64 * RR_TY * RR_PX; t += 64 * RR_TY) tmin[t] = 0x7fffffff;
   __syncthreads();
   const int mark = 1 + round % 7, mark_prev = round > 0 ? 1 + (round - 1) % 7 : 8;      // (8: matches nothing - before round 0 no plane lags)
-  const int yb = blockIdx.y * (RR_TY * RR_PX) + threadIdx.y * RR_PX;      // the thread's RR_PX pixels lie below one another: each is the other's vertical neighbour
-  const int x = blockIdx.x * 64 + threadIdx.x;
+  const int yb = by * (RR_TY * RR_PX) + threadIdx.y * RR_PX;      // the thread's RR_PX pixels lie below one another: each is the other's vertical neighbour
+  const int x = bx * 64 + threadIdx.x;
   int p0[RR_PX], og[RR_PX], g[RR_PX], nx[RR_PX], w0[RR_PX];
   unsigned a[RR_PX];
   bool valid[RR_PX], todo[RR_PX];
@@ -750,7 +771,7 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
     // Launch 1: every pixel has a parent of its own and proposes to it - two million atomics on top of the two million own words.  The
     // parent is the pixel ~10 rows above, for four out of five pixels inside the block's tile: those proposals meet in LDS and leave with the
     // parent's own word, as ONE atomic per pixel; the rest go to memory as in the other launches.
-    const int origin = blockIdx.y * (RR_TY * RR_PX) * iw + blockIdx.x * 64;
+    const int origin = by * (RR_TY * RR_PX) * iw + bx * 64;
     const float inv_iw = 1.0f / (float)iw;
 #pragma unroll
     for (int k = 0; k < RR_PX; k++) {
@@ -1788,8 +1809,10 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
   hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS), nz), dim3(64, 4), 0, s, A, B, allow, pix, mask, edge, iw, ih, cdiv(iw, 64), flags, size_out, zs);
   const dim3 grid(cdiv(iw, 64), cdiv(ih, RR_TY * RR_PX), nz);
   for (int r = 1; r < ROUNDS; r++) {       // (launch 0 was evaluated by k_region_init)
-    if (r & 1) hipLaunchKernelGGL(k_region_round, grid, dim3(64, RR_TY), 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r, zs);
-    else hipLaunchKernelGGL(k_region_round, grid, dim3(64, RR_TY), 0, s, A, B, (const uint8_t *)allow, iw, ih, flags, r, zs);
+    const int gx = (int)grid.x, gy = (int)grid.y, gz = (int)grid.z;
+    const dim3 lg((!RR_XCD || gz == 8) ? gx * gy * gz : 8 * ((gx + 7) / 8) * gy * gz);
+    if (r & 1) hipLaunchKernelGGL(k_region_round, lg, dim3(64, RR_TY), 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r, zs, gx, gy, gz);
+    else hipLaunchKernelGGL(k_region_round, lg, dim3(64, RR_TY), 0, s, A, B, (const uint8_t *)allow, iw, ih, flags, r, zs, gx, gy, gz);
   }
   if (marked) *marked = 1;
 }
