@@ -129,6 +129,33 @@ template <typename T> __device__ __forceinline__ T *rd_zs_ptr(T *p, size_t off) 
 #define RD_ZS_PICK(_1, _2, _3, _4, _5, _6, _7, _8, _9, _10, NAME, ...) NAME
 #define RD_ZSHIFT(...) RD_ZS_PICK(__VA_ARGS__, RD_ZS_10, RD_ZS_9, RD_ZS_8, RD_ZS_7, RD_ZS_6, RD_ZS_5, RD_ZS_4, RD_ZS_3, RD_ZS_2, RD_ZS_1)(__VA_ARGS__)
 
+// Frame / XCD affinity of tile kernels.  The hardware hands the blocks of a launch to the 8 XCDs in turn (block b -> XCD b mod 8), each XCD with an L2 of its own; a
+// tile kernel with a halo re-reads its neighbours' pixels, and with tile x as the fastest block coordinate every neighbour sat in another L2 (64-76 % of the
+// L2 requests of such kernels missed).  These kernels are launched ONE-DIMENSIONAL over gx x gy tiles x nz frames and ask rd_block_tile() which tile they are: in
+// a group launch of 8 frames block b works on frame b mod 8 - one frame per XCD, its tiles in raster order -, otherwise in plain raster order.  Speed only: nothing
+// depends on where a block runs.  gdim = rd_gdim(gx, gy, nz).
+struct rd_tile { int x, y, z; };
+__host__ __device__ inline int rd_gdim(int gx, int gy, int nz) { return gx | (gy << 12) | (nz << 24); }
+__device__ __forceinline__ rd_tile rd_block_tile(int gdim) {
+  const int gx = gdim & 4095, gy = (gdim >> 12) & 4095, nz = gdim >> 24, b = (int)blockIdx.x;
+  rd_tile t;
+  if (nz == 8) { t.z = b & 7; const int q = b >> 3; t.y = q / gx; t.x = q - t.y * gx; }
+  else { const int per = gx * gy; t.z = b / per; const int q = b - t.z * per; t.y = q / gx; t.x = q - t.y * gx; }
+  return t;
+}
+// RD_ZSHIFT for such a kernel: the frame is rd_block_tile().z, not blockIdx.z
+#define RD_ZA_1(a) RD_ZS1(a)
+#define RD_ZA_2(a, b) RD_ZS1(a); RD_ZS1(b)
+#define RD_ZA_3(a, b, c) RD_ZA_2(a, b); RD_ZS1(c)
+#define RD_ZA_4(a, b, c, d) RD_ZA_3(a, b, c); RD_ZS1(d)
+#define RD_ZA_5(a, b, c, d, e) RD_ZA_4(a, b, c, d); RD_ZS1(e)
+#define RD_ZA_6(a, b, c, d, e, f) RD_ZA_5(a, b, c, d, e); RD_ZS1(f)
+#define RD_ZA_7(a, b, c, d, e, f, g) RD_ZA_6(a, b, c, d, e, f); RD_ZS1(g)
+#define RD_ZA_8(a, b, c, d, e, f, g, h) RD_ZA_7(a, b, c, d, e, f, g); RD_ZS1(h)
+#define RD_ZA_9(a, b, c, d, e, f, g, h, i) RD_ZA_8(a, b, c, d, e, f, g, h); RD_ZS1(i)
+#define RD_ZA_PICK(_1, _2, _3, _4, _5, _6, _7, _8, _9, NAME, ...) NAME
+#define RD_ZSHIFTZ(z, zs, ...) const size_t rd_zoff_ = (size_t)(z) * (zs); RD_ZA_PICK(__VA_ARGS__, RD_ZA_9, RD_ZA_8, RD_ZA_7, RD_ZA_6, RD_ZA_5, RD_ZA_4, RD_ZA_3, RD_ZA_2, RD_ZA_1)(__VA_ARGS__)
+
 // L2-coherent (device-scope) load: used to guard hot atomics so that later waves see an earlier wave's update instead of
 // a stale L1 line and skip the atomic
 __device__ __forceinline__ int ld_agent(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

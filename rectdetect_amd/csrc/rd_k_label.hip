@@ -58,25 +58,26 @@ __device__ __forceinline__ void lt_union(int *lab, int a, int b) {
 // mask0 / pix_out (and zero_plane cleared) as k_rect_tidy would.
 template <int SRC, int TY>
 __global__ __launch_bounds__(64 * TY) void k_label_tile(int *__restrict__ label, const int *__restrict__ pix, int bgc, int iw, int ih, int *__restrict__ pix_out,
-                                                    const float *__restrict__ nms, int *__restrict__ mask0, int *__restrict__ zero_plane, size_t zs) {
+                                                    const float *__restrict__ nms, int *__restrict__ mask0, int *__restrict__ zero_plane, size_t zs, int gdim) {
   constexpr bool BOUNDARY = SRC == 1;
-  RD_ZSHIFT(zs, label, pix, pix_out, nms, mask0, zero_plane);
+  const rd_tile rd_b = rd_block_tile(gdim);
+  RD_ZSHIFTZ(rd_b.z, zs, label, pix, pix_out, nms, mask0, zero_plane);
   __shared__ int lab[LT_W * LT_H];
   __shared__ int pv[LT_W * LT_H];
-  const int tx = threadIdx.x, x = blockIdx.x * LT_W + tx, y0 = blockIdx.y * LT_H;
+  const int tx = threadIdx.x, x = rd_b.x * LT_W + tx, y0 = rd_b.y * LT_H;
   const bool xin = x < iw;
   int v00;
   bool uniform = true;
   int pv8[LT_H / TY];            // this thread's pixels, requested together (one wait for memory instead of one per row)
   if constexpr (SRC == 2) {
     __shared__ __align__(16) uint8_t A[(LT_H + 2 * TD_M) * TD_P], B[(LT_H + 2 * TD_M) * TD_P];
-    rect_tidy_tile<LT_H>(A, B, blockIdx.x * LT_W, y0, threadIdx.y * 64 + tx, nms, mask0, pix_out, zero_plane, iw, ih, pv8);
+    rect_tidy_tile<LT_H>(A, B, rd_b.x * LT_W, y0, threadIdx.y * 64 + tx, nms, mask0, pix_out, zero_plane, iw, ih, pv8);
     __shared__ int s_t00;            // the value of the tile's first pixel, for the uniform-tile test below
     if (threadIdx.y == 0 && tx == 0) s_t00 = pv8[0];
     __syncthreads();
     v00 = s_t00;
   } else if constexpr (!BOUNDARY) {
-    v00 = pix[(size_t)y0 * iw + blockIdx.x * LT_W];   // the tile's first pixel is always inside the frame
+    v00 = pix[(size_t)y0 * iw + rd_b.x * LT_W];   // the tile's first pixel is always inside the frame
 #pragma unroll
     for (int k = 0; k < LT_H / TY; k++) {
       const int y = y0 + threadIdx.y + k * TY;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(64 * TY) void k_label_tile(int *__restrict__ label,
   } else {
     __shared__ int t[(LT_H + 4) * LT_MP];
     __shared__ uint8_t hu[(LT_H + 4) * 64];
-    const int x0 = blockIdx.x * LT_W, tid = threadIdx.y * 64 + tx;
+    const int x0 = rd_b.x * LT_W, tid = threadIdx.y * 64 + tx;
     const int r00 = pix[(size_t)y0 * iw + x0];
     bool flat = true;
     stage_cells<(LT_H + 4) * LT_MP, 64 * TY>(tid, pix,
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(64 * TY) void k_label_tile(int *__restrict__ label,
   // fast path: the whole tile holds one value (background, the inside of a large component): one component, no unions
   {
     if (__syncthreads_and(uniform)) {
-      const int l = v00 == bgc ? -1 : y0 * iw + blockIdx.x * LT_W;
+      const int l = v00 == bgc ? -1 : y0 * iw + rd_b.x * LT_W;
 #pragma unroll
       for (int r = threadIdx.y; r < LT_H; r += TY) {
         const int y = y0 + r;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(64 * TY) void k_label_tile(int *__restrict__ label,
     if (!xin || y >= ih) continue;
     const int q = r * LT_W + tx;
     int l = lab[q];
-    if (l >= 0) { l = lt_find(lab, l); l = (y0 + l / LT_W) * iw + blockIdx.x * LT_W + l % LT_W; }
+    if (l >= 0) { l = lt_find(lab, l); l = (y0 + l / LT_W) * iw + rd_b.x * LT_W + l % LT_W; }
     label[y * iw + x] = l;
   }
 }
@@ -449,7 +450,7 @@ namespace rdk {
 
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, int skip_flatten) {
   const size_t zs = 0;
-  hipLaunchKernelGGL((k_label_tile<0, LT_TY>), dim3(cdiv(iw, LT_W), cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, pix, bgc, iw, ih, (int *)nullptr, (const float *)nullptr, (int *)nullptr, (int *)nullptr, zs);
+  hipLaunchKernelGGL((k_label_tile<0, LT_TY>), dim3(cdiv(iw, LT_W) * cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, pix, bgc, iw, ih, (int *)nullptr, (const float *)nullptr, (int *)nullptr, (int *)nullptr, zs, rd_gdim(cdiv(iw, LT_W), cdiv(ih, LT_H), 1));
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
   if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb), dim3(256), 0, s, label, pix, bgc, iw, ih, hb, zs);
@@ -461,7 +462,7 @@ void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, 
 
 // rect_tidy(mask0, tidy, nms, zero_plane) + label8(label, tidy, background -1, skip_flatten) with the tidy computed inside the tile kernel
 void label8_tidy(hipStream_t s, int *label, int *mask0, int *tidy, const float *nms, int *zero_plane, int iw, int ih, int skip_flatten, int nz, size_t zs) {
-  hipLaunchKernelGGL((k_label_tile<2, 4>), dim3(cdiv(iw, LT_W), cdiv(ih, LT_H), nz), dim3(64, 4), 0, s, label, (const int *)nullptr, -1, iw, ih, tidy, nms, mask0, zero_plane, zs);
+  hipLaunchKernelGGL((k_label_tile<2, 4>), dim3(cdiv(iw, LT_W) * cdiv(ih, LT_H) * nz), dim3(64, 4), 0, s, label, (const int *)nullptr, -1, iw, ih, tidy, nms, mask0, zero_plane, zs, rd_gdim(cdiv(iw, LT_W), cdiv(ih, LT_H), nz));
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
   // (this plane is labelled with its background, one component that spans the frame: uniting the tiles of a row first and the rows
@@ -478,7 +479,7 @@ void label8_tidy(hipStream_t s, int *label, int *mask0, int *tidy, const float *
 
 // region boundaries (oclrect.cl:373-390) marked into `marks` and their 8-connected components labelled into `label`
 void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih, int *vt_table, int *vt_claim, int *vt_list, int nz, size_t zs) {
-  hipLaunchKernelGGL((k_label_tile<1, LT_TY1>), dim3(cdiv(iw, LT_W), cdiv(ih, LT_H), nz), dim3(64, LT_TY1), 0, s, label, region, -1, iw, ih, marks, (const float *)nullptr, (int *)nullptr, (int *)nullptr, zs);
+  hipLaunchKernelGGL((k_label_tile<1, LT_TY1>), dim3(cdiv(iw, LT_W) * cdiv(ih, LT_H) * nz), dim3(64, LT_TY1), 0, s, label, region, -1, iw, ih, marks, (const float *)nullptr, (int *)nullptr, (int *)nullptr, zs, rd_gdim(cdiv(iw, LT_W), cdiv(ih, LT_H), nz));
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
   if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb, 1, nz), dim3(256), 0, s, label, (const int *)marks, -1, iw, ih, hb, zs);

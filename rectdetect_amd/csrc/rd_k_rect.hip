@@ -164,8 +164,9 @@ __global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ e
 __device__ __forceinline__ unsigned div_small_m(unsigned s, unsigned m) { return __umul24(s, m) >> 19; }
 
 #define BP_TY 16         // thread rows per block (4 / 8 / 16 at full rate: 2003 / 2111 / 2126 frames/s)
-__global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih, size_t zs) {
-  RD_ZSHIFT(zs, out, ext, in);
+__global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih, size_t zs, int gdim) {
+  const rd_tile rd_b = rd_block_tile(gdim);
+  RD_ZSHIFTZ(rd_b.z, zs, out, ext, in);
   // one array: the staged input, the horizontal result, and a REGION of zeros - the sample beyond a run is read at `zero region + the
   // same constant offset as the sample inside the run`, so that a sample's address is one select between two registers and the offset
   // travels in the load instruction (with single zero slots the compiler paid an add or a constant per sample)
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict
   uint2 *const src = lds, *const hz = lds + SRC_N;
   __shared__ unsigned rwt[16];                                   // ceil(2^19 / w)
   const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BP_ROWS;
+  const int x0 = rd_b.x * 64, y0 = rd_b.y * BP_ROWS;
   const int x = x0 + tx;
   // the run extents of this thread's pixels (3 rows of the horizontal strip, 2 rows of the output tile): requested first so
   // that their latency overlaps the staging of the tile
@@ -322,8 +323,9 @@ __global__ void k_quant24_lut() {
 #define DS_P 66
 // QN > 0: the input is quantised to QN levels per field on the fly (rc:207-216 fused in: no separate pass over the plane)
 template <int QN>
-__global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, const uint32_t *__restrict__ in, const float *__restrict__ edge, int iw, int ih, size_t zs) {
-  RD_ZSHIFT(zs, out, in, edge);
+__global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, const uint32_t *__restrict__ in, const float *__restrict__ edge, int iw, int ih, size_t zs, int gdim) {
+  const rd_tile rd_b = rd_block_tile(gdim);
+  RD_ZSHIFTZ(rd_b.z, zs, out, in, edge);
   constexpr int NC = (DS_ROWS + 2) * DS_P, IT = (NC + 255) / 256;
   __shared__ uint32_t tq[NC];
   __shared__ uint8_t tf[NC];        // bit 0: replaced as a centre (!(e < 1e-6)), bit 1: skipped as a neighbour (e >= 1e-6), bit 2: outside the frame
@@ -331,7 +333,7 @@ __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, c
   __shared__ int nlist;
   __shared__ uint32_t qlut[QN == 24 ? 2560 : 1];      // g_quant24, two entries per word
   const int tx = threadIdx.x, tid = threadIdx.y * 64 + tx;
-  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * DS_ROWS;
+  const int x0 = rd_b.x * 64, y0 = rd_b.y * DS_ROWS;
   if (tid == 0) nlist = 0;
   if (QN == 24) {
     uint32_t w[10];
@@ -489,8 +491,9 @@ __global__ __launch_bounds__(256) void k_mm_gather(unsigned long long *__restric
 // mask / edge: the merge mask and the strong mask as bit planes (wpr words per row); size_out (optional) <- the junction counts of the strong mask
 // (rc:74-95), which the region sizes start from (quirk H2: the reference counts into the plane that still holds them)
 __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *__restrict__ B, uint8_t *__restrict__ allow, const int *__restrict__ pix, const u64 *__restrict__ mask,
-                                                     const u64 *__restrict__ edge, int iw, int ih, int wpr, int *__restrict__ flags, int *__restrict__ size_out, size_t zs) {
-  RD_ZSHIFT(zs, A, B, allow, pix, mask, edge, flags, size_out);
+                                                     const u64 *__restrict__ edge, int iw, int ih, int wpr, int *__restrict__ flags, int *__restrict__ size_out, size_t zs, int gdim) {
+  const rd_tile rd_b = rd_block_tile(gdim);
+  RD_ZSHIFTZ(rd_b.z, zs, A, B, allow, pix, mask, edge, flags, size_out);
   __shared__ u64 sm[(RI_ROWS + 2) * 2];        // merge mask: rows y0 .. y0 + RI_ROWS + 1, words k and k + 1
   __shared__ u64 se[(RI_ROWS + 3) * 3];        // strong mask: rows y0 - 1 .. y0 + RI_ROWS + 1, words k - 1, k, k + 1
   __shared__ int col[RI_NC];                  // colours, then (in place) nothing: kept for the allow bits
@@ -500,8 +503,8 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
   // (also: the round flags start at zero - flags[0] = 1: the first launch, evaluated here, counts as one that changed something - and the
   //  size plane starts from size_init - quirk H2 - without extra launches)
   const int tid = threadIdx.y * 64 + threadIdx.x;
-  if (blockIdx.x == 0 && blockIdx.y == 0 && tid < RR_NFLAGS) flags[tid] = tid == 0 ? 1 : 0;
-  const int gx0 = blockIdx.x * 64 - RI_H, gy0 = blockIdx.y * RI_ROWS - RI_H;
+  if (rd_b.x == 0 && rd_b.y == 0 && tid < RR_NFLAGS) flags[tid] = tid == 0 ? 1 : 0;
+  const int gx0 = rd_b.x * 64 - RI_H, gy0 = rd_b.y * RI_ROWS - RI_H;
   // colours of the region (cells outside the frame: marked by lnk = -1 below), and - for the tile and two more rows / columns - "merge mask
   // set" and "strong edge" as two bits (all loads of a thread in flight together)
   stage_cells<RI_NC, 256>(tid, pix,
@@ -509,7 +512,7 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
     [&](int t, bool ok, int v) { col[t] = v; lnk[t] = ok ? 0 : -1; });
   constexpr int MW = 64 + 2, MH = RI_ROWS + 2, MN = MW * MH;       // cells (RI_H .. RI_H + 65, RI_H .. RI_H + RI_ROWS + 1)
   {
-    const int k = blockIdx.x, y0 = blockIdx.y * RI_ROWS;
+    const int k = rd_b.x, y0 = rd_b.y * RI_ROWS;
     if (tid < (RI_ROWS + 2) * 2) { const int r = tid >> 1, kk = k + (tid & 1), yy = y0 + r; sm[tid] = (yy < ih && kk < wpr) ? mask[(size_t)yy * wpr + kk] : 0ull; }
     if (tid < (RI_ROWS + 3) * 3) { const int r = tid / 3, kk = k - 1 + tid % 3, yy = y0 - 1 + r; se[tid] = (yy >= 0 && yy < ih && kk >= 0 && kk < wpr) ? edge[(size_t)yy * wpr + kk] : 0ull; }
   }
@@ -591,10 +594,10 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
   }
   __syncthreads();
   // the labels after the first launch, the allow bytes, the sizes' start values
-  const int x = blockIdx.x * 64 + threadIdx.x;
+  const int x = rd_b.x * 64 + threadIdx.x;
   if (x >= iw) return;
   for (int r = threadIdx.y; r < RI_ROWS; r += 4) {
-    const int y = blockIdx.y * RI_ROWS + r;
+    const int y = rd_b.y * RI_ROWS + r;
     if (y >= ih) break;
     const int c = (r + RI_H) * RI_RW + threadIdx.x + RI_H, p = y * iw + x;
     int l = lnk[c];
@@ -1136,15 +1139,16 @@ __device__ __forceinline__ void ab_record(int *__restrict__ rec, int p, int rl, 
 
 // (list: room for reccap records)
 __global__ __launch_bounds__(AB_NT) void k_absorb_tile(int *__restrict__ out, int *__restrict__ list, int reccap, int *count, const int *__restrict__ old, const int *__restrict__ size,
-                                                       int thre, int iw, int ih, size_t zs) {
-  RD_ZSHIFT(zs, out, list, count, old, size);
+                                                       int thre, int iw, int ih, size_t zs, int gdim) {
+  const rd_tile rd_b = rd_block_tile(gdim);
+  RD_ZSHIFTZ(rd_b.z, zs, out, list, count, old, size);
   __shared__ ab_word cell[AB_NC];
   __shared__ unsigned short slist[AB_NT * AB_R];
   __shared__ unsigned short rlist[AB_TW * AB_TH];      // undecided pixels of the tile (cell indices)
   __shared__ int nsmall, nres, base;
   const int tid = threadIdx.x;
   if (tid == 0) { nsmall = 0; nres = 0; }
-  const int gx0 = blockIdx.x * AB_TW - AB_HK - 1, gy0 = blockIdx.y * AB_TH - AB_HK - 1;
+  const int gx0 = rd_b.x * AB_TW - AB_HK - 1, gy0 = rd_b.y * AB_TH - AB_HK - 1;
   // old labels and their region sizes for every loaded cell (cells outside the frame: size 0 - they never win a comparison)
   {
     constexpr int IT = (AB_NC + AB_NT - 1) / AB_NT;
@@ -1227,9 +1231,9 @@ __global__ __launch_bounds__(AB_NT) void k_absorb_tile(int *__restrict__ out, in
     }
   }
   // the tile's own pixels: final labels (the undecided ones are written below)
-  const int tx = tid & 63, x = blockIdx.x * AB_TW + tx;
+  const int tx = tid & 63, x = rd_b.x * AB_TW + tx;
   for (int r = tid >> 6; r < AB_TH; r += AB_NT / 64) {
-    const int y = blockIdx.y * AB_TH + r;
+    const int y = rd_b.y * AB_TH + r;
     if (x >= iw || y >= ih) continue;
     const int ci = (r + AB_HK + 1) * AB_LW + tx + AB_HK + 1;
     const ab_word w = cell[ci];
@@ -1783,13 +1787,13 @@ void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, in
   hipLaunchKernelGGL(k_blblur_extents, dim3(cdiv(iw, 64), cdiv(ih, BE_ROWS), nz), dim3(64, 4), 0, s, ext, edge, iw, ih, zs);
 }
 void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih, int nz, size_t zs) {
-  hipLaunchKernelGGL(k_blblur_pair, dim3(cdiv(iw, 64), cdiv(ih, BP_ROWS), nz), dim3(64, BP_TY), 0, s, out, ext, in, iw, ih, zs);
+  hipLaunchKernelGGL(k_blblur_pair, dim3(cdiv(iw, 64) * cdiv(ih, BP_ROWS) * nz), dim3(64, BP_TY), 0, s, out, ext, in, iw, ih, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, BP_ROWS), nz));
 }
 // fills the quantisation tables of the current device (once per device, before its first frame; the caller synchronises)
 void quant_lut_init(hipStream_t s) { hipLaunchKernelGGL(k_quant24_lut, dim3(20), dim3(256), 0, s); }
 void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih, int quantize24, int nz, size_t zs) {
-  if (quantize24) hipLaunchKernelGGL(k_despeckle<24>, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS), nz), dim3(64, 4), 0, s, out, in, edge, iw, ih, zs);
-  else hipLaunchKernelGGL(k_despeckle<0>, dim3(cdiv(iw, 64), cdiv(ih, DS_ROWS), nz), dim3(64, 4), 0, s, out, in, edge, iw, ih, zs);
+  if (quantize24) hipLaunchKernelGGL(k_despeckle<24>, dim3(cdiv(iw, 64) * cdiv(ih, DS_ROWS) * nz), dim3(64, 4), 0, s, out, in, edge, iw, ih, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, DS_ROWS), nz));
+  else hipLaunchKernelGGL(k_despeckle<0>, dim3(cdiv(iw, 64) * cdiv(ih, DS_ROWS) * nz), dim3(64, 4), 0, s, out, in, edge, iw, ih, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, DS_ROWS), nz));
 }
 // out: the merge mask as a bit plane (ih * ceil(iw / 64) words); bits: what junction_bits() left
 void merge_mask(hipStream_t s, unsigned long long *out, const unsigned long long *bits, int iw, int ih, int nz, size_t zs) {
@@ -1806,7 +1810,7 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
   int *flags = scratch + n;
   uint8_t *allow = (uint8_t *)(flags + RR_NFLAGS);
   int *A = label, *B = scratch + 2 * (size_t)n;   // the two planes of the rounds; the result is in A
-  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64), cdiv(ih, RI_ROWS), nz), dim3(64, 4), 0, s, A, B, allow, pix, mask, edge, iw, ih, cdiv(iw, 64), flags, size_out, zs);
+  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64) * cdiv(ih, RI_ROWS) * nz), dim3(64, 4), 0, s, A, B, allow, pix, mask, edge, iw, ih, cdiv(iw, 64), flags, size_out, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, RI_ROWS), nz));
   const dim3 grid(cdiv(iw, 64), cdiv(ih, RR_TY * RR_PX), nz);
   for (int r = 1; r < ROUNDS; r++) {       // (launch 0 was evaluated by k_region_init)
     const int gx = (int)grid.x, gy = (int)grid.y, gz = (int)grid.z;
@@ -1832,7 +1836,7 @@ void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int 
   int nsteps = 1;
   while ((1 << nsteps) < (iw > ih ? iw : ih)) nsteps++;
   if (!count_is_zero) { if (nz != 1) { fprintf(stderr, "despeckle2: a group launch needs count_is_zero\n"); abort(); } (void)hipMemsetAsync(count, 0, sizeof(int), s); }
-  hipLaunchKernelGGL(k_absorb_tile, dim3(cdiv(iw, AB_TW), cdiv(ih, AB_TH), nz), dim3(AB_NT), 0, s, out, list, reccap, count, in, size, thre, iw, ih, zs);
+  hipLaunchKernelGGL(k_absorb_tile, dim3(cdiv(iw, AB_TW) * cdiv(ih, AB_TH) * nz), dim3(AB_NT), 0, s, out, list, reccap, count, in, size, thre, iw, ih, zs, rd_gdim(cdiv(iw, AB_TW), cdiv(ih, AB_TH), nz));
   static std::atomic<unsigned> lds_set{0};
   set_max_lds_once((const void *)k_absorb_tail, (int)((AT_CAP + 1) * sizeof(ab_word)), lds_set);
   hipLaunchKernelGGL(k_absorb_tail, dim3(1, 1, nz), dim3(AT_NT), (AT_CAP + 1) * sizeof(ab_word), s, out, (const int *)list, reccap, (const int *)count, size, nsteps, status, zs);
