@@ -61,6 +61,7 @@ __global__ __launch_bounds__(64 * TY) void k_label_tile(int *__restrict__ label,
                                                     const float *__restrict__ nms, int *__restrict__ mask0, int *__restrict__ zero_plane, size_t zs, int gdim) {
   constexpr bool BOUNDARY = SRC == 1;
   const rd_tile rd_b = rd_block_tile(gdim);
+  if (rd_b.x < 0) return;
   RD_ZSHIFTZ(rd_b.z, zs, label, pix, pix_out, nms, mask0, zero_plane);
   __shared__ int lab[LT_W * LT_H];
   __shared__ int pv[LT_W * LT_H];
@@ -450,7 +451,7 @@ namespace rdk {
 
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, int skip_flatten) {
   const size_t zs = 0;
-  hipLaunchKernelGGL((k_label_tile<0, LT_TY>), dim3(cdiv(iw, LT_W) * cdiv(ih, LT_H)), dim3(64, LT_TY), 0, s, label, pix, bgc, iw, ih, (int *)nullptr, (const float *)nullptr, (int *)nullptr, (int *)nullptr, zs, rd_gdim(cdiv(iw, LT_W), cdiv(ih, LT_H), 1));
+  hipLaunchKernelGGL((k_label_tile<0, LT_TY>), dim3(rd_tile_blocks(cdiv(iw, LT_W), cdiv(ih, LT_H), 1)), dim3(64, LT_TY), 0, s, label, pix, bgc, iw, ih, (int *)nullptr, (const float *)nullptr, (int *)nullptr, (int *)nullptr, zs, rd_gdim(cdiv(iw, LT_W), cdiv(ih, LT_H), 1));
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
   if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb), dim3(256), 0, s, label, pix, bgc, iw, ih, hb, zs);
@@ -462,7 +463,7 @@ void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, 
 
 // rect_tidy(mask0, tidy, nms, zero_plane) + label8(label, tidy, background -1, skip_flatten) with the tidy computed inside the tile kernel
 void label8_tidy(hipStream_t s, int *label, int *mask0, int *tidy, const float *nms, int *zero_plane, int iw, int ih, int skip_flatten, int nz, size_t zs) {
-  hipLaunchKernelGGL((k_label_tile<2, 4>), dim3(cdiv(iw, LT_W) * cdiv(ih, LT_H) * nz), dim3(64, 4), 0, s, label, (const int *)nullptr, -1, iw, ih, tidy, nms, mask0, zero_plane, zs, rd_gdim(cdiv(iw, LT_W), cdiv(ih, LT_H), nz));
+  hipLaunchKernelGGL((k_label_tile<2, 4>), dim3(rd_tile_blocks(cdiv(iw, LT_W), cdiv(ih, LT_H), nz)), dim3(64, 4), 0, s, label, (const int *)nullptr, -1, iw, ih, tidy, nms, mask0, zero_plane, zs, rd_gdim(cdiv(iw, LT_W), cdiv(ih, LT_H), nz));
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
   // (this plane is labelled with its background, one component that spans the frame: uniting the tiles of a row first and the rows
@@ -479,7 +480,7 @@ void label8_tidy(hipStream_t s, int *label, int *mask0, int *tidy, const float *
 
 // region boundaries (oclrect.cl:373-390) marked into `marks` and their 8-connected components labelled into `label`
 void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih, int *vt_table, int *vt_claim, int *vt_list, int nz, size_t zs) {
-  hipLaunchKernelGGL((k_label_tile<1, LT_TY1>), dim3(cdiv(iw, LT_W) * cdiv(ih, LT_H) * nz), dim3(64, LT_TY1), 0, s, label, region, -1, iw, ih, marks, (const float *)nullptr, (int *)nullptr, (int *)nullptr, zs, rd_gdim(cdiv(iw, LT_W), cdiv(ih, LT_H), nz));
+  hipLaunchKernelGGL((k_label_tile<1, LT_TY1>), dim3(rd_tile_blocks(cdiv(iw, LT_W), cdiv(ih, LT_H), nz)), dim3(64, LT_TY1), 0, s, label, region, -1, iw, ih, marks, (const float *)nullptr, (int *)nullptr, (int *)nullptr, zs, rd_gdim(cdiv(iw, LT_W), cdiv(ih, LT_H), nz));
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
   if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb, 1, nz), dim3(256), 0, s, label, (const int *)marks, -1, iw, ih, hb, zs);

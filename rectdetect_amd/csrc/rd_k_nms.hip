@@ -41,6 +41,7 @@ struct GnTaps { uint32_t *plab1; float2 *vxy; float *strength; };
 template <int TAPS>
 __global__ __launch_bounds__(GN_NT) void k_grad_nms(float *__restrict__ out, P3c bl, int iw, int ih, size_t zs, GnTaps taps, int gdim) {
   const rd_tile rd_b = rd_block_tile(gdim);
+  if (rd_b.x < 0) return;
   RD_ZSHIFTZ(rd_b.z, zs, out, bl.p[0], bl.p[1], bl.p[2], taps.plab1, taps.vxy, taps.strength);
   // [0] raw L, [1..3] the re-packed fields as floats; after the strength is known the same memory holds the list of local maxima
   __shared__ float lab[4][GN_LH * GN_LW];
@@ -218,7 +219,7 @@ int grad_nms_fits(int iw, int ih) {
 void grad_nms(hipStream_t s, float *nms, float *const bl[3], int iw, int ih, int nz, size_t zs, uint32_t *tap_plab1, float *tap_vxy, float *tap_strength) {
   P3c b = { { bl[0], bl[1], bl[2] } };
   GnTaps t = { tap_plab1, (float2 *)tap_vxy, tap_strength };
-  const dim3 grid(cdiv(iw, 64) * cdiv(ih, GN_ROWS) * nz);
+  const dim3 grid(rd_tile_blocks(cdiv(iw, 64), cdiv(ih, GN_ROWS), nz));
   const int gdim = rd_gdim(cdiv(iw, 64), cdiv(ih, GN_ROWS), nz);
   if (tap_plab1) hipLaunchKernelGGL(k_grad_nms<1>, grid, dim3(64, GN_TY), 0, s, nms, b, iw, ih, zs, t, gdim);
   else hipLaunchKernelGGL(k_grad_nms<0>, grid, dim3(64, GN_TY), 0, s, nms, b, iw, ih, zs, t, gdim);

@@ -166,6 +166,7 @@ __device__ __forceinline__ unsigned div_small_m(unsigned s, unsigned m) { return
 #define BP_TY 16         // thread rows per block (4 / 8 / 16 at full rate: 2003 / 2111 / 2126 frames/s)
 __global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih, size_t zs, int gdim) {
   const rd_tile rd_b = rd_block_tile(gdim);
+  if (rd_b.x < 0) return;
   RD_ZSHIFTZ(rd_b.z, zs, out, ext, in);
   // one array: the staged input, the horizontal result, and a REGION of zeros - the sample beyond a run is read at `zero region + the
   // same constant offset as the sample inside the run`, so that a sample's address is one select between two registers and the offset
@@ -325,6 +326,7 @@ __global__ void k_quant24_lut() {
 template <int QN>
 __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, const uint32_t *__restrict__ in, const float *__restrict__ edge, int iw, int ih, size_t zs, int gdim) {
   const rd_tile rd_b = rd_block_tile(gdim);
+  if (rd_b.x < 0) return;
   RD_ZSHIFTZ(rd_b.z, zs, out, in, edge);
   constexpr int NC = (DS_ROWS + 2) * DS_P, IT = (NC + 255) / 256;
   __shared__ uint32_t tq[NC];
@@ -493,6 +495,7 @@ __global__ __launch_bounds__(256) void k_mm_gather(unsigned long long *__restric
 __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *__restrict__ B, uint8_t *__restrict__ allow, const int *__restrict__ pix, const u64 *__restrict__ mask,
                                                      const u64 *__restrict__ edge, int iw, int ih, int wpr, int *__restrict__ flags, int *__restrict__ size_out, size_t zs, int gdim) {
   const rd_tile rd_b = rd_block_tile(gdim);
+  if (rd_b.x < 0) return;
   RD_ZSHIFTZ(rd_b.z, zs, A, B, allow, pix, mask, edge, flags, size_out);
   __shared__ u64 sm[(RI_ROWS + 2) * 2];        // merge mask: rows y0 .. y0 + RI_ROWS + 1, words k and k + 1
   __shared__ u64 se[(RI_ROWS + 3) * 3];        // strong mask: rows y0 - 1 .. y0 + RI_ROWS + 1, words k - 1, k, k + 1
@@ -668,29 +671,13 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
 #define RR_DEEP 3          // rounds in which the trees are still the chains of the initial links (a pixel's parent is 1, 10, 91 rows above it)
 #endif
 __device__ __forceinline__ int rr_label(const int *X, unsigned q) { return at32(X, q) >> RR_MBITS; }
-// Block -> (tile, frame): the launch is one-dimensional and the hardware hands consecutive blocks to the 8 XCDs in turn, each with an L2 of its own.  A group launch
-// of 8 frames gives every XCD ONE frame (frame = block mod 8): a tile's neighbours and the pixels its labels name - the rows above it - are then served by the L2
-// that fetched them for the neighbouring tiles, instead of eight L2s each fetching a copy from memory (64 % of this kernel's L2 requests missed).  Other launches
-// give every XCD a band of tile columns.  Speed only: nothing depends on where a block runs.
-#ifndef RR_XCD
-#define RR_XCD 1
-#endif
-__device__ __forceinline__ void rr_block_to_tile(int gx, int gy, int gz, int &bx, int &by, int &bz) {
-  const int b = blockIdx.x;
-  if (!RR_XCD) { bx = b % gx; by = (b / gx) % gy; bz = b / (gx * gy); return; }
-  if (gz == 8) { bz = b & 7; const int t = b >> 3; by = t / gx; bx = t - by * gx; return; }
-  // bands of columns: XCD k takes tile columns [k * cw, (k + 1) * cw) of every frame, walking down its band row by row
-  const int cw = (gx + 7) / 8, per = cw * gy * gz, k = b & 7, t = b >> 3;      // (the grid is padded to 8 * per blocks: the launcher)
-  bz = t / (cw * gy);
-  const int r = t - bz * (cw * gy);
-  by = r / cw; bx = k * cw + (r - by * cw);
-  if (t >= per || bx >= gx) { bx = -1; }
-}
-__global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round, size_t zs, int gx, int gy, int gz) {
-  int bx, by, bz;
-  rr_block_to_tile(gx, gy, gz, bx, by, bz);
-  if (bx < 0) return;
-  { const size_t rd_zoff_ = (size_t)bz * zs; RD_ZS1(X); RD_ZS1(Y); RD_ZS1(allow); RD_ZS1(flags); }
+// (Block -> tile and frame: rd_block_tile, rd_device.h - a tile's neighbours and the pixels its labels name, the rows above it, are served by the L2 that fetched
+//  them for the neighbouring tiles: 64 % of this kernel's L2 requests missed before.)
+__global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round, size_t zs, int gdim) {
+  const rd_tile rd_b = rd_block_tile(gdim);
+  if (rd_b.x < 0) return;
+  const int bx = rd_b.x, by = rd_b.y;
+  RD_ZSHIFTZ(rd_b.z, zs, X, Y, allow, flags);
   if (round > 0 && flags[round - 1] == 0) return;
   __shared__ int hk[512], hv[512];
   __shared__ int tmin[64 * RR_TY * RR_PX];      // launch 1 only: the smallest proposal for each pixel of the block's tile (see below)
@@ -1141,6 +1128,7 @@ __device__ __forceinline__ void ab_record(int *__restrict__ rec, int p, int rl, 
 __global__ __launch_bounds__(AB_NT) void k_absorb_tile(int *__restrict__ out, int *__restrict__ list, int reccap, int *count, const int *__restrict__ old, const int *__restrict__ size,
                                                        int thre, int iw, int ih, size_t zs, int gdim) {
   const rd_tile rd_b = rd_block_tile(gdim);
+  if (rd_b.x < 0) return;
   RD_ZSHIFTZ(rd_b.z, zs, out, list, count, old, size);
   __shared__ ab_word cell[AB_NC];
   __shared__ unsigned short slist[AB_NT * AB_R];
@@ -1787,13 +1775,13 @@ void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, in
   hipLaunchKernelGGL(k_blblur_extents, dim3(cdiv(iw, 64), cdiv(ih, BE_ROWS), nz), dim3(64, 4), 0, s, ext, edge, iw, ih, zs);
 }
 void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih, int nz, size_t zs) {
-  hipLaunchKernelGGL(k_blblur_pair, dim3(cdiv(iw, 64) * cdiv(ih, BP_ROWS) * nz), dim3(64, BP_TY), 0, s, out, ext, in, iw, ih, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, BP_ROWS), nz));
+  hipLaunchKernelGGL(k_blblur_pair, dim3(rd_tile_blocks(cdiv(iw, 64), cdiv(ih, BP_ROWS), nz)), dim3(64, BP_TY), 0, s, out, ext, in, iw, ih, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, BP_ROWS), nz));
 }
 // fills the quantisation tables of the current device (once per device, before its first frame; the caller synchronises)
 void quant_lut_init(hipStream_t s) { hipLaunchKernelGGL(k_quant24_lut, dim3(20), dim3(256), 0, s); }
 void despeckle(hipStream_t s, uint32_t *out, const uint32_t *in, const float *edge, int iw, int ih, int quantize24, int nz, size_t zs) {
-  if (quantize24) hipLaunchKernelGGL(k_despeckle<24>, dim3(cdiv(iw, 64) * cdiv(ih, DS_ROWS) * nz), dim3(64, 4), 0, s, out, in, edge, iw, ih, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, DS_ROWS), nz));
-  else hipLaunchKernelGGL(k_despeckle<0>, dim3(cdiv(iw, 64) * cdiv(ih, DS_ROWS) * nz), dim3(64, 4), 0, s, out, in, edge, iw, ih, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, DS_ROWS), nz));
+  if (quantize24) hipLaunchKernelGGL(k_despeckle<24>, dim3(rd_tile_blocks(cdiv(iw, 64), cdiv(ih, DS_ROWS), nz)), dim3(64, 4), 0, s, out, in, edge, iw, ih, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, DS_ROWS), nz));
+  else hipLaunchKernelGGL(k_despeckle<0>, dim3(rd_tile_blocks(cdiv(iw, 64), cdiv(ih, DS_ROWS), nz)), dim3(64, 4), 0, s, out, in, edge, iw, ih, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, DS_ROWS), nz));
 }
 // out: the merge mask as a bit plane (ih * ceil(iw / 64) words); bits: what junction_bits() left
 void merge_mask(hipStream_t s, unsigned long long *out, const unsigned long long *bits, int iw, int ih, int nz, size_t zs) {
@@ -1810,13 +1798,13 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
   int *flags = scratch + n;
   uint8_t *allow = (uint8_t *)(flags + RR_NFLAGS);
   int *A = label, *B = scratch + 2 * (size_t)n;   // the two planes of the rounds; the result is in A
-  hipLaunchKernelGGL(k_region_init, dim3(cdiv(iw, 64) * cdiv(ih, RI_ROWS) * nz), dim3(64, 4), 0, s, A, B, allow, pix, mask, edge, iw, ih, cdiv(iw, 64), flags, size_out, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, RI_ROWS), nz));
+  hipLaunchKernelGGL(k_region_init, dim3(rd_tile_blocks(cdiv(iw, 64), cdiv(ih, RI_ROWS), nz)), dim3(64, 4), 0, s, A, B, allow, pix, mask, edge, iw, ih, cdiv(iw, 64), flags, size_out, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, RI_ROWS), nz));
   const dim3 grid(cdiv(iw, 64), cdiv(ih, RR_TY * RR_PX), nz);
   for (int r = 1; r < ROUNDS; r++) {       // (launch 0 was evaluated by k_region_init)
-    const int gx = (int)grid.x, gy = (int)grid.y, gz = (int)grid.z;
-    const dim3 lg((!RR_XCD || gz == 8) ? gx * gy * gz : 8 * ((gx + 7) / 8) * gy * gz);
-    if (r & 1) hipLaunchKernelGGL(k_region_round, lg, dim3(64, RR_TY), 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r, zs, gx, gy, gz);
-    else hipLaunchKernelGGL(k_region_round, lg, dim3(64, RR_TY), 0, s, A, B, (const uint8_t *)allow, iw, ih, flags, r, zs, gx, gy, gz);
+    const dim3 lg(rd_tile_blocks((int)grid.x, (int)grid.y, (int)grid.z));
+    const int gdim = rd_gdim((int)grid.x, (int)grid.y, (int)grid.z);
+    if (r & 1) hipLaunchKernelGGL(k_region_round, lg, dim3(64, RR_TY), 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r, zs, gdim);
+    else hipLaunchKernelGGL(k_region_round, lg, dim3(64, RR_TY), 0, s, A, B, (const uint8_t *)allow, iw, ih, flags, r, zs, gdim);
   }
   if (marked) *marked = 1;
 }
@@ -1836,7 +1824,7 @@ void despeckle2(hipStream_t s, int *out, const int *in, int *scratch, const int 
   int nsteps = 1;
   while ((1 << nsteps) < (iw > ih ? iw : ih)) nsteps++;
   if (!count_is_zero) { if (nz != 1) { fprintf(stderr, "despeckle2: a group launch needs count_is_zero\n"); abort(); } (void)hipMemsetAsync(count, 0, sizeof(int), s); }
-  hipLaunchKernelGGL(k_absorb_tile, dim3(cdiv(iw, AB_TW) * cdiv(ih, AB_TH) * nz), dim3(AB_NT), 0, s, out, list, reccap, count, in, size, thre, iw, ih, zs, rd_gdim(cdiv(iw, AB_TW), cdiv(ih, AB_TH), nz));
+  hipLaunchKernelGGL(k_absorb_tile, dim3(rd_tile_blocks(cdiv(iw, AB_TW), cdiv(ih, AB_TH), nz)), dim3(AB_NT), 0, s, out, list, reccap, count, in, size, thre, iw, ih, zs, rd_gdim(cdiv(iw, AB_TW), cdiv(ih, AB_TH), nz));
   static std::atomic<unsigned> lds_set{0};
   set_max_lds_once((const void *)k_absorb_tail, (int)((AT_CAP + 1) * sizeof(ab_word)), lds_set);
   hipLaunchKernelGGL(k_absorb_tail, dim3(1, 1, nz), dim3(AT_NT), (AT_CAP + 1) * sizeof(ab_word), s, out, (const int *)list, reccap, (const int *)count, size, nsteps, status, zs);
