@@ -187,7 +187,9 @@ __global__ __launch_bounds__(256) void k_transpose(P3 dst, P3c src, P3c fwd, P3c
 #define IIR_C13 -0.0000097781f
 #define IIR_C14 0.0000006462f
 #define IIR_WARM 11
-#define IIR_CH 16
+#ifndef IIR_CH
+#define IIR_CH 16               // rows per chunk of the interior path (loads of the next chunk in flight while one is evaluated)
+#endif
 
 // Both sweeps and the combination (iu:580-589 / iu:629-637: anti-causal + causal - c0 * input) for one 64-column x IF_ROWS
 // block of one plane in ONE wave: the causal outputs of the block wait in LDS while the anti-causal sweep runs over the same
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
   float *__restrict__ tl = tails + ((size_t)(k * nchunks + c) * 4 * 7) * W + (xin ? x : W - 1);
   const int ylo = -IIR_WARM, yhi = H + IIR_WARM;
   float cur[IIR_CH], nxt[IIR_CH];
-  static_assert(IIR_CH == 16 && IF_WU % IIR_CH == 0 && (IF_ROWS / 2) % IIR_CH == 0, "the interior path walks whole chunks, half a block per phase");
+  static_assert(IIR_CH >= 8 && IF_WU % IIR_CH == 0 && (IF_ROWS / 2) % IIR_CH == 0, "the interior path walks whole chunks, half a block per phase");
   if (s0 - IF_WU >= 0 && s1 + IF_WU <= H && s1 - s0 == IF_ROWS) {
     // Interior block (all but the first and last of a column): no mirrored rows, no clamping, a full block - the same steps
     // as below with every row test resolved at compile time (the scalar address and branch work of the general form costs
@@ -867,7 +869,10 @@ static int if_pick_rows(int np, int W, int H, int transpose_out, int nz) {
   (void)transpose_out;
   // (group launches: 128 rows - a quarter instead of half as much run-in, half as many borders to check; 2154-2167 against 2121-2151 frames/s
   //  in four interleaved pairs of runs; single frames keep 64: more blocks for the same device)
-  if (nz > 1) return 128;
+#ifndef IF_GROUP_ROWS
+#define IF_GROUP_ROWS 128
+#endif
+  if (nz > 1) return IF_GROUP_ROWS;
   return 64;     // 32 rows of run-in per 64 rows of output: with several frames in flight the instruction count matters more than the wave count (48 / 32 rows ran 5 % slower there, though faster alone)
 }
 
