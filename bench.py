@@ -248,7 +248,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames-per-step", type=int, default=512, help="frames of the stream resident in HBM and handed over per step (512 x 6.2 MB = 3.2 GB; 20 steps then run about 5 s)")
-    ap.add_argument("--slots", type=int, default=32, help="frames in flight per GPU (from three on: one stream per frame on four shared streams; from 6 / 12 / 32 on: groups of 2 / 4 / 8 frames per set of launches; 32 measured 3 %% above 16)")
+    ap.add_argument("--slots", type=int, default=64, help="frames in flight per GPU (from three on: one stream per frame on four shared streams; from 6 / 12 / 32 on: groups of 2 / 4 / 8 frames per set of launches; 64 = two groups queued on each of the four streams, so that a stream never waits for the host to collect a group and hand over the next: 32 / 48 / 64 / 96 measured 2316-2329 / 2354 / 2373-2396 / 2402 frames/s on one box)")
     ap.add_argument("--host-frames", action="store_true", help="hand over host buffers (PCIe upload inside the timed region); not the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="profiling runs only: skip the sequential verification pass and the host-frames pass (the line then says outputs_verified: null)")
