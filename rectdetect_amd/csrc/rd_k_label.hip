@@ -279,12 +279,16 @@ __global__ __launch_bounds__(256) void k_label_flatten(int *label, int n, int *v
     int l[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) { const int i = i0 + k * stride; l[k] = i < n ? label[i] : -1; }
+    int r[4], n[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-      if (l[k] < 0) continue;
-      const int r = uf_find(label, l[k]);
-      if (r != l[k]) label[i0 + k * stride] = r;
+    for (int k = 0; k < 4; k++) { r[k] = l[k] < 0 ? 0 : l[k]; n[k] = l[k] < 0 ? 0 : label[r[k]]; }
+    while ((n[0] != r[0]) | (n[1] != r[1]) | (n[2] != r[2]) | (n[3] != r[3])) {      // the four walks take their steps together
+#pragma unroll
+      for (int k = 0; k < 4; k++) { r[k] = n[k]; const int v = label[r[k]]; n[k] = l[k] < 0 ? 0 : v; }      // (unconditional loads: a walk that has arrived re-reads its root, one that never started reads word 0 and stays at 0)
     }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (l[k] >= 0 && r[k] != l[k]) label[i0 + k * stride] = r[k];
   }
   if (vt_list != nullptr && blockIdx.x == 0) {
     const int m = vt_list[0];
@@ -324,14 +328,24 @@ __global__ __launch_bounds__(256) void k_calc_strength(int *out, const float *__
     as[k] = add != nullptr ? add[p] : 0;
   }
   if (flatten) {
+    // the thread's walks to the roots take their steps together (chains of dependent loads: the background's are as long as the border kernel left them)
+    int r[CS_ROWS], n[CS_ROWS];
+    bool act[CS_ROWS];
 #pragma unroll
-    for (int k = 0; k < CS_ROWS; k++) {
-      const int y = yb + 4 * k;
-      if (x < iw && y < ih && ls[k] >= 0) {
-        const int r = uf_find(label, ls[k]);
-        if (r != ls[k]) { label[y * iw + x] = r; ls[k] = r; }
-      }
+    for (int k = 0; k < CS_ROWS; k++) { act[k] = x < iw && yb + 4 * k < ih && ls[k] >= 0; r[k] = act[k] ? ls[k] : 0; }
+#pragma unroll
+    for (int k = 0; k < CS_ROWS; k++) n[k] = act[k] ? label[r[k]] : 0;
+    for (;;) {
+      bool moving = false;
+#pragma unroll
+      for (int k = 0; k < CS_ROWS; k++) moving = moving || n[k] != r[k];
+      if (!moving) break;
+#pragma unroll
+      for (int k = 0; k < CS_ROWS; k++) { r[k] = n[k]; const int v = label[r[k]]; n[k] = act[k] ? v : 0; }      // (unconditional loads: a walk that has arrived re-reads its root, one that never started reads word 0 and stays at 0)
     }
+#pragma unroll
+    for (int k = 0; k < CS_ROWS; k++)
+      if (act[k] && r[k] != ls[k]) { label[(yb + 4 * k) * iw + x] = r[k]; ls[k] = r[k]; }
   }
   __syncthreads();
 #pragma unroll
