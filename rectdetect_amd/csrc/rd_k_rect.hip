@@ -297,6 +297,165 @@ __global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict
   }
 }
 
+// The same pair of passes with RUNNING SUMS along the axis instead of ten samples per pixel.  A window's sum is a difference of two prefix values plus the
+// centre:  sum = P[c + nr] - P[c + 1 - nl] + v[c]  (P[i] = sum of the cells before i; covers nl = 0, nr = 0 and both), and the prefix words are plain 32-bit
+// sums of the expanded cells (L | a << 16, b): whatever a prefix wrapped to or carried between its fields, the DIFFERENCE is the window's own sum, whose
+// fields stay below 2^16 - exact.  That takes the ten selected LDS reads, ten compares, ten selects and ten additions of a pixel down to four reads and six
+// subtractions; what it costs is building the prefixes, which is arranged so that the thread that produces a cell also holds its neighbours along the axis:
+//   horizontal: lanes = the tile's 62 rows, wave s walks columns 9s .. 9s+8 of its row with the sum in registers (row pitch 73: conflict-free), the
+//               segment totals meet in LDS, every thread adds the totals of the segments before its own and writes its nine prefix values in place;
+//   vertical:   lanes = columns, wave w computes the horizontal results of rows 8w .. 8w+7 (from the row prefixes) and sums them on the way; totals and
+//               offsets as before; the column prefixes take the memory the row prefixes had.
+// Tile: 64 x BQ_ROWS outputs (BQ_ROWS + 8 <= 64 rows of the horizontal strip are the lanes of a wave), 512 threads, 42 KB of LDS.
+#ifndef BQ_ROWS
+#define BQ_ROWS 54            // (1080 = 20 x 54)
+#endif
+#define BQ_HR (BQ_ROWS + 8)   // rows of the staged tile / horizontal strip
+#define BQ_SW 73
+__global__ __launch_bounds__(512) void k_blblur_pair_ps(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih, size_t zs, int gdim) {
+  const rd_tile rd_b = rd_block_tile(gdim);
+  if (rd_b.x < 0) return;
+  RD_ZSHIFTZ(rd_b.z, zs, out, ext, in);
+  __shared__ uint2 pl[64 * BQ_SW];            // staged cells -> row prefixes (73 per row) -> column prefixes (64 rows x 64)
+  __shared__ uint2 tot[8 * 64];               // segment totals of the scan in progress
+  __shared__ unsigned rwt[16];
+  const int tx = threadIdx.x, wv = threadIdx.y, tid = wv * 64 + tx;
+  const int x0 = rd_b.x * 64, y0 = rd_b.y * BQ_ROWS;
+  const int x = x0 + tx;
+  constexpr int NV = (BQ_ROWS + 7) / 8;
+  unsigned eh[8], ev[NV];
+  uint32_t q[9];
+  // staging: wave wv takes rows wv + 8 i of the tile, its lanes columns 0..63; the eight columns left over are a cell per thread (row tid / 8) - no division,
+  // row addresses advance by a scalar.  Run extents of the thread's pixels: rows 8 wv .. 8 wv + 7 of the horizontal strip, rows wv + 8 k of the output tile.
+  // Every load is unconditional (clamped address, value replaced afterwards) and requested before the first is used.
+  const int sr = tid >> 3, sc = 64 + (tid & 7);
+  const bool interior = x0 >= 4 && y0 >= 4 && x0 + 68 <= iw && y0 + BQ_ROWS + 4 <= ih;
+  if (interior) {
+    const unsigned ib = (unsigned)((y0 - 4 + wv) * iw + x0 - 4 + tx);
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = wv + 8 * i < BQ_HR ? atu(in, ib + (unsigned)(8 * i * iw)) : 0u;
+    q[8] = sr < BQ_HR ? atu(in, (unsigned)((y0 - 4) * iw + x0 - 4) + (unsigned)__umul24(sr, iw) + (unsigned)sc) : 0u;
+    const unsigned eb = (unsigned)((y0 - 4 + 8 * wv) * iw + x);
+#pragma unroll
+    for (int j = 0; j < 8; j++) eh[j] = 8 * wv + j < BQ_HR ? (unsigned)atu(ext, eb + (unsigned)(j * iw)) : 0u;
+    const unsigned vb = (unsigned)((y0 + wv) * iw + x);
+#pragma unroll
+    for (int k = 0; k < NV; k++) ev[k] = wv + 8 * k < BQ_ROWS ? (unsigned)atu(ext, vb + (unsigned)(8 * k * iw)) : 0u;
+  } else {
+    bool okq[9], okh[8], okv[NV];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int r = i < 8 ? wv + 8 * i : sr, c = i < 8 ? tx : sc;
+      const int xx = x0 - 4 + c, yy = y0 - 4 + r;
+      okq[i] = r < BQ_HR && xx >= 0 && xx < iw && yy >= 0 && yy < ih;
+      q[i] = atu(in, okq[i] ? (unsigned)(yy * iw + xx) : 0u);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int r = 8 * wv + j, y = y0 - 4 + r;
+      okh[j] = r < BQ_HR && x < iw && y >= 0 && y < ih;
+      eh[j] = atu(ext, okh[j] ? (unsigned)(y * iw + x) : 0u);
+    }
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      const int r = wv + 8 * k, y = y0 + r;
+      okv[k] = r < BQ_ROWS && x < iw && y < ih;
+      ev[k] = atu(ext, okv[k] ? (unsigned)(y * iw + x) : 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) if (!okq[i]) q[i] = 0u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (!okh[j]) eh[j] = 0u;
+#pragma unroll
+    for (int k = 0; k < NV; k++) if (!okv[k]) ev[k] = 0u;
+  }
+  if (tid < 16) rwt[tid] = tid >= 1 && tid <= 10 ? ((1u << 19) + (unsigned)tid - 1u) / (unsigned)tid : 0u;
+#pragma unroll
+  for (int i = 0; i < 9; i++) {
+    const int r = i < 8 ? wv + 8 * i : sr, c = i < 8 ? tx : sc;
+    const uint32_t v = q[i];
+    if (r < BQ_HR) pl[r * BQ_SW + c] = make_uint2((v & 4095u) | ((v << 4) & 0x3ff0000u), v >> 22);
+  }
+  __syncthreads();
+  // ---- row prefixes: lane = row, wave = segment of nine columns
+  {
+    uint2 p[10];
+    unsigned sx = 0, sy = 0;
+    const int b = tx * BQ_SW + 9 * wv;
+    uint2 v[9];
+#pragma unroll
+    for (int j = 0; j < 9; j++) v[j] = pl[b + j];
+#pragma unroll
+    for (int j = 0; j < 9; j++) { p[j] = make_uint2(sx, sy); sx += v[j].x; sy += v[j].y; }
+    p[9] = make_uint2(sx, sy);
+    tot[wv * 64 + tx] = p[9];
+    __syncthreads();
+    unsigned ox = 0, oy = 0;
+    for (int s2 = 0; s2 < wv; s2++) { const uint2 t = tot[s2 * 64 + tx]; ox += t.x; oy += t.y; }
+#pragma unroll
+    for (int j = 0; j < 9; j++) pl[b + j] = make_uint2(p[j].x + ox, p[j].y + oy);
+    if (wv == 7) pl[b + 9] = make_uint2(p[9].x + ox, p[9].y + oy);      // P[72]
+  }
+  __syncthreads();
+  // ---- horizontal results of rows 8 wv .. 8 wv + 7 (lane = column), summed down the column on the way
+  uint2 pv[9];
+  {
+    unsigned sx = 0, sy = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const int r = 8 * wv + j;
+      uint2 o = make_uint2(0u, 0u);
+      if (r < BQ_HR) {
+        const unsigned e = eh[j];
+        const int nl = e & 7, nr = (e >> 3) & 7;
+        const int c = r * BQ_SW + tx + 4;
+        const uint2 hi = pl[c + nr], lo = pl[c + 1 - nl], c0 = pl[c], c1 = pl[c + 1];
+        const unsigned vx = c1.x - c0.x, vy = c1.y - c0.y;
+        const unsigned ax = hi.x - lo.x + vx, ay = hi.y - lo.y + vy;
+        const int w = nl + nr;
+        o = make_uint2(vx, vy);
+        if (w > 0) {
+          const unsigned rw = rwt[w];
+          o = make_uint2(div_small_m(ax & 0xffffu, rw) | (div_small_m(ax >> 16, rw) << 16), div_small_m(ay, rw));
+        }
+      }
+      pv[j] = make_uint2(sx, sy);
+      sx += o.x; sy += o.y;
+    }
+    pv[8] = make_uint2(sx, sy);
+  }
+  __syncthreads();          // (every read of the row prefixes is done: their memory takes the column prefixes)
+  tot[wv * 64 + tx] = pv[8];
+  __syncthreads();
+  {
+    unsigned ox = 0, oy = 0;
+    for (int s2 = 0; s2 < wv; s2++) { const uint2 t = tot[s2 * 64 + tx]; ox += t.x; oy += t.y; }
+#pragma unroll
+    for (int j = 0; j < 8; j++) pl[(8 * wv + j) * 64 + tx] = make_uint2(pv[j].x + ox, pv[j].y + oy);
+  }
+  __syncthreads();
+  if (x >= iw) return;
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    const int r = wv + 8 * k;
+    const int y = y0 + r;
+    if (r >= BQ_ROWS || y >= ih) break;
+    const unsigned e = ev[k] >> 6;
+    const int nl = e & 7, nr = (e >> 3) & 7;
+    const int c = (r + 4) * 64 + tx;
+    const uint2 hi = pl[c + nr * 64], lo = pl[c + (1 - nl) * 64], c0 = pl[c], c1 = pl[c + 64];
+    const unsigned vx = c1.x - c0.x, vy = c1.y - c0.y;
+    const unsigned ax = hi.x - lo.x + vx, ay = hi.y - lo.y + vy;
+    const int w = nl + nr;
+    uint2 o = make_uint2(vx, vy);
+    if (w > 0) {
+      const unsigned rw = rwt[w];
+      o = make_uint2(div_small_m(ax & 0xffffu, rw) | (div_small_m(ax >> 16, rw) << 16), div_small_m(ay, rw));
+    }
+    atu(out, (unsigned)(y * iw + x)) = (o.x & 0xffffu) | ((o.x >> 16) << 12) | (o.y << 22);
+  }
+}
+
 // rc:207-216: each Lab field rounded to n levels
 __device__ __forceinline__ uint32_t quantize_plab(uint32_t v, int n0, int n1, int n2) {
   float L, a, b;
@@ -1775,6 +1934,10 @@ void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, in
   hipLaunchKernelGGL(k_blblur_extents, dim3(cdiv(iw, 64), cdiv(ih, BE_ROWS), nz), dim3(64, 4), 0, s, ext, edge, iw, ih, zs);
 }
 void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih, int nz, size_t zs) {
+#ifndef BLUR_OLD
+  hipLaunchKernelGGL(k_blblur_pair_ps, dim3(rd_tile_blocks(cdiv(iw, 64), cdiv(ih, BQ_ROWS), nz)), dim3(64, 8), 0, s, out, ext, in, iw, ih, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, BQ_ROWS), nz));
+  return;
+#endif
   hipLaunchKernelGGL(k_blblur_pair, dim3(rd_tile_blocks(cdiv(iw, 64), cdiv(ih, BP_ROWS), nz)), dim3(64, BP_TY), 0, s, out, ext, in, iw, ih, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, BP_ROWS), nz));
 }
 // fills the quantisation tables of the current device (once per device, before its first frame; the caller synchronises)
