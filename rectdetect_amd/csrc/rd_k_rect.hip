@@ -146,158 +146,22 @@ __global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ e
       uv |= (unsigned)((w >> tx) & 1ull) << d;
     }
     const int nlv = __clz((int)tv) - 27, nrv = __ffs((int)uv) - 1;
-    ext[y * iw + x] = (uint16_t)((unsigned)(nl | (nr << 3)) | ((unsigned)(nlv | (nrv << 3)) << 6));
+    // (a pixel without any run keeps its value: written as "the centre alone" - 0 samples towards smaller, 1 towards larger coordinates - which the passes'
+    //  sum / count reproduces exactly, so that they need no special case)
+    const int nrh = (nl | nr) ? nr : 1, nrvv = (nlv | nrv) ? nrv : 1;
+    ext[y * iw + x] = (uint16_t)((unsigned)(nl | (nrh << 3)) | ((unsigned)(nlv | (nrvv << 3)) << 6));
   }
 }
 
-// One (horizontal, vertical) pair of passes (rh:286-296) in a single launch.  The block stages a (64+8) x (BP_ROWS+8)
-// tile of the input in LDS in EXPANDED form (uint2: L | a << 16, b - 16-bit fields, so that a sum of 10 samples is two
-// plain adds without carries between fields), runs the horizontal pass for the 64 x (BP_ROWS+8) strip into a second LDS
-// tile (4 extra rows above and below) and the vertical pass from there: the intermediate plane never travels through
-// HBM, every sample is one unconditional ds_read_b64 (samples beyond the run read a zero slot), and all reads of a pixel
-// are in flight together.
-#define BP_ROWS 64
-#define BP_SW 73              // row pitch of the staged input (72 used)
 // floor(s / w) for a sum s of w samples of a field (s <= 4095 w, 1 <= w <= 10) as one 24-bit multiplication and a shift: s * ceil(2^19 / w) >> 19
 // (exhaustively checked: tools/check_div_small.py; the product stays below 2^32.  Before: float(s) * (1/w) + 0.5 * (1/w) through a conversion, an
 // fma and a conversion back - three operations per field instead of two)
 __device__ __forceinline__ unsigned div_small_m(unsigned s, unsigned m) { return __umul24(s, m) >> 19; }
 
-#define BP_TY 16         // thread rows per block (4 / 8 / 16 at full rate: 2003 / 2111 / 2126 frames/s)
-__global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih, size_t zs, int gdim) {
-  const rd_tile rd_b = rd_block_tile(gdim);
-  if (rd_b.x < 0) return;
-  RD_ZSHIFTZ(rd_b.z, zs, out, ext, in);
-  // one array: the staged input, the horizontal result, and a REGION of zeros - the sample beyond a run is read at `zero region + the
-  // same constant offset as the sample inside the run`, so that a sample's address is one select between two registers and the offset
-  // travels in the load instruction (with single zero slots the compiler paid an add or a constant per sample)
-  constexpr int SRC_N = (BP_ROWS + 8) * BP_SW, HZ_N = (BP_ROWS + 8) * 64, ZR_N = 2048 / 8 + 8;
-  __shared__ uint2 lds[SRC_N + HZ_N + ZR_N];
-  uint2 *const src = lds, *const hz = lds + SRC_N;
-  __shared__ unsigned rwt[16];                                   // ceil(2^19 / w)
-  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
-  const int x0 = rd_b.x * 64, y0 = rd_b.y * BP_ROWS;
-  const int x = x0 + tx;
-  // the run extents of this thread's pixels (3 rows of the horizontal strip, 2 rows of the output tile): requested first so
-  // that their latency overlaps the staging of the tile
-  // (every load below is unconditional - the address of a cell outside the frame is clamped, its value replaced afterwards -
-  //  so that all eight are in flight together: a block's critical path holds one trip to memory, not one per staging step)
-  constexpr int NT = 64 * BP_TY, NH = (BP_ROWS + 8 + BP_TY - 1) / BP_TY, NV = BP_ROWS / BP_TY, NQ = ((BP_ROWS + 8) * 72 + NT - 1) / NT;
-  unsigned eh[NH], ev[NV];
-  uint32_t q[NQ];
-  bool okh[NH], okv[NV], okq[NQ];
-  // (a block whose staged patch lies inside the frame - all but the frame's rim - needs no clamping and no validity flags: that
-  //  bookkeeping was an eighth of the kernel's vector instructions)
-  const bool interior = x0 >= 4 && y0 >= 4 && x0 + 68 <= iw && y0 + BP_ROWS + 4 <= ih;
-  // (element indices as unsigned 32-bit offsets from the planes' bases - atu() - keep the address arithmetic out of the vector unit)
-  if (interior) {
-    const unsigned eb = (unsigned)((y0 - 4 + ty) * iw + x);
-#pragma unroll
-    for (int k = 0; k < NH; k++) { okh[k] = ty + BP_TY * k < BP_ROWS + 8; eh[k] = okh[k] ? atu(ext, eb + (unsigned)(BP_TY * k * iw)) : (uint16_t)0; }
-#pragma unroll
-    for (int k = 0; k < NV; k++) { okv[k] = true; ev[k] = atu(ext, eb + (unsigned)((BP_TY * k + 4) * iw)); }
-    const unsigned ib = (unsigned)((y0 - 4) * iw + x0 - 4);
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-      const int t = tid + NT * i;
-      const int r = t / 72, c = t % 72;
-      okq[i] = t < (BP_ROWS + 8) * 72;
-      q[i] = okq[i] ? atu(in, ib + (unsigned)(r * iw + c)) : 0u;
-    }
-  } else {
-#pragma unroll
-  for (int k = 0; k < NH; k++) {
-    const int y = y0 - 4 + ty + BP_TY * k;
-    okh[k] = ty + BP_TY * k < BP_ROWS + 8 && x < iw && y >= 0 && y < ih;
-    eh[k] = atu(ext, okh[k] ? (unsigned)(y * iw + x) : 0u);
-  }
-#pragma unroll
-  for (int k = 0; k < NV; k++) {
-    const int y = y0 + ty + BP_TY * k;
-    okv[k] = x < iw && y < ih;
-    ev[k] = atu(ext, okv[k] ? (unsigned)(y * iw + x) : 0u);
-  }
-#pragma unroll
-  for (int i = 0; i < NQ; i++) {
-    const int t = tid + NT * i;
-    const int r = t / 72, c = t % 72;
-    const int xx = x0 - 4 + c, yy = y0 - 4 + r;
-    okq[i] = t < (BP_ROWS + 8) * 72 && xx >= 0 && xx < iw && yy >= 0 && yy < ih;
-    q[i] = atu(in, okq[i] ? (unsigned)(yy * iw + xx) : 0u);
-  }
-  }
-  for (int t = tid; t < ZR_N; t += 64 * BP_TY) lds[SRC_N + HZ_N + t] = make_uint2(0, 0);     // (whatever the block size)
-  unsigned zrs = (unsigned)(SRC_N + HZ_N) * 8u, zrh = (unsigned)ZR_N * 0u + (unsigned)HZ_N * 8u;      // the zero region's byte offset from `src` / from `hz`
-  asm volatile("" : "+v"(zrs), "+v"(zrh));      // (opaque to the optimiser: it would fold the per-sample constants into them again)
-  if (tid < 16) rwt[tid] = tid >= 1 && tid <= 10 ? ((1u << 19) + (unsigned)tid - 1u) / (unsigned)tid : 0u;
-#pragma unroll
-  for (int i = 0; i < NQ; i++) {
-    const int t = tid + NT * i;
-    const uint32_t v = okq[i] ? q[i] : 0u;
-    if (t < (BP_ROWS + 8) * 72) src[(t / 72) * BP_SW + t % 72] = make_uint2((v & 4095u) | ((v << 4) & 0x3ff0000u), v >> 22);
-  }
-#pragma unroll
-  for (int k = 0; k < NH; k++) if (!okh[k]) eh[k] = 0u;
-#pragma unroll
-  for (int k = 0; k < NV; k++) if (!okv[k]) ev[k] = 0u;
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NH; k++) {
-    const int r = ty + BP_TY * k;
-    if (r >= BP_ROWS + 8) break;
-    const unsigned e = eh[k];
-    const int nl = e & 7, nr = (e >> 3) & 7;
-    const int c = r * BP_SW + tx + 4;
-    uint2 v[10];
-    // (byte addresses: a sample's address is `selected base + constant`, so the constant travels in the instruction)
-    const unsigned cb = (unsigned)c * 8u, cbm = cb - 32u;
-#pragma unroll
-    for (int d = 0; d < 5; d++) {
-      v[d] = *(const uint2 *)((const char *)src + ((d < nl ? cbm : zrs) + (32u - 8u * d)));
-      v[5 + d] = *(const uint2 *)((const char *)src + ((d < nr ? cb : zrs) + 8u * d));
-    }
-    unsigned lo = 0, hi = 0;
-#pragma unroll
-    for (int d = 0; d < 10; d++) { lo += v[d].x; hi += v[d].y; }
-    const int w = nl + nr;
-    uint2 o = src[c];
-    if (w > 0) {
-      const unsigned rw = rwt[w];
-      o = make_uint2(div_small_m(lo & 0xffffu, rw) | (div_small_m(lo >> 16, rw) << 16), div_small_m(hi, rw));   // fields cannot exceed their range: no clamp needed
-    }
-    hz[r * 64 + tx] = o;
-  }
-  __syncthreads();
-  if (x >= iw) return;
-#pragma unroll
-  for (int k = 0; k < NV; k++) {
-    const int r = ty + BP_TY * k;
-    const int y = y0 + r;
-    if (y >= ih) break;
-    const unsigned e = ev[k] >> 6;
-    const int nl = e & 7, nr = (e >> 3) & 7;
-    const int c = (r + 4) * 64 + tx;
-    uint2 v[10];
-    const unsigned cb = (unsigned)c * 8u, cbm = cb - 2048u;
-#pragma unroll
-    for (int d = 0; d < 5; d++) {
-      v[d] = *(const uint2 *)((const char *)hz + ((d < nl ? cbm : zrh) + (2048u - 512u * d)));
-      v[5 + d] = *(const uint2 *)((const char *)hz + ((d < nr ? cb : zrh) + 512u * d));
-    }
-    unsigned lo = 0, hi = 0;
-#pragma unroll
-    for (int d = 0; d < 10; d++) { lo += v[d].x; hi += v[d].y; }
-    const int w = nl + nr;
-    uint2 o = hz[c];
-    if (w > 0) {
-      const unsigned rw = rwt[w];
-      o = make_uint2(div_small_m(lo & 0xffffu, rw) | (div_small_m(lo >> 16, rw) << 16), div_small_m(hi, rw));
-    }
-    atu(out, (unsigned)(y * iw + x)) = (o.x & 0xffffu) | ((o.x >> 16) << 12) | (o.y << 22);
-  }
-}
-
-// The same pair of passes with RUNNING SUMS along the axis instead of ten samples per pixel.  A window's sum is a difference of two prefix values plus the
+// One (horizontal, vertical) pair of passes (rh:286-296) in a single launch, with RUNNING SUMS along the axis instead of ten samples per pixel (the form of
+// rounds 1-3 and most of round 4 staged the tile in LDS and read a pixel's ten samples - five per side, the ones beyond the run from a region of zeros -
+// with a compare and a select per sample: 59 vector instructions per pixel and pass, 70.0 us per launch of 8 frames against 53.4).
+// A window's sum is a difference of two prefix values plus the
 // centre:  sum = P[c + nr] - P[c + 1 - nl] + v[c]  (P[i] = sum of the cells before i; covers nl = 0, nr = 0 and both), and the prefix words are plain 32-bit
 // sums of the expanded cells (L | a << 16, b): whatever a prefix wrapped to or carried between its fields, the DIFFERENCE is the window's own sum, whose
 // fields stay below 2^16 - exact.  That takes the ten selected LDS reads, ten compares, ten selects and ten additions of a pixel down to four reads and six
@@ -306,18 +170,26 @@ __global__ __launch_bounds__(64 * BP_TY) void k_blblur_pair(uint32_t *__restrict
 //               segment totals meet in LDS, every thread adds the totals of the segments before its own and writes its nine prefix values in place;
 //   vertical:   lanes = columns, wave w computes the horizontal results of rows 8w .. 8w+7 (from the row prefixes) and sums them on the way; totals and
 //               offsets as before; the column prefixes take the memory the row prefixes had.
-// Tile: 64 x BQ_ROWS outputs (BQ_ROWS + 8 <= 64 rows of the horizontal strip are the lanes of a wave), 512 threads, 42 KB of LDS.
+// Tile: 64 x BQ_ROWS outputs (BQ_ROWS + 8 <= 64 rows of the horizontal strip are the lanes of a wave), 512 threads, 40 KB of LDS and 60 registers: four blocks per CU.
 #ifndef BQ_ROWS
 #define BQ_ROWS 54            // (1080 = 20 x 54)
 #endif
 #define BQ_HR (BQ_ROWS + 8)   // rows of the staged tile / horizontal strip
 #define BQ_SW 73
-__global__ __launch_bounds__(512) void k_blblur_pair_ps(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih, size_t zs, int gdim) {
+static_assert(BQ_ROWS + 9 <= 64, "the column prefixes have 64 rows: the last output row reads prefix row BQ_ROWS + 8");
+#ifndef BQ_WB
+#define BQ_WB 2              // pixels of a thread evaluated together (1 / 2 / 4 / 8: 53.4 / 53.1 / 54.0 / 62.5 us per launch of 8 frames - 8 costs a wave per SIMD)
+#endif
+__global__ __launch_bounds__(512) void k_blblur_pair(uint32_t *__restrict__ out, const uint16_t *__restrict__ ext, const uint32_t *__restrict__ in, int iw, int ih, size_t zs, int gdim) {
   const rd_tile rd_b = rd_block_tile(gdim);
   if (rd_b.x < 0) return;
   RD_ZSHIFTZ(rd_b.z, zs, out, ext, in);
-  __shared__ uint2 pl[64 * BQ_SW];            // staged cells -> row prefixes (73 per row) -> column prefixes (64 rows x 64)
-  __shared__ uint2 tot[8 * 64];               // segment totals of the scan in progress
+  typedef unsigned long long u64;             // a cell, a prefix, a window sum: (L | a << 16) in the low word, b in the high word - one 64-bit addition per step
+  __shared__ u64 pl[BQ_HR * BQ_SW > 64 * 64 ? BQ_HR * BQ_SW : 64 * 64];      // staged cells -> row prefixes (73 per row) -> column prefixes (64 rows x 64); 40 KB with the totals: four blocks per CU
+#ifndef BQ_PAD
+#define BQ_PAD 0
+#endif
+  __shared__ u64 tot[8 * 64 + BQ_PAD];        // segment totals of the scan in progress
   __shared__ unsigned rwt[16];
   const int tx = threadIdx.x, wv = threadIdx.y, tid = wv * 64 + tx;
   const int x0 = rd_b.x * 64, y0 = rd_b.y * BQ_ROWS;
@@ -374,85 +246,94 @@ __global__ __launch_bounds__(512) void k_blblur_pair_ps(uint32_t *__restrict__ o
   for (int i = 0; i < 9; i++) {
     const int r = i < 8 ? wv + 8 * i : sr, c = i < 8 ? tx : sc;
     const uint32_t v = q[i];
-    if (r < BQ_HR) pl[r * BQ_SW + c] = make_uint2((v & 4095u) | ((v << 4) & 0x3ff0000u), v >> 22);
+    if (r < BQ_HR) pl[r * BQ_SW + c] = (u64)((v & 4095u) | ((v << 4) & 0x3ff0000u)) | ((u64)(v >> 22) << 32);
   }
   __syncthreads();
   // ---- row prefixes: lane = row, wave = segment of nine columns
   {
-    uint2 p[10];
-    unsigned sx = 0, sy = 0;
-    const int b = tx * BQ_SW + 9 * wv;
-    uint2 v[9];
+    u64 p[10], v[9], sum = 0;
+    const int b = (tx < BQ_HR ? tx : BQ_HR - 1) * BQ_SW + 9 * wv;
 #pragma unroll
     for (int j = 0; j < 9; j++) v[j] = pl[b + j];
 #pragma unroll
-    for (int j = 0; j < 9; j++) { p[j] = make_uint2(sx, sy); sx += v[j].x; sy += v[j].y; }
-    p[9] = make_uint2(sx, sy);
-    tot[wv * 64 + tx] = p[9];
+    for (int j = 0; j < 9; j++) { p[j] = sum; sum += v[j]; }
+    p[9] = sum;
+    tot[wv * 64 + tx] = sum;
     __syncthreads();
-    unsigned ox = 0, oy = 0;
-    for (int s2 = 0; s2 < wv; s2++) { const uint2 t = tot[s2 * 64 + tx]; ox += t.x; oy += t.y; }
+    u64 off = 0;
 #pragma unroll
-    for (int j = 0; j < 9; j++) pl[b + j] = make_uint2(p[j].x + ox, p[j].y + oy);
-    if (wv == 7) pl[b + 9] = make_uint2(p[9].x + ox, p[9].y + oy);      // P[72]
+    for (int s2 = 0; s2 < 7; s2++) { const u64 t = tot[s2 * 64 + tx]; if (s2 < wv) off += t; }      // (all seven reads in flight together; a loop of wv dependent reads: 55.2 against 53.1 us)
+    if (tx < BQ_HR) {      // (lanes 62, 63 have no row)
+#pragma unroll
+      for (int j = 0; j < 9; j++) pl[b + j] = p[j] + off;
+      if (wv == 7) pl[b + 9] = p[9] + off;      // P[72]
+    }
   }
   __syncthreads();
   // ---- horizontal results of rows 8 wv .. 8 wv + 7 (lane = column), summed down the column on the way
-  uint2 pv[9];
+  // (BQ_WB pixels at a time: all their reads are requested before the first is used.  No pixel of the frame has an empty window - k_blblur_extents turns
+  //  "no run at all" into "the centre alone", which divides to itself; cells outside the frame carry extents 0 and weight 0 and come out as the zeros they are)
+  u64 pv[9];
   {
-    unsigned sx = 0, sy = 0;
+    u64 sum = 0;
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-      const int r = 8 * wv + j;
-      uint2 o = make_uint2(0u, 0u);
-      if (r < BQ_HR) {
-        const unsigned e = eh[j];
+    for (int j0 = 0; j0 < 8; j0 += BQ_WB) {
+      u64 hi[BQ_WB], lo[BQ_WB], c0[BQ_WB], c1[BQ_WB];
+      unsigned rw[BQ_WB];
+#pragma unroll
+      for (int u = 0; u < BQ_WB; u++) {
+        const unsigned e = eh[j0 + u];
         const int nl = e & 7, nr = (e >> 3) & 7;
-        const int c = r * BQ_SW + tx + 4;
-        const uint2 hi = pl[c + nr], lo = pl[c + 1 - nl], c0 = pl[c], c1 = pl[c + 1];
-        const unsigned vx = c1.x - c0.x, vy = c1.y - c0.y;
-        const unsigned ax = hi.x - lo.x + vx, ay = hi.y - lo.y + vy;
-        const int w = nl + nr;
-        o = make_uint2(vx, vy);
-        if (w > 0) {
-          const unsigned rw = rwt[w];
-          o = make_uint2(div_small_m(ax & 0xffffu, rw) | (div_small_m(ax >> 16, rw) << 16), div_small_m(ay, rw));
-        }
+        const int c = (8 * wv + j0 + u < BQ_HR ? 8 * wv + j0 + u : BQ_HR - 1) * BQ_SW + tx + 4;      // (rows 62, 63 of wave 7 do not exist: any address, the result is dropped)
+        hi[u] = pl[c + nr]; lo[u] = pl[c + 1 - nl]; c0[u] = pl[c]; c1[u] = pl[c + 1];
+        rw[u] = rwt[nl + nr];
       }
-      pv[j] = make_uint2(sx, sy);
-      sx += o.x; sy += o.y;
-    }
-    pv[8] = make_uint2(sx, sy);
-  }
-  __syncthreads();          // (every read of the row prefixes is done: their memory takes the column prefixes)
-  tot[wv * 64 + tx] = pv[8];
-  __syncthreads();
-  {
-    unsigned ox = 0, oy = 0;
-    for (int s2 = 0; s2 < wv; s2++) { const uint2 t = tot[s2 * 64 + tx]; ox += t.x; oy += t.y; }
 #pragma unroll
-    for (int j = 0; j < 8; j++) pl[(8 * wv + j) * 64 + tx] = make_uint2(pv[j].x + ox, pv[j].y + oy);
+      for (int u = 0; u < BQ_WB; u++) {
+        const u64 a = (hi[u] + c1[u]) - (lo[u] + c0[u]);
+        const unsigned ax = (unsigned)a, ay = (unsigned)(a >> 32);
+        u64 o = (u64)(div_small_m(ax & 0xffffu, rw[u]) | (div_small_m(ax >> 16, rw[u]) << 16)) | ((u64)div_small_m(ay, rw[u]) << 32);
+        if (8 * wv + j0 + u >= BQ_HR) o = 0;
+        pv[j0 + u] = sum;
+        sum += o;
+      }
+    }
+    pv[8] = sum;
+  }
+  tot[wv * 64 + tx] = pv[8];       // (the totals of the row scan were last read before the barrier above)
+  __syncthreads();                 // (every read of the row prefixes is done as well: their memory takes the column prefixes)
+  {
+    u64 off = 0;
+#pragma unroll
+    for (int s2 = 0; s2 < 7; s2++) { const u64 t = tot[s2 * 64 + tx]; if (s2 < wv) off += t; }
+#pragma unroll
+    for (int j = 0; j < 8; j++) pl[(8 * wv + j) * 64 + tx] = pv[j] + off;
   }
   __syncthreads();
   if (x >= iw) return;
 #pragma unroll
-  for (int k = 0; k < NV; k++) {
-    const int r = wv + 8 * k;
-    const int y = y0 + r;
-    if (r >= BQ_ROWS || y >= ih) break;
-    const unsigned e = ev[k] >> 6;
-    const int nl = e & 7, nr = (e >> 3) & 7;
-    const int c = (r + 4) * 64 + tx;
-    const uint2 hi = pl[c + nr * 64], lo = pl[c + (1 - nl) * 64], c0 = pl[c], c1 = pl[c + 64];
-    const unsigned vx = c1.x - c0.x, vy = c1.y - c0.y;
-    const unsigned ax = hi.x - lo.x + vx, ay = hi.y - lo.y + vy;
-    const int w = nl + nr;
-    uint2 o = make_uint2(vx, vy);
-    if (w > 0) {
-      const unsigned rw = rwt[w];
-      o = make_uint2(div_small_m(ax & 0xffffu, rw) | (div_small_m(ax >> 16, rw) << 16), div_small_m(ay, rw));
+  for (int k0 = 0; k0 < NV; k0 += BQ_WB) {
+    u64 hi[BQ_WB], lo[BQ_WB], c0[BQ_WB], c1[BQ_WB];
+    unsigned rw[BQ_WB];
+#pragma unroll
+    for (int u = 0; u < BQ_WB; u++) {
+      if (k0 + u >= NV) continue;
+      const unsigned e = ev[k0 + u] >> 6;
+      const int nl = e & 7, nr = (e >> 3) & 7;
+      const int r = wv + 8 * (k0 + u);
+      const int c = ((r < BQ_ROWS ? r : 0) + 4) * 64 + tx;
+      hi[u] = pl[c + nr * 64]; lo[u] = pl[c + (1 - nl) * 64]; c0[u] = pl[c]; c1[u] = pl[c + 64];
+      rw[u] = rwt[nl + nr];
     }
-    atu(out, (unsigned)(y * iw + x)) = (o.x & 0xffffu) | ((o.x >> 16) << 12) | (o.y << 22);
+#pragma unroll
+    for (int u = 0; u < BQ_WB; u++) {
+      if (k0 + u >= NV) continue;
+      const int r = wv + 8 * (k0 + u);
+      const int y = y0 + r;
+      const u64 a = (hi[u] + c1[u]) - (lo[u] + c0[u]);
+      const unsigned ax = (unsigned)a, ay = (unsigned)(a >> 32);
+      if (r < BQ_ROWS && y < ih) atu(out, (unsigned)(y * iw + x)) = div_small_m(ax & 0xffffu, rw[u]) | (div_small_m(ax >> 16, rw[u]) << 12) | (div_small_m(ay, rw[u]) << 22);
+    }
   }
 }
 
@@ -1934,11 +1815,7 @@ void blblur_extents(hipStream_t s, uint16_t *ext, const int8_t *edge, int iw, in
   hipLaunchKernelGGL(k_blblur_extents, dim3(cdiv(iw, 64), cdiv(ih, BE_ROWS), nz), dim3(64, 4), 0, s, ext, edge, iw, ih, zs);
 }
 void blblur_pair(hipStream_t s, uint32_t *out, const uint16_t *ext, const uint32_t *in, int iw, int ih, int nz, size_t zs) {
-#ifndef BLUR_OLD
-  hipLaunchKernelGGL(k_blblur_pair_ps, dim3(rd_tile_blocks(cdiv(iw, 64), cdiv(ih, BQ_ROWS), nz)), dim3(64, 8), 0, s, out, ext, in, iw, ih, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, BQ_ROWS), nz));
-  return;
-#endif
-  hipLaunchKernelGGL(k_blblur_pair, dim3(rd_tile_blocks(cdiv(iw, 64), cdiv(ih, BP_ROWS), nz)), dim3(64, BP_TY), 0, s, out, ext, in, iw, ih, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, BP_ROWS), nz));
+  hipLaunchKernelGGL(k_blblur_pair, dim3(rd_tile_blocks(cdiv(iw, 64), cdiv(ih, BQ_ROWS), nz)), dim3(64, 8), 0, s, out, ext, in, iw, ih, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, BQ_ROWS), nz));
 }
 // fills the quantisation tables of the current device (once per device, before its first frame; the caller synchronises)
 void quant_lut_init(hipStream_t s) { hipLaunchKernelGGL(k_quant24_lut, dim3(20), dim3(256), 0, s); }
