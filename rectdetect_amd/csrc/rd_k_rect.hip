@@ -191,7 +191,8 @@ __global__ __launch_bounds__(512) void k_blblur_pair(uint32_t *__restrict__ out,
 #endif
   __shared__ u64 tot[8 * 64 + BQ_PAD];        // segment totals of the scan in progress
   __shared__ unsigned rwt[16];
-  const int tx = threadIdx.x, wv = threadIdx.y, tid = wv * 64 + tx;
+  // (the wave's index as a SCALAR: everything that depends on it alone - row numbers, row addresses, "this row does not exist" - stays out of the vector unit)
+  const int tx = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y), tid = wv * 64 + tx;
   const int x0 = rd_b.x * 64, y0 = rd_b.y * BQ_ROWS;
   const int x = x0 + tx;
   constexpr int NV = (BQ_ROWS + 7) / 8;
@@ -260,9 +261,11 @@ __global__ __launch_bounds__(512) void k_blblur_pair(uint32_t *__restrict__ out,
     p[9] = sum;
     tot[wv * 64 + tx] = sum;
     __syncthreads();
-    u64 off = 0;
+    u64 off = 0, ts[7];
 #pragma unroll
-    for (int s2 = 0; s2 < 7; s2++) { const u64 t = tot[s2 * 64 + tx]; if (s2 < wv) off += t; }      // (all seven reads in flight together; a loop of wv dependent reads: 55.2 against 53.1 us)
+    for (int s2 = 0; s2 < 7; s2++) ts[s2] = s2 < wv ? tot[s2 * 64 + tx] : 0;      // (wv is scalar: only the totals that count are read, all of them in flight together)
+#pragma unroll
+    for (int s2 = 0; s2 < 7; s2++) off += ts[s2];
     if (tx < BQ_HR) {      // (lanes 62, 63 have no row)
 #pragma unroll
       for (int j = 0; j < 9; j++) pl[b + j] = p[j] + off;
@@ -303,9 +306,11 @@ __global__ __launch_bounds__(512) void k_blblur_pair(uint32_t *__restrict__ out,
   tot[wv * 64 + tx] = pv[8];       // (the totals of the row scan were last read before the barrier above)
   __syncthreads();                 // (every read of the row prefixes is done as well: their memory takes the column prefixes)
   {
-    u64 off = 0;
+    u64 off = 0, ts[7];
 #pragma unroll
-    for (int s2 = 0; s2 < 7; s2++) { const u64 t = tot[s2 * 64 + tx]; if (s2 < wv) off += t; }
+    for (int s2 = 0; s2 < 7; s2++) ts[s2] = s2 < wv ? tot[s2 * 64 + tx] : 0;
+#pragma unroll
+    for (int s2 = 0; s2 < 7; s2++) off += ts[s2];
 #pragma unroll
     for (int j = 0; j < 8; j++) pl[(8 * wv + j) * 64 + tx] = pv[j] + off;
   }
