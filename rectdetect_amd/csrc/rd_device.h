@@ -134,6 +134,9 @@ template <typename T> __device__ __forceinline__ T *rd_zs_ptr(T *p, size_t off) 
 // L2 requests of such kernels missed).  These kernels are launched ONE-DIMENSIONAL over gx x gy tiles x nz frames and ask rd_block_tile() which tile they are: in
 // a group launch of 8 frames block b works on frame b mod 8 - one frame per XCD, its tiles in raster order -, otherwise in plain raster order.  Speed only: nothing
 // depends on where a block runs.  gdim = rd_gdim(gx, gy, nz).
+// threadIdx.y of a block whose rows are waves (every 2-D block here is 64 threads wide) as a SCALAR: row numbers, row addresses and row tests that depend on
+// it alone then run on the scalar unit instead of costing every lane a vector instruction
+__device__ __forceinline__ int rd_ty() { return __builtin_amdgcn_readfirstlane((int)threadIdx.y); }
 struct rd_tile { int x, y, z; };
 __host__ __device__ inline int rd_gdim(int gx, int gy, int nz) { return gx | (gy << 12) | (nz << 24); }
 // blocks to launch for gx x gy tiles x nz frames

@@ -31,7 +31,7 @@ __device__ __forceinline__ int lerp_lut(const unsigned short *t, int c) { return
 
 __global__ __launch_bounds__(256) void k_bgr2plab(uint32_t *__restrict__ out, const uint8_t *__restrict__ bgr, int iw, int ih, int ws) {
   __shared__ unsigned short s_s2l[RD_LUT_S2L_N], s_cf[RD_LUT_CF_N], s_cf2[RD_LUT_CF_N];
-  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int tid = rd_ty() * 64 + threadIdx.x;
   for (int i = tid; i < RD_LUT_S2L_N; i += 256) s_s2l[i] = rd_lut_s2l[i];
   for (int i = tid; i < RD_LUT_CF_N; i += 256) { s_cf[i] = rd_lut_cfunc[i]; s_cf2[i] = rd_lut_cfunc2[i]; }
   __syncthreads();
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_bgr2plab(uint32_t *__restrict__ out, co
   if (x >= iw) return;
   // 4 rows per thread-row so that the LUT staging is amortised over 1024 pixels per block
   for (int r = 0; r < 4; r++) {
-    const int y = (blockIdx.y * 4 + threadIdx.y) * 4 + r;
+    const int y = (blockIdx.y * 4 + rd_ty()) * 4 + r;
     if (y >= ih) break;
     const uint8_t *p = bgr + (size_t)y * ws + x * 3;
     const int ib = s_s2l[p[0]], ig = s_s2l[p[1]], ir = s_s2l[p[2]];
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_bgr2plab_t(uint32_t *__restrict__ out, 
   RD_ZSHIFT(zs, out, dst.p[0], dst.p[1], dst.p[2]);
   __shared__ unsigned short s_s2l[RD_LUT_S2L_N], s_cf[RD_LUT_CF_N], s_cf2[RD_LUT_CF_N];
   __shared__ unsigned short tile[3][64][66];
-  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int tid = rd_ty() * 64 + threadIdx.x;
   for (int i = tid; i < RD_LUT_S2L_N; i += 256) s_s2l[i] = rd_lut_s2l[i];
   for (int i = tid; i < RD_LUT_CF_N; i += 256) { s_cf[i] = rd_lut_cfunc[i]; s_cf2[i] = rd_lut_cfunc2[i]; }
   __syncthreads();
@@ -77,13 +77,13 @@ __global__ __launch_bounds__(256) void k_bgr2plab_t(uint32_t *__restrict__ out, 
   uint8_t pb[16], pg[16], pr[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    const int y = y0 + threadIdx.y + 4 * k;
+    const int y = y0 + rd_ty() + 4 * k;
     const uint8_t *p = bgr + ((x < iw && y < ih) ? (size_t)y * ws + x * 3 : 0);
     pb[k] = p[0]; pg[k] = p[1]; pr[k] = p[2];
   }
 #pragma unroll
   for (int k = 0; k < 16; k++) {
-    const int r = threadIdx.y + 4 * k;
+    const int r = rd_ty() + 4 * k;
     const int y = y0 + r;
     if (x >= iw || y >= ih) continue;
     const int ib = s_s2l[pb[k]], ig = s_s2l[pg[k]], ir = s_s2l[pr[k]];
@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void k_bgr2plab_t(uint32_t *__restrict__ out, 
     tile[0][r][threadIdx.x] = (unsigned short)(v & 4095u); tile[1][r][threadIdx.x] = (unsigned short)((v >> 12) & 1023u); tile[2][r][threadIdx.x] = (unsigned short)((v >> 22) & 1023u);
   }
   __syncthreads();
-  for (int r = threadIdx.y; r < 64; r += 4) {
+  for (int r = rd_ty(); r < 64; r += 4) {
     const int ox = y0 + threadIdx.x, oy = x0 + r;   // output planes are ih wide, iw tall
     if (ox < ih && oy < iw)
       for (int k = 0; k < 3; k++) ((unsigned short *)dst.p[k])[(size_t)oy * ih + ox] = tile[k][threadIdx.x][r];
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_transpose(P3 dst, P3c src, P3c fwd, P3c
   if (only_if && *only_if == 0) return;
   __shared__ float tile[3][64][65];
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
-  for (int r = threadIdx.y; r < 64; r += 4) {
+  for (int r = rd_ty(); r < 64; r += 4) {
     const int x = x0 + threadIdx.x, y = y0 + r;
     if (x < W && y < H) {
       const size_t i = (size_t)y * W + x;
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_transpose(P3 dst, P3c src, P3c fwd, P3c
     }
   }
   __syncthreads();
-  for (int r = threadIdx.y; r < 64; r += 4) {
+  for (int r = rd_ty(); r < 64; r += 4) {
     const int ox = y0 + threadIdx.x, oy = x0 + r;   // output plane is H wide, W tall
     if (ox < H && oy < W)
       for (int k = 0; k < np; k++) dst.p[k][(size_t)oy * H + ox] = tile[k][threadIdx.x][r];
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
 template <int TOUT, int SRC16, int EAGER>
 __global__ __launch_bounds__(64 * IC_CH) void k_iir_check_fix(P3 dst, P3c src, P3 fwd, const float *__restrict__ tails, int *bad, int W, int H, int nchunks, int IF_ROWS, int force, int np, size_t zs) {
   const int x = blockIdx.x * 64 + threadIdx.x;
-  const int k = blockIdx.y % np, c = blockIdx.z * IC_CH + threadIdx.y;      // (one wave per chunk, IC_CH chunks per block: a block per wave was 6000 dispatches per plane set)
+  const int k = blockIdx.y % np, c = blockIdx.z * IC_CH + rd_ty();      // (one wave per chunk, IC_CH chunks per block: a block per wave was 6000 dispatches per plane set)
   if (c >= nchunks) return;
   { const size_t rd_zoff_ = (size_t)(blockIdx.y / np) * zs; RD_ZS1(dst.p[0]); RD_ZS1(dst.p[1]); RD_ZS1(dst.p[2]); RD_ZS1(src.p[0]); RD_ZS1(src.p[1]); RD_ZS1(src.p[2]); RD_ZS1(fwd.p[0]); RD_ZS1(fwd.p[1]); RD_ZS1(fwd.p[2]); RD_ZS1(tails); RD_ZS1(bad); }
   if (x >= W) return;
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(64 * IC_CH) void k_iir_check_fix(P3 dst, P3c src, P
 // oclimgutil_iirblur_f_f with r != 2 (no caller in the reference passes one; sigma = (r + 1) / 3, coefficients iu:900-1125).
 // The blocked evaluation above rests on the sigma = 1 filter forgetting its start within a few dozen samples, bit for bit; wider
 // filters do not, so these radii take the reference's own shape: every line swept over its full length (iu:542-627), the causal
-// sweep by one thread and the anti-causal sweep by its neighbour in threadIdx.y, each into its scratch plane, then combined.
+// sweep by one thread and the anti-causal sweep by its neighbour in rd_ty(), each into its scratch plane, then combined.
 #define RD_IIRCOEF_ATTR __device__ __constant__
 #include "rd_iircoef.h"
 __global__ __launch_bounds__(128) void k_iir_line(float *dst, const float *__restrict__ src, float *fw, float *bw, int W, int H, int r) {
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(128) void k_iir_line(float *dst, const float *__res
     d += C[8] * t0 + C[9] * t1 + C[10] * t2 + C[11] * t3 + C[12] * t4 + C[13] * t5 + C[14] * t6;                         \
     i7 = i6; i6 = i5; i5 = i4; i4 = i3; i3 = i2; i2 = i1; i1 = i0;                                                       \
     t6 = t5; t5 = t4; t4 = t3; t3 = t2; t2 = t1; t1 = t0; t0 = d;
-    if (threadIdx.y == 0) {
+    if (rd_ty() == 0) {
       float *o = fw + x;
       for (int yy = -warm; yy < H; yy++) { IIR_LINE_STEP; if (yy >= 0) o[(size_t)yy * W] = d; }
     } else {
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(128) void k_iir_line(float *dst, const float *__res
   }
   __syncthreads();
   if (!xin) return;
-  for (int yy = threadIdx.y; yy < H; yy += 2) {       // iu:580-589 / iu:629-637: tmp1 + tmp0 - in * c0
+  for (int yy = rd_ty(); yy < H; yy += 2) {       // iu:580-589 / iu:629-637: tmp1 + tmp0 - in * c0
     const size_t p = (size_t)yy * W + x;
     dst[p] = bw[p] + fw[p] - src[p] * C[0];
   }
@@ -518,7 +518,7 @@ __device__ __forceinline__ void ev_finish(float2 *__restrict__ dst, int p, float
 }
 __global__ __launch_bounds__(256) void k_edgevec(float2 *__restrict__ dst, const float *__restrict__ in, int iw, int ih, uint32_t *__restrict__ pack_out, const float *__restrict__ pa, const float *__restrict__ pb, size_t zs) {
   RD_ZSHIFT(zs, dst, in, pack_out, pa, pb);
-  const int x = blockIdx.x * 64 + threadIdx.x, y0 = (blockIdx.y * 4 + threadIdx.y) * EV_PX;
+  const int x = blockIdx.x * 64 + threadIdx.x, y0 = (blockIdx.y * 4 + rd_ty()) * EV_PX;
   if (x >= iw || y0 >= ih) return;
   if (pack_out != nullptr) {
 #pragma unroll
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256) void k_edgevec(float2 *__restrict__ dst, const
 #endif
 __global__ __launch_bounds__(256) void k_edge_plab(float *__restrict__ out, const uint32_t *__restrict__ in, int iw, int ih, size_t zs) {
   RD_ZSHIFT(zs, out, in);
-  const int x = blockIdx.x * 64 + threadIdx.x, y0 = (blockIdx.y * 4 + threadIdx.y) * EP_PX;
+  const int x = blockIdx.x * 64 + threadIdx.x, y0 = (blockIdx.y * 4 + rd_ty()) * EP_PX;
   if (x >= iw || y0 >= ih) return;
   const bool interior = blockIdx.x > 0 && blockIdx.y > 0 && (int)(blockIdx.x * 64 + 64) < iw && (int)((blockIdx.y * 4 + 4) * EP_PX) < ih;
   if (interior) {
@@ -643,14 +643,14 @@ __global__ __launch_bounds__(256) void k_thinthres(float *__restrict__ out, cons
   __shared__ int lpix[64 * TT_ROWS];            // ... and its tile cell (row * 64 + column)
   __shared__ int nlst;
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * TT_ROWS;
-  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int tid = rd_ty() * 64 + threadIdx.x;
   const int x = x0 + threadIdx.x;
   if (tid == 0) nlst = 0;
   // the directions of this thread's pixels are requested together with the tile (one wait for memory per block)
   float2 dir[TT_ROWS / 4];
 #pragma unroll
   for (int k = 0; k < TT_ROWS / 4; k++) {
-    const int y = y0 + threadIdx.y + 4 * k;
+    const int y = y0 + rd_ty() + 4 * k;
     dir[k] = vxy[(x < iw && y < ih) ? y * iw + x : 0];
   }
   stage_cells<(TT_ROWS + 7) * TT_PITCH, 256>(tid, in,
@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256) void k_thinthres(float *__restrict__ out, cons
   __syncthreads();
 #pragma unroll
   for (int k = 0; k < TT_ROWS / 4; k++) {
-    const int r = threadIdx.y + 4 * k;
+    const int r = rd_ty() + 4 * k;
     const int y = y0 + r;
     const bool inside = x < iw && y < ih;
     bool peak = false;
@@ -725,7 +725,7 @@ inline int ew_grid(int n) { int g = cdiv(n, 256 * 4); return g < 1 ? 1 : (g > 40
 
 // iu:283-289
 __global__ __launch_bounds__(256) void k_convert_bgr_lumaf(uint8_t *__restrict__ out, const float *__restrict__ in, float f, int iw, int ih, int ws) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + rd_ty();
   if (x >= iw || y >= ih) return;
   const uint8_t v = (uint8_t)clampi((int)floorf(in[y * iw + x] * f * 255), 0, 255);
   uint8_t *o = out + (size_t)y * ws + x * 3;
@@ -734,7 +734,7 @@ __global__ __launch_bounds__(256) void k_convert_bgr_lumaf(uint8_t *__restrict__
 
 // iu:291-321
 __global__ __launch_bounds__(256) void k_convert_bgr_labeli(uint8_t *__restrict__ out, const int *__restrict__ in, int bgc, int iw, int ih, int ws) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + rd_ty();
   if (x >= iw || y >= ih) return;
   const int c = in[y * iw + x];
   uint8_t *o = out + (size_t)y * ws + x * 3;
@@ -749,7 +749,7 @@ __global__ __launch_bounds__(256) void k_convert_bgr_labeli(uint8_t *__restrict_
 __device__ __forceinline__ float icfunc(float ft) { return ft > 0.20689270648f ? ft * ft * ft : (ft - 16.0f / 116) * (1.0f / 7.787f); }
 
 __global__ __launch_bounds__(256) void k_plab2bgr(uint8_t *__restrict__ out, const uint32_t *__restrict__ in, int iw, int ih, int ws) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + rd_ty();
   if (x >= iw || y >= ih) return;
   const float xn = 0.950456f, zn = 1.088754f;
   float L, a, b;
@@ -773,7 +773,7 @@ __global__ __launch_bounds__(256) void k_plab2bgr(uint8_t *__restrict__ out, con
 
 // iu:439-453
 __global__ __launch_bounds__(256) void k_edge_f(float *__restrict__ out, const float *__restrict__ in, int iw, int ih) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + rd_ty();
   if (x >= iw || y >= ih) return;
   const float n = in[mirror2(x, y - 1, iw, ih)], s = in[mirror2(x, y + 1, iw, ih)], w = in[mirror2(x - 1, y, iw, ih)], e = in[mirror2(x + 1, y, iw, ih)];
   float sum = 0, t;
@@ -786,7 +786,7 @@ __global__ __launch_bounds__(256) void k_edge_f(float *__restrict__ out, const f
 
 // iu:354-393: gradient direction of the channel with the largest response, sign taken from the L channel
 __global__ __launch_bounds__(256) void k_edgevec_plab(float2 *__restrict__ dst, const uint32_t *__restrict__ in, int iw, int ih) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + rd_ty();
   if (x >= iw || y >= ih) return;
   float vx3[3] = { 0, 0, 0 }, vy3[3] = { 0, 0, 0 };
 #pragma unroll
@@ -817,7 +817,7 @@ __global__ __launch_bounds__(256) void k_edgevec_plab(float2 *__restrict__ dst, 
 
 // iu:473-491: like k_thinthres, with a 1 % tolerance and all four samples in the comparison
 __global__ __launch_bounds__(256) void k_thincubic(float *__restrict__ out, const float *__restrict__ in, const float2 *__restrict__ vxy, int iw, int ih) {
-  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y;
+  const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + rd_ty();
   if (x >= iw || y >= ih) return;
   const int p0 = y * iw + x;
   const float2 v = vxy[p0];

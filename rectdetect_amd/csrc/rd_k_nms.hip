@@ -49,7 +49,7 @@ __global__ __launch_bounds__(GN_NT) void k_grad_nms(float *__restrict__ out, P3c
   __shared__ int nlst;
   static_assert(4 * GN_LH * GN_LW * 4 >= 64 * GN_ROWS * 20, "the list of maxima lives in the Lab tile's memory");
   const int x0 = rd_b.x * 64, y0 = rd_b.y * GN_ROWS;
-  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+  const int tx = threadIdx.x, ty = rd_ty(), tid = ty * 64 + tx;
   if (tid == 0) nlst = 0;
   // ---- stage L, a, b (+ halo): a wave takes every fourth row of the tile, its lanes columns 0..63 (row address uniform, column address fixed per
   // lane); the 9 columns left over are a cell per thread.  All loads of a thread are in flight before the first is used.

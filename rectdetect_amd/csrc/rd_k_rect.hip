@@ -19,7 +19,7 @@ const dim3 block2(64, 4);
 inline dim3 grid2(int iw, int ih) { return dim3(cdiv(iw, 64), cdiv(ih, 4)); }
 inline int ew_grid(int n) { int g = cdiv(n, 256 * 4); return g < 1 ? 1 : (g > 4096 ? 4096 : g); }
 
-#define RD_XY const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + threadIdx.y
+#define RD_XY const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y * 4 + rd_ty()
 
 // ------------------------------------------------------------------------------------------------ edge tidy
 typedef unsigned long long u64;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void k_blblur_extents(uint16_t *__restrict__ e
   __shared__ u64 HLa[BE_NR], HLb[BE_NR], HRa[BE_NR], HRb[BE_NR];   // along x: stop bits towards smaller / larger x (centre not on an edge)
   __shared__ u64 VL[BE_NR], VR[BE_NR], VE[BE_NR];                  // along y, tile columns only (bit = column - x0)
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * BE_ROWS;
-  const int tx = threadIdx.x, ty = threadIdx.y, tid = ty * 64 + tx;
+  const int tx = threadIdx.x, ty = rd_ty(), tid = ty * 64 + tx;
   {
     constexpr int IT = (BE_NR + 3) / 4;
     int8_t va[IT], vb[IT];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512) void k_blblur_pair(uint32_t *__restrict__ out,
   __shared__ u64 tot[8 * 64 + BQ_PAD];        // segment totals of the scan in progress
   __shared__ unsigned rwt[16];
   // (the wave's index as a SCALAR: everything that depends on it alone - row numbers, row addresses, "this row does not exist" - stays out of the vector unit)
-  const int tx = threadIdx.x, wv = __builtin_amdgcn_readfirstlane(threadIdx.y), tid = wv * 64 + tx;
+  const int tx = threadIdx.x, wv = rd_ty(), tid = wv * 64 + tx;
   const int x0 = rd_b.x * 64, y0 = rd_b.y * BQ_ROWS;
   const int x = x0 + tx;
   constexpr int NV = (BQ_ROWS + 7) / 8;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, c
   __shared__ int list[64 * DS_ROWS];
   __shared__ int nlist;
   __shared__ uint32_t qlut[QN == 24 ? 2560 : 1];      // g_quant24, two entries per word
-  const int tx = threadIdx.x, tid = threadIdx.y * 64 + tx;
+  const int tx = threadIdx.x, tid = rd_ty() * 64 + tx;
   const int x0 = rd_b.x * 64, y0 = rd_b.y * DS_ROWS;
   if (tid == 0) nlist = 0;
   if (QN == 24) {
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, c
     }
   }
   __syncthreads();
-  for (int r = threadIdx.y; r < DS_ROWS; r += 4) {
+  for (int r = rd_ty(); r < DS_ROWS; r += 4) {
     const int x = x0 + tx, y = y0 + r;
     const int i = (r + 1) * DS_P + tx + 1;
     bool hot = false;
@@ -498,7 +498,7 @@ __global__ __launch_bounds__(256) void k_mm_gather(unsigned long long *__restric
   __shared__ unsigned long long sb[(MM_ROWS + 16) * 6];
   const int k = blockIdx.x;                 // word holding this block's own 64 columns
   const int y0 = blockIdx.y * MM_ROWS;
-  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int tid = rd_ty() * 64 + threadIdx.x;
   for (int t = tid; t < (MM_ROWS + 16) * 6; t += 256) {
     const int r = t / 6, j = t % 6;         // j: word k-1, k, k+1 of class any (0..2) / end (3..5)
     const int yy = y0 - 8 + r, kk = k - 1 + j % 3;
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
   __shared__ unsigned char alw[RI_NC];
   // (also: the round flags start at zero - flags[0] = 1: the first launch, evaluated here, counts as one that changed something - and the
   //  size plane starts from size_init - quirk H2 - without extra launches)
-  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int tid = rd_ty() * 64 + threadIdx.x;
   if (rd_b.x == 0 && rd_b.y == 0 && tid < RR_NFLAGS) flags[tid] = tid == 0 ? 1 : 0;
   const int gx0 = rd_b.x * 64 - RI_H, gy0 = rd_b.y * RI_ROWS - RI_H;
   // colours of the region (cells outside the frame: marked by lnk = -1 below), and - for the tile and two more rows / columns - "merge mask
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
   // the labels after the first launch, the allow bytes, the sizes' start values
   const int x = rd_b.x * 64 + threadIdx.x;
   if (x >= iw) return;
-  for (int r = threadIdx.y; r < RI_ROWS; r += 4) {
+  for (int r = rd_ty(); r < RI_ROWS; r += 4) {
     const int y = rd_b.y * RI_ROWS + r;
     if (y >= ih) break;
     const int c = (r + RI_H) * RI_RW + threadIdx.x + RI_H, p = y * iw + x;
@@ -726,13 +726,13 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
   if (round > 0 && flags[round - 1] == 0) return;
   __shared__ int hk[512], hv[512];
   __shared__ int tmin[64 * RR_TY * RR_PX];      // launch 1 only: the smallest proposal for each pixel of the block's tile (see below)
-  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int tid = rd_ty() * 64 + threadIdx.x;
   const bool near = round == 1;               // the trees are still the first launch's: a pixel's parent lies ~10 rows above it, mostly inside the tile
   for (int t = tid; t < 512; t += 64 * RR_TY) { hk[t] = -1; hv[t] = 0x7fffffff; }
   if (near) for (int t = tid; t < 64 * RR_TY * RR_PX; t += 64 * RR_TY) tmin[t] = 0x7fffffff;
   __syncthreads();
   const int mark = 1 + round % 7, mark_prev = round > 0 ? 1 + (round - 1) % 7 : 8;      // (8: matches nothing - before round 0 no plane lags)
-  const int yb = by * (RR_TY * RR_PX) + threadIdx.y * RR_PX;      // the thread's RR_PX pixels lie below one another: each is the other's vertical neighbour
+  const int yb = by * (RR_TY * RR_PX) + rd_ty() * RR_PX;      // the thread's RR_PX pixels lie below one another: each is the other's vertical neighbour
   const int x = bx * 64 + threadIdx.x;
   int p0[RR_PX], og[RR_PX], g[RR_PX], nx[RR_PX], w0[RR_PX];
   unsigned a[RR_PX];
@@ -829,7 +829,7 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
       if (!valid[k]) continue;
       const bool lag = (w0[k] & 7) == mark_prev;
       int w = (todo[k] || lag) ? ((g[k] << RR_MBITS) | (todo[k] ? mark : 0)) : 0x7fffffff;
-      const int h = tmin[(threadIdx.y * RR_PX + k) * 64 + threadIdx.x];
+      const int h = tmin[(rd_ty() * RR_PX + k) * 64 + threadIdx.x];
       if (h != 0x7fffffff) { const int wh = (h << RR_MBITS) | mark; w = wh < w ? wh : w; }
       if (w != 0x7fffffff) atomicMin(&Y[p0[k]], w);
     }
@@ -955,7 +955,7 @@ __global__ __launch_bounds__(256) void k_despeckle2_first(int *__restrict__ nxt,
                                                            const int *__restrict__ old, const int *__restrict__ size, int thre, int iw, int ih) {
   __shared__ int loc[64 * D2_ROWS];
   __shared__ int nloc, base;
-  if (threadIdx.x == 0 && threadIdx.y == 0) {
+  if (threadIdx.x == 0 && rd_ty() == 0) {
     nloc = 0;
     if (blockIdx.x == 0 && blockIdx.y == 0) count[1] = count[2] = 0;     // the counters of the two other work lists
   }
@@ -965,14 +965,14 @@ __global__ __launch_bounds__(256) void k_despeckle2_first(int *__restrict__ nxt,
   int l0s[D2_ROWS / 4], szs[D2_ROWS / 4];
 #pragma unroll
   for (int k = 0; k < D2_ROWS / 4; k++) {
-    const int y = blockIdx.y * D2_ROWS + threadIdx.y + 4 * k;
+    const int y = blockIdx.y * D2_ROWS + rd_ty() + 4 * k;
     l0s[k] = old[(x < iw && y < ih) ? y * iw + x : 0];
   }
 #pragma unroll
   for (int k = 0; k < D2_ROWS / 4; k++) szs[k] = size[l0s[k]];
 #pragma unroll
   for (int k = 0; k < D2_ROWS / 4; k++) {
-    const int r = threadIdx.y + 4 * k;
+    const int r = rd_ty() + 4 * k;
     const int y = blockIdx.y * D2_ROWS + r;
     const bool inside = x < iw && y < ih;
     const int p0 = y * iw + x;
@@ -994,7 +994,7 @@ __global__ __launch_bounds__(256) void k_despeckle2_first(int *__restrict__ nxt,
     }
   }
   __syncthreads();
-  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const int tid = rd_ty() * 64 + threadIdx.x;
   if (tid == 0 && nloc > 0) base = atomicAdd(count, nloc);
   __syncthreads();
   for (int i = tid; i < nloc; i += 256) list[base + i] = loc[i];
