@@ -555,9 +555,39 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
   const int gx0 = rd_b.x * 64 - RI_H, gy0 = rd_b.y * RI_ROWS - RI_H;
   // colours of the region (cells outside the frame: marked by lnk = -1 below), and - for the tile and two more rows / columns - "merge mask
   // set" and "strong edge" as two bits (all loads of a thread in flight together)
-  stage_cells<RI_NC, 256>(tid, pix,
-    [&](int t, int &a) { const int gx = gx0 + t % RI_RW, gy = gy0 + t / RI_RW; a = gy * iw + gx; return gx >= 0 && gx < iw && gy >= 0 && gy < ih; },
-    [&](int t, bool ok, int v) { col[t] = v; lnk[t] = ok ? 0 : -1; });
+  {
+    // wave w takes rows w + 4 i of the region, its lanes columns 0..63; the 12 columns left over are cells (row t >> 4, column 64 + (t & 15)) of a 16-wide
+    // strip: no division, a scalar row address, all loads of a thread in flight together
+    constexpr int NR = (RI_RH + 3) / 4, NS = (RI_RH * 16 + 255) / 256;
+    const int wv = rd_ty(), lx = threadIdx.x;
+    int v[NR + NS];
+    bool ok[NR + NS];
+    const int gxl = gx0 + lx;
+    const bool cok = gxl >= 0 && gxl < iw;
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+      const int r = wv + 4 * i, gy = gy0 + r;
+      ok[i] = r < RI_RH && gy >= 0 && gy < ih && cok;
+      v[i] = atu(pix, ok[i] ? (unsigned)(gy * iw + gxl) : 0u);
+    }
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+      const int t = tid + 256 * j, r = t >> 4, c = 64 + (t & 15);
+      const int gx = gx0 + c, gy = gy0 + r;
+      ok[NR + j] = r < RI_RH && c < RI_RW && gx < iw && gy >= 0 && gy < ih;      // (gx >= 54: never negative)
+      v[NR + j] = atu(pix, ok[NR + j] ? (unsigned)(gy * iw + gx) : 0u);
+    }
+#pragma unroll
+    for (int i = 0; i < NR; i++) {
+      const int r = wv + 4 * i;
+      if (r < RI_RH) { col[r * RI_RW + lx] = v[i]; lnk[r * RI_RW + lx] = ok[i] ? 0 : -1; }
+    }
+#pragma unroll
+    for (int j = 0; j < NS; j++) {
+      const int t = tid + 256 * j, r = t >> 4, c = 64 + (t & 15);
+      if (r < RI_RH && c < RI_RW) { col[r * RI_RW + c] = v[NR + j]; lnk[r * RI_RW + c] = ok[NR + j] ? 0 : -1; }
+    }
+  }
   constexpr int MW = 64 + 2, MH = RI_ROWS + 2, MN = MW * MH;       // cells (RI_H .. RI_H + 65, RI_H .. RI_H + RI_ROWS + 1)
   {
     const int k = rd_b.x, y0 = rd_b.y * RI_ROWS;
@@ -565,32 +595,51 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
     if (tid < (RI_ROWS + 3) * 3) { const int r = tid / 3, kk = k - 1 + tid % 3, yy = y0 - 1 + r; se[tid] = (yy >= 0 && yy < ih && kk >= 0 && kk < wpr) ? edge[(size_t)yy * wpr + kk] : 0ull; }
   }
   __syncthreads();
-  for (int t = tid; t < MN; t += 256) {
-    const int cx = t % MW, cy = t / MW;
-    const int gx = gx0 + RI_H + cx, gy = gy0 + RI_H + cy;
-    const unsigned mbit = (unsigned)(sm[cy * 2 + (cx >> 6)] >> (cx & 63)) & 1u, ebit = (unsigned)(se[(cy + 1) * 3 + 1 + (cx >> 6)] >> (cx & 63)) & 1u;
-    alw[(RI_H + cy) * RI_RW + RI_H + cx] = (unsigned char)((gx < iw && gy < ih) ? (mbit | (ebit ? 0u : 2u)) : 0u);      // bit 0: mask set, bit 1: NOT a strong edge
+  (void)MN;
+  {
+    auto cell = [&](int cy, int cx) {
+      const int gx = gx0 + RI_H + cx, gy = gy0 + RI_H + cy;
+      const unsigned mbit = (unsigned)(sm[cy * 2 + (cx >> 6)] >> (cx & 63)) & 1u, ebit = (unsigned)(se[(cy + 1) * 3 + 1 + (cx >> 6)] >> (cx & 63)) & 1u;
+      alw[(RI_H + cy) * RI_RW + RI_H + cx] = (unsigned char)((gx < iw && gy < ih) ? (mbit | (ebit ? 0u : 2u)) : 0u);      // bit 0: mask set, bit 1: NOT a strong edge
+    };
+    for (int cy = rd_ty(); cy < MH; cy += 4) cell(cy, (int)threadIdx.x);            // (rows by waves, columns 0..63 by lanes: no division)
+    if (tid < 2 * MH) cell(tid >> 1, 64 + (tid & 1));                              // columns 64, 65
+    static_assert(MW == 66, "two columns beyond the lanes");
   }
   // raw links (cells of the first row / column of the region cannot know theirs: nothing reads them, see RI_H)
-  for (int t = tid; t < RI_NC; t += 256) {
-    if (lnk[t] < 0) continue;
-    const int cx = t % RI_RW, cy = t / RI_RW;
-    const int gx = gx0 + cx, gy = gy0 + cy;
-    int l = t;
-    if (gy > 0 && cy > 0 && col[t] == col[t - RI_RW]) l = t - RI_RW;
-    else if (gx > 0 && cx > 0 && col[t] == col[t - 1]) l = t - 1;
-    lnk[t] = (short)l;
+  {
+    auto cell = [&](int cy, int cx) {
+      const int t = cy * RI_RW + cx;
+      if (lnk[t] < 0) return;
+      const int gx = gx0 + cx, gy = gy0 + cy;
+      int l = t;
+      if (gy > 0 && cy > 0 && col[t] == col[t - RI_RW]) l = t - RI_RW;
+      else if (gx > 0 && cx > 0 && col[t] == col[t - 1]) l = t - 1;
+      lnk[t] = (short)l;
+    };
+    for (int cy = rd_ty(); cy < RI_RH; cy += 4) cell(cy, (int)threadIdx.x);
+    for (int t = tid; t < RI_RH * 16; t += 256) { const int c = 64 + (t & 15); if (c < RI_RW) cell(t >> 4, c); }
   }
   __syncthreads();
   // allowed directions for the cells whose proposals are needed: the tile and one more row / column (in place of the two bits: a cell's
   // byte is read by itself - its own bits - and by its left and upper neighbours - bit 1 -, so the bytes are rewritten after a barrier)
-  unsigned char anew[((64 + 1) * (RI_ROWS + 1) + 255) / 256];
+  // (cells of the 65 x (RI_ROWS + 1) block: rows by waves - slot i = row wv + 4 i -, columns 0..63 by lanes, column 64 a cell of the first RI_ROWS + 1 threads: no division)
+  constexpr int NPR = (RI_ROWS + 1 + 3) / 4, NP = NPR + 1;
+  const int wvp = rd_ty(), lxp = threadIdx.x;
+  int pcx[NP], pcy[NP];
+  bool pin[NP];
 #pragma unroll
-  for (int i = 0; i < (int)sizeof(anew); i++) {
-    const int t = tid + i * 256;
+  for (int i = 0; i < NP; i++) {
+    pcy[i] = i < NPR ? wvp + 4 * i : tid;
+    pcx[i] = i < NPR ? lxp : 64;
+    pin[i] = pcy[i] < RI_ROWS + 1;
+  }
+  unsigned char anew[NP];
+#pragma unroll
+  for (int i = 0; i < NP; i++) {
     unsigned a = 0;
-    if (t < (64 + 1) * (RI_ROWS + 1)) {
-      const int cx = RI_H + t % 65, cy = RI_H + t / 65, c = cy * RI_RW + cx;
+    if (pin[i]) {
+      const int cx = RI_H + pcx[i], cy = RI_H + pcy[i], c = cy * RI_RW + cx;
       const int gx = gx0 + cx, gy = gy0 + cy;
       if (gx > 0 && gy > 0 && gx < iw - 1 && gy < ih - 1) {
         const unsigned b0 = alw[c];
@@ -607,21 +656,17 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
   }
   __syncthreads();
 #pragma unroll
-  for (int i = 0; i < (int)sizeof(anew); i++) {
-    const int t = tid + i * 256;
-    if (t < (64 + 1) * (RI_ROWS + 1)) alw[(RI_H + t / 65) * RI_RW + RI_H + t % 65] = anew[i];
-  }
+  for (int i = 0; i < NP; i++)
+    if (pin[i]) alw[(RI_H + pcy[i]) * RI_RW + RI_H + pcx[i]] = anew[i];
   __syncthreads();
   // proposals (the jumps level by level for all of a thread's cells: eight dependent LDS reads per thread, not per cell)
   {
-    constexpr int NP = ((64 + 1) * (RI_ROWS + 1) + 255) / 256;
     int m[NP], og[NP], cc[NP];
     bool act[NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) {
-      const int t = tid + i * 256;
-      const bool in = t < (64 + 1) * (RI_ROWS + 1);
-      const int c = in ? (RI_H + t / 65) * RI_RW + RI_H + t % 65 : RI_H * RI_RW + RI_H;
+      const bool in = pin[i];
+      const int c = in ? (RI_H + pcy[i]) * RI_RW + RI_H + pcx[i] : RI_H * RI_RW + RI_H;
       const unsigned a = in ? alw[c] : 0u;
       cc[i] = in ? c : -1;
       act[i] = (a & 16) != 0;
