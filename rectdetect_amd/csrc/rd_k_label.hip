@@ -90,9 +90,34 @@ __global__ __launch_bounds__(64 * TY) void k_label_tile(int *__restrict__ label,
     const int x0 = rd_b.x * LT_W, tid = threadIdx.y * 64 + tx;
     const int r00 = pix[(size_t)y0 * iw + x0];
     bool flat = true;
-    stage_cells<(LT_H + 4) * LT_MP, 64 * TY>(tid, pix,
-      [&](int c, int &a) { const int xx = x0 - 2 + c % LT_MP, yy = y0 - 2 + c / LT_MP; a = yy * iw + xx; return xx >= 0 && xx < iw && yy >= 0 && yy < ih; },
-      [&](int c, bool inside, int v) { flat = flat && (!inside || v == r00); t[c] = inside ? v : 0; });
+    {
+      // rows of the staged tile by waves, columns 0..63 by lanes, the 4 columns left over a cell of the first 4 (LT_H + 4) threads: no division per cell,
+      // all loads of a thread in flight together
+      constexpr int NR = (LT_H + 4 + TY - 1) / TY;
+      static_assert(LT_MP == 68 && 4 * (LT_H + 4) <= 64 * TY, "four columns beyond the lanes, one cell per thread");
+      int v[NR + 1];
+      bool ok[NR + 1];
+      const int xl = x0 - 2 + tx;
+      const bool cok = xl >= 0 && xl < iw;
+#pragma unroll
+      for (int i = 0; i < NR; i++) {
+        const int r = threadIdx.y + TY * i, yy = y0 - 2 + r;
+        ok[i] = r < LT_H + 4 && cok && yy >= 0 && yy < ih;
+        v[i] = pix[ok[i] ? yy * iw + xl : 0];
+      }
+      const int sr = tid >> 2, sc = 64 + (tid & 3);
+      {
+        const int xx = x0 - 2 + sc, yy = y0 - 2 + sr;
+        ok[NR] = sr < LT_H + 4 && xx < iw && yy >= 0 && yy < ih;
+        v[NR] = pix[ok[NR] ? yy * iw + xx : 0];
+      }
+#pragma unroll
+      for (int i = 0; i < NR; i++) {
+        const int r = threadIdx.y + TY * i;
+        if (r < LT_H + 4) { flat = flat && (!ok[i] || v[i] == r00); t[r * LT_MP + tx] = ok[i] ? v[i] : 0; }
+      }
+      if (sr < LT_H + 4) { flat = flat && (!ok[NR] || v[NR] == r00); t[sr * LT_MP + sc] = ok[NR] ? v[NR] : 0; }
+    }
     if (__syncthreads_and(flat)) {
       // no differing cell anywhere in reach: nothing is a boundary pixel, nothing to label
 #pragma unroll
