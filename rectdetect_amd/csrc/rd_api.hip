@@ -347,6 +347,7 @@ struct rd_detector {
   int8_t *prev_ring; int nring;
   hipEvent_t last_strong; int have_last_strong;
   long next_enqueue, next_poll;
+  long done_seq;                          // one more than the highest sequence number whose device work a worker has seen finished
   int last_polled_slot;
   void *last_segs; int last_nsegs;
   int use_graph, poly_mode, force_redo, fork_poly, fixed_rounds, budget_cycle; long n_redo, n_redo_rounds, n_redo_absorb;
@@ -1017,7 +1018,16 @@ static void *slot_worker(void *arg) {
     const double tan = d->tan_aov;
     pthread_mutex_unlock(&d->tan_mu);
     if (s->quit) return NULL;
+    // Frames finish roughly in sequence order, and the caller collects them in that order: only the workers of the frames next in line watch their event
+    // closely (a query every 30 us); the others - with 64 frames in flight, most of them, for most of the 25 ms their frame spends on the device - sleep in
+    // longer steps until the front of finished frames comes within two groups of theirs.  (All of them polling was two million event queries a second
+    // through the runtime's locks, next to the thread that launches.)
+    {
+      const long window = 2L * (d->zb > 1 ? d->zb : 4);
+      while (!s->quit && s->seq >= __atomic_load_n(&d->done_seq, __ATOMIC_RELAXED) + window) { struct timespec ts = { 0, 250000 }; nanosleep(&ts, NULL); }
+    }
     wait_event_outside_captures(d, s->ev_done);
+    { long cur = __atomic_load_n(&d->done_seq, __ATOMIC_RELAXED); while (cur < s->seq + 1 && !__atomic_compare_exchange_n(&d->done_seq, &cur, s->seq + 1, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { } }
     void *segs = NULL; int ns = 0;
     slot_finish_device(d, s);
     void *r = slot_rectangles(d, s, tan, &segs, &ns);
