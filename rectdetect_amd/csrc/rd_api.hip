@@ -789,10 +789,10 @@ static void group_launch(rd_detector *d, int g0) {
   run_group_segment(d, lead, zb, 0, st);
   for (int i = 0; i < zb; i++) {      // the strong masks, frame by frame (each on top of its predecessor's)
     Slot *s = &d->slots[g0 + i];
-    if (d->have_last_strong) RD_HIP(hipStreamWaitEvent(st, d->last_strong, 0));
+    // (within the group the stream orders the frames; only the first waits for the group before - another stream - and only the last is waited for)
+    if (i == 0 && d->have_last_strong) RD_HIP(hipStreamWaitEvent(st, d->last_strong, 0));
     frame_strong(d, s, st);
-    RD_HIP(hipEventRecord(s->ev_strong, st));
-    d->last_strong = s->ev_strong; d->have_last_strong = 1;
+    if (i == zb - 1) { RD_HIP(hipEventRecord(s->ev_strong, st)); d->last_strong = s->ev_strong; d->have_last_strong = 1; }
   }
   const int rounds = d->fixed_rounds ? d->fixed_rounds : __atomic_load_n(&d->rounds_budget, __ATOMIC_RELAXED);
   const int pm = current_poly_mode(d);
