@@ -94,7 +94,8 @@ def test_native_library_is_what_runs():
     assert "librectdetect_hip.so" in maps
 
 
-@pytest.mark.parametrize("iw,ih,seed,nframes", [(640, 480, 0, 2), (333, 217, 2, 1), (1280, 720, 1, 2)])
+# (the last three sizes: one pixel beyond / exactly / one tile row and column short of the 64 x 54 tiles of the edge-stopped blur)
+@pytest.mark.parametrize("iw,ih,seed,nframes", [(640, 480, 0, 2), (333, 217, 2, 1), (1280, 720, 1, 2), (65, 55, 9, 1), (64, 54, 11, 1), (130, 109, 10, 2), (191, 161, 12, 1)])
 def test_rect_stages_bit_exact_vs_oracle(iw, ih, seed, nframes):
     N = iw * ih
     det = ra.Detector(iw, ih, nslots=1)
