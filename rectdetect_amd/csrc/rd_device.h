@@ -173,9 +173,11 @@ __device__ __forceinline__ int uf_find(const int *label, int a) {
   while (l != a) { a = l; l = label[a]; }
   return a;
 }
-__device__ __forceinline__ int uf_find_volatile(volatile int *label, int a) {
-  int l = label[a];
-  while (l != a) { a = l; l = label[a]; }
+// (the walk of a union: words other threads lower meanwhile - device-scope relaxed loads of the GLOBAL plane.  A `volatile` pointer loses its address space and
+//  made every step a flat load with system-scope bits.)
+__device__ __forceinline__ int uf_find_volatile(const int *label, int a) {
+  int l = ld_agent(label + a);
+  while (l != a) { a = l; l = ld_agent(label + a); }
   return a;
 }
 __device__ __forceinline__ void uf_union(int *label, int a, int b) {

@@ -247,18 +247,26 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
   const int lane = threadIdx.x & 63, anti = threadIdx.x >> 6;
   // (grid: x = 64-column strips, y = plane + np * frame of a group launch, z = blocks of rows)
   const int k = blockIdx.y % np, c = blockIdx.z;
-  { const size_t rd_zoff_ = (size_t)(blockIdx.y / np) * zs; RD_ZS1(dst.p[0]); RD_ZS1(dst.p[1]); RD_ZS1(dst.p[2]); RD_ZS1(src.p[0]); RD_ZS1(src.p[1]); RD_ZS1(src.p[2]); RD_ZS1(tails); RD_ZS1(bad); }
+  // The plane's pointers picked by comparisons, not by indexing the structs: an index that is not a constant sends the struct through memory, the pointers come
+  // back without their address space and every access becomes a flat instruction with a 64-bit address per lane.  Rows are then addressed as a UNIFORM row pointer
+  // (scalar registers, advanced by scalar additions) plus the lane's 32-bit byte offset - no vector instruction per access.
+  float *dk = k == 0 ? dst.p[0] : (k == 1 ? dst.p[1] : dst.p[2]);
+  const float *sk = k == 0 ? src.p[0] : (k == 1 ? src.p[1] : src.p[2]);
+  { const size_t rd_zoff_ = (size_t)(blockIdx.y / np) * zs; RD_ZS1(dk); RD_ZS1(sk); RD_ZS1(tails); RD_ZS1(bad); }
   if (blockIdx.x == 0 && k == 0 && blockIdx.z == 0 && threadIdx.x == 0) *bad = 0;      // diagnostics flag of the check that follows this launch
   const int x = blockIdx.x * 64 + lane;
   const bool xin = x < W;
   typedef typename iir_src<SRC16>::T TS;
-  const TS *__restrict__ in = (const TS *)src.p[k] + (xin ? x : W - 1);
+  const TS *__restrict__ in = (const TS *)sk;                              // (uniform)
+  const unsigned xs = (unsigned)(xin ? x : W - 1) * (unsigned)sizeof(TS), x4 = (unsigned)(xin ? x : W - 1) * 4u;      // the lane's byte offset within a row
+#define IIR_ROW(ptr) (*(const TS *)((const char *)(ptr) + xs))               /* the lane's element of the source row that starts at `ptr` */
+#define IIR_OUT(ptr) (*(float *)((char *)(ptr) + x4))                        /* the lane's element of a row of floats */
   const float sc = k == 0 ? 1.0f / 4096 : 1.0f / 1024, hf = k == 0 ? 0.5f / 4096 : 0.5f / 1024;
 #define IIR_LD(v) iir_field<SRC16>(v, sc, hf)
   const int s0 = c * IF_ROWS, s1 = (c == nchunks - 1) ? H : s0 + IF_ROWS;
   const int mid = s0 + (s1 - s0) / 2;             // rows [s0, mid) are finished by the anti-causal wave, [mid, s1) by the causal one
   // tails: [plane][chunk][set: 0 fwd warm, 1 fwd true, 2 bwd warm, 3 bwd true][7][W]
-  float *__restrict__ tl = tails + ((size_t)(k * nchunks + c) * 4 * 7) * W + (xin ? x : W - 1);
+  float *__restrict__ tl = tails + ((size_t)(k * nchunks + c) * 4 * 7) * W;      // (uniform)
   const int ylo = -IIR_WARM, yhi = H + IIR_WARM;
   float cur[IIR_CH], nxt[IIR_CH];
   static_assert(IIR_CH >= 8 && IF_WU % IIR_CH == 0 && (IF_ROWS / 2) % IIR_CH == 0, "the interior path walks whole chunks, half a block per phase");
@@ -271,11 +279,11 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
 #define IIR_CHUNK(PTR, STEP, STORE, TAIL, TIDX) IIR_CHUNK_(PTR, STEP, STORE, TAIL, TIDX, 1)
 #define IIR_CHUNK_(PTR, STEP, STORE, TAIL, TIDX, MORE)                                                                  \
     {                                                                                                                    \
-      if (MORE) { _Pragma("unroll") for (int j = 0; j < IIR_CH; j++) nxt[j] = IIR_LD((PTR)[((long)(IIR_CH + j) * (STEP)) * W]); } \
+      if (MORE) { _Pragma("unroll") for (int j = 0; j < IIR_CH; j++) nxt[j] = IIR_LD(IIR_ROW((PTR) + ((long)(IIR_CH + j) * (STEP)) * W)); } \
       _Pragma("unroll") for (int j = 0; j < IIR_CH; j++) {                                                               \
         IIR_STEP(cur[j]);                                                                                                \
         STORE;                                                                                                           \
-        if ((TAIL) >= 0 && j >= IIR_CH - 7 && xin) tl[(size_t)((TAIL) * 7 + (TIDX)) * W] = d;                            \
+        if ((TAIL) >= 0 && j >= IIR_CH - 7 && xin) IIR_OUT(tl + (size_t)((TAIL) * 7 + (TIDX)) * W) = d;                            \
         IIR_SHIFT(cur[j]);                                                                                               \
       }                                                                                                                  \
       _Pragma("unroll") for (int j = 0; j < IIR_CH; j++) cur[j] = nxt[j];                                                \
@@ -285,28 +293,28 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
     if (!anti) {   // causal: rows s0 - IF_WU .. s1 - 1
       const TS *p = in + (size_t)(s0 - IF_WU) * W;
 #pragma unroll
-      for (int j = 0; j < IIR_CH; j++) cur[j] = IIR_LD(p[(size_t)j * W]);
+      for (int j = 0; j < IIR_CH; j++) cur[j] = IIR_LD(IIR_ROW(p + (size_t)j * W));
       for (int q = 0; q < IF_WU / IIR_CH - 1; q++) { IIR_CHUNK(p, 1, (void)0, -1, 0); p += (size_t)IIR_CH * W; }
       IIR_CHUNK(p, 1, (void)0, 0, j - (IIR_CH - 7)); p += (size_t)IIR_CH * W;                    // rows s0-16 .. s0-1: "warm" tails
       float *f = fwt + lane;
       for (int q = 0; q < HALF; q++) { IIR_CHUNK(p, 1, f[j * IF_PITCH] = d, -1, 0); p += (size_t)IIR_CH * W; f += IIR_CH * IF_PITCH; }
       __syncthreads();
-      float *o = TOUT ? nullptr : dst.p[k] + (size_t)mid * W + (xin ? x : W - 1);
-#define IIR_FINISH_F { const float r = (f[j * IF_PITCH] + d) - cur[j] * IIR_C0; if (TOUT) f[j * IF_PITCH] = r; else if (xin) o[(long)j * W] = r; }
+      float *o = TOUT ? nullptr : dk + (size_t)mid * W;
+#define IIR_FINISH_F { const float r = (f[j * IF_PITCH] + d) - cur[j] * IIR_C0; if (TOUT) f[j * IF_PITCH] = r; else if (xin) IIR_OUT(o + (long)j * W) = r; }
       for (int q = 0; q < HALF - 1; q++) { IIR_CHUNK(p, 1, IIR_FINISH_F, -1, 0); p += (size_t)IIR_CH * W; f += IIR_CH * IF_PITCH; if (!TOUT) o += (size_t)IIR_CH * W; }
       IIR_CHUNK_(p, 1, IIR_FINISH_F, 1, j - (IIR_CH - 7), 0);                                     // rows s1-16 .. s1-1: "true" tails
 #undef IIR_FINISH_F
     } else {       // anti-causal: rows s1 - 1 + IF_WU .. s0
       const TS *p = in + (size_t)(s1 - 1 + IF_WU) * W;
 #pragma unroll
-      for (int j = 0; j < IIR_CH; j++) cur[j] = IIR_LD(p[-(long)j * W]);
+      for (int j = 0; j < IIR_CH; j++) cur[j] = IIR_LD(IIR_ROW(p - (long)j * W));
       for (int q = 0; q < IF_WU / IIR_CH - 1; q++) { IIR_CHUNK(p, -1, (void)0, -1, 0); p -= (size_t)IIR_CH * W; }
       IIR_CHUNK(p, -1, (void)0, 2, (IIR_CH - 1) - j); p -= (size_t)IIR_CH * W;                   // rows s1+15 .. s1: "warm" tails (index = row - s1)
       float *f = fwt + (IF_ROWS - 1) * IF_PITCH + lane;
       for (int q = 0; q < HALF; q++) { IIR_CHUNK(p, -1, f[-j * IF_PITCH] = d, -1, 0); p -= (size_t)IIR_CH * W; f -= IIR_CH * IF_PITCH; }
       __syncthreads();
-      float *o = TOUT ? nullptr : dst.p[k] + (size_t)(mid - 1) * W + (xin ? x : W - 1);
-#define IIR_FINISH_B { const float r = d + f[-j * IF_PITCH] - cur[j] * IIR_C0; if (TOUT) f[-j * IF_PITCH] = r; else if (xin) o[-(long)j * W] = r; }
+      float *o = TOUT ? nullptr : dk + (size_t)(mid - 1) * W;
+#define IIR_FINISH_B { const float r = d + f[-j * IF_PITCH] - cur[j] * IIR_C0; if (TOUT) f[-j * IF_PITCH] = r; else if (xin) IIR_OUT(o - (long)j * W) = r; }
       for (int q = 0; q < HALF - 1; q++) { IIR_CHUNK(p, -1, IIR_FINISH_B, -1, 0); p -= (size_t)IIR_CH * W; f -= IIR_CH * IF_PITCH; if (!TOUT) o -= (size_t)IIR_CH * W; }
       IIR_CHUNK_(p, -1, IIR_FINISH_B, 3, (IIR_CH - 1) - j, 0);                                     // rows s0+15 .. s0: "true" tails (index = row - s0)
 #undef IIR_FINISH_B
@@ -319,10 +327,10 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
       const int fb = (s0 - IF_WU <= ylo) ? ylo : s0 - IF_WU;
       const int total = s1 - fb;
 #pragma unroll
-      for (int j = 0; j < IIR_CH; j++) cur[j] = IIR_LD(in[(size_t)mirror1(clampi(fb + j, ylo, yhi), H) * W]);
+      for (int j = 0; j < IIR_CH; j++) cur[j] = IIR_LD(IIR_ROW(in + (size_t)mirror1(clampi(fb + j, ylo, yhi), H) * W));
       for (int base = 0; base < total; base += IIR_CH) {
 #pragma unroll
-        for (int j = 0; j < IIR_CH; j++) nxt[j] = IIR_LD(in[(size_t)mirror1(clampi(fb + base + IIR_CH + j, ylo, yhi), H) * W]);
+        for (int j = 0; j < IIR_CH; j++) nxt[j] = IIR_LD(IIR_ROW(in + (size_t)mirror1(clampi(fb + base + IIR_CH + j, ylo, yhi), H) * W));
 #pragma unroll
         for (int j = 0; j < IIR_CH; j++) {
           const int yy = fb + base + j;
@@ -332,10 +340,10 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
           else if (yy >= mid && yy < s1) {
             const float o = (fwt[(yy - s0) * IF_PITCH + lane] + d) - cur[j] * IIR_C0;
             if (TOUT) fwt[(yy - s0) * IF_PITCH + lane] = o;
-            else if (xin) dst.p[k][(size_t)yy * W + x] = o;
+            else if (xin) IIR_OUT(dk + (size_t)yy * W) = o;
           }
-          if (xin && yy >= s0 - 7 && yy < s0) tl[(size_t)(0 * 7 + yy - (s0 - 7)) * W] = d;
-          if (xin && yy >= s1 - 7 && yy < s1) tl[(size_t)(1 * 7 + yy - (s1 - 7)) * W] = d;
+          if (xin && yy >= s0 - 7 && yy < s0) IIR_OUT(tl + (size_t)(0 * 7 + yy - (s0 - 7)) * W) = d;
+          if (xin && yy >= s1 - 7 && yy < s1) IIR_OUT(tl + (size_t)(1 * 7 + yy - (s1 - 7)) * W) = d;
           IIR_SHIFT(cur[j]);
         }
 #pragma unroll
@@ -345,10 +353,10 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
       const int bb = (s1 - 1 + IF_WU >= yhi) ? yhi : s1 - 1 + IF_WU;
       const int total = bb - s0 + 1;
 #pragma unroll
-      for (int j = 0; j < IIR_CH; j++) cur[j] = IIR_LD(in[(size_t)mirror1(clampi(bb - j, ylo, yhi), H) * W]);
+      for (int j = 0; j < IIR_CH; j++) cur[j] = IIR_LD(IIR_ROW(in + (size_t)mirror1(clampi(bb - j, ylo, yhi), H) * W));
       for (int base = 0; base < total; base += IIR_CH) {
 #pragma unroll
-        for (int j = 0; j < IIR_CH; j++) nxt[j] = IIR_LD(in[(size_t)mirror1(clampi(bb - (base + IIR_CH + j), ylo, yhi), H) * W]);
+        for (int j = 0; j < IIR_CH; j++) nxt[j] = IIR_LD(IIR_ROW(in + (size_t)mirror1(clampi(bb - (base + IIR_CH + j), ylo, yhi), H) * W));
 #pragma unroll
         for (int j = 0; j < IIR_CH; j++) {
           const int yy = bb - (base + j);
@@ -358,10 +366,10 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
           else if (yy >= s0 && yy < mid) {
             const float o = d + fwt[(yy - s0) * IF_PITCH + lane] - cur[j] * IIR_C0;
             if (TOUT) fwt[(yy - s0) * IF_PITCH + lane] = o;
-            else if (xin) dst.p[k][(size_t)yy * W + x] = o;
+            else if (xin) IIR_OUT(dk + (size_t)yy * W) = o;
           }
-          if (xin && yy >= s1 && yy < s1 + 7) tl[(size_t)(2 * 7 + yy - s1) * W] = d;
-          if (xin && yy >= s0 && yy < s0 + 7) tl[(size_t)(3 * 7 + yy - s0) * W] = d;
+          if (xin && yy >= s1 && yy < s1 + 7) IIR_OUT(tl + (size_t)(2 * 7 + yy - s1) * W) = d;
+          if (xin && yy >= s0 && yy < s0 + 7) IIR_OUT(tl + (size_t)(3 * 7 + yy - s0) * W) = d;
           IIR_SHIFT(cur[j]);
         }
 #pragma unroll
@@ -375,13 +383,15 @@ __global__ __launch_bounds__(128) void k_iir_fused(P3 dst, P3c src, float *__res
     for (int col = anti; col < 64; col += 2) {
       const int xx = blockIdx.x * 64 + col;
       if (xx >= W) break;
-      float *__restrict__ o = dst.p[k] + (size_t)xx * H + s0;
-      for (int r = lane; r < rows; r += 64) o[r] = fwt[r * IF_PITCH + col];
+      float *__restrict__ o = dk + (size_t)xx * H + s0;
+      for (int r = lane; r < rows; r += 64) at32(o, (unsigned)r) = fwt[r * IF_PITCH + col];
     }
   }
 }
 
 #undef IIR_LD
+#undef IIR_ROW
+#undef IIR_OUT
 
 // The state a block reached after its warm-up must equal, bit for bit, what its neighbour computed for the same rows.  One
 // wave per (64 columns, plane, chunk) compares the chunk's two borders; a column with a difference - none has been seen, the
@@ -396,7 +406,10 @@ __global__ __launch_bounds__(64 * IC_CH) void k_iir_check_fix(P3 dst, P3c src, P
   const int x = blockIdx.x * 64 + threadIdx.x;
   const int k = blockIdx.y % np, c = blockIdx.z * IC_CH + rd_ty();      // (one wave per chunk, IC_CH chunks per block: a block per wave was 6000 dispatches per plane set)
   if (c >= nchunks) return;
-  { const size_t rd_zoff_ = (size_t)(blockIdx.y / np) * zs; RD_ZS1(dst.p[0]); RD_ZS1(dst.p[1]); RD_ZS1(dst.p[2]); RD_ZS1(src.p[0]); RD_ZS1(src.p[1]); RD_ZS1(src.p[2]); RD_ZS1(fwd.p[0]); RD_ZS1(fwd.p[1]); RD_ZS1(fwd.p[2]); RD_ZS1(tails); RD_ZS1(bad); }
+  // (the plane's pointers by comparisons: k_iir_fused)
+  float *dk = k == 0 ? dst.p[0] : (k == 1 ? dst.p[1] : dst.p[2]), *fk = k == 0 ? fwd.p[0] : (k == 1 ? fwd.p[1] : fwd.p[2]);
+  const float *sk = k == 0 ? src.p[0] : (k == 1 ? src.p[1] : src.p[2]);
+  { const size_t rd_zoff_ = (size_t)(blockIdx.y / np) * zs; RD_ZS1(dk); RD_ZS1(sk); RD_ZS1(fk); RD_ZS1(tails); RD_ZS1(bad); }
   if (x >= W) return;
   const int s0 = c * IF_ROWS, s1 = (c == nchunks - 1) ? H : s0 + IF_ROWS;
   const float *me = tails + ((size_t)(k * nchunks + c) * 4 * 7) * W + x;
@@ -429,9 +442,9 @@ __global__ __launch_bounds__(64 * IC_CH) void k_iir_check_fix(P3 dst, P3c src, P
   if (!differ) return;
   atomicOr(bad, 1);
   typedef typename iir_src<SRC16>::T TS;
-  const TS *__restrict__ in = (const TS *)src.p[k] + x;
+  const TS *__restrict__ in = (const TS *)sk + x;
   const float sc = k == 0 ? 1.0f / 4096 : 1.0f / 1024, hf = k == 0 ? 0.5f / 4096 : 0.5f / 1024;
-  float *fw = fwd.p[k] + x;
+  float *fw = fk + x;
   {
     IIR_STATE;
     for (int yy = -IIR_WARM; yy < H; yy++) {
@@ -448,7 +461,7 @@ __global__ __launch_bounds__(64 * IC_CH) void k_iir_check_fix(P3 dst, P3c src, P
       IIR_STEP(i0);
       if (yy < H) {
         const float o = d + fw[(size_t)yy * W] - i0 * IIR_C0;
-        if (TOUT) dst.p[k][(size_t)x * H + yy] = o; else dst.p[k][(size_t)yy * W + x] = o;
+        if (TOUT) dk[(size_t)x * H + yy] = o; else dk[(size_t)yy * W + x] = o;
       }
       IIR_SHIFT(i0);
     }

@@ -24,9 +24,12 @@ inline dim3 grid2(int iw, int ih) { return dim3(cdiv(iw, 64), cdiv(ih, 4)); }
 #ifndef LT_H
 #define LT_H 32
 #endif
-__device__ __forceinline__ int lt_find(const volatile int *lab, int a) {
-  int l = lab[a];
-  while (l != a) { a = l; l = lab[a]; }
+// (the walks re-read words other lanes lower meanwhile: relaxed atomic loads, workgroup scope - LDS reads as ds_read.  A `volatile` pointer instead loses its
+//  address space: every step of every walk was a FLAT load with system-scope bits, several times the latency of the LDS instruction)
+__device__ __forceinline__ int lt_ld(const int *lab, int a) { return __hip_atomic_load(lab + a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ int lt_find(const int *lab, int a) {
+  int l = lt_ld(lab, a);
+  while (l != a) { a = l; l = lt_ld(lab, a); }
   return a;
 }
 __device__ __forceinline__ void lt_union(int *lab, int a, int b) {
@@ -223,13 +226,12 @@ __device__ __forceinline__ void border_union(int *label, int la, int lb, bool wa
   const int pa = __shfl_up(la, 1), pb = __shfl_up(lb, 1);
   if (want && !(__lane_id() > 0 && pa == la && pb == lb)) {
     int a = la, b = lb;
-    volatile int *vl = label;
     for (;;) {
       // both walks to the roots together: they are chains of dependent loads (the background's tile roots form chains as long as a row of tiles until
       // the shortcuts below shorten them), and a wave waits for the longest - one walk after the other 61 us per launch of 8 frames, together 46.
       // (Not kept: hanging every node that is left under its grandparent on the way, 66 us; a thread's three candidate pairs walked and hooked together, 75 us.)
-      int na = vl[a], nb = vl[b];
-      while (na != a || nb != b) { a = na; b = nb; na = vl[a]; nb = vl[b]; }
+      int na = ld_agent(label + a), nb = ld_agent(label + b);      // (device-scope loads of a global plane; a `volatile` pointer made them flat, system-scope ones)
+      while (na != a || nb != b) { a = na; b = nb; na = ld_agent(label + a); nb = ld_agent(label + b); }
       if (a == b) break;
       if (a < b) { const int t = a; a = b; b = t; }
       const int old = atomicMin(&label[a], b);

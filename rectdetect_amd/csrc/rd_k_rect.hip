@@ -757,6 +757,12 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
 #define RR_TY 8          // thread rows per block (2 / 4 / 8 at full rate: 2094 / 2118 / 2124 frames/s)
 #endif
 #define RR_MBITS 3
+#ifndef RR_GUARD1
+#define RR_GUARD1 0        // launch 1, proposals for parents outside the tile: 1 = the thread's guarding loads together, 0 = no guard, 2 = load and atomic pixel by pixel
+#endif
+#ifndef RR_GUARD2
+#define RR_GUARD2 2        // the same for launch 2 (every pixel's parent)
+#endif
 #ifndef RR_DEEP
 #define RR_DEEP 3          // rounds in which the trees are still the chains of the initial links (a pixel's parent is 1, 10, 91 rows above it)
 #endif
@@ -790,7 +796,10 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
       const int y = yb + k;
       valid[k] = x < iw && y < ih;
       p0[k] = valid[k] ? y * iw + x : 0;
-      a[k] = valid[k] ? allow[(unsigned)p0[k]] : 0u;
+      // (every load of this kernel is UNCONDITIONAL, with the address of a pixel that exists where the value is not wanted: a load under a condition becomes a
+      //  branch with a wait for ALL loads in flight behind it - the six pixels' loads then travel one after the other, six trips to memory instead of one)
+      const unsigned ab = allow[(unsigned)p0[k]];
+      a[k] = valid[k] ? ab : 0u;
       // neighbour addresses clamped into the plane: the loads are unconditional, their use depends on the allow bits
       q[k][0] = p0[k];
       q[k][1] = (valid[k] && y > 0) ? p0[k] - iw : p0[k];
@@ -827,8 +836,12 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
   }
   // rc:328: the eight pointer jumps (a root maps to itself), level by level for the thread's RR_PX pixels together: seven dependent
   // trips to memory per thread, not seven per pixel - in the first rounds the trees are the raw chains of rc:289-298 and every jump is real
+  const float inv_iw = 1.0f / (float)iw;
 #pragma unroll
-  for (int k = 0; k < RR_PX; k++) nx[k] = (a[k] & 16) ? rr_label(X, (unsigned)g[k]) : g[k];
+  for (int k = 0; k < RR_PX; k++) {
+    const int v = rr_label(X, (unsigned)g[k]);      // (g is a pixel index for every lane: a pixel that does not act holds its own label)
+    nx[k] = (a[k] & 16) ? v : g[k];
+  }
   for (int j = 1; j < 8; j++) {
     bool moving = false;
 #pragma unroll
@@ -852,10 +865,9 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
     // parent is the pixel ~10 rows above, for four out of five pixels inside the block's tile: those proposals meet in LDS and leave with the
     // parent's own word, as ONE atomic per pixel; the rest go to memory as in the other launches.
     const int origin = by * (RR_TY * RR_PX) * iw + bx * 64;
-    const float inv_iw = 1.0f / (float)iw;
+    bool out[RR_PX];       // proposals for parents outside the tile
 #pragma unroll
     for (int k = 0; k < RR_PX; k++) {
-      if (!todo[k]) continue;
       const int d = og[k] - origin;
       bool inside = false;
       int cell = 0;
@@ -865,8 +877,31 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
         inside = col < 64 && row < RR_TY * RR_PX;
         cell = row * 64 + col;
       }
-      if (inside) atomicMin(&tmin[cell], g[k]);
-      else { const int w = (g[k] << RR_MBITS) | mark; if (w < ld_agent(&Y[og[k]])) atomicMin(&Y[og[k]], w); }
+      if (todo[k] && inside) atomicMin(&tmin[cell], g[k]);
+      out[k] = todo[k] && !inside;
+    }
+    auto far_hooks = [&]() {
+      int cur[RR_PX];
+#pragma unroll
+      for (int k = 0; k < RR_PX; k++) cur[k] = ld_agent(&Y[out[k] ? og[k] : p0[k]]);
+#pragma unroll
+      for (int k = 0; k < RR_PX; k++) { const int w = (g[k] << RR_MBITS) | mark; if (out[k] && w < cur[k]) atomicMin(&Y[og[k]], w); }
+    };
+    {   // (the guarding loads of the thread's pixels together, see the note on unconditional loads)
+#if RR_GUARD1 == 3
+#elif RR_GUARD1 == 1
+      int cur[RR_PX];
+#pragma unroll
+      for (int k = 0; k < RR_PX; k++) cur[k] = ld_agent(&Y[out[k] ? og[k] : p0[k]]);
+#pragma unroll
+      for (int k = 0; k < RR_PX; k++) { const int w = (g[k] << RR_MBITS) | mark; if (out[k] && w < cur[k]) atomicMin(&Y[og[k]], w); }
+#elif RR_GUARD1 == 0
+#pragma unroll
+      for (int k = 0; k < RR_PX; k++) { const int w = (g[k] << RR_MBITS) | mark; if (out[k]) atomicMin(&Y[og[k]], w); }
+#else
+#pragma unroll
+      for (int k = 0; k < RR_PX; k++) { const int w = (g[k] << RR_MBITS) | mark; if (out[k] && w < ld_agent(&Y[og[k]])) atomicMin(&Y[og[k]], w); }
+#endif
     }
     __syncthreads();
 #pragma unroll
@@ -878,35 +913,59 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
       if (h != 0x7fffffff) { const int wh = (h << RR_MBITS) | mark; w = wh < w ? wh : w; }
       if (w != 0x7fffffff) atomicMin(&Y[p0[k]], w);
     }
+#if RR_GUARD1 == 3
+    far_hooks();
+#endif
     if (__any(any_todo) && threadIdx.x == 0) flags[round] = 1;
     return;
   }
   // Hooking the old parent: once the trees are shallow, all pixels of a tree share one parent, so the block first reduces its
   // (parent -> smallest proposal) pairs in a small LDS hash and then issues one guarded atomic per distinct parent.
+  auto hook = [&](int key, int val) {
+    const int w = (val << RR_MBITS) | mark;
+    if (w < ld_agent(&Y[key])) atomicMin(&Y[key], w);
+  };
+  bool need[RR_PX];
 #pragma unroll
   for (int k = 0; k < RR_PX; k++) {
     // a lane whose (parent, proposal) pair repeats its left neighbour's adds nothing to a min: skip it (most lanes inside a region)
     const int pog = __shfl_up(og[k], 1), pg = __shfl_up(g[k], 1), pt = __shfl_up((int)todo[k], 1);
-    if (!todo[k] || (threadIdx.x > 0 && pt && pog == og[k] && pg == g[k])) continue;
-    if (round < RR_DEEP) {       // the first rounds climb the raw chains: every pixel has a parent of its own (the pixel above it), nothing to combine
-      const int w = (g[k] << RR_MBITS) | mark;
-      if (w < ld_agent(&Y[og[k]])) atomicMin(&Y[og[k]], w);
-      continue;
-    }
-    unsigned h = ((unsigned)og[k] * 2654435761u) >> 23;
-    int probes = 0;
-    for (;;) {
-      const int kprev = atomicCAS(&hk[h], -1, og[k]);
-      if (kprev == -1 || kprev == og[k]) { atomicMin(&hv[h], g[k]); break; }
-      h = (h + 1) & 511;
-      if (++probes == 16) { const int w = (g[k] << RR_MBITS) | mark; if (w < ld_agent(&Y[og[k]])) atomicMin(&Y[og[k]], w); break; }
+    need[k] = todo[k] && !(threadIdx.x > 0 && pt && pog == og[k] && pg == g[k]);
+  }
+  if (round < RR_DEEP) {       // the first rounds climb the raw chains: every pixel has a parent of its own (the pixel above it), nothing to combine
+#if RR_GUARD2 == 1 || RR_GUARD2 == 3
+    if (RR_GUARD2 == 3) __syncthreads();
+    int cur[RR_PX];            // (the guarding loads of the thread's pixels together)
+#pragma unroll
+    for (int k = 0; k < RR_PX; k++) cur[k] = ld_agent(&Y[need[k] ? og[k] : p0[k]]);
+#pragma unroll
+    for (int k = 0; k < RR_PX; k++) { const int w = (g[k] << RR_MBITS) | mark; if (need[k] && w < cur[k]) atomicMin(&Y[og[k]], w); }
+#elif RR_GUARD2 == 0
+#pragma unroll
+    for (int k = 0; k < RR_PX; k++) { const int w = (g[k] << RR_MBITS) | mark; if (need[k]) atomicMin(&Y[og[k]], w); }
+#else
+#pragma unroll
+    for (int k = 0; k < RR_PX; k++) { const int w = (g[k] << RR_MBITS) | mark; if (need[k] && w < ld_agent(&Y[og[k]])) atomicMin(&Y[og[k]], w); }
+#endif
+  } else {
+#pragma unroll
+    for (int k = 0; k < RR_PX; k++) {
+      if (!need[k]) continue;
+      unsigned h = ((unsigned)og[k] * 2654435761u) >> 23;
+      int probes = 0;
+      for (;;) {
+        const int kprev = atomicCAS(&hk[h], -1, og[k]);
+        if (kprev == -1 || kprev == og[k]) { atomicMin(&hv[h], g[k]); break; }
+        h = (h + 1) & 511;
+        if (++probes == 16) { hook(og[k], g[k]); break; }
+      }
     }
   }
   if (__any(any_todo) && threadIdx.x == 0) flags[round] = 1;
   __syncthreads();
   for (int t = tid; t < 512; t += 64 * RR_TY) {
     const int key = hk[t];
-    if (key != -1) { const int w = (hv[t] << RR_MBITS) | mark; if (w < ld_agent(&Y[key])) atomicMin(&Y[key], w); }
+    if (key != -1) hook(key, hv[t]);
   }
 }
 
