@@ -757,6 +757,9 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
 #define RR_TY 8          // thread rows per block (2 / 4 / 8 at full rate: 2094 / 2118 / 2124 frames/s)
 #endif
 #define RR_MBITS 3
+#ifndef RR_NARROW
+#define RR_NARROW 1        // 0: every launch on 64 x RR_PX footprints, 2: every launch on 16 x (4 RR_PX)
+#endif
 #ifndef RR_GUARD1
 #define RR_GUARD1 0        // launch 1, proposals for parents outside the tile: 1 = the thread's guarding loads together, 0 = no guard, 2 = load and atomic pixel by pixel
 #endif
@@ -769,22 +772,31 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
 __device__ __forceinline__ int rr_label(const int *X, unsigned q) { return at32(X, q) >> RR_MBITS; }
 // (Block -> tile and frame: rd_block_tile, rd_device.h - a tile's neighbours and the pixels its labels name, the rows above it, are served by the L2 that fetched
 //  them for the neighbouring tiles: 64 % of this kernel's L2 requests missed before.)
+// PHASE: 1 = launch 1 (proposals meet in the tile), 2 = the other launches that climb raw chains (every pixel hooks its own parent), 3 = the rest (parents combined per block)
+template <int PHASE>
 __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round, size_t zs, int gdim) {
   const rd_tile rd_b = rd_block_tile(gdim);
   if (rd_b.x < 0) return;
   const int bx = rd_b.x, by = rd_b.y;
   RD_ZSHIFTZ(rd_b.z, zs, X, Y, allow, flags);
   if (round > 0 && flags[round - 1] == 0) return;
-  __shared__ int hk[512], hv[512];
-  __shared__ int tmin[64 * RR_TY * RR_PX];      // launch 1 only: the smallest proposal for each pixel of the block's tile (see below)
+  __shared__ int hk[PHASE == 3 ? 512 : 1], hv[PHASE == 3 ? 512 : 1];
+  __shared__ int tmin[PHASE == 1 ? 64 * RR_TY * RR_PX : 1];      // launch 1 only: the smallest proposal for each pixel of the block's tile (see below)
   const int tid = rd_ty() * 64 + threadIdx.x;
-  const bool near = round == 1;               // the trees are still the first launch's: a pixel's parent lies ~10 rows above it, mostly inside the tile
-  for (int t = tid; t < 512; t += 64 * RR_TY) { hk[t] = -1; hv[t] = 0x7fffffff; }
+  constexpr bool near = PHASE == 1;           // the trees are still the first launch's: a pixel's parent lies ~10 rows above it, mostly inside the tile
+  if (PHASE == 3) for (int t = tid; t < 512; t += 64 * RR_TY) { hk[t] = -1; hv[t] = 0x7fffffff; }
   if (near) for (int t = tid; t < 64 * RR_TY * RR_PX; t += 64 * RR_TY) tmin[t] = 0x7fffffff;
-  __syncthreads();
+  if (PHASE != 2) __syncthreads();
   const int mark = 1 + round % 7, mark_prev = round > 0 ? 1 + (round - 1) % 7 : 8;      // (8: matches nothing - before round 0 no plane lags)
-  const int yb = by * (RR_TY * RR_PX) + rd_ty() * RR_PX;      // the thread's RR_PX pixels lie below one another: each is the other's vertical neighbour
-  const int x = bx * 64 + threadIdx.x;
+  // Which pixels a wave takes.  The launches that climb raw chains (PHASE 1, 2) are bound by the lines their gathers touch: the chains of neighbouring columns fall out of
+  // step wherever a vertical run ends (7 % of the pixels of the bench stream), so the 64 lanes of a row segment land on ~20 different 64-byte lines per jump.  There a wave
+  // takes a footprint 16 pixels wide (one line per row) and 4 x RR_PX rows tall: 9 lines per jump (simulated on the stream: 159 -> 74 lines per pixel row and launch 1, 87 -> 38
+  // in launch 2).  Once the trees are shallow the jumps read a few roots and the neighbour loads dominate: 64 x RR_PX as before.
+  constexpr bool NARROW = (RR_NARROW == 2 || (RR_NARROW == 1 && PHASE != 3)) && RR_TY == 8;
+  const int wv = rd_ty(), lx = NARROW ? ((wv & 3) * 16 + ((int)threadIdx.x & 15)) : (int)threadIdx.x;      // column and first row inside the block's 64 x (RR_TY * RR_PX) tile
+  const int ly = NARROW ? ((wv >> 2) * (4 * RR_PX) + ((int)threadIdx.x >> 4) * RR_PX) : wv * RR_PX;
+  const int yb = by * (RR_TY * RR_PX) + ly;      // the thread's RR_PX pixels lie below one another: each is the other's vertical neighbour
+  const int x = bx * 64 + lx;
   int p0[RR_PX], og[RR_PX], g[RR_PX], nx[RR_PX], w0[RR_PX];
   unsigned a[RR_PX];
   bool valid[RR_PX], todo[RR_PX];
@@ -909,7 +921,7 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
       if (!valid[k]) continue;
       const bool lag = (w0[k] & 7) == mark_prev;
       int w = (todo[k] || lag) ? ((g[k] << RR_MBITS) | (todo[k] ? mark : 0)) : 0x7fffffff;
-      const int h = tmin[(rd_ty() * RR_PX + k) * 64 + threadIdx.x];
+      const int h = tmin[(ly + k) * 64 + lx];
       if (h != 0x7fffffff) { const int wh = (h << RR_MBITS) | mark; w = wh < w ? wh : w; }
       if (w != 0x7fffffff) atomicMin(&Y[p0[k]], w);
     }
@@ -932,7 +944,7 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
     const int pog = __shfl_up(og[k], 1), pg = __shfl_up(g[k], 1), pt = __shfl_up((int)todo[k], 1);
     need[k] = todo[k] && !(threadIdx.x > 0 && pt && pog == og[k] && pg == g[k]);
   }
-  if (round < RR_DEEP) {       // the first rounds climb the raw chains: every pixel has a parent of its own (the pixel above it), nothing to combine
+  if (PHASE == 2) {       // the first rounds climb the raw chains: every pixel has a parent of its own (the pixel above it), nothing to combine
 #if RR_GUARD2 == 1 || RR_GUARD2 == 3
     if (RR_GUARD2 == 3) __syncthreads();
     int cur[RR_PX];            // (the guarding loads of the thread's pixels together)
@@ -962,6 +974,7 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
     }
   }
   if (__any(any_todo) && threadIdx.x == 0) flags[round] = 1;
+  if (PHASE != 3) return;
   __syncthreads();
   for (int t = tid; t < 512; t += 64 * RR_TY) {
     const int key = hk[t];
@@ -1952,8 +1965,10 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
   for (int r = 1; r < ROUNDS; r++) {       // (launch 0 was evaluated by k_region_init)
     const dim3 lg(rd_tile_blocks((int)grid.x, (int)grid.y, (int)grid.z));
     const int gdim = rd_gdim((int)grid.x, (int)grid.y, (int)grid.z);
-    if (r & 1) hipLaunchKernelGGL(k_region_round, lg, dim3(64, RR_TY), 0, s, B, A, (const uint8_t *)allow, iw, ih, flags, r, zs, gdim);
-    else hipLaunchKernelGGL(k_region_round, lg, dim3(64, RR_TY), 0, s, A, B, (const uint8_t *)allow, iw, ih, flags, r, zs, gdim);
+    int *X = (r & 1) ? B : A, *Y = (r & 1) ? A : B;
+    if (r == 1) hipLaunchKernelGGL(k_region_round<1>, lg, dim3(64, RR_TY), 0, s, X, Y, (const uint8_t *)allow, iw, ih, flags, r, zs, gdim);
+    else if (r < RR_DEEP) hipLaunchKernelGGL(k_region_round<2>, lg, dim3(64, RR_TY), 0, s, X, Y, (const uint8_t *)allow, iw, ih, flags, r, zs, gdim);
+    else hipLaunchKernelGGL(k_region_round<3>, lg, dim3(64, RR_TY), 0, s, X, Y, (const uint8_t *)allow, iw, ih, flags, r, zs, gdim);
   }
   if (marked) *marked = 1;
 }
