@@ -382,8 +382,28 @@ def main():
         elapsed = float(t.item())
         dist.barrier()
 
-    # who did what: every rank reports its device, stream seed, frames and time (host-side gather of a few bytes, not a data-path collective)
-    mine = {"rank": rank, "device": None if args.dry_run else dev, "stream_seed": seed_stream, "frames": args.steps * F, "frames_per_s": round(args.steps * F / own_elapsed, 2),
+    # (1) EVERY rank checks its timed run's outputs against a plain sequential pass over its own stream (one frame in flight, no worker threads,
+    #     post-process inline), outside the timed region: a run that returned garbage on any GPU cannot print a valid line
+    digest = lambda lists: zlib.crc32(b"".join(np.ascontiguousarray(r).tobytes() for r in lists)) & 0xFFFFFFFF
+    verify = None
+    rho = None
+    if det is not None and not args.no_verify:
+        timed_lists = results[args.warmup * F:]
+        nrect = int(sum(len(r) for r in timed_lists))
+        chk = ra.Detector(IW, IH, device=dev, nslots=1, nworkers=0)
+        seq = []
+        for k in range((args.warmup + args.steps) * F):
+            chk.enqueue(dframes[k % F], ws=IW * 3, on_device=True)
+            seq.append(chk.poll(TAN_AOV))
+        ctr = chk.plane("polyctr", np.int32, 64)
+        rho = {"chain_pixels": int(ctr[0]), "chains": int(ctr[1]), "live_pixels": int(ctr[24]), "edge_density": round(float(ctr[0]) / (IW * IH), 5)}
+        chk.close()
+        verify = {"outputs_verified": bool(len(timed_lists) == args.steps * F and digest(timed_lists) == digest(seq[args.warmup * F:])),
+                  "rectangles_in_timed_frames": nrect, "rect_list_crc32": "%08x" % digest(timed_lists),
+                  "against": "sequential pass of the same %d-frame stream, 1 frame in flight, no worker threads, outside the timed region" % len(seq)}
+
+    # who did what: every rank reports its device, stream seed, frames, time and the outcome of its own check (host-side gather of a few bytes, not a data-path collective)
+    mine = {"rank": rank, "outputs_verified": verify["outputs_verified"] if verify else None, "rect_list_crc32": verify["rect_list_crc32"] if verify else None, "device": None if args.dry_run else dev, "stream_seed": seed_stream, "frames": args.steps * F, "frames_per_s": round(args.steps * F / own_elapsed, 2),
             "rectangles": int(sum(len(r) for r in results[args.warmup * F:])), "own_elapsed_s": round(own_elapsed, 4), "pinned_cpus": None if args.dry_run else pinned,
             "pci_bus_id": None if args.dry_run else device_bus_id(ra.lib(), dev), "pid": os.getpid()}
     per_rank = [mine]
@@ -399,26 +419,11 @@ def main():
         fps = total_frames / elapsed
         N = IW * IH
         achieved = fps / world * B_ALG_PER_PIXEL * N      # bytes/s per GPU
-        digest = lambda lists: zlib.crc32(b"".join(np.ascontiguousarray(r).tobytes() for r in lists)) & 0xFFFFFFFF
-        verify = None
         host_rate = None
-        rho = None
-        if det is not None and not args.no_verify:
-            # (1) the timed run's outputs against a plain sequential pass over the same stream (one frame in flight, no worker threads,
-            #     post-process inline), outside the timed region: a run that returned garbage cannot print a valid line
-            timed_lists = results[args.warmup * F:]
-            nrect = int(sum(len(r) for r in timed_lists))
-            chk = ra.Detector(IW, IH, device=dev, nslots=1, nworkers=0)
-            seq = []
-            for k in range((args.warmup + args.steps) * F):
-                chk.enqueue(dframes[k % F], ws=IW * 3, on_device=True)
-                seq.append(chk.poll(TAN_AOV))
-            ctr = chk.plane("polyctr", np.int32, 64)
-            rho = {"chain_pixels": int(ctr[0]), "chains": int(ctr[1]), "live_pixels": int(ctr[24]), "edge_density": round(float(ctr[0]) / N, 5)}
-            chk.close()
-            verify = {"outputs_verified": bool(len(timed_lists) == args.steps * F and digest(timed_lists) == digest(seq[args.warmup * F:])),
-                      "rectangles_in_timed_frames": nrect, "rect_list_crc32": "%08x" % digest(timed_lists),
-                      "against": "sequential pass of the same %d-frame stream, 1 frame in flight, no worker threads, outside the timed region" % len(seq)}
+        if verify is not None:
+            if world > 1:      # the line is valid only if every rank's lists passed its own check
+                verify = dict(verify, outputs_verified=all(r["outputs_verified"] is True for r in per_rank), rectangles_in_timed_frames=int(sum(r["rectangles"] for r in per_rank)),
+                              against=verify["against"] + " - on every rank, each against its own stream")
             # (2) the same work with host buffers handed over (memcpy into pinned memory + PCIe upload inside the timed region):
             #     SURVEY.md 8(d)'s "upload -> ... -> post-process" unit; reported beside the HBM-resident headline, never as `value`
             if world == 1 and not args.host_frames:
@@ -449,6 +454,10 @@ def main():
                          "algorithmic_bytes_dense_stages": 132 * N, "algorithmic_bytes_polyline_stages_priced_dense": 697 * N,
                          "frac_dense_stages_only": round(fps / world * 132 * N / HBM_PEAK, 4), "stream_statistics": rho,
                          "traffic": traffic, "traffic_unit": "bytes/frame", "traffic_source": traffic_src,
+                         # "rocprof-reported achieved HBM GB/s against the gfx950 peak" (north_star): counter bytes per frame x this run's frames/s (per GPU); 6.29 TB/s = what a
+                         # streaming copy reaches on this part (MI355X_MICROARCH.md)
+                         "hbm_measured": None if not traffic else {"GB_per_s": round(traffic * fps / world / 1e9, 1), "frac_of_peak_8.0TBps": round(traffic * fps / world / HBM_PEAK, 4),
+                                                                   "frac_of_achievable_6.29TBps": round(traffic * fps / world / 6.29e12, 4)},
                          # HIP events on each frame's own stream over the timed region (rank 0): first kernel start -> last copy end.
                          # With several frames in flight these intervals overlap, which is why `achieved` is taken from the aggregate rate.
                          "frame_device_us_avg": round((dev1[0] - dev0[0]) / max(1, dev1[1] - dev0[1]), 1), "frames_in_flight": args.slots, "frames_per_launch": None if args.dry_run else det.frames_per_launch(),
