@@ -345,6 +345,7 @@ struct rd_detector {
   // pixel: a ring of nslots + 1 planes - frame t reads plane t mod (nslots + 1) and writes the next one, so what a frame read stays intact as
   // long as its slot's planes do (debug plane "strsum")
   int8_t *prev_ring; int nring;
+  int t_edge, t_strong;                   // thresholds of the strength sums (500, 2500; RD_TEST_THRESHOLDS)
   hipEvent_t last_strong; int have_last_strong;
   long next_enqueue, next_poll;
   long done_seq;                          // one more than the highest sequence number whose device work a worker has seen finished
@@ -558,7 +559,7 @@ static void frame_strong(rd_detector *d, Slot *s, hipStream_t st) {
   const long t = s->seq;
   s->prev_in = d->prev_ring + (size_t)(t % d->nring) * N;
   int8_t *out = d->prev_ring + (size_t)((t + 1) % d->nring) * N;
-  rdk::strength_masks(st, NULL, out, NULL, s->e8, s->label1, s->strsum, 500, 2500, d->iw, d->ih, s->prev_in, s->strongbits);      // (the mask as bytes for the next frame, as bits for this frame's polylines; nobody reads it as ints)
+  rdk::strength_masks(st, NULL, out, NULL, s->e8, s->label1, s->strsum, d->t_edge, d->t_strong, d->iw, d->ih, s->prev_in, s->strongbits);      // (the mask as bytes for the next frame, as bits for this frame's polylines; nobody reads it as ints)
 }
 
 // gradient direction, re-packed blurred Lab, strength, non-max suppression (oclrect.c:251-258) of nz frames: one tile kernel that keeps the three
@@ -787,13 +788,19 @@ static void group_launch(rd_detector *d, int g0) {
   }
   rdk::bgr2plab_transposed(st, lead->plab0, lead->tr, srcs, d->iw, d->ih, ws, zb, d->slot_pitch);
   run_group_segment(d, lead, zb, 0, st);
-  for (int i = 0; i < zb; i++) {      // the strong masks, frame by frame (each on top of its predecessor's)
-    Slot *s = &d->slots[g0 + i];
-    // (within the group the stream orders the frames; only the first waits for the group before - another stream - and only the last is waited for)
-    if (i == 0 && d->have_last_strong) RD_HIP(hipStreamWaitEvent(st, d->last_strong, 0));
-    frame_strong(d, s, st);
-    if (i == zb - 1) { RD_HIP(hipEventRecord(s->ev_strong, st)); d->last_strong = s->ev_strong; d->have_last_strong = 1; }
+  // the strong masks: each frame's on top of its predecessor's (H1) - one launch for the group where its planes allow 16-byte accesses (the mask of the frame before
+  // only decides sums that stand one below a threshold, and is then evaluated on the spot: k_strength_masks_group), else frame by frame
+  static const bool strong_by_frame = getenv("RD_STRONG_BY_FRAME") != NULL;
+  if (d->have_last_strong) RD_HIP(hipStreamWaitEvent(st, d->last_strong, 0));      // (only the first frame waits for the group before - another stream - and only the last is waited for)
+  bool consecutive = true;
+  for (int i = 1; i < zb; i++) consecutive = consecutive && d->slots[g0 + i].seq == lead->seq + i;
+  if (!strong_by_frame && consecutive && rdk::strength_masks_group_fits(d->iw, lead->label1, d->prev_ring, lead->e8, d->slot_pitch) && (d->N & 3) == 0) {
+    for (int i = 0; i < zb; i++) d->slots[g0 + i].prev_in = d->prev_ring + (size_t)(d->slots[g0 + i].seq % d->nring) * (size_t)d->N;
+    rdk::strength_masks_group(st, d->prev_ring, lead->e8, lead->label1, lead->strsum, d->t_edge, d->t_strong, d->iw, d->ih, lead->strongbits, lead->seq, d->nring, zb, d->slot_pitch);
+  } else {
+    for (int i = 0; i < zb; i++) frame_strong(d, &d->slots[g0 + i], st);
   }
+  { Slot *s = &d->slots[g0 + zb - 1]; RD_HIP(hipEventRecord(s->ev_strong, st)); d->last_strong = s->ev_strong; d->have_last_strong = 1; }
   const int rounds = d->fixed_rounds ? d->fixed_rounds : __atomic_load_n(&d->rounds_budget, __ATOMIC_RELAXED);
   const int pm = current_poly_mode(d);
   for (int i = 0; i < zb; i++) {
@@ -1081,6 +1088,11 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   // more are beyond it as a rule: their streams start on the multi-launch form instead of overflowing - and being repeated - until the two-overflow rule
   // below finds that out (3840x2160: 12 of the first 16 frames).  Smaller frames that overflow anyway are still caught by that rule.
   d->poly_overflows = (long)iw * ih > 3000000L ? 1 : 0;
+  d->t_edge = 500; d->t_strong = 2500;      // oclrect.c:277-284, 307-313
+  if (getenv("RD_TEST_THRESHOLDS")) {      // tests only: other thresholds, so that many strength sums stand exactly one below one (where the mask of the frame before decides, H1)
+    int a = 0, b = 0;
+    if (sscanf(getenv("RD_TEST_THRESHOLDS"), "%d,%d", &a, &b) == 2 && a > 0 && b >= a) { d->t_edge = a; d->t_strong = b; }
+  }
   d->budget_cycle = getenv("RD_BUDGET_CYCLE") ? atoi(getenv("RD_BUDGET_CYCLE")) : 0;      // tests: the launch budget changes every so many frames (12, 14, .. 20, 12, ..)
   pthread_mutex_init(&d->tan_mu, NULL); pthread_cond_init(&d->tan_cv, NULL);
   pthread_mutex_init(&d->launch_mu, NULL);

@@ -490,9 +490,82 @@ __global__ __launch_bounds__(256) void k_strength_masks(int *__restrict__ strong
   if (ln != l) label[p] = ln;
 }
 
+// The strong masks of the nz consecutive frames of a group launch in ONE launch (frame = blockIdx.z, planes zs bytes apart), where the frame-by-frame form above
+// needs nz launches one after the other: frame z's sums start from the strong mask of frame z - 1 (H1).  That mask is 0 or 1, so it only decides where a sum stands
+// exactly one below a threshold - sum = t - 1 - and then it is needed at ONE pixel, the component's root: the thread evaluates the mask of the frame before at that
+// pixel itself (the same rule, one level down, and so on to the frame before the group, whose mask plane - ring plane t0 mod nring - is complete: the launch waits
+// for the group before).  A label read from an earlier frame of the group may or may not have been filtered by that frame's own threads yet: a pixel is filtered
+// exactly when its mask is 0, so both readings answer the same.  Every frame still leaves its mask in the ring (plane (t0 + z + 1) mod nring) for whoever comes next.
+// 16-byte accesses: needs iw % 4 == 0 and aligned planes like the VEC form above.
+__device__ int strong_before(const int *label0, const int *str0, const int8_t *ring0, size_t zs, int zz, int q, int iw, int ih, int t_strong) {
+  for (;;) {
+    if (zz < 0) return (int)ring0[q];
+    const int l2 = *(const int *)((const char *)label0 + (size_t)zz * zs + (size_t)q * 4);
+    if (l2 <= 0) return 0;
+    const int qy = q / iw, qx = q - qy * iw;
+    if (!(qx > 0 && qy > 0 && qx < iw - 1 && qy < ih - 1)) return 1;      // (the frame's ring is never filtered)
+    const int s2 = *(const int *)((const char *)str0 + (size_t)zz * zs + (size_t)l2 * 4);
+    if (s2 >= t_strong) return 1;
+    if (s2 + 1 < t_strong) return 0;
+    q = l2; zz--;           // the sum stands one below the threshold: the frame before decides, at this component's root
+  }
+}
+__global__ __launch_bounds__(256) void k_strength_masks_group(int8_t *__restrict__ ring, int8_t *__restrict__ edge8, int *__restrict__ label, const int *__restrict__ str, int t_edge, int t_strong,
+                                                               int iw, int ih, unsigned long long *__restrict__ bits, long t0, int nring, size_t zs) {
+  const int z = blockIdx.z;
+  const int *label0 = label, *str0 = str;
+  const size_t N = (size_t)iw * ih;
+  const int8_t *ring0 = ring + (size_t)(t0 % nring) * N;
+  int8_t *out = ring + (size_t)((t0 + z + 1) % nring) * N;
+  RD_ZSHIFT(zs, edge8, label, str, bits);
+  const int x = (blockIdx.x * 64 + threadIdx.x) * 4, y = blockIdx.y * 4 + threadIdx.y;
+  if (x >= iw || y >= ih) return;
+  const int p = y * iw + x;
+  const int4 lv = *(const int4 *)(label + p);
+  const int l[4] = { lv.x, lv.y, lv.z, lv.w };
+  const bool rowin = y > 0 && y < ih - 1;
+  bool interior[4], need[4]; int sa[4], sb[4];
+  bool ask = false;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    interior[k] = rowin && x + k > 0 && x + k < iw - 1;
+    need[k] = l[k] > 0 && interior[k];
+    sa[k] = str[need[k] ? l[k] : 0];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) { sb[k] = 0; ask = ask || (need[k] && (sa[k] == t_strong - 1 || sa[k] == t_edge - 1)); }
+  if (__any(ask)) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (need[k] && (sa[k] == t_strong - 1 || sa[k] == t_edge - 1)) sb[k] = strong_before(label0, str0, ring0, zs, z - 1, l[k], iw, ih, t_strong);
+  }
+  int vs[4], ve[4], ln[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) strength_mask_one(l[k], need[k] ? sa[k] + sb[k] : 0, interior[k], t_edge, t_strong, vs[k], ve[k], ln[k]);
+  *(uint32_t *)(out + p) = (uint32_t)vs[0] | ((uint32_t)vs[1] << 8) | ((uint32_t)vs[2] << 16) | ((uint32_t)vs[3] << 24);
+  {
+    const unsigned long long b0 = __ballot(vs[0] != 0), b1 = __ballot(vs[1] != 0), b2 = __ballot(vs[2] != 0), b3 = __ballot(vs[3] != 0);
+    const int j = threadIdx.x;
+    const int wx = blockIdx.x * 4 + j, wpr = (iw + 63) >> 6;
+    if (j < 4 && wx < wpr) {
+      const int sh = 16 * j;
+      bits[(size_t)y * wpr + wx] = spread4((b0 >> sh) & 0xffffull) | (spread4((b1 >> sh) & 0xffffull) << 1) | (spread4((b2 >> sh) & 0xffffull) << 2) | (spread4((b3 >> sh) & 0xffffull) << 3);
+    }
+  }
+  *(uint32_t *)(edge8 + p) = (uint32_t)ve[0] | ((uint32_t)ve[1] << 8) | ((uint32_t)ve[2] << 16) | ((uint32_t)ve[3] << 24);
+  if (ln[0] != l[0] || ln[1] != l[1] || ln[2] != l[2] || ln[3] != l[3]) *(int4 *)(label + p) = make_int4(ln[0], ln[1], ln[2], ln[3]);
+}
+
 }  // namespace
 
 namespace rdk {
+
+// 1 if the frames of a group can take strength_masks_group (16-byte rows and planes)
+int strength_masks_group_fits(int iw, const void *label, const void *ring, const void *edge8, size_t zs) {
+  return (iw & 3) == 0 && (((uintptr_t)label | zs) & 15) == 0 && (((uintptr_t)ring | (uintptr_t)edge8) & 3) == 0;
+}
+void strength_masks_group(hipStream_t s, int8_t *ring, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih, unsigned long long *bits, long t0, int nring, int nz, size_t zs) {
+  hipLaunchKernelGGL(k_strength_masks_group, dim3(cdiv(iw, 256), cdiv(ih, 4), nz), block2, 0, s, ring, edge8, label, str, t_edge, t_strong, iw, ih, bits, t0, nring, zs);
+}
 
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, int skip_flatten) {
   const size_t zs = 0;

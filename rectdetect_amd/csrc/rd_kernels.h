@@ -69,6 +69,9 @@ void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int i
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih);
 // strong mask at t_strong (two copies) + edge mask at t_edge (int, int8), both from the unfiltered labels, + filter_strength at t_strong (label in place), one pass; t_edge <= t_strong
 // prev (optional): a 0/1 byte plane added to the sums element by element (sum of label l = str[l] + prev[l]: quirk H1 without a pass of its own); strong2 != prev
+// the strong masks of the nz frames of a group launch (frame z = sequence number t0 + z, planes zs bytes apart, masks in ring planes (t0 + z + 1) mod nring) in one launch
+int strength_masks_group_fits(int iw, const void *label, const void *ring, const void *edge8, size_t zs);
+void strength_masks_group(hipStream_t s, int8_t *ring, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih, unsigned long long *bits, long t0, int nring, int nz, size_t zs);
 void strength_masks(hipStream_t s, int *strong, int8_t *strong2, int *edge /* may be NULL */, int8_t *edge8, int *label, const int *str, int t_edge, int t_strong, int iw, int ih, const int8_t *prev = nullptr, unsigned long long *bits = nullptr);   // bits (optional): the strong mask as a bit plane too (ceil(iw / 64) words per row); strong may then be null
 
 // ---- rd_k_rect.hip: rect-path stages

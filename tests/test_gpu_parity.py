@@ -708,6 +708,51 @@ def test_group_launches_any_polling_pattern(zb, nslots, pattern, on_device, monk
 
 
 @pytest.mark.gpu
+def test_group_strong_masks_where_the_frame_before_decides(monkeypatch):
+    """A frame's strength sums start from the strong mask of the frame before (H1).  Group launches evaluate the masks of their 8 frames in ONE launch: the mask of the
+    frame before is 0 or 1, so it only decides sums that stand exactly one below a threshold, and is then evaluated on the spot, level by level down to the frame
+    before the group (k_strength_masks_group).  With the reference's thresholds hardly a sum of these streams stands there, so the thresholds are moved (test hook
+    RD_TEST_THRESHOLDS) onto the most frequent sums of the stream - thousands of components per frame then hang on their predecessor - and the group form must equal
+    the frame-by-frame form in every list of every frame, and in the mask planes of the last one."""
+    iw, ih, n = 640, 480, 40
+    frames = [synth.frame(synth.SEED0 + 35, iw, ih, t) for t in range(n)]
+    probe = ra.Detector(iw, ih, nslots=1, nworkers=0)
+    sums = []
+    for f in frames[:4]:
+        probe.enqueue(f); probe.poll(TAN36)
+        st = probe.plane("strsum")
+        sums.append(st[st > 1])      # (sums live at the components' roots; the debug plane shows them on top of the previous mask: 0 / 1 elsewhere)
+    probe.close()
+    vals, cnt = np.unique(np.concatenate(sums), return_counts=True)
+    common = vals[np.argsort(-cnt)][:3].tolist()
+    hits = 0
+    for te, ts in [(int(common[0]) + 1, int(common[0]) + 1), (int(min(common[:2])) + 1, int(max(common[:2])) + 1), (int(common[2]) + 1, 4 * int(common[2]) + 7)]:
+        monkeypatch.setenv("RD_TEST_THRESHOLDS", "%d,%d" % (te, ts))
+        outs = []
+        for env, nslots in (("1", 1), ("1", 32), (None, 32)):      # frame by frame alone, frame by frame inside groups, the group launch
+            if env: monkeypatch.setenv("RD_STRONG_BY_FRAME", env)
+            else: monkeypatch.delenv("RD_STRONG_BY_FRAME", raising=False)
+            det = ra.Detector(iw, ih, nslots=nslots, nworkers=1 if nslots > 1 else 0)
+            got, k = [], 0
+            for f in frames:
+                if k - len(got) == nslots: got.append((det.poll(TAN36), det.last_segments()))
+                det.enqueue(f); k += 1
+            while len(got) < k: got.append((det.poll(TAN36), det.last_segments()))
+            planes = (det.plane("strong"), det.plane("edge500"), det.plane("strsum"))
+            if nslots > 1: assert det.frames_per_launch() == 8
+            det.close()
+            outs.append((got, planes))
+        st = outs[0][1][2]
+        hits += int(((st == ts - 1) | (st == te - 1)).sum())
+        for other in outs[1:]:
+            for t, ((r1, s1), (r2, s2)) in enumerate(zip(outs[0][0], other[0])):
+                assert helpers.rects_equal(r1, r2) and helpers.segments_equal(s1, s2), (te, ts, t)
+            assert np.array_equal(outs[0][1][0], other[1][0]) and np.array_equal(outs[0][1][1], other[1][1]), (te, ts)
+    print("components whose sum stands one below a threshold in the last frames:", hits)
+    assert hits > 100, "the thresholds must sit on frequent sums, or the test shows nothing"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("zb,nslots", [(4, 9), (None, 7), (3, 8), (8, 33), (2, 7), (None, 64), (None, 128)])      # (64: bench.py's default; 128: workers that wait in two steps)
 def test_group_launches_sliding_window_with_slot_counts_that_are_no_multiple_of_the_group(zb, nslots, monkeypatch):
     """The steady state of a real caller (and of bench.py): nslots frames in flight, poll one, enqueue one - with a slot count that is
