@@ -751,15 +751,13 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
 // costs 6 + 2 + 12 label loads instead of 30 (measured at full rate, same box: 2, 3, 4, 6, 8 pixels: 2056, 2080, 2083 / 2067, 2079, 2062
 // frames/s) - and issues all of their label loads before using any, then the first pointer jumps together.
 #ifndef RR_PX
-#define RR_PX 6
+#define RR_PX 8
 #endif
 #ifndef RR_TY
-#define RR_TY 8          // thread rows per block (2 / 4 / 8 at full rate: 2094 / 2118 / 2124 frames/s)
+#define RR_TY 4          // thread rows per block.  (Round 5, once the thread's loads travelled together: 8 x 6 pixels 2646-2696 frames/s, 4 x 6 2755-2774, 4 x 8 2727-2734, 2 x 8 2699-2742,
+                         //  8 x 4 2669-2722, 8 x 12 2607-2623 - smaller blocks give their wave slots back sooner; before, with the loads one after the other, 2 / 4 / 8 rows: 2094 / 2118 / 2124.)
 #endif
 #define RR_MBITS 3
-#ifndef RR_NARROW
-#define RR_NARROW 1        // 0: every launch on 64 x RR_PX footprints, 2: every launch on 16 x (4 RR_PX)
-#endif
 #ifndef RR_GUARD1
 #define RR_GUARD1 0        // launch 1, proposals for parents outside the tile: 1 = the thread's guarding loads together, 0 = no guard, 2 = load and atomic pixel by pixel
 #endif
@@ -788,13 +786,10 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
   if (near) for (int t = tid; t < 64 * RR_TY * RR_PX; t += 64 * RR_TY) tmin[t] = 0x7fffffff;
   if (PHASE != 2) __syncthreads();
   const int mark = 1 + round % 7, mark_prev = round > 0 ? 1 + (round - 1) % 7 : 8;      // (8: matches nothing - before round 0 no plane lags)
-  // Which pixels a wave takes.  The launches that climb raw chains (PHASE 1, 2) are bound by the lines their gathers touch: the chains of neighbouring columns fall out of
-  // step wherever a vertical run ends (7 % of the pixels of the bench stream), so the 64 lanes of a row segment land on ~20 different 64-byte lines per jump.  There a wave
-  // takes a footprint 16 pixels wide (one line per row) and 4 x RR_PX rows tall: 9 lines per jump (simulated on the stream: 159 -> 74 lines per pixel row and launch 1, 87 -> 38
-  // in launch 2).  Once the trees are shallow the jumps read a few roots and the neighbour loads dominate: 64 x RR_PX as before.
-  constexpr bool NARROW = (RR_NARROW == 2 || (RR_NARROW == 1 && PHASE != 3)) && RR_TY == 8;
-  const int wv = rd_ty(), lx = NARROW ? ((wv & 3) * 16 + ((int)threadIdx.x & 15)) : (int)threadIdx.x;      // column and first row inside the block's 64 x (RR_TY * RR_PX) tile
-  const int ly = NARROW ? ((wv >> 2) * (4 * RR_PX) + ((int)threadIdx.x >> 4) * RR_PX) : wv * RR_PX;
+  // (A wave takes 64 pixels of RR_PX rows.  In the launches that climb raw chains the 64 lanes of a row land on ~20 different 64-byte lines per jump - the chains of neighbouring
+  //  columns fall out of step wherever a vertical run ends, 7 % of the pixels of the bench stream - and footprints 16 pixels wide and 4 RR_PX rows tall halve that (simulated: 159 -> 74
+  //  lines per pixel row in launch 1); measured +0.3 % with blocks of 8 x 6, -1.5 % with 4 x 8: the lines are not what those launches wait for.  profiles/NOTES_r05.md.)
+  const int lx = (int)threadIdx.x, ly = rd_ty() * RR_PX;      // column and first row inside the block's 64 x (RR_TY * RR_PX) tile
   const int yb = by * (RR_TY * RR_PX) + ly;      // the thread's RR_PX pixels lie below one another: each is the other's vertical neighbour
   const int x = bx * 64 + lx;
   int p0[RR_PX], og[RR_PX], g[RR_PX], nx[RR_PX], w0[RR_PX];
