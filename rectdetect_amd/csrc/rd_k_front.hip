@@ -68,12 +68,10 @@ __global__ __launch_bounds__(256) void k_bgr2plab_t(uint32_t *__restrict__ out, 
   __shared__ unsigned short s_s2l[RD_LUT_S2L_N], s_cf[RD_LUT_CF_N], s_cf2[RD_LUT_CF_N];
   __shared__ unsigned short tile[3][64][66];
   const int tid = rd_ty() * 64 + threadIdx.x;
-  for (int i = tid; i < RD_LUT_S2L_N; i += 256) s_s2l[i] = rd_lut_s2l[i];
-  for (int i = tid; i < RD_LUT_CF_N; i += 256) { s_cf[i] = rd_lut_cfunc[i]; s_cf2[i] = rd_lut_cfunc2[i]; }
-  __syncthreads();
   const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
   const int x = x0 + threadIdx.x;
-  // the thread's 16 pixels: all of their bytes are requested before the first is used (one wait for memory instead of sixteen)
+  // the thread's 16 pixels: all of their bytes are requested before the first is used (one wait for memory instead of sixteen) - and before the tables are
+  // staged, so that the frame's bytes travel while the tables do (the tables' loops wait for memory three times over)
   uint8_t pb[16], pg[16], pr[16];
 #pragma unroll
   for (int k = 0; k < 16; k++) {
@@ -81,6 +79,9 @@ __global__ __launch_bounds__(256) void k_bgr2plab_t(uint32_t *__restrict__ out, 
     const uint8_t *p = bgr + ((x < iw && y < ih) ? (size_t)y * ws + x * 3 : 0);
     pb[k] = p[0]; pg[k] = p[1]; pr[k] = p[2];
   }
+  for (int i = tid; i < RD_LUT_S2L_N; i += 256) s_s2l[i] = rd_lut_s2l[i];
+  for (int i = tid; i < RD_LUT_CF_N; i += 256) { s_cf[i] = rd_lut_cfunc[i]; s_cf2[i] = rd_lut_cfunc2[i]; }
+  __syncthreads();
 #pragma unroll
   for (int k = 0; k < 16; k++) {
     const int r = rd_ty() + 4 * k;

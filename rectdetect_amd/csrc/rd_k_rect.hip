@@ -374,23 +374,17 @@ __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, c
   if (rd_b.x < 0) return;
   RD_ZSHIFTZ(rd_b.z, zs, out, in, edge);
   constexpr int NC = (DS_ROWS + 2) * DS_P, IT = (NC + 255) / 256;
-  __shared__ uint32_t tq[NC];
-  __shared__ uint8_t tf[NC];        // bit 0: replaced as a centre (!(e < 1e-6)), bit 1: skipped as a neighbour (e >= 1e-6), bit 2: outside the frame
+  __shared__ uint32_t tq[IT * 256];      // (padded to whole rounds of the block: the staging below is straight-line code - no `cell exists` branch for the compiler to sink a load into)
+  __shared__ uint8_t tf[IT * 256];        // bit 0: replaced as a centre (!(e < 1e-6)), bit 1: skipped as a neighbour (e >= 1e-6), bit 2: outside the frame
   __shared__ int list[64 * DS_ROWS];
   __shared__ int nlist;
   __shared__ uint32_t qlut[QN == 24 ? 2560 : 1];      // g_quant24, two entries per word
   const int tx = threadIdx.x, tid = rd_ty() * 64 + tx;
   const int x0 = rd_b.x * 64, y0 = rd_b.y * DS_ROWS;
   if (tid == 0) nlist = 0;
-  if (QN == 24) {
-    uint32_t w[10];
-#pragma unroll
-    for (int i = 0; i < 10; i++) w[i] = ((const uint32_t *)g_quant24)[tid + 256 * i];
-#pragma unroll
-    for (int i = 0; i < 10; i++) qlut[tid + 256 * i] = w[i];
-    __syncthreads();
-  }
   {
+    // the tile's cells and the quantisation tables are requested together (the cells were loaded a pair at a time before, each pair behind the previous
+    // one's stores - the compiler had sunk every load into the branch that used it: five trips to memory one after the other, after the tables' one)
     uint32_t v[IT];
     float e[IT];
     bool ok[IT];
@@ -403,10 +397,17 @@ __global__ __launch_bounds__(256) void k_despeckle(uint32_t *__restrict__ out, c
       v[i] = in[a];
       e[i] = edge[a];
     }
+    if (QN == 24) {
+      uint32_t w[10];
+#pragma unroll
+      for (int i = 0; i < 10; i++) w[i] = ((const uint32_t *)g_quant24)[tid + 256 * i];
+#pragma unroll
+      for (int i = 0; i < 10; i++) qlut[tid + 256 * i] = w[i];
+      __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < IT; i++) {
       const int t = tid + 256 * i;
-      if (t >= NC) break;
       uint32_t qv = v[i];
       if (QN == 24) {
         const uint16_t *q16 = (const uint16_t *)qlut;
@@ -562,6 +563,15 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
     const int wv = rd_ty(), lx = threadIdx.x;
     int v[NR + NS];
     bool ok[NR + NS];
+    // (the words of the two bit planes travel with the colours: unconditional loads of clamped addresses, stored further down - requested after the colours'
+    //  stores, each behind a branch, they were two more trips to memory one after the other)
+    u64 wm = 0, we = 0;
+    bool okm = false, oke = false;
+    {
+      const int k = rd_b.x, yb0 = rd_b.y * RI_ROWS;
+      { const int r = tid >> 1, kk = k + (tid & 1), yy = yb0 + r; okm = tid < (RI_ROWS + 2) * 2 && yy < ih && kk < wpr; wm = mask[okm ? (size_t)yy * wpr + kk : 0]; }
+      { const int r = tid / 3, kk = k - 1 + tid % 3, yy = yb0 - 1 + r; oke = tid < (RI_ROWS + 3) * 3 && yy >= 0 && yy < ih && kk >= 0 && kk < wpr; we = edge[oke ? (size_t)yy * wpr + kk : 0]; }
+    }
     const int gxl = gx0 + lx;
     const bool cok = gxl >= 0 && gxl < iw;
 #pragma unroll
@@ -587,13 +597,10 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
       const int t = tid + 256 * j, r = t >> 4, c = 64 + (t & 15);
       if (r < RI_RH && c < RI_RW) { col[r * RI_RW + c] = v[NR + j]; lnk[r * RI_RW + c] = ok[NR + j] ? 0 : -1; }
     }
+    if (tid < (RI_ROWS + 2) * 2) sm[tid] = okm ? wm : 0ull;
+    if (tid < (RI_ROWS + 3) * 3) se[tid] = oke ? we : 0ull;
   }
   constexpr int MW = 64 + 2, MH = RI_ROWS + 2, MN = MW * MH;       // cells (RI_H .. RI_H + 65, RI_H .. RI_H + RI_ROWS + 1)
-  {
-    const int k = rd_b.x, y0 = rd_b.y * RI_ROWS;
-    if (tid < (RI_ROWS + 2) * 2) { const int r = tid >> 1, kk = k + (tid & 1), yy = y0 + r; sm[tid] = (yy < ih && kk < wpr) ? mask[(size_t)yy * wpr + kk] : 0ull; }
-    if (tid < (RI_ROWS + 3) * 3) { const int r = tid / 3, kk = k - 1 + tid % 3, yy = y0 - 1 + r; se[tid] = (yy >= 0 && yy < ih && kk >= 0 && kk < wpr) ? edge[(size_t)yy * wpr + kk] : 0ull; }
-  }
   __syncthreads();
   (void)MN;
   {
