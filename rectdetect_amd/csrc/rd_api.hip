@@ -1307,16 +1307,19 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
   struct { const char *n; const void *p; size_t bytes; } tab[] = {
     { "plab0", s->plab0, N * 4 }, { "plab1", s->plab1, N * 4 }, { "lblur", s->bl[0], N * 4 }, { "vxy", s->vxy, N * 8 }, { "strength", s->strength, N * 4 },
     { "nms", s->nms, N * 4 }, { "mask0", s->mask0, N * 4 }, { "tidy", s->tidy, N * 4 }, { "label1", s->label1, N * 4 }, { "strsum", s->strsum, N * 4 },
-    { "edge500", s->e8, N }, { "smooth", s->smooth, N * 4 }, { "quant", s->quant, N * 4 }, { "strong", s->strongbits, N * 4 }, { "junction", s->strongbits, N * 4 },
-    { "mergemask", s->mmbits, N * 4 }, { "region", s->region, N * 4 }, { "region0", s->region0, N * 4 }, { "rsize", s->rsize, N * 4 }, { "boundarysrc", s->boundarysrc, N * 4 },
+    { "edge500", s->e8, N }, { "smooth", s->smooth, N * 4 }, { "quant", s->quant, N * 4 }, { "strong", s->strongbits, (size_t)((d->iw + 63) / 64) * d->ih * 8 }, { "junction", s->strongbits, (size_t)((d->iw + 63) / 64) * d->ih * 8 },
+    { "mergemask", s->mmbits, (size_t)((d->iw + 63) / 64) * d->ih * 8 }, /* (bit planes: handed out as int planes by the branch below) */ { "region", s->region, N * 4 }, { "region0", s->region0, N * 4 }, { "rsize", s->rsize, N * 4 }, { "boundarysrc", s->boundarysrc, N * 4 },
     { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 }, { "polyctr", rdk::poly_scratch_counters(s->ps), 64 * 4 }, { "iirflags", s->flags, 16 * 4 }, { "d2work", s->d2s + N, 16 * 4 }, { "absorb", s->scratch2 + N + 64, 8 * 4 },
   };
   for (size_t i = 0; i < sizeof(tab) / sizeof(tab[0]); i++)
     if (!strcmp(tab[i].n, name)) {
       const size_t b = tab[i].bytes < max_bytes ? tab[i].bytes : max_bytes;
+      // (launches of a test tap: under the lock that keeps launches out of another thread's graph capture)
+      pthread_mutex_lock(&d->launch_mu);
       if (!strcmp(name, "lsid")) rdk::polyline_ids(s->st, s->frame, 1, (int)N);   // not part of the frame path: built from the compact state
       if ((!strcmp(name, "plab1") || !strcmp(name, "vxy") || !strcmp(name, "strength")) && front_is_fused(d))
         frames_grad_nms(d, s, s->st, 1, 0, 1);      // these never leave the chip on the frame path: the same kernel again, writing them out (the blurred planes are intact)
+      pthread_mutex_unlock(&d->launch_mu);
       RD_HIP(hipStreamSynchronize(s->st));
       if (!strcmp(name, "strong") || !strcmp(name, "mergemask") || !strcmp(name, "junction")) {
         // kept as bit planes on the device (what the polyline stage traces / what the region stage reads); handed out as the int planes of
@@ -1324,6 +1327,7 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
         const size_t n = N * 4 <= max_bytes ? N : max_bytes / 4;
         const int wpr = (d->iw + 63) / 64, iw = d->iw, ih = d->ih;
         unsigned long long *tmp = (unsigned long long *)malloc((size_t)wpr * ih * 8 + 8);
+        if (!tmp) exitf(-1, "rd_detector_debug_plane: out of memory\n");
         RD_HIP(hipMemcpy(tmp, tab[i].p, (size_t)wpr * ih * 8, hipMemcpyDeviceToHost));
         auto bit = [&](int x, int y) { return (int)((tmp[(size_t)y * wpr + (x >> 6)] >> (x & 63)) & 1ull); };
         for (size_t k = 0; k < n; k++) {

@@ -7,6 +7,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #define RD_WAVE 64
 
@@ -136,9 +138,25 @@ template <typename T> __device__ __forceinline__ T *rd_zs_ptr(T *p, size_t off) 
 // depends on where a block runs.  gdim = rd_gdim(gx, gy, nz).
 // threadIdx.y of a block whose rows are waves (every 2-D block here is 64 threads wide) as a SCALAR: row numbers, row addresses and row tests that depend on
 // it alone then run on the scalar unit instead of costing every lane a vector instruction
-__device__ __forceinline__ int rd_ty() { return __builtin_amdgcn_readfirstlane((int)threadIdx.y); }
+// (Only right for blocks whose rows are whole waves: 64 threads wide on a wave64 target.  gfx950 is wave64 - checked here - and every launch that uses it goes
+//  through dim3(64, rows); a build with -DRD_DEBUG_LAUNCH checks blockDim.x.)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "these kernels are written for gfx950 (64-wide waves: rd_ty(), the ballots and the DPP wave shifts rest on it)"
+#endif
+__device__ __forceinline__ int rd_ty() {
+#ifdef RD_DEBUG_LAUNCH
+  if (blockDim.x != 64) __builtin_trap();
+#endif
+  return __builtin_amdgcn_readfirstlane((int)threadIdx.y);
+}
 struct rd_tile { int x, y, z; };
-__host__ __device__ inline int rd_gdim(int gx, int gy, int nz) { return gx | (gy << 12) | (nz << 24); }
+// (12 bits each for the tile columns and rows, 7 for the frames: a launch beyond that would decode the wrong tile - the host side refuses it)
+__host__ __device__ inline int rd_gdim(int gx, int gy, int nz) {
+#if !defined(__HIP_DEVICE_COMPILE__)
+  if (gx < 1 || gy < 1 || nz < 1 || gx >= 4096 || gy >= 4096 || nz >= 128) { fprintf(stderr, "rd_gdim: %d x %d tiles x %d frames do not fit the packed grid word (4095 x 4095 x 127)\n", gx, gy, nz); abort(); }
+#endif
+  return gx | (gy << 12) | (nz << 24);
+}
 // blocks to launch for gx x gy tiles x nz frames
 __host__ __device__ inline int rd_tile_blocks(int gx, int gy, int nz) { return gx * gy * nz; }
 // the block's tile (x < 0 would mean "a block of padding": none at present - other launches than 8-frame groups keep the plain raster order; giving each XCD a

@@ -1182,6 +1182,12 @@ void polyline(hipStream_t st, const PolyFrame *frames_host, int nb, int lslist_b
 
   // tidy (oclpolyline.c:222-235) and compaction of the chain pixels in raster order, on bit planes
   const int wpr = cdiv(iw, 64);
+  // (all frames of a launch come from one caller: either all hand over the strong mask as a bit plane - then the stale-ring emulation of H3 takes its constant form and a
+  //  ring source cannot be honoured - or all as int planes)
+  for (int z = 0; z < nb; z++) {
+    if ((frames_host[z].in_bits == nullptr) != (frames_host[0].in_bits == nullptr)) { fprintf(stderr, "polyline: the frames of one launch mix bit-plane and int-plane input\n"); abort(); }
+    if (frames_host[z].in_bits != nullptr && frames_host[z].ring_src != nullptr) { fprintf(stderr, "polyline: a frame hands over a bit plane AND a ring source (the ring is only read from int planes)\n"); abort(); }
+  }
   if (frames_host[0].in_bits == nullptr) hipLaunchKernelGGL(k_mask_bits, dim3(wpr, cdiv(ih, 4), nb), dim3(64, 4), 0, st, frames, iw, ih, wpr);      // (all frames of a launch come from one caller)
   hipLaunchKernelGGL(k_tidy_bits, dim3(cdiv(wpr, 4), cdiv(ih, TB_OUT), nb), dim3(256), 0, st, frames, ring_const, iw, ih, wpr);
   hipLaunchKernelGGL(k_row_prefix, dim3(cdiv(ih, 4), 1, nb), dim3(256), 0, st, frames, ih, wpr);

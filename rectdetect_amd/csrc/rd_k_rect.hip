@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256) void k_mm_gather(unsigned long long *__restric
 #define RI_NC (RI_RW * RI_RH)
 // mask / edge: the merge mask and the strong mask as bit planes (wpr words per row); size_out (optional) <- the junction counts of the strong mask
 // (rc:74-95), which the region sizes start from (quirk H2: the reference counts into the plane that still holds them)
-__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *__restrict__ B, uint8_t *__restrict__ allow, const int *__restrict__ pix, const u64 *__restrict__ mask,
+__global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *__restrict__ B, u64 *__restrict__ allow, const int *__restrict__ pix, const u64 *__restrict__ mask,
                                                      const u64 *__restrict__ edge, int iw, int ih, int wpr, int *__restrict__ flags, int *__restrict__ size_out, size_t zs, int gdim) {
   const rd_tile rd_b = rd_block_tile(gdim);
   if (rd_b.x < 0) return;
@@ -708,7 +708,6 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
     const int w = ((gy0 + l / RI_RW) * iw + gx0 + l % RI_RW) << 3;
     A[p] = w;
     B[p] = w;
-    allow[p] = alw[c];
     if (size_out) {
       // rc:74-95: on-pixels of the 3x3 block, the pixel's own included; 1 -> 0; the frame's border and off-pixels 0
       int j = 0;
@@ -724,6 +723,17 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
         j = cnt == 1 ? 0 : cnt;
       }
       size_out[p] = j;
+    }
+  }
+  // the allow bytes of 8 rows as one word per column (word (y >> 3) * iw + x, byte y & 7): a thread of the rounds takes 8 rows of a column and reads them with one load
+  static_assert(RI_ROWS == 32, "four waves, eight rows each");
+  {
+    const int r0 = rd_ty() * 8, y0 = rd_b.y * RI_ROWS + r0;
+    if (y0 < ih) {
+      u64 w = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) w |= (u64)((y0 + k < ih) ? alw[(r0 + k + RI_H) * RI_RW + threadIdx.x + RI_H] : 0) << (8 * k);
+      allow[(size_t)(y0 >> 3) * iw + x] = w;
     }
   }
 }
@@ -765,6 +775,9 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
                          //  8 x 4 2669-2722, 8 x 12 2607-2623 - smaller blocks give their wave slots back sooner; before, with the loads one after the other, 2 / 4 / 8 rows: 2094 / 2118 / 2124.)
 #endif
 #define RR_MBITS 3
+#ifndef RR_DPP
+#define RR_DPP 1           // the left / right neighbours' words from the neighbouring lanes (0: loaded)
+#endif
 #ifndef RR_GUARD1
 #define RR_GUARD1 0        // launch 1, proposals for parents outside the tile: 1 = the thread's guarding loads together, 0 = no guard, 2 = load and atomic pixel by pixel
 #endif
@@ -779,7 +792,7 @@ __device__ __forceinline__ int rr_label(const int *X, unsigned q) { return at32(
 //  them for the neighbouring tiles: 64 % of this kernel's L2 requests missed before.)
 // PHASE: 1 = launch 1 (proposals meet in the tile), 2 = the other launches that climb raw chains (every pixel hooks its own parent), 3 = the rest (parents combined per block)
 template <int PHASE>
-__global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, const uint8_t *__restrict__ allow, int iw, int ih, int *flags, int round, size_t zs, int gdim) {
+__global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, const u64 *__restrict__ allow, int iw, int ih, int *flags, int round, size_t zs, int gdim) {
   const rd_tile rd_b = rd_block_tile(gdim);
   if (rd_b.x < 0) return;
   const int bx = rd_b.x, by = rd_b.y;
@@ -803,27 +816,51 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
   unsigned a[RR_PX];
   bool valid[RR_PX], todo[RR_PX];
   {
-    unsigned q[RR_PX][5];       // (unsigned element indices: the loads then take the plane's base from scalar registers and a 32-bit offset, no 64-bit address arithmetic per access)
+    // (unsigned element indices: the loads take the plane's base from scalar registers and a 32-bit offset, no 64-bit address arithmetic per access.
+    //  Every load of this kernel is UNCONDITIONAL, with the address of a pixel that exists where the value is not wanted: a load under a condition becomes a
+    //  branch with a wait for ALL loads in flight behind it - the thread's loads then travel one after the other.)
     int l[RR_PX][5];
+    static_assert(RR_PX == 8, "the allow bytes of a thread's 8 rows are one word (k_region_init)");
+    const bool colin = x < iw && yb < ih;
+    const u64 aw = allow[colin ? (size_t)(yb >> 3) * iw + x : 0];
 #pragma unroll
     for (int k = 0; k < RR_PX; k++) {
       const int y = yb + k;
       valid[k] = x < iw && y < ih;
       p0[k] = valid[k] ? y * iw + x : 0;
-      // (every load of this kernel is UNCONDITIONAL, with the address of a pixel that exists where the value is not wanted: a load under a condition becomes a
-      //  branch with a wait for ALL loads in flight behind it - the six pixels' loads then travel one after the other, six trips to memory instead of one)
-      const unsigned ab = allow[(unsigned)p0[k]];
-      a[k] = valid[k] ? ab : 0u;
-      // neighbour addresses clamped into the plane: the loads are unconditional, their use depends on the allow bits
-      q[k][0] = p0[k];
-      q[k][1] = (valid[k] && y > 0) ? p0[k] - iw : p0[k];
-      q[k][2] = (valid[k] && x > 0) ? p0[k] - 1 : p0[k];
-      q[k][3] = (valid[k] && x < iw - 1) ? p0[k] + 1 : p0[k];
-      q[k][4] = (valid[k] && y < ih - 1) ? p0[k] + iw : p0[k];
-#pragma unroll
-      for (int c = 0; c < 5; c++)
-        if (!((c == 1 && k > 0) || (c == 4 && k < RR_PX - 1))) l[k][c] = at32(X, q[k][c]);
+      a[k] = valid[k] ? (unsigned)(aw >> (8 * k)) & 0xffu : 0u;
+      l[k][0] = at32(X, (unsigned)p0[k]);
     }
+    // neighbours: above / below inside the thread's own column, or one load each for the first and the last row; left / right from the neighbouring LANES (wave shifts,
+    // no memory instruction) - the wave's outermost lanes take theirs from one more load per row in which the lower half of the wave asks for the pixel left of the tile
+    // and the upper half for the pixel right of it (two addresses per load).  Addresses clamped into the plane; whether a neighbour counts depends on the allow bits,
+    // which are 0 towards anything outside the frame.
+    l[0][1] = at32(X, (unsigned)((valid[0] && yb > 0) ? p0[0] - iw : p0[0]));
+    l[RR_PX - 1][4] = at32(X, (unsigned)((valid[RR_PX - 1] && yb + RR_PX - 1 < ih - 1) ? p0[RR_PX - 1] + iw : p0[RR_PX - 1]));
+#if RR_DPP
+    {
+      const int x0 = bx * 64;
+      const bool lowhalf = threadIdx.x < 32;
+      const int xe = lowhalf ? x0 - 1 : x0 + 64;
+      int ed[RR_PX];
+#pragma unroll
+      for (int k = 0; k < RR_PX; k++) {
+        const int y = yb + k;
+        ed[k] = at32(X, (unsigned)((y < ih && xe >= 0 && xe < iw) ? y * iw + xe : p0[k]));
+      }
+#pragma unroll
+      for (int k = 0; k < RR_PX; k++) {
+        l[k][2] = __builtin_amdgcn_update_dpp(ed[k], l[k][0], 0x138, 0xf, 0xf, false);      // wave_shr:1 - lane i takes lane i - 1's word, lane 0 keeps `ed` (the pixel left of the tile)
+        l[k][3] = __builtin_amdgcn_update_dpp(ed[k], l[k][0], 0x130, 0xf, 0xf, false);      // wave_shl:1 - lane i takes lane i + 1's word, lane 63 keeps `ed` (the pixel right of the tile)
+      }
+    }
+#else
+#pragma unroll
+    for (int k = 0; k < RR_PX; k++) {
+      l[k][2] = at32(X, (unsigned)((valid[k] && x > 0) ? p0[k] - 1 : p0[k]));
+      l[k][3] = at32(X, (unsigned)((valid[k] && x < iw - 1) ? p0[k] + 1 : p0[k]));
+    }
+#endif
 #pragma unroll
     for (int k = 0; k < RR_PX; k++) {       // (the neighbours inside the thread's own column: no loads; an invalid pixel's word is never used - its neighbour above is on the ring)
       if (k > 0) l[k][1] = l[k - 1][0];
@@ -1960,7 +1997,7 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
   const int n = iw * ih;
   if (ROUNDS < 2 || (ROUNDS & 1) || ROUNDS > 64) { fprintf(stderr, "region_merge: the number of launches must be even, 2..64 (got %d)\n", ROUNDS); abort(); }
   int *flags = scratch + n;
-  uint8_t *allow = (uint8_t *)(flags + RR_NFLAGS);
+  u64 *allow = (u64 *)(((uintptr_t)(flags + RR_NFLAGS) + 7) & ~(uintptr_t)7);      // ceil(ih / 8) * iw words: the allow bytes of 8 rows per column (k_region_init)
   int *A = label, *B = scratch + 2 * (size_t)n;   // the two planes of the rounds; the result is in A
   hipLaunchKernelGGL(k_region_init, dim3(rd_tile_blocks(cdiv(iw, 64), cdiv(ih, RI_ROWS), nz)), dim3(64, 4), 0, s, A, B, allow, pix, mask, edge, iw, ih, cdiv(iw, 64), flags, size_out, zs, rd_gdim(cdiv(iw, 64), cdiv(ih, RI_ROWS), nz));
   const dim3 grid(cdiv(iw, 64), cdiv(ih, RR_TY * RR_PX), nz);
@@ -1968,9 +2005,9 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
     const dim3 lg(rd_tile_blocks((int)grid.x, (int)grid.y, (int)grid.z));
     const int gdim = rd_gdim((int)grid.x, (int)grid.y, (int)grid.z);
     int *X = (r & 1) ? B : A, *Y = (r & 1) ? A : B;
-    if (r == 1) hipLaunchKernelGGL(k_region_round<1>, lg, dim3(64, RR_TY), 0, s, X, Y, (const uint8_t *)allow, iw, ih, flags, r, zs, gdim);
-    else if (r < RR_DEEP) hipLaunchKernelGGL(k_region_round<2>, lg, dim3(64, RR_TY), 0, s, X, Y, (const uint8_t *)allow, iw, ih, flags, r, zs, gdim);
-    else hipLaunchKernelGGL(k_region_round<3>, lg, dim3(64, RR_TY), 0, s, X, Y, (const uint8_t *)allow, iw, ih, flags, r, zs, gdim);
+    if (r == 1) hipLaunchKernelGGL(k_region_round<1>, lg, dim3(64, RR_TY), 0, s, X, Y, (const u64 *)allow, iw, ih, flags, r, zs, gdim);
+    else if (r < RR_DEEP) hipLaunchKernelGGL(k_region_round<2>, lg, dim3(64, RR_TY), 0, s, X, Y, (const u64 *)allow, iw, ih, flags, r, zs, gdim);
+    else hipLaunchKernelGGL(k_region_round<3>, lg, dim3(64, RR_TY), 0, s, X, Y, (const u64 *)allow, iw, ih, flags, r, zs, gdim);
   }
   if (marked) *marked = 1;
 }

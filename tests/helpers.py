@@ -200,19 +200,33 @@ def segments_equal(a, b):
 
 
 # ---- parity report: what the GPU tests MEASURE about the deviation from the reference's raster-order output (counts, not pass / fail), kept as a
-# file so that it shows up in the driver's record (__graft_entry__.smoke() prints it) instead of being swallowed by `pytest -q`
+# file so that it shows up in the driver's record (__graft_entry__.smoke() prints it) instead of being swallowed by `pytest -q`.  The tests write the scratch
+# copy under gpurun_out/ only (untracked; stamped with the commit it was measured at and cleared when the commit changes); tools/update_parity_report.py
+# copies it to the tracked tests/parity_report.json when a round's numbers are to be kept.
 PARITY_REPORT = os.path.join(ROOT, "tests", "parity_report.json")
+PARITY_SCRATCH = os.path.join(ROOT, "gpurun_out", "parity_report.json")
+
+
+def _commit():
+    import subprocess
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip() or None
+    except Exception:
+        return None
 
 
 def parity_report(section, key, value):
     import json
+    here = _commit() or os.environ.get("RD_COMMIT") or "unknown (no .git on the GPU box)"
     try:
-        with open(PARITY_REPORT) as f:
+        with open(PARITY_SCRATCH) as f:
             rep = json.load(f)
+        if rep.get("_measured_at", {}).get("commit") != here:
+            rep = {}
     except (OSError, ValueError):
         rep = {}
+    rep["_measured_at"] = {"commit": here}
     rep.setdefault(section, {})[key] = value
-    for path in (PARITY_REPORT, os.path.join(ROOT, "gpurun_out", "parity_report.json")):
-        if os.path.isdir(os.path.dirname(path)):
-            with open(path, "w") as f:
-                json.dump(rep, f, indent=1, sort_keys=True)
+    os.makedirs(os.path.dirname(PARITY_SCRATCH), exist_ok=True)
+    with open(PARITY_SCRATCH, "w") as f:
+        json.dump(rep, f, indent=1, sort_keys=True)

@@ -1370,7 +1370,7 @@ def test_builtin_sensitivity_report():
     contraction) are choices of ours.  tests/golden/builtin_sensitivity.npz (tools/make_golden_builtins.py) holds what THE
     REFERENCE returns for seven fixture frames under the other legal choices.  Here: which of those variants' rectangle lists the HIP path's list
     equals - it must equal the baseline's, the definitions the HIP kernels share - and how far the other variants move the reference itself;
-    written to tests/parity_report.json so that it shows in the driver's record."""
+    written to the parity report (gpurun_out/parity_report.json; tools/update_parity_report.py keeps a round's copy) so that it shows in the driver's record."""
     g = golden("builtin_sensitivity")
     variants = [str(v) for v in g["variants"]]
     key = lambda r: r["c2"].tobytes() + r["c3"].tobytes() + r["value"].tobytes() + r["status"].tobytes()
