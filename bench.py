@@ -158,6 +158,22 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def reference_opencl_baseline(timeout_s=150):
+    """The reference ITSELF on this box's OpenCL device - on the GPU box that is the MI355X the HIP path runs on, through ROCm's OpenCL: oracle/_ref/librdref_ocl.so
+    (the reference's unchanged host C linked against the system's OpenCL loader; its .cl sources are compiled at run time by the device's own compiler).  A same-box,
+    same-device baseline beside the CPU one; checker-side code (oracle/), in a process of its own with a time limit - None where there is no OpenCL device or library."""
+    import subprocess
+    so = os.path.join(ROOT, "oracle", "_ref", "librdref_ocl.so")
+    if not os.path.exists(so):
+        return None
+    try:
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ref_on_opencl.py"), "bench"], cwd=ROOT, capture_output=True, text=True, timeout=timeout_s)
+        lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if p.returncode == 0 and lines else {"value": None, "error": (p.stderr or p.stdout)[-300:]}
+    except Exception as e:      # (no device, no loader, time limit: a baseline that is missing must not take the line with it)
+        return {"value": None, "error": str(e)[-300:]}
+
+
 def side_config(ra, L, label, iw, ih, seed, nframes, slots, dev, min_seconds=1.5):
     """one of the other single-GPU configurations of BASELINE.json, the way the headline is measured: `nframes` consecutive frames of the
     synthetic stream resident in HBM, `slots` frames in flight, one untimed pass (graph capture, round budget), then whole passes over
@@ -471,13 +487,20 @@ def main():
                          "frames_repeated": {"round_budget": det.region_round_budget()[1], "polyline_overflow": det.redone_frames(), "absorption_slow_path": det.absorption()[2]} if det is not None else None},
         }
         if det is not None and world == 1 and not args.no_configs and not args.no_verify:
-            # BASELINE.json configs[2] and configs[3] (configs[1], the 1920x1080 still, is a frame of the headline stream), outside the timed region
+            # BASELINE.json configs[2] and configs[3] (configs[1], the 1920x1080 still, is a frame of the headline stream), outside the timed region - each
+            # configuration alone on the device, as it would run: the headline's detector (its 64 slots of planes, its worker threads) is closed first
+            det.close()
+            det = None
+            for p in dframes:
+                L.rd_device_free(p)
+            dframes = []
             out["configs"] = [side_config(ra, L, "vidrect 1280x720 synthetic 300-frame stream (BASELINE.json configs[2])", 1280, 720, 1, 300, args.slots, dev),
                               side_config(ra, L, "vidrect 3840x2160 synthetic stream, 16 frames resident (BASELINE.json configs[3])", 3840, 2160, 4, 16, min(args.slots, 16), dev)]
             out["configs"] += reference_api_config(ra, frames, dev)
         out.update(verify or {"outputs_verified": None})
         if not args.dry_run and not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
+            out["reference_opencl_same_gpu"] = reference_opencl_baseline()
         if args.dry_run:
             out["dry_run"] = True
         print(json.dumps(out), flush=True)

@@ -66,7 +66,7 @@ def compare(a, b, tol=1e-4):
         d = np.abs(b["c2"] - r["c2"]).reshape(len(b), -1).max(1)
         far = max(far, float(d.min()))
         matched += int(d.min() <= 1.0)
-    return {"equal": ka == kb, "within_1e-4": within, "n": len(a), "n_golden": len(b), "common_bitwise": len(ka & kb), "matched_within_1px": matched, "max_nearest_corner_distance": far}
+    return {"equal": ka == kb, "within_1e-4": within, "n": len(a), "n_golden": len(b), "n_distinct": len(ka), "n_golden_distinct": len(kb), "common_bitwise": len(ka & kb), "matched_within_1px": matched, "max_nearest_corner_distance": far}
 
 
 class Rect:
@@ -119,6 +119,10 @@ def section_poly(R, rep):
             m = (got[1:]["polyid"] != 0) & (gold[1:]["polyid"] != 0)
             row["records_differing"] = int(sum(got[1:][m][k].tobytes() != gold[1:][m][k].tobytes() for k in range(int(m.sum()))))
             row["max_coordinate_difference"] = max(float(np.abs(got[1:][m][c] - gold[1:][m][c]).max(initial=0)) for c in ("x0", "y0", "x1", "y1"))
+        # (record ids follow the work-item order of the split rounds: compare the segments as a set of end-point quadruples as well)
+        quad = lambda a: {(float(r["x0"]), float(r["y0"]), float(r["x1"]), float(r["y1"])) for r in a[1:] if r["polyid"] != 0}
+        qa, qb = quad(got), quad(gold)
+        row["valid_segments"], row["valid_segments_golden"], row["segments_common_as_end_point_quadruples"] = len(qa), len(qb), len(qa & qb)
         rows.append(row)
         print("poly", row, flush=True)
     rep["poly"] = rows
@@ -182,7 +186,40 @@ def section_timing(R, rep):
     rep["timing"] = out
 
 
+def bench_line():
+    """bench.py's baseline leg: the reference on this box's OpenCL device, 1920x1080, one JSON line on stdout (bounded: ~40 frames)"""
+    R = load()
+    iw, ih, n = 1920, 1080, 40
+    frames = [np.ascontiguousarray(synth.frame(synth.SEED0, iw, ih, t)) for t in range(4)]
+    t_init = time.perf_counter()
+    d = Rect(R, iw, ih)
+    res = np.zeros(1024, RECT_DTYPE)
+    d.once(frames[0])
+    t_init = time.perf_counter() - t_init
+    lat = []
+    for t in range(8):
+        t0 = time.perf_counter()
+        d.once(frames[t % 4])
+        lat.append(time.perf_counter() - t0)
+    R.rdref_rect_enqueue(d.h, frames[0].ctypes.data, frames[0].strides[0])
+    t0 = time.perf_counter()
+    for t in range(1, n + 1):
+        f = frames[t % 4]
+        R.rdref_rect_enqueue(d.h, f.ctypes.data, f.strides[0])
+        R.rdref_rect_poll(d.h, TAN36, res.ctypes.data, 1024)
+    dt = time.perf_counter() - t0
+    R.rdref_rect_poll(d.h, TAN36, res.ctypes.data, 1024)
+    d.close()
+    print(json.dumps({"value": round(n / dt, 2), "unit": "frames/s", "kind": "reference", "device": "this box's OpenCL device (ROCm OpenCL: the GPU the HIP path runs on)",
+                      "execute_once_ms_median": round(float(np.median(lat)) * 1e3, 2), "init_and_first_frame_s": round(t_init, 1),
+                      "sample": "%d consecutive 1920x1080 frames, oclrect_enqueueTask / oclrect_pollTask two deep (vidrect.cpp:159-205), after 9 untimed; the reference's unchanged host C and .cl sources, "
+                                "built at run time by the device's OpenCL compiler with the reference's own (empty) options" % n}), flush=True)
+
+
 def main():
+    if sys.argv[1:] == ["bench"]:
+        bench_line()
+        return
     want = sys.argv[1:] or ["stills", "poly", "stream", "repeat", "timing"]
     try:
         with open(OUT) as f:
