@@ -594,7 +594,7 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t 
   // mask of positive responses and the rect-path tidy (oclrect.c:262-272)
   // components (background included) of the tidied mask; the tidy itself runs inside the labelling's tile kernel (and clears the
   // strength sums for the H1 segment); the walk to the roots happens in the first kernel of the next segment
-  rdk::label8_tidy(st, s->label1, s->mask0, s->tidy, s->nms, s->strsum, iw, ih, 1);
+  rdk::label8_tidy(st, s->label1, NULL, s->tidy, s->nms, s->strsum, iw, ih, 1);      // (the mask of positive responses, oclrect.c:262-264, is not stored: nothing reads it - debug plane "mask0" derives it from the responses)
   // strength sums per component (oclrect.c:274-275) - without the strong mask of the frame before (H1), which frame_strong() adds
   rdk::calc_strength(st, s->strsum, s->nms, s->label1, iw, ih, NULL, 1);
   return;
@@ -712,7 +712,7 @@ static void group_segment(rd_detector *d, Slot *s, int nz, int seg, hipStream_t 
     { const float *c[3] = { s->tr[0], s->tr[1], s->tr[2] }; rdk::iir_blur_pass(st, s->hz, c, s->fw, s->bw, 3, ih, iw, 1, s->tails, s->flags, 1, nz, zs); }
     { const float *c[3] = { s->hz[0], s->hz[1], s->hz[2] }; rdk::iir_blur_pass(st, s->bl, c, s->fw, s->bw, 3, iw, ih, 0, s->tails, s->flags + 1, 0, nz, zs); }
     frames_grad_nms(d, s, st, nz, zs);
-    rdk::label8_tidy(st, s->label1, s->mask0, s->tidy, s->nms, s->strsum, iw, ih, 1, nz, zs);
+    rdk::label8_tidy(st, s->label1, NULL, s->tidy, s->nms, s->strsum, iw, ih, 1, nz, zs);
     rdk::calc_strength(st, s->strsum, s->nms, s->label1, iw, ih, NULL, 1, nz, zs);
     return;
   }
@@ -1306,7 +1306,7 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
   const size_t N = (size_t)d->N;
   struct { const char *n; const void *p; size_t bytes; } tab[] = {
     { "plab0", s->plab0, N * 4 }, { "plab1", s->plab1, N * 4 }, { "lblur", s->bl[0], N * 4 }, { "vxy", s->vxy, N * 8 }, { "strength", s->strength, N * 4 },
-    { "nms", s->nms, N * 4 }, { "mask0", s->mask0, N * 4 }, { "tidy", s->tidy, N * 4 }, { "label1", s->label1, N * 4 }, { "strsum", s->strsum, N * 4 },
+    { "nms", s->nms, N * 4 }, { "mask0", s->nms, N * 4 }, { "tidy", s->tidy, N * 4 }, { "label1", s->label1, N * 4 }, { "strsum", s->strsum, N * 4 },
     { "edge500", s->e8, N }, { "smooth", s->smooth, N * 4 }, { "quant", s->quant, N * 4 }, { "strong", s->strongbits, (size_t)((d->iw + 63) / 64) * d->ih * 8 }, { "junction", s->strongbits, (size_t)((d->iw + 63) / 64) * d->ih * 8 },
     { "mergemask", s->mmbits, (size_t)((d->iw + 63) / 64) * d->ih * 8 }, /* (bit planes: handed out as int planes by the branch below) */ { "region", s->region, N * 4 }, { "region0", s->region0, N * 4 }, { "rsize", s->rsize, N * 4 }, { "boundarysrc", s->boundarysrc, N * 4 },
     { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 }, { "polyctr", rdk::poly_scratch_counters(s->ps), 64 * 4 }, { "iirflags", s->flags, 16 * 4 }, { "d2work", s->d2s + N, 16 * 4 }, { "absorb", s->scratch2 + N + 64, 8 * 4 },
@@ -1339,6 +1339,15 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
           }
           ((int *)dst)[k] = v;
         }
+        free(tmp);
+        return n * 4;
+      }
+      if (!strcmp(name, "mask0")) {         // not stored on the frame path: the mask of positive responses (oclrect.c:262-264), from the suppressed strength
+        const size_t n = N * 4 <= max_bytes ? N : max_bytes / 4;
+        float *tmp = (float *)malloc(n ? n * 4 : 4);
+        if (!tmp) exitf(-1, "rd_detector_debug_plane: out of memory\n");
+        RD_HIP(hipMemcpy(tmp, s->nms, n * 4, hipMemcpyDeviceToHost));
+        for (size_t k = 0; k < n; k++) ((int *)dst)[k] = tmp[k] > 0.0f ? 1 : 0;
         free(tmp);
         return n * 4;
       }

@@ -36,7 +36,7 @@ __device__ __forceinline__ void br_count8(bitrow u, bitrow m, bitrow d, bitrow &
 // mask (NMS response > 0, rh:262-264) -> junction counts -> gap closing -> two thinning passes (rh:266-272; rc:67-135) for one
 // 64 x ROWS tile: the four stencils need 4 cells of margin in total.
 // Block of 256 threads (64 x 4), tid = ty * 64 + tx.  A, B: (ROWS + 8) * 72 bytes of LDS each, 16-byte aligned (they hold three bit
-// planes each).  The results of the tile's own pixels are stored to mask0 / tidy (and zero_plane cleared, if given) and returned in
+// planes each).  The results of the tile's own pixels are stored to mask0 (if given) / tidy (and zero_plane cleared, if given) and returned in
 // outv[j] for row ty + 4 j, column tx (0 for pixels outside the frame).
 #define TD_M 4
 #define TD_P (64 + 2 * TD_M)
@@ -72,7 +72,7 @@ __device__ __forceinline__ void rect_tidy_tile(uint8_t *A, uint8_t *B, int x0, i
       if (r < R && lane == 0) M[r] = br(ba, bb);
       // the tile's own cells of the mask plane: columns 0..59 from the first load, 60..63 from the second
       const int ta = lane - TD_M, tb = lane + 64 - TD_M, tr = r - TD_M;
-      if (tr >= 0 && tr < ROWS) {
+      if (mask0 != nullptr && tr >= 0 && tr < ROWS) {      // (the mask as an int plane: the operator's output; the frame path keeps it as these bit rows only)
         if (oka[k] && ta >= 0) mask0[y * iw + x0 + ta] = va ? 1 : 0;
         if (okb[k] && tb < 64) mask0[y * iw + x0 + tb] = vb ? 1 : 0;
       }
