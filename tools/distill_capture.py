@@ -24,7 +24,7 @@ with open(os.path.join(P, pre + "_size_sweep.txt"), "w") as f:
 for name, out in (("trace_default", "kernel_stats_1080p_default.txt"), ("trace_slots1", "kernel_stats_1080p_slots1.txt")):
     db = os.path.join(C, name, "t_results.db")
     con = sqlite3.connect(db)
-    frames = con.execute("select total_calls from top_kernels where name like '%k_strength_masks%'").fetchone()[0]
+    frames = 256 if name == "trace_default" else 16      # (steps + warmup) x frames per step of the command below
     head = "# rocprofv3 --kernel-trace --stats -- python bench.py %s (%d frames)\n" % (
         "--steps 3 --warmup 1 --frames-per-step 64 --no-cpu-baseline --no-verify --no-configs" if name == "trace_default" else "--steps 1 --warmup 1 --slots 1 --frames-per-step 8 --no-cpu-baseline --no-verify --no-configs", frames)
     with open(os.path.join(P, pre + "_" + out), "w") as f:
@@ -35,7 +35,7 @@ for name, out, cmd in (("trace_720p", "kernel_stats_720p_default.txt", "--frame 
     db = os.path.join(C, name, "t_results.db")
     if not os.path.exists(db):
         continue
-    frames = sqlite3.connect(db).execute("select total_calls from top_kernels where name like '%k_strength_masks%'").fetchone()[0]
+    frames = 256 if name == "trace_720p" else 64      # (steps + warmup) x frames per step
     with open(os.path.join(P, pre + "_" + out), "w") as f:
         f.write("# rocprofv3 --kernel-trace --stats -- python bench.py %s (%d frames)\n" % (cmd, frames) + run(os.path.join(R, "tools", "prof_summary.py"), db, str(frames)))
 
@@ -46,16 +46,23 @@ with open(os.path.join(P, pre + "_pmc_sq_1080p.txt"), "w") as f:
 
 
 def total(db, counter, like=None):
+    """sum of a counter over the capture; without `like`: over the FRAME PATH's kernels - the runtime's fill / copy kernels and the table set-up run once per
+    detector (vote tables, ring planes of 64 slots: 55 MB per frame of a 48-frame capture) and are no part of a frame in the steady state"""
     con = sqlite3.connect(db)
     q = "select sum(value) from counters_collection where counter_name=?"
     a = [counter]
     if like:
         q += " and kernel_name like ?"; a.append(like)
+    else:
+        q += " and kernel_name not like '%__amd_rocclr_%' and kernel_name not like '%k_quant24_lut%'"
     return con.execute(q, a).fetchone()[0] or 0.0
 
 
+FRAMES = {"pmc_rd": 48, "pmc_wr": 48, "pmc_rd_720p": 48, "pmc_wr_720p": 48, "pmc_rd_4k": 24, "pmc_wr_4k": 24}      # (steps + warmup) x frames per step of tools/gpu_pmc.sh's commands
+
+
 def frames_in(db):
-    return sqlite3.connect(db).execute("select count(*) from counters_collection where kernel_name like '%k_strength_masks%'").fetchone()[0]
+    return FRAMES[os.path.basename(os.path.dirname(db))]
 
 
 TRAFFIC_CMD = "python bench.py --steps 2 --warmup 1 --frames-per-step 16 --no-cpu-baseline --no-verify --no-configs"
@@ -98,7 +105,10 @@ with open(os.path.join(P, ROUND + "_traffic.json"), "w") as f:
     json.dump({"commit": captured, "command": TRAFFIC_CMD, "frames": nf_rd, "other_configurations": other,
                "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes over the benchmarked configuration (default slots, graphs on; profiles/%s_pmc_traffic_1080p.txt); "
                "each corrected by the factor the calibration copy of 3 x 1 GiB (4 B/lane coalesced, tools/pmc_calibrate.py) yields in the same capture "
-               "(FETCH_SIZE reports half of the bytes read on gfx950, as MI355X_MICROARCH.md describes)" % pre,
+               "(FETCH_SIZE reports half of the bytes read on gfx950, as MI355X_MICROARCH.md describes); the runtime's fill / copy kernels of detector set-up are left out (steady state)" % pre,
                "fetch_size_kib_per_frame": int(rd), "write_size_kib_per_frame": int(wr), "fetch_correction": corr_rd, "write_correction": corr_wr,
                "hbm_bytes_per_frame": hbm}, f, indent=1)
+for src, dst in (("ref_opencl.json", pre + "_ref_opencl.json"), ("pytest_gpu.log", pre + "_pytest_gpu.txt")):
+    if os.path.exists(os.path.join(C, src)):
+        shutil.copy(os.path.join(C, src), os.path.join(P, dst))
 print("fetch %.0f KiB x %.3f, write %.0f KiB x %.3f -> %.3f GB/frame" % (rd, corr_rd, wr, corr_wr, hbm / 1e9))
