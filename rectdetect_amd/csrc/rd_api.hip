@@ -507,9 +507,9 @@ static void frame_tail(rd_detector *d, Slot *s, int mode) {   // both, in order,
 
 // regions, their sizes, absorption of small ones, boundaries and boundary components (oclrect.c:325-342).  Reads planes that
 // nothing later in the frame modifies (quant, mergemask, label1, junction), so it can be repeated with a larger round budget.
-static void frame_regions(rd_detector *d, Slot *s) {
+static void frame_regions(rd_detector *d, Slot *s, hipStream_t st_over = NULL) {
   const int iw = d->iw, ih = d->ih, N = d->N;
-  hipStream_t st = s->st;
+  hipStream_t st = st_over ? st_over : s->st;
   // regions (oclrect.c:325-336)
   int *d2scratch = s->d2s;
   int marked = 0;
@@ -876,12 +876,17 @@ static void slot_finish_device(rd_detector *d, Slot *s) {
   if (s->rounds <= 20 && s->h_ctr[32 + s->rounds - 1] != 0) {   // the region merge was still changing in its last launch: again with as many launches as it takes
     // (32 first - the frames that exceed a budget of 12-14 need 13-20 as a rule, and every launch after the settling one still costs a
     //  dispatch of the whole grid - then the definition's limit of 64)
+    // (on a stream of the slot's own: the slot's regular stream is one of the four that carry the groups, and the repeat would wait there behind a whole group of
+    //  other frames; nothing but this frame's result depends on it - the frame is finished, ev_done has been waited for)
+    static const bool redo_inline = getenv("RD_REDO_ON_MAIN_STREAM") != NULL;
+    if (!s->st_redo && !redo_inline) RD_HIP(hipStreamCreateWithFlags(&s->st_redo, hipStreamNonBlocking));
+    hipStream_t rst = redo_inline ? s->st : s->st_redo;
     for (int budget = 32; budget <= 64; budget *= 2) {
       s->rounds = budget;
       pthread_mutex_lock(&d->launch_mu);
-      frame_regions(d, s);
-      redo_votes(d, s, s->st);
-      RD_HIP(hipEventRecord(s->ev_redo, s->st));
+      frame_regions(d, s, rst);
+      redo_votes(d, s, rst);
+      RD_HIP(hipEventRecord(s->ev_redo, rst));
       pthread_mutex_unlock(&d->launch_mu);
       wait_event_outside_captures(d, s->ev_redo);
       int still = 0;
