@@ -1193,6 +1193,47 @@ def test_two_real_detector_processes_share_the_gpu():
     print("two ranks on one GPU:", out["value"], "frames/s;", ranks)
 
 
+def test_reference_on_the_real_opencl_device_against_the_hip_path():
+    """The one third-party execution of the reference this environment offers: its unchanged host C (oracle/_ref/librdref_ocl.so, built by `make -C oracle ref_ocl`) on the
+    box's OpenCL device - the MI355X through ROCm's OpenCL, the reference's .cl sources compiled at run time by the vendor's compiler - with contraction switched off and
+    correctly rounded divide / sqrt through the runtime's AMD_OCL_BUILD_OPTIONS_APPEND (the goldens' arithmetic contract; the reference's own options are empty,
+    i.e. contraction on), in a process of its own.  Compared with the HIP path on seven stills: the same number of rectangles, every rectangle within a pixel of one of the other
+    list - asserted - and how many lists / rectangles are identical in every bit - reported (the device's builtins and its work-item order are its own: DESIGN.md (c))."""
+    import subprocess
+    import sys
+    import tempfile
+    so = os.path.join(helpers.ROOT, "oracle", "_ref", "librdref_ocl.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/librdref_ocl.so not built (needs /root/reference at build time)")
+    specs = [(0, 640, 480, 0), (5, 640, 480, 0), (1, 1280, 720, 0), (0, 1920, 1080, 0), (0, 1920, 1080, 1), (0, 1920, 1080, 2), (7, 1920, 1080, 0)]
+    with tempfile.TemporaryDirectory() as td:
+        f = os.path.join(td, "ref.npz")
+        env = dict(os.environ, AMD_OCL_BUILD_OPTIONS_APPEND="-Wf,-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt")
+        p = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tools", "ref_on_opencl.py"), "dump", f] + [str(v) for sp in specs for v in sp], cwd=helpers.ROOT, env=env,
+                           capture_output=True, text=True, timeout=600)
+        if p.returncode != 0:
+            pytest.skip("no usable OpenCL device for the reference here: " + (p.stderr or p.stdout)[-200:])
+        with np.load(f) as z:
+            ref = [z["f%d" % i].view(ra.RECT_DTYPE) if z["f%d" % i].dtype != ra.RECT_DTYPE else z["f%d" % i] for i in range(len(specs))]
+    key = lambda r: r["c2"].tobytes() + r["c3"].tobytes() + r["value"].tobytes() + r["status"].tobytes()
+    rows, same_lists, same_rects, total = {}, 0, 0, 0
+    for (seed, iw, ih, t), want in zip(specs, ref):
+        det = ra.Detector(iw, ih, nslots=1, nworkers=0)
+        det.enqueue(synth.frame(synth.SEED0 + seed, iw, ih, t))
+        got = det.poll(TAN36)
+        det.close()
+        assert len(got) == len(want), (seed, iw, ih, t, len(got), len(want))
+        far = 0.0
+        for r in got:
+            far = max(far, float(np.abs(want["c2"] - r["c2"]).reshape(len(want), -1).max(1).min()) if len(want) else 0.0)
+        assert far <= 1.0, (seed, iw, ih, t, far)
+        ka, kb = {key(r) for r in got}, {key(r) for r in want}
+        same_lists += ka == kb; same_rects += len(ka & kb); total += len(kb)
+        rows["seed %d %dx%d t %d" % (seed, iw, ih, t)] = {"rectangles": len(got), "bit_identical": len(ka & kb), "lists_bit_identical": ka == kb, "largest_corner_distance_px": far}
+    helpers.parity_report("the reference on the box's OpenCL device (contraction off, correctly rounded divide / sqrt) against the HIP path", "stills", dict(rows, lists_bit_identical=int(same_lists), rectangles_bit_identical="%d of %d" % (same_rects, total)))
+    print("reference on the OpenCL device vs HIP: %d of %d lists and %d of %d rectangles identical in every bit; all within a pixel" % (same_lists, len(specs), same_rects, total))
+
+
 def test_four_ranks_with_all_their_workers_keep_the_rate_of_one():
     """What 8 ranks on the node's two sockets will stress, as far as a one-GPU box can show it: `bench.py --gpus 4 --share-gpus` - four real
     per-GPU processes, each with its own detector, 64 frames in flight and 64 worker threads that poll events, all on this box's only GPU - must reach, TOGETHER, at least

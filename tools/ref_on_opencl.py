@@ -9,7 +9,9 @@ third-party execution of the reference this environment offers; it bounds what t
   * the polyline fixture's segment list against the golden;
   * run-to-run repeatability of the reference on this device (the in-place region stages depend on the work-item order);
   * the reference's frames/s on this device (oclrect_enqueueTask / pollTask two deep as vidrect.cpp does, and oclrect_executeOnce) - a same-box baseline.
-usage (GPU box): python tools/ref_on_opencl.py [section ...]   -> gpurun_out/ref_opencl.json     (sections: stills poly stream repeat timing)"""
+usage (GPU box): python tools/ref_on_opencl.py [section ...]   -> gpurun_out/ref_opencl.json     (sections: stills poly stream repeat timing)
+Build options can be appended without touching the reference through the AMD runtime's AMD_OCL_BUILD_OPTIONS_APPEND, e.g. "-Wf,-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt"
+(the arithmetic contract of the goldens): tools/gpu_probe_ocl2.sh."""
 import ctypes
 import json
 import os
@@ -216,9 +218,24 @@ def bench_line():
                                 "built at run time by the device's OpenCL compiler with the reference's own (empty) options" % n}), flush=True)
 
 
+def dump(path, specs):
+    """rectangle lists of single frames (seed offset, iw, ih, t), each from a fresh detector -> npz (f0, f1, ..): what tests compare the HIP path with"""
+    R = load()
+    out = {}
+    for i, (seed, iw, ih, t) in enumerate(specs):
+        d = Rect(R, iw, ih)
+        out["f%d" % i] = d.once(synth.frame(synth.SEED0 + seed, iw, ih, t))
+        d.close()
+    np.savez(path, **out)
+
+
 def main():
     if sys.argv[1:] == ["bench"]:
         bench_line()
+        return
+    if len(sys.argv) > 2 and sys.argv[1] == "dump":
+        v = [int(a) for a in sys.argv[3:]]
+        dump(sys.argv[2], [tuple(v[k:k + 4]) for k in range(0, len(v), 4)])
         return
     want = sys.argv[1:] or ["stills", "poly", "stream", "repeat", "timing"]
     try:
