@@ -11,3 +11,7 @@ for opt in "-Wf,-ffp-contract=off" "-Wf,-ffp-contract=off -cl-fp32-correctly-rou
   done
   cp gpurun_out/ref_opencl.json gpurun_out/ref_opencl_$tag.json 2>/dev/null
 done
+# operator by operator (tools/ref_ops_on_opencl.py): the reference's own options, then the goldens' arithmetic contract
+timeout 300 python tools/ref_ops_on_opencl.py default 2>&1 | grep -v "^W\|^E" | cut -c1-900
+AMD_OCL_BUILD_OPTIONS_APPEND="-Wf,-ffp-contract=off" timeout 300 python tools/ref_ops_on_opencl.py contract_off 2>&1 | grep -v "^W\|^E" | cut -c1-900
+AMD_OCL_BUILD_OPTIONS_APPEND="-Wf,-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt" timeout 300 python tools/ref_ops_on_opencl.py contract_off_rounded 2>&1 | grep -v "^W\|^E" | cut -c1-900
