@@ -1198,30 +1198,35 @@ def test_operator_goldens_are_what_the_reference_computes_on_the_real_opencl_dev
     device (oracle/_ref/librdref_ocl.so; the vendor's compiler builds the reference's .cl sources at run time), under the goldens' arithmetic contract (contraction off, correctly
     rounded divide / sqrt - appended through the runtime's AMD_OCL_BUILD_OPTIONS_APPEND, the reference's sources and options untouched), operator by operator on the goldens' own
     inputs: all 18 IIR outputs (9 radii, 2 sizes) and 17 of the 21 other operators must equal the goldens in every bit; the four that may differ are the direction vectors and what
-    is sampled along them - the device's own rsqrt, one unit in the last place (the builtin the sensitivity study varies: tests/golden/builtin_sensitivity.json)."""
+    is sampled along them - the device's own rsqrt, one unit in the last place (the builtin the sensitivity study varies: tests/golden/builtin_sensitivity.json).  With the three
+    loosely specified builtins pinned to the stand-in's definitions (a forced include), all 21 must."""
     import json
     import subprocess
     import sys
     so = os.path.join(helpers.ROOT, "oracle", "_ref", "librdref_ocl.so")
     if not os.path.exists(so):
         pytest.skip("oracle/_ref/librdref_ocl.so not built (needs /root/reference at build time)")
-    env = dict(os.environ, AMD_OCL_BUILD_OPTIONS_APPEND="-Wf,-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt")
-    p = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tools", "ref_ops_on_opencl.py"), "test"], cwd=helpers.ROOT, env=env, capture_output=True, text=True, timeout=600)
-    if p.returncode != 0:
-        pytest.skip("no usable OpenCL device for the reference here: " + (p.stderr or p.stdout)[-200:])
-    rep = json.load(open(os.path.join(helpers.ROOT, "gpurun_out", "ref_ops_opencl_test.json")))["fixtures"]
+    contract = "-Wf,-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt"
     may_differ = {"edgevec_f2_f", "edgevec_f2_plab", "thincubic_f_f_f2", "thinthres_f_f_f2"}
-    summary = {}
-    for fx, rows in rep.items():
-        bad = {k: v for k, v in rows.items() if v.get("differing") != 0}
-        summary[fx] = {"operators": len(rows), "bit_identical": len(rows) - len(bad), "differing": {k: [v.get("differing"), v.get("max_abs_difference")] for k, v in bad.items()}}
-        if fx.startswith("ops_iir"):
-            assert not bad, (fx, bad)
-        else:
-            assert set(bad) <= may_differ, (fx, bad)
-            assert all(v.get("max_abs_difference", 1.0) <= 2e-6 for v in bad.values()), (fx, bad)
-    helpers.parity_report("operator goldens against the reference on the box's OpenCL device (contraction off, correctly rounded divide / sqrt)", "operators", summary)
-    print("operator goldens vs the reference on the OpenCL device:", {k: "%d of %d" % (v["bit_identical"], v["operators"]) for k, v in summary.items()})
+    # (a) the device's own builtins; (b) rsqrt, hypot and distance - the three whose accuracy OpenCL leaves to the device - pinned to the stand-in's definitions by a header
+    #     forced into the reference's programs (oracle/refshim/rdcl_pins.h): then EVERY operator must equal the goldens in every bit
+    for tag, opts, allowed in (("device_builtins", contract, may_differ), ("pinned_builtins", contract + " -Wf,-include" + os.path.join(helpers.ROOT, "oracle", "refshim", "rdcl_pins.h"), set())):
+        env = dict(os.environ, AMD_OCL_BUILD_OPTIONS_APPEND=opts)
+        p = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tools", "ref_ops_on_opencl.py"), "test"], cwd=helpers.ROOT, env=env, capture_output=True, text=True, timeout=600)
+        if p.returncode != 0:
+            pytest.skip("no usable OpenCL device for the reference here: " + (p.stderr or p.stdout)[-200:])
+        rep = json.load(open(os.path.join(helpers.ROOT, "gpurun_out", "ref_ops_opencl_test.json")))["fixtures"]
+        summary = {}
+        for fx, rows in rep.items():
+            bad = {k: v for k, v in rows.items() if v.get("differing") != 0}
+            summary[fx] = {"operators": len(rows), "bit_identical": len(rows) - len(bad), "differing": {k: [v.get("differing"), v.get("max_abs_difference")] for k, v in bad.items()}}
+            if fx.startswith("ops_iir"):
+                assert not bad, (tag, fx, bad)
+            else:
+                assert set(bad) <= allowed, (tag, fx, bad)
+                assert all(v.get("max_abs_difference", 1.0) <= 2e-6 for v in bad.values()), (tag, fx, bad)
+        helpers.parity_report("operator goldens against the reference on the box's OpenCL device (contraction off, correctly rounded divide / sqrt)", tag, summary)
+        print("operator goldens vs the reference on the OpenCL device,", tag + ":", {k: "%d of %d" % (v["bit_identical"], v["operators"]) for k, v in summary.items()})
 
 
 def test_reference_on_the_real_opencl_device_against_the_hip_path():
