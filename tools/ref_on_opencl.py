@@ -125,6 +125,14 @@ def section_poly(R, rep):
         quad = lambda a: {(float(r["x0"]), float(r["y0"]), float(r["x1"]), float(r["y1"])) for r in a[1:] if r["polyid"] != 0}
         qa, qb = quad(got), quad(gold)
         row["valid_segments"], row["valid_segments_golden"], row["segments_common_as_end_point_quadruples"] = len(qa), len(qb), len(qa & qb)
+        # the golden segments that have no identical twin: how far is the nearest segment of this run (largest end-point coordinate difference, either direction of travel)?
+        A = np.array(sorted(qa), np.float64).reshape(-1, 4)
+        near = []
+        for g in sorted(qb - qa):
+            g = np.array(g)
+            d = np.minimum(np.abs(A - g).max(1), np.abs(A - g[[2, 3, 0, 1]]).max(1)).min() if len(A) else float("inf")
+            near.append(float(d))
+        row["unmatched_golden_segments_nearest_distance"] = sorted(round(d, 3) for d in near)
         rows.append(row)
         print("poly", row, flush=True)
     rep["poly"] = rows
