@@ -778,12 +778,6 @@ __global__ __launch_bounds__(256) void k_region_init(int *__restrict__ A, int *_
 #ifndef RR_DPP
 #define RR_DPP 1           // the left / right neighbours' words from the neighbouring lanes (0: loaded)
 #endif
-#ifndef RR_GUARD1
-#define RR_GUARD1 0        // launch 1, proposals for parents outside the tile: 1 = the thread's guarding loads together, 0 = no guard, 2 = load and atomic pixel by pixel
-#endif
-#ifndef RR_GUARD2
-#define RR_GUARD2 2        // the same for launch 2 (every pixel's parent)
-#endif
 #ifndef RR_DEEP
 #define RR_DEEP 3          // rounds in which the trees are still the chains of the initial links (a pixel's parent is 1, 10, 91 rows above it)
 #endif
@@ -931,29 +925,9 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
       if (todo[k] && inside) atomicMin(&tmin[cell], g[k]);
       out[k] = todo[k] && !inside;
     }
-    auto far_hooks = [&]() {
-      int cur[RR_PX];
+    // (the proposals for parents outside the tile - a fifth of the pixels - go without a guarding load: with the guards, read together or pixel by pixel, the launch was no faster)
 #pragma unroll
-      for (int k = 0; k < RR_PX; k++) cur[k] = ld_agent(&Y[out[k] ? og[k] : p0[k]]);
-#pragma unroll
-      for (int k = 0; k < RR_PX; k++) { const int w = (g[k] << RR_MBITS) | mark; if (out[k] && w < cur[k]) atomicMin(&Y[og[k]], w); }
-    };
-    {   // (the guarding loads of the thread's pixels together, see the note on unconditional loads)
-#if RR_GUARD1 == 3
-#elif RR_GUARD1 == 1
-      int cur[RR_PX];
-#pragma unroll
-      for (int k = 0; k < RR_PX; k++) cur[k] = ld_agent(&Y[out[k] ? og[k] : p0[k]]);
-#pragma unroll
-      for (int k = 0; k < RR_PX; k++) { const int w = (g[k] << RR_MBITS) | mark; if (out[k] && w < cur[k]) atomicMin(&Y[og[k]], w); }
-#elif RR_GUARD1 == 0
-#pragma unroll
-      for (int k = 0; k < RR_PX; k++) { const int w = (g[k] << RR_MBITS) | mark; if (out[k]) atomicMin(&Y[og[k]], w); }
-#else
-#pragma unroll
-      for (int k = 0; k < RR_PX; k++) { const int w = (g[k] << RR_MBITS) | mark; if (out[k] && w < ld_agent(&Y[og[k]])) atomicMin(&Y[og[k]], w); }
-#endif
-    }
+    for (int k = 0; k < RR_PX; k++) { const int w = (g[k] << RR_MBITS) | mark; if (out[k]) atomicMin(&Y[og[k]], w); }
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < RR_PX; k++) {
@@ -964,9 +938,6 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
       if (h != 0x7fffffff) { const int wh = (h << RR_MBITS) | mark; w = wh < w ? wh : w; }
       if (w != 0x7fffffff) atomicMin(&Y[p0[k]], w);
     }
-#if RR_GUARD1 == 3
-    far_hooks();
-#endif
     if (__any(any_todo) && threadIdx.x == 0) flags[round] = 1;
     return;
   }
@@ -984,20 +955,10 @@ __global__ __launch_bounds__(64 * RR_TY) void k_region_round(int *X, int *Y, con
     need[k] = todo[k] && !(threadIdx.x > 0 && pt && pog == og[k] && pg == g[k]);
   }
   if (PHASE == 2) {       // the first rounds climb the raw chains: every pixel has a parent of its own (the pixel above it), nothing to combine
-#if RR_GUARD2 == 1 || RR_GUARD2 == 3
-    if (RR_GUARD2 == 3) __syncthreads();
-    int cur[RR_PX];            // (the guarding loads of the thread's pixels together)
-#pragma unroll
-    for (int k = 0; k < RR_PX; k++) cur[k] = ld_agent(&Y[need[k] ? og[k] : p0[k]]);
-#pragma unroll
-    for (int k = 0; k < RR_PX; k++) { const int w = (g[k] << RR_MBITS) | mark; if (need[k] && w < cur[k]) atomicMin(&Y[og[k]], w); }
-#elif RR_GUARD2 == 0
-#pragma unroll
-    for (int k = 0; k < RR_PX; k++) { const int w = (g[k] << RR_MBITS) | mark; if (need[k]) atomicMin(&Y[og[k]], w); }
-#else
+    // (guard and atomic pixel by pixel: a guard only saves its atomic when the parent's own thread has written already, and the later it looks the more often that is - the
+    //  eight guards read together made this launch 195 instead of 151 us; no guards at all cost 3 % of the frame rate: the atomics are what is expensive)
 #pragma unroll
     for (int k = 0; k < RR_PX; k++) { const int w = (g[k] << RR_MBITS) | mark; if (need[k] && w < ld_agent(&Y[og[k]])) atomicMin(&Y[og[k]], w); }
-#endif
   } else {
 #pragma unroll
     for (int k = 0; k < RR_PX; k++) {
