@@ -156,6 +156,24 @@ def section_stream(R, rep):
     rep["streams"] = rows
 
 
+def section_streamlong(R, rep):
+    """the four long streams of the parity table (516 frames), rectangle lists only"""
+    rows = {}
+    for name in ("stream_1920x1080_s0_100", "stream_1920x1080_s7_100", "stream_1280x720_s1_300", "stream_3840x2160_s4_16"):
+        z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        iw, ih, seed, tan = int(z["iw"]), int(z["ih"]), int(z["seed"]), float(z["tan_aov"])
+        d = Rect(R, iw, ih)
+        fr = [compare(d.once(synth.frame(seed, iw, ih, t), tan), z["f%d_rects" % t]) for t in range(int(z["nframes"]))]
+        d.close()
+        far = [c["max_nearest_corner_distance"] for c in fr if c["n"]]
+        rows[name] = {"frames": len(fr), "lists_bit_identical": sum(c["equal"] for c in fr), "lists_within_1e-4": sum(c["within_1e-4"] for c in fr), "same_count": sum(c["n"] == c["n_golden"] for c in fr),
+                      "rectangles_golden_distinct": sum(c["n_golden_distinct"] for c in fr), "rectangles_bit_identical": sum(c["common_bitwise"] for c in fr),
+                      "rectangles": sum(c["n"] for c in fr), "rectangles_matched_within_1px": sum(c["matched_within_1px"] for c in fr),
+                      "largest_corner_distance_to_nearest_golden_px": max(far) if far else 0.0, "frames_with_a_rectangle_further_than_0.01px": sum(1 for v in far if v > 0.01)}
+        print("streamlong", name, rows[name], flush=True)
+    rep["streams_long"] = rows
+
+
 def section_repeat(R, rep):
     """the same frame, fresh detector each time: does this device repeat itself?"""
     iw, ih = 1920, 1080
