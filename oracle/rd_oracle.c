@@ -7,8 +7,10 @@
  * kernels + host C executed on the serial OpenCL shim (oracle/_ref, built from /root/reference).
  * The reference ships no tests or golden vectors of its own.  Round 5: the same reference objects also link against the
  * system's real OpenCL loader (oracle/_ref/librdref_ocl.so); on the GPU box the vendor's compiler and the MI355X reproduce all operator
- * goldens bit for bit under this file's arithmetic contract (tools/ref_ops_on_opencl.py); the polyline / rect stage goldens
- * are pinned by the stand-in only - parity "partial" by the tier's strict rule.
+ * goldens bit for bit under this file's arithmetic contract (tools/ref_ops_on_opencl.py), and in whole frames every plane of
+ * this file up to the merge masks (16 planes, observed launch by launch: refshim/rdcl_observe.c, tools/ref_stages_on_opencl.py); the stages
+ * from the in-place region merge on depend on the device's work-item order and are pinned by the stand-in's raster order only - parity
+ * "partial" by the tier's strict rule.
  *
  * Canonical semantics: work-items in raster order; labelling stages are run to
  * convergence (label = smallest pixel index of the component); no FMA contraction; OpenCL

@@ -1229,6 +1229,38 @@ def test_operator_goldens_are_what_the_reference_computes_on_the_real_opencl_dev
         print("operator goldens vs the reference on the OpenCL device,", tag + ":", {k: "%d of %d" % (v["bit_identical"], v["operators"]) for k, v in summary.items()})
 
 
+def test_reference_stage_by_stage_on_the_real_opencl_device_against_the_oracle():
+    """The reference's unchanged host C and .cl sources on the box's REAL OpenCL device, whole frames, observed launch by launch (oracle/refshim/rdcl_observe.c forwards the
+    OpenCL calls untouched and reads a buffer back after the launch that completes it - the launches tests/helpers.py: REF_SNAPSHOTS names), under the goldens' arithmetic
+    contract with the three loosely specified builtins pinned (as the operator test above): on five frames up to 1920 x 1080 every plane from the colour conversion to the merge
+    masks - 16 planes: the whole front end, the thinning, both labellings, the strength filter, the ten smoothing passes, quantisation, despeckle - must equal the oracle's in
+    every bit.  The oracle's planes are the ones the HIP path's are compared with bit for bit (the device stage tests above), so for those 16 the HIP path equals the reference
+    as the vendor's OpenCL runs it.  From the region merge on (labelMergeMain works in place: what a work-item reads depends on which others ran before it - DESIGN.md (c)) the
+    device's order is its own: reported, not asserted."""
+    import json
+    import subprocess
+    import sys
+    so = os.path.join(helpers.ROOT, "oracle", "_ref", "librdref_ocl.so")
+    if not os.path.exists(so):
+        pytest.skip("oracle/_ref/librdref_ocl.so not built (needs /root/reference at build time)")
+    opts = "-Wf,-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt -Wf,-include" + os.path.join(helpers.ROOT, "oracle", "refshim", "rdcl_pins.h")
+    p = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tools", "ref_stages_on_opencl.py"), "test"], cwd=helpers.ROOT, env=dict(os.environ, AMD_OCL_BUILD_OPTIONS_APPEND=opts),
+                       capture_output=True, text=True, timeout=900)
+    if p.returncode != 0:
+        pytest.skip("no usable OpenCL device for the reference here: " + (p.stderr or p.stdout)[-200:])
+    rep = json.load(open(os.path.join(helpers.ROOT, "gpurun_out", "ref_stages_opencl_test.json")))["frames"]
+    before_the_merge = ["plab0", "Lblur", "plab1", "vxy", "strength", "nms", "mask0", "tidy", "str_sum", "edge500", "smooth", "quant", "strong", "label1", "junction", "mergemask"]
+    assert len(rep) == 5
+    summary = {}
+    for name, fr in rep.items():
+        assert fr["launches"] == 220, (name, fr["launches"])
+        for k in before_the_merge:
+            assert fr["planes"][k] != "no snapshot" and fr["planes"][k]["differing"] == 0, (name, k, fr["planes"][k])
+        summary[name] = {"bit_identical_planes": before_the_merge, "after_the_merge_differing_elements": {k: v["differing"] for k, v in fr["planes"].items() if k not in before_the_merge}}
+    helpers.parity_report("the reference stage by stage on the box's OpenCL device against the oracle (goldens' contract, pinned builtins)", "planes", summary)
+    print("reference on the OpenCL device stage by stage: 16 planes identical in every bit on", len(rep), "frames; after the merge:", {k: v["after_the_merge_differing_elements"] for k, v in summary.items()})
+
+
 def test_reference_on_the_real_opencl_device_against_the_hip_path():
     """The one third-party execution of the reference this environment offers: its unchanged host C (oracle/_ref/librdref_ocl.so, built by `make -C oracle ref_ocl`) on the
     box's OpenCL device - the MI355X through ROCm's OpenCL, the reference's .cl sources compiled at run time by the vendor's compiler - with contraction switched off and
