@@ -65,6 +65,9 @@ def _declare(L):
         "rd_detector_debug_plane": (cz, [vp, ctypes.c_char_p, vp, cz]),
         "rd_postprocess_planes": (vp, [vp, vp, vp, ci, ci, cd]),
         "rd_post_run": (vp, [vp, ci, vp, ci, ci, cd]),
+        "rd_post_helpers_configure": (None, [ci]),
+        "rd_post_helpers_arm": (None, []),
+        "rd_post_helpers": (ci, []),
         "rd_synth_frame": (None, [vp, ci, ci, ci, ctypes.c_uint64, ci, ci]),
         "rd_synth_num_quads": (ci, [ci, ci]),
         # reference API (oclhelper.h / raw cl*)

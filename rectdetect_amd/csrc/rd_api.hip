@@ -355,6 +355,8 @@ struct rd_detector {
   int overflow_streak;
   int poly_overflows;                     // set once two frames in a row overflowed the single-launch polyline kernel: later frames go multi-launch
   int rounds_budget, need_hist[64]; unsigned need_pos; long budget_count[RD_NBUDGETS], need_count[21];
+  int graph_fork;            // the forked segment (one or two frames in flight: polyline chain beside the blur / region chain) as a captured graph too
+  int post_helpers;          // helper threads armed by every poll (rd_post.c), 0 = none
   long host_enqueue_ns;      // wall time the caller spent inside rd_detector_enqueue
   long dev_us, dev_frames;   // sum over polled frames of (last kernel end - first kernel start) on the frame's stream, HIP events
   double tan_aov; int have_tan;    // what the workers use ahead of the poll that asks for the result
@@ -412,8 +414,22 @@ static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
   s->shares_streams = share != NULL;
   if (share) { s->st = share->st; s->st2 = share->st2; }
   else {
+    // One or two frames in flight: each frame spreads over two streams, and the four streams of two frames need four hardware queues of their own.  The
+    // runtime hands its four queues per priority level to the streams in the order they first launch something, and the null stream (set-up copies) and the
+    // caller's command queue hold two of them: the second frame's streams then land on the queues of the first frame's - its main chain behind the other's polyline
+    // chain (traced: two frames in flight ran 1.18 times as fast as one).  The streams of such a detector therefore come from the pool of another priority
+    // level, where nothing else lives.  (Raising the number of queues for everybody - GPU_MAX_HW_QUEUES=8 - does the same for this path, 1420 -> 1590 frames/s, but
+    // costs the group path, whose four streams are best served by four queues, 9 %.)
+    static const int fork_prio = getenv("RD_FORK_STREAM_PRIORITY") ? atoi(getenv("RD_FORK_STREAM_PRIORITY")) : 1;
+    if (d->fork_poly && fork_prio) {
+      int lo = 0, hi = 0;
+      RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      RD_HIP(hipStreamCreateWithPriority(&s->st, hipStreamNonBlocking, hi));
+      RD_HIP(hipStreamCreateWithPriority(&s->st2, hipStreamNonBlocking, hi));
+    } else {
     RD_HIP(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
     RD_HIP(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
+    }
   }
   RD_HIP(hipEventCreateWithFlags(&s->ev_fork, hipEventDisableTiming));
   RD_HIP(hipEventCreateWithFlags(&s->ev_join, hipEventDisableTiming));
@@ -604,14 +620,17 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t 
   //   2nd stream : junction counts of the filtered labels -> merge mask                      (oclrect.c:315-321)
   //                then the polyline stage, which needs nothing but the strong mask          (oclrect.c:361)
   // Inside a captured graph the streams become parallel branches.
+  static const int fork_order = getenv("RD_FORK_ORDER") ? atoi(getenv("RD_FORK_ORDER")) : 1;      // (0: polyline chain launched first, 1: after the region stage, 2: before it)
   if (d->fork_poly) {      // (else: everything on the main stream, blur chain first)
     RD_HIP(hipEventRecord(s->ev_fork, st));
     RD_HIP(hipStreamWaitEvent(s->st2, s->ev_fork, 0));
     rdk::junction_bits(s->st2, (unsigned long long *)s->scratch2, s->strongbits, iw, ih);
     rdk::merge_mask(s->st2, s->mmbits, (const unsigned long long *)s->scratch2, iw, ih);
     RD_HIP(hipEventRecord(s->ev_mm, s->st2));
+    if (fork_order == 0) {
     frame_polyline(d, s, s->st2, s->poly_mode);
     RD_HIP(hipEventRecord(s->ev_join, s->st2));
+    }
   }
 
   // edge-preserving smoothing x10, quantise, despeckle (oclrect.c:286-303)
@@ -629,7 +648,9 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t 
     rdk::merge_mask(st, s->mmbits, (const unsigned long long *)s->scratch2, iw, ih);
   }
 
+  if (d->fork_poly && fork_order == 2) { frame_polyline(d, s, s->st2, s->poly_mode); RD_HIP(hipEventRecord(s->ev_join, s->st2)); }
   frame_regions(d, s);
+  if (d->fork_poly && fork_order == 1) { frame_polyline(d, s, s->st2, s->poly_mode); RD_HIP(hipEventRecord(s->ev_join, s->st2)); }
 
   if (d->batch > 1) return;      // the sparse stages of the group's frames follow in one set of launches (sparse_launch)
   if (d->fork_poly) RD_HIP(hipStreamWaitEvent(st, s->ev_join, 0));
@@ -653,7 +674,7 @@ static const int kRoundBudgets[RD_NBUDGETS] = { 8, 10, 12, 14, 16, 18, 20 };
 
 static void run_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t st_over = NULL) {      // st_over (segment 1 only): another stream than the slot's
   hipStream_t lst = st_over ? st_over : s->st;
-  if (!d->use_graph) { frame_segment(d, s, ws, seg, lst); return; }
+  if (!d->use_graph || (seg == 2 && d->fork_poly && !d->graph_fork)) { frame_segment(d, s, ws, seg, lst); return; }
   hipGraphExec_t *ge = &s->gexec[seg];
   if (seg == 2) for (int k = 0; k < RD_NBUDGETS; k++) if (kRoundBudgets[k] == s->rounds) ge = &s->gexec2[k * 3 + (d->batch == 1 ? s->poly_mode : 0)];
   if (!*ge) {
@@ -1068,6 +1089,7 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->prev_ring = dnew<int8_t>((size_t)d->N * d->nring);
   RD_HIP(hipMemset(d->prev_ring, 0, (size_t)d->N * d->nring));
   d->use_graph = getenv("RD_NO_GRAPH") ? 0 : 1;
+  d->graph_fork = getenv("RD_GRAPH_FORK") ? atoi(getenv("RD_GRAPH_FORK")) : 0;
   d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : 1;      // (tests: the ~85-launch form for every frame)
   d->force_redo = (getenv("RD_POLY_FORCE_REDO") ? 1 : 0) | (getenv("RD_ABSORB_FORCE_SLOW") ? 2 : 0);   // tests: every frame also takes the polyline / absorption fallback
   // candidate funnel + pose estimation on the device (rd_k_post.hip) instead of on one worker thread per frame slot: RD_DEVICE_POST=0|1 decides;
@@ -1083,6 +1105,15 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   // frames in flight a frame spreads over two streams (polyline chain beside the blur chain: shortest latency); from three
   // frames on every frame keeps to one stream, so that four frames occupy the four queues (highest throughput).
   d->fork_poly = nslots <= 2 ? 1 : 0;
+  // One or two frames in flight and no worker threads = the reference's call sequence (executeOnce, enqueueTask / pollTask): the caller's thread runs the
+  // post-process at the end of every frame's latency; helper threads share its pose estimations (rd_post.c), RD_POST_HELPERS=n overrides their number
+  d->post_helpers = 0;
+  if (nworkers == 0 && nslots <= 2) {
+    cpu_set_t set;
+    const int ncpu = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : 0;
+    d->post_helpers = getenv("RD_POST_HELPERS") ? atoi(getenv("RD_POST_HELPERS")) : (ncpu >= 16 ? 4 : (ncpu >= 8 ? 2 : (ncpu >= 4 ? 1 : 0)));      // (1 / 3 / 5 / 7 helpers: 1.19 / 1.14-1.20 / 1.11 / 1.12-1.20 ms per executeOnce against 1.28 without)
+    if (d->post_helpers > 0) rd_post_helpers_configure(d->post_helpers);
+  }
   // round budget of the region merge: what the last 64 frames needed + margin (8 / 12 / 16 / 20 launched rounds; the rounds after
   // the merge has settled are no-ops, but each still costs two launches of a thousand blocks), frames that turn out to need more
   // are repeated with all 20; RD_REGION_ROUNDS_FIXED=8|12|16|20 pins the budget (20: never repeat anything).
@@ -1185,10 +1216,12 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
   else if (d->zb == 1) {
     // a single frame: the copy into pinned memory and the upload in four pieces, so that a piece travels while the next is being copied
     // (6 MB at 1920x1080: the copy alone takes a third of a millisecond of the caller's latency)
-    const size_t piece = ((bytes + 3) / 4 + 4095) & ~(size_t)4095;
+    static const bool nt_copy = getenv("RD_NT_COPY") ? atoi(getenv("RD_NT_COPY")) != 0 : true;
+    static const int npieces = getenv("RD_UPLOAD_PIECES") ? atoi(getenv("RD_UPLOAD_PIECES")) : 4;
+    const size_t piece = ((bytes + npieces - 1) / npieces + 4095) & ~(size_t)4095;
     for (size_t o = 0; o < bytes; o += piece) {
       const size_t m = bytes - o < piece ? bytes - o : piece;
-      memcpy((char *)s->h_bgr + o, (const char *)frame + o, m);
+      if (nt_copy) rd_copy_to_staging((char *)s->h_bgr + o, (const char *)frame + o, m); else memcpy((char *)s->h_bgr + o, (const char *)frame + o, m);
       RD_HIP(hipMemcpyAsync(s->bgr + o, (char *)s->h_bgr + o, m, hipMemcpyHostToDevice, s->st));
     }
     s->src = s->bgr;
@@ -1246,6 +1279,7 @@ void *rd_detector_poll(rd_detector *d, double tanAOV) {
       r = slot_rectangles(d, s, tanAOV, &segs, &ns);
     }
   } else {
+    if (d->post_helpers) rd_post_helpers_arm();      // (they wake while the device is still busy with the frame: rd_post.c)
     RD_HIP(hipEventSynchronize(s->ev_done));
     slot_finish_device(d, s);
     r = slot_rectangles(d, s, tanAOV, &segs, &ns);
@@ -1384,7 +1418,7 @@ struct oclrect_t *init_oclrect(struct oclimgutil_t *oclimgutil, struct oclpolyli
   (void)oclimgutil; (void)oclpolyline; (void)context; (void)queue;
   struct oclrect_t *t = (struct oclrect_t *)calloc(1, sizeof(*t));
   t->magic = MAGIC_RECT; t->iw = iw; t->ih = ih;
-  t->det = rd_detector_create(device ? device->ordinal : rdrt::current_device(), iw, ih, 2, 0);   // two pages like oclrect.c:54
+  t->det = rd_detector_create(device ? device->ordinal : rdrt::current_device(), iw, ih, 2, getenv("RD_API_WORKERS") ? atoi(getenv("RD_API_WORKERS")) : 0);   // two pages like oclrect.c:54
   return t;
 }
 

@@ -11,9 +11,11 @@
  */
 #define _GNU_SOURCE
 #include <math.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #define CL_TARGET_OPENCL_VERSION 120
 #include <CL/cl.h>
@@ -35,13 +37,17 @@ typedef struct {
   double dir[RDP_PAIRINGS][4];      /* search direction */
   double rp[RDP_PAIRINGS];          /* res . pre of the current point */
   int since_restart[RDP_PAIRINGS];
+  double f0[RDP_PAIRINGS];          /* residual at t, when have_f0 */
+  int have_f0[RDP_PAIRINGS];
 } descent2;
 
 /* central differences along the four axes (rh:492-512) -> res = -gradient; pre = res / curvature per axis when every
- * curvature is positive, else res (rh:538-555) */
+ * curvature is positive, else res (rh:538-555).  D->f0[m] = the residual at the current depths (the reference evaluates it again here:
+ * the same arguments, the same value - taken from the walk that produced the depths when there was one) */
 static void probe_axes(const rdp_rays *R, descent2 *D) {
   for (int m = 0; m < RDP_PAIRINGS; m++) {
-    const double f0 = rdp_defect(R, m, D->t[m]);
+    if (!D->have_f0[m]) { D->f0[m] = rdp_defect(R, m, D->t[m]); D->have_f0[m] = 1; }
+    const double f0 = D->f0[m];
     double curv[4];
     int convex = 1;
     for (int i = 0; i < 4; i++) {
@@ -60,30 +66,37 @@ static void probe_axes(const rdp_rays *R, descent2 *D) {
 }
 
 /* RDP_WALK_STEPS damped Newton steps along dir (rh:514-536): slope and curvature from a three-point stencil, the step is halved
- * whenever it does not lower the residual, a pairing stops once its step falls below 1e-10 */
+ * whenever it does not lower the residual, a pairing stops once its step falls below 1e-10.  The reference evaluates the residual four
+ * times per step (centre, both stencil points, the candidate); a step that was refused leaves the depths - hence the first three and
+ * everything derived from them - as they were, and an accepted candidate's residual is the next step's centre: those evaluations are
+ * reused instead of repeated (the same arguments give the same bits), which leaves three per accepted and one per refused step. */
 static void walk_along(const rdp_rays *R, descent2 *D) {
-  double u[RDP_PAIRINGS][4], damp[RDP_PAIRINGS];
-  int done[RDP_PAIRINGS];
   for (int m = 0; m < RDP_PAIRINGS; m++) {
+    double u[4], damp = 1.0, len = 0;
     const double k = 1.0 / (sqrt(D->dir[m][0] * D->dir[m][0] + D->dir[m][1] * D->dir[m][1] + D->dir[m][2] * D->dir[m][2] + D->dir[m][3] * D->dir[m][3]) + 1e-20);
-    for (int i = 0; i < 4; i++) u[m][i] = D->dir[m][i] * k;
-    damp[m] = 1.0; done[m] = 0;
-  }
-  for (int step = 0; step < RDP_WALK_STEPS; step++)
-    for (int m = 0; m < RDP_PAIRINGS; m++) {
-      if (done[m]) continue;
-      double fwd[4], bwd[4], cand[4];
-      for (int i = 0; i < 4; i++) { fwd[i] = D->t[m][i] + u[m][i] * RDP_FD_STEP; bwd[i] = D->t[m][i] + u[m][i] * -RDP_FD_STEP; }
-      const double f0 = rdp_defect(R, m, D->t[m]), ff = rdp_defect(R, m, fwd), fb = rdp_defect(R, m, bwd);
-      const double slope = (ff - fb) * (1.0 / (2 * RDP_FD_STEP));
-      double curv = (ff + fb - 2 * f0) * (1.0 / (RDP_FD_STEP * RDP_FD_STEP));
-      if (curv * curv < 1e-10) curv = 1;
-      const double len = fabs(slope / curv);
-      if (len < 1e-10) { done[m] = 1; continue; }
-      for (int i = 0; i < 4; i++) cand[i] = D->t[m][i] + u[m][i] * (len * damp[m]);
-      if (f0 < rdp_defect(R, m, cand)) { damp[m] *= 0.5; continue; }
+    for (int i = 0; i < 4; i++) u[i] = D->dir[m][i] * k;
+    if (!D->have_f0[m]) { D->f0[m] = rdp_defect(R, m, D->t[m]); D->have_f0[m] = 1; }
+    int have_len = 0;
+    for (int step = 0; step < RDP_WALK_STEPS; step++) {
+      double cand[4];
+      if (!have_len) {
+        double fwd[4], bwd[4];
+        for (int i = 0; i < 4; i++) { fwd[i] = D->t[m][i] + u[i] * RDP_FD_STEP; bwd[i] = D->t[m][i] + u[i] * -RDP_FD_STEP; }
+        const double f0 = D->f0[m], ff = rdp_defect(R, m, fwd), fb = rdp_defect(R, m, bwd);
+        const double slope = (ff - fb) * (1.0 / (2 * RDP_FD_STEP));
+        double curv = (ff + fb - 2 * f0) * (1.0 / (RDP_FD_STEP * RDP_FD_STEP));
+        if (curv * curv < 1e-10) curv = 1;
+        len = fabs(slope / curv);
+        have_len = 1;
+      }
+      if (len < 1e-10) break;
+      for (int i = 0; i < 4; i++) cand[i] = D->t[m][i] + u[i] * (len * damp);
+      const double fc = rdp_defect(R, m, cand);
+      if (D->f0[m] < fc) { damp *= 0.5; continue; }
       for (int i = 0; i < 4; i++) D->t[m][i] = cand[i];
+      D->f0[m] = fc; have_len = 0;
     }
+  }
 }
 
 /* rh:557-588: Polak-Ribiere conjugate gradients on the preconditioned residual, restarted every RDP_CG_RESTART steps and whenever
@@ -115,26 +128,150 @@ static void descend(const rdp_rays *R, descent2 *D) {
   }
 }
 
-/* a surviving candidate (four sides in w->out, their centre) -> rect_t */
-static rect_t candidate_rect(const rdp_work *w, rdp_p2 centre, int iw, int ih, double tanAOV, uint32_t status) {
+/* a surviving candidate (its four sides in angular order, their centre) -> rect_t */
+static rect_t candidate_rect(const rdp_seg *sides, rdp_p2 centre, int iw, int ih, double tanAOV, uint32_t status) {
   rdp_rays R;
   descent2 D;
   int first;
   memset(&D, 0, sizeof(D));
-  rdp_pose_setup(w->out, centre, iw, ih, tanAOV, &R, &first, D.t);
+  rdp_pose_setup(sides, centre, iw, ih, tanAOV, &R, &first, D.t);
   descend(&R, &D);
-  const double f[2] = { rdp_defect(&R, 0, D.t[0]), rdp_defect(&R, 1, D.t[1]) };
+  const double f[2] = { D.have_f0[0] ? D.f0[0] : rdp_defect(&R, 0, D.t[0]), D.have_f0[1] ? D.f0[1] : rdp_defect(&R, 1, D.t[1]) };
   rdp_rect r;
-  rdp_pose_finish(w->out, first, &R, (const double (*)[4])D.t, f, status, &r);
+  rdp_pose_finish(sides, first, &R, (const double (*)[4])D.t, f, status, &r);
   rect_t out;
   memcpy(&out, &r, sizeof(out));
   return out;
+}
+
+/* ------------------------------------------------------------------ the pose estimations of a frame's candidates, side by side
+ * The funnel leaves ~a dozen candidates per 1080p frame and the descent of one takes 20-25 us on a core: with the caller's thread alone that is
+ * a quarter of a millisecond at the end of EVERY frame's latency (the reference does the same on its caller's thread, rh:1049-1226).  The
+ * candidates are independent, so helper threads take some of them - but a sleeping thread takes longer to wake than its share is worth.  So
+ * the caller ARMS the helpers when it begins to wait for the device (rd_post_helpers_arm): they wake while the device is still busy and spin,
+ * for a bounded time, until the candidates are published; then everybody - the caller included - claims candidates one by one.  Results
+ * land in candidate order: the returned list does not depend on who computed what.  One frame at a time: a caller that finds the helpers
+ * taken (another detector's poll) runs its candidates alone. */
+typedef struct { rdp_seg sides[4]; rdp_p2 centre; uint32_t status; rect_t out; } pose_job;
+
+static struct {
+  pthread_mutex_t mu;             /* guards everything below */
+  pthread_cond_t cv;
+  pthread_mutex_t owner;          /* the caller whose candidates the helpers work on */
+  pthread_t th[RD_POST_MAX_HELPERS];
+  int nthreads, quit;
+  unsigned arm_gen;               /* raised by every rd_post_helpers_arm */
+  pose_job *jobs; int njobs, next, done;
+  int iw, ih; double tan_aov;
+  volatile int pending;           /* njobs - next, readable without the lock */
+} pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_MUTEX_INITIALIZER };
+
+static double mono_us(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
+
+/* claims and runs candidates until none is left; returns how many this thread ran */
+static int pool_work(void) {
+  int ran = 0;
+  for (;;) {
+    pthread_mutex_lock(&pool.mu);
+    if (pool.next >= pool.njobs) { pthread_mutex_unlock(&pool.mu); return ran; }
+    pose_job *j = &pool.jobs[pool.next++];
+    pool.pending = pool.njobs - pool.next;
+    const int iw = pool.iw, ih = pool.ih; const double tn = pool.tan_aov;
+    pthread_mutex_unlock(&pool.mu);
+    j->out = candidate_rect(j->sides, j->centre, iw, ih, tn, j->status);
+    ran++;
+    pthread_mutex_lock(&pool.mu);
+    pool.done++;
+    pthread_mutex_unlock(&pool.mu);
+  }
+}
+
+static void *pool_helper(void *arg) {
+  (void)arg;
+  unsigned seen = 0;
+  for (;;) {
+    pthread_mutex_lock(&pool.mu);
+    while (pool.arm_gen == seen && !pool.quit) pthread_cond_wait(&pool.cv, &pool.mu);
+    seen = pool.arm_gen;
+    if (pool.quit) { pthread_mutex_unlock(&pool.mu); return NULL; }
+    pthread_mutex_unlock(&pool.mu);
+    /* armed: a caller is waiting for its frame - spin until its candidates appear (or RD_POST_SPIN_US have passed: a frame that takes
+     * longer than that is not one whose latency these threads can save).  A call of arm that arrives meanwhile is seen by the wait above. */
+    const double until = mono_us() + RD_POST_SPIN_US;
+    for (;;) {
+      if (pool.pending > 0) { if (pool_work() > 0) break; }
+      else if (mono_us() > until) break;
+      else __builtin_ia32_pause();
+    }
+  }
+}
+
+void rd_post_helpers_configure(int n) {
+  if (n > RD_POST_MAX_HELPERS) n = RD_POST_MAX_HELPERS;
+  pthread_mutex_lock(&pool.mu);
+  while (pool.nthreads < n) {
+    if (pthread_create(&pool.th[pool.nthreads], NULL, pool_helper, NULL) != 0) break;
+    pool.nthreads++;
+  }
+  pthread_mutex_unlock(&pool.mu);
+}
+
+void rd_post_helpers_arm(void) {
+  if (pool.nthreads == 0) return;
+  pthread_mutex_lock(&pool.mu);
+  pool.arm_gen++;
+  pthread_cond_broadcast(&pool.cv);
+  pthread_mutex_unlock(&pool.mu);
+}
+
+int rd_post_helpers(void) { return pool.nthreads; }
+
+static void run_pose_jobs(pose_job *jobs, int n, int iw, int ih, double tanAOV) {
+  if (n > 1 && pool.nthreads > 0 && pthread_mutex_trylock(&pool.owner) == 0) {
+    pthread_mutex_lock(&pool.mu);
+    pool.jobs = jobs; pool.njobs = n; pool.next = 0; pool.done = 0; pool.iw = iw; pool.ih = ih; pool.tan_aov = tanAOV;
+    pool.pending = n;
+    pthread_mutex_unlock(&pool.mu);
+    pool_work();
+    for (;;) {      /* candidates the helpers claimed: they are running them right now */
+      pthread_mutex_lock(&pool.mu);
+      const int fin = pool.done == pool.njobs;
+      if (fin) { pool.njobs = 0; pool.next = 0; pool.pending = 0; pool.jobs = NULL; }
+      pthread_mutex_unlock(&pool.mu);
+      if (fin) break;
+      __builtin_ia32_pause();
+    }
+    pthread_mutex_unlock(&pool.owner);
+    return;
+  }
+  for (int i = 0; i < n; i++) jobs[i].out = candidate_rect(jobs[i].sides, jobs[i].centre, iw, ih, tanAOV, jobs[i].status);
 }
 
 typedef struct { int *v; int n, cap; } intlist;
 static void il_push(intlist *l, int x) {
   if (l->n == l->cap) { l->cap = l->cap ? l->cap * 2 : 16; l->v = (int *)realloc(l->v, sizeof(int) * (size_t)l->cap); }
   l->v[l->n++] = x;
+}
+
+/* ------------------------------------------------------------------ the frame's way into pinned memory */
+#include <immintrin.h>
+__attribute__((target("avx2"))) static void copy_stream_avx2(char *d, const char *s, size_t n) {
+  while (((uintptr_t)d & 31) && n) { *d++ = *s++; n--; }
+  for (; n >= 128; n -= 128, d += 128, s += 128) {
+    const __m256i a = _mm256_loadu_si256((const __m256i *)s), b = _mm256_loadu_si256((const __m256i *)(s + 32));
+    const __m256i c = _mm256_loadu_si256((const __m256i *)(s + 64)), e = _mm256_loadu_si256((const __m256i *)(s + 96));
+    _mm256_stream_si256((__m256i *)d, a); _mm256_stream_si256((__m256i *)(d + 32), b);
+    _mm256_stream_si256((__m256i *)(d + 64), c); _mm256_stream_si256((__m256i *)(d + 96), e);
+  }
+  _mm_sfence();
+  if (n) memcpy(d, s, n);
+}
+
+void rd_copy_to_staging(void *dst, const void *src, size_t n) {
+  static int avx2 = -1;
+  if (avx2 < 0) avx2 = __builtin_cpu_supports("avx2") ? 1 : 0;
+  if (avx2 && n >= 4096) copy_stream_avx2((char *)dst, (const char *)src, n);
+  else memcpy(dst, src, n);
 }
 
 /* ------------------------------------------------------------------ rh:1049-1226 */
@@ -145,9 +282,11 @@ void *rd_post_run(const void *segs, int max_records, const int *probes, int iw, 
   if (n > max_records - 1) n = max_records - 1;
   if (n < 0) n = 0;
 
-  rect_t *ret = (rect_t *)calloc(16, sizeof(rect_t));
-  int nret = 1, capret = 16;
-#define PUSH_RECT(r) do { if (nret == capret) { capret *= 2; ret = (rect_t *)realloc(ret, sizeof(rect_t) * (size_t)capret); } ret[nret++] = (r); } while (0)
+  /* the candidates that survive the funnel, in the reference's list order; their poses are estimated afterwards, side by side */
+  pose_job *jobs = (pose_job *)malloc(16 * sizeof(pose_job));
+  int njobs = 0, capjobs = 16;
+#define PUSH_CANDIDATE(st) do { if (njobs == capjobs) { capjobs *= 2; jobs = (pose_job *)realloc(jobs, sizeof(pose_job) * (size_t)capjobs); } \
+    memcpy(jobs[njobs].sides, w.out, sizeof(jobs[njobs].sides)); jobs[njobs].centre = centre; jobs[njobs].status = (st); njobs++; } while (0)
   /* work space of the funnel: a candidate never holds more segments than the frame has */
   rdp_work w;
   void *wmem = malloc(RDP_WORK_BYTES(n + 4));
@@ -192,7 +331,7 @@ void *rd_post_run(const void *segs, int max_records, const int *probes, int iw, 
       w.als[na].e0 = rdp_pt(x0, y0); w.als[na].e1 = rdp_pt(x1, y1);
       na++;
     }
-    if (rdp_funnel(&w, na, &centre)) PUSH_RECT(candidate_rect(&w, centre, iw, ih, tanAOV, 0));
+    if (rdp_funnel(&w, na, &centre)) PUSH_CANDIDATE(0);
   }
   for (int gi = 0; gi < ngroups; gi++) { intlist *set = (intlist *)ArrayMap_get(groups, keys[gi]); free(set->v); free(set); }
   free(keys);
@@ -206,11 +345,15 @@ void *rd_post_run(const void *segs, int max_records, const int *probes, int iw, 
       const rdp_p2 e0 = rdp_pt(ls[j].x0, ls[j].y0), e1 = rdp_pt(ls[j].x1, ls[j].y1);
       if (rdp_d2(e0, e1) > 32.0 * 32.0) { w.als[na].e0 = e0; w.als[na].e1 = e1; na++; }
     }
-    if (rdp_funnel(&w, na, &centre)) PUSH_RECT(candidate_rect(&w, centre, iw, ih, tanAOV, 2));
+    if (rdp_funnel(&w, na, &centre)) PUSH_CANDIDATE(2);
   }
   free(wmem);
 
-  ret[0].nItems = nret;
+  run_pose_jobs(jobs, njobs, iw, ih, tanAOV);
+  rect_t *ret = (rect_t *)calloc((size_t)njobs + 1, sizeof(rect_t));
+  for (int i = 0; i < njobs; i++) ret[i + 1] = jobs[i].out;
+  free(jobs);
+  ret[0].nItems = njobs + 1;
   return ret;
 }
 

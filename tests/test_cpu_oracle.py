@@ -113,6 +113,41 @@ def test_oracle_edge_cases():
         orc.close()
 
 
+def test_post_process_with_helper_threads_returns_the_same_bytes():
+    """The pose estimations of a frame's candidates shared with helper threads (csrc/rd_post.c: armed by the poll that waits for the frame, spinning until the candidates
+    are published) against the caller's thread alone: the same rect_t bytes in the same order, whoever computed which candidate - armed and not armed (helpers asleep: the
+    caller runs everything), and from two threads at once (one finds the helpers taken and runs alone)."""
+    import threading
+    L = ra.lib()
+    iw, ih = 640, 480
+    cases = []
+    for seed in (0, 5):
+        orc = helpers.OracleRect(iw, ih)
+        orc.frame(synth.frame(synth.SEED0 + seed, iw, ih, 0))
+        cases.append((orc.segments().copy(), orc.plane("boundary").copy(), orc.plane("table").copy()))
+        orc.close()
+    run = lambda c: ra.postprocess_planes(c[0], c[1], c[2], iw, ih, 0.7).tobytes()
+    alone = [run(c) for c in cases]      # (no helper exists yet in this process, unless an earlier test made some: then this is "not armed")
+    assert any(len(a) >= 2 * 176 for a in alone), "the frames should have several candidates"
+    L.rd_post_helpers_configure(3)
+    assert L.rd_post_helpers() >= 3
+    for rep in range(20):
+        for c, want in zip(cases, alone):
+            if rep % 2 == 0:
+                L.rd_post_helpers_arm()
+            assert run(c) == want
+    bad = []
+    def worker(i):
+        for rep in range(20):
+            L.rd_post_helpers_arm()
+            if run(cases[i]) != alone[i]:
+                bad.append(i)
+    ths = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not bad
+
+
 @pytest.mark.ref
 def test_oracle_against_live_reference_new_seed():
     """where the reference build exists: a seed that has no golden file, compared plane by plane"""

@@ -9,7 +9,7 @@ TAN = float(np.tan(36.0 / 180 * np.pi))
 frames = []
 for t in range(16):
     a = np.zeros((1080, 1920, 3), np.uint8); L.rd_synth_frame(a.ctypes.data, 1920, 1080, 1920 * 3, synth.SEED0, t, 1); frames.append(a)
-for label, post in (("host post-process", 0), ("device post-process", 1)):
+for label, post in (("host post-process", 0), ("device post-process", 1))[:1 if os.environ.get("LAT_HOST_POST_ONLY") else 2]:
     os.environ["RD_DEVICE_POST"] = str(post)
     det = ra.Detector(1920, 1080, nslots=1, nworkers=0, aperture=TAN)
     for k in range(8):
