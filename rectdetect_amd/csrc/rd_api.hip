@@ -279,6 +279,7 @@ cl_event oclpolyline_execute(oclpolyline_t *thiz, cl_mem lsList, int lsListSize,
 struct Slot {
   hipStream_t st;
   hipStream_t st2;                        // second stream of the slot: polyline stage, parallel to the region stages
+  int pooled_streams;                     // st / st2 come from the process-wide pool of high-priority streams and go back there
   int shares_streams;                     // st / st2 belong to another slot (see rd_detector_create)
   hipEvent_t ev_fork, ev_mm, ev_join;
   hipEvent_t ev_begin, ev_done, ev_strong;   // ev_begin/ev_done carry timestamps: device time of the frame (rd_detector_counter)
@@ -408,6 +409,41 @@ static void slot_planes(rd_detector *d, Slot *s, PlaneAlloc &A) {
   s->probes = A.get<int>((size_t)d->maxrec_dev * 15 * 6);
 }
 
+// Streams of the high-priority pool (see slot_alloc) are kept for the life of the process and handed to the next detector of the same device: a detector
+// that is closed and another one opened (bench.py's side configurations after the headline) then runs on the same hardware queues instead of a second set.
+static struct { pthread_mutex_t mu; hipStream_t st[64]; int dev[64]; int n; } stream_pool = { PTHREAD_MUTEX_INITIALIZER };
+static hipStream_t pooled_stream(int device) {
+  hipStream_t st = NULL;
+  pthread_mutex_lock(&stream_pool.mu);
+  for (int i = 0; i < stream_pool.n; i++) if (stream_pool.dev[i] == device) { st = stream_pool.st[i]; stream_pool.st[i] = stream_pool.st[stream_pool.n - 1]; stream_pool.dev[i] = stream_pool.dev[stream_pool.n - 1]; stream_pool.n--; break; }
+  pthread_mutex_unlock(&stream_pool.mu);
+  if (st) return st;
+  int lo = 0, hi = 0;
+  RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  RD_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
+  return st;
+}
+static void unpool_stream(int device, hipStream_t st) {
+  pthread_mutex_lock(&stream_pool.mu);
+  const bool room = stream_pool.n < 64;
+  if (room) { stream_pool.st[stream_pool.n] = st; stream_pool.dev[stream_pool.n] = device; stream_pool.n++; }
+  pthread_mutex_unlock(&stream_pool.mu);
+  if (!room) RD_HIP(hipStreamDestroy(st));
+}
+
+// A slot's stream for repeats and fetches (created on first use): from the runtime's high-priority pool of hardware queues.  As ordinary streams they share the
+// four queues of the default pool with the four streams that carry the groups, so a repeat - the oldest frame in flight, the one the caller waits for - stood in a queue
+// behind whole groups of later frames after all (the reason it has a stream of its own); with queues of their own: 2853 against 2776-2791 frames/s on one box
+// (RD_REDO_STREAM_PRIORITY=0: ordinary streams).  The group streams themselves stay in the default pool: moved to the high-priority pool they gain as much at 1920x1080
+// but a detector opened after another one was closed in the same process (bench.py's side configurations) then ran 10-16 % slower - not understood, not kept.
+static hipStream_t make_redo_stream() {
+  static const int prio = getenv("RD_REDO_STREAM_PRIORITY") ? atoi(getenv("RD_REDO_STREAM_PRIORITY")) : 1;
+  hipStream_t st = NULL;
+  if (prio) { int lo = 0, hi = 0; RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi)); RD_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi)); }
+  else RD_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+  return st;
+}
+
 // share: the slot whose streams this one uses as well (NULL: own streams)
 static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
   const size_t N = (size_t)d->N;
@@ -422,10 +458,9 @@ static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
     // costs the group path, whose four streams are best served by four queues, 9 %.)
     static const int fork_prio = getenv("RD_FORK_STREAM_PRIORITY") ? atoi(getenv("RD_FORK_STREAM_PRIORITY")) : 1;
     if (d->fork_poly && fork_prio) {
-      int lo = 0, hi = 0;
-      RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-      RD_HIP(hipStreamCreateWithPriority(&s->st, hipStreamNonBlocking, hi));
-      RD_HIP(hipStreamCreateWithPriority(&s->st2, hipStreamNonBlocking, hi));
+      s->st = pooled_stream(d->device);
+      s->st2 = pooled_stream(d->device);
+      s->pooled_streams = 1;
     } else {
     RD_HIP(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
     RD_HIP(hipStreamCreateWithFlags(&s->st2, hipStreamNonBlocking));
@@ -462,7 +497,7 @@ static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
   f.post_scratch = s->post_scratch; f.post_out = s->h_post_dev;
 }
 
-static void slot_free(Slot *s) {
+static void slot_free(Slot *s, int device) {
   RD_HIP(hipStreamSynchronize(s->st));
   void *all[] = { s->bgr, s->plab0, s->plab1, s->smooth, s->quant, s->vxy, s->strength, s->nms, s->i0, s->i1, s->mask0, s->tidy, s->label1, s->strsum,
                   s->region, s->rsize, s->scratch2, s->d2s, s->boundarysrc, s->boundary, s->lsid, s->table, s->claim, s->tlist, s->region0, s->probes, s->e8, s->strongbits, s->mmbits, s->ext, s->tails, s->flags, s->lslist };
@@ -478,8 +513,11 @@ static void slot_free(Slot *s) {
   if (s->st_redo) RD_HIP(hipStreamDestroy(s->st_redo));
   dfree(s->big_probes);
   if (!s->shares_streams) {
+    if (s->pooled_streams) { RD_HIP(hipStreamSynchronize(s->st2)); RD_HIP(hipStreamSynchronize(s->st)); unpool_stream(device, s->st2); unpool_stream(device, s->st); }
+    else {
     RD_HIP(hipStreamDestroy(s->st2));
     RD_HIP(hipStreamDestroy(s->st));
+    }
   }
 }
 
@@ -556,7 +594,7 @@ static void redo_votes(rd_detector *d, Slot *s, hipStream_t st) {
 // regions), by rounds over work lists until nothing changes, then everything downstream of it.  Runs on a stream of the slot's own
 // that is never captured (the loop synchronises), after the frame's ev_done: nothing else touches the slot's planes.
 static void frame_absorb_slow(rd_detector *d, Slot *s) {
-  if (!s->st_redo) RD_HIP(hipStreamCreateWithFlags(&s->st_redo, hipStreamNonBlocking));
+  if (!s->st_redo) s->st_redo = make_redo_stream();
   hipStream_t st = s->st_redo;
   rdk::despeckle2_slow(st, s->region, s->region0, s->d2s, s->rsize, 16, d->iw, d->ih);
   rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, d->iw, d->ih, s->table, s->claim, s->tlist);
@@ -900,7 +938,7 @@ static void slot_finish_device(rd_detector *d, Slot *s) {
     // (on a stream of the slot's own: the slot's regular stream is one of the four that carry the groups, and the repeat would wait there behind a whole group of
     //  other frames; nothing but this frame's result depends on it - the frame is finished, ev_done has been waited for)
     static const bool redo_inline = getenv("RD_REDO_ON_MAIN_STREAM") != NULL;
-    if (!s->st_redo && !redo_inline) RD_HIP(hipStreamCreateWithFlags(&s->st_redo, hipStreamNonBlocking));
+    if (!s->st_redo && !redo_inline) s->st_redo = make_redo_stream();
     hipStream_t rst = redo_inline ? s->st : s->st_redo;
     for (int budget = 32; budget <= 64; budget *= 2) {
       s->rounds = budget;
@@ -970,7 +1008,7 @@ static void wait_event_outside_captures(rd_detector *d, hipEvent_t ev) {
 // device -> host copy for a slot whose device work is complete, from any thread: on the slot's private stream (never the legacy stream -
 // a plain hipMemcpy would make that depend on a stream another thread may be capturing a graph on)
 static void slot_fetch(Slot *s, void *dst, const void *src, size_t bytes) {
-  if (!s->st_redo) RD_HIP(hipStreamCreateWithFlags(&s->st_redo, hipStreamNonBlocking));
+  if (!s->st_redo) s->st_redo = make_redo_stream();
   RD_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s->st_redo));
   RD_HIP(hipStreamSynchronize(s->st_redo));
 }
@@ -1008,7 +1046,7 @@ static void *slot_rectangles(rd_detector *d, Slot *s, double tanAOV, void **segs
     if (n + 1 > d->maxrec_dev) {
       // more records than the slot's probe buffer holds (the list itself has the reference's capacity, 16N / 56 records, pl:456): the
       // probes of all of them are taken again into a buffer that grows on demand - nothing is ever dropped
-      if (!s->st_redo) RD_HIP(hipStreamCreateWithFlags(&s->st_redo, hipStreamNonBlocking));
+      if (!s->st_redo) s->st_redo = make_redo_stream();
       if (s->big_probes_cap < n + 1) { dfree(s->big_probes); s->big_probes = dnew<int>((size_t)(n + 1) * 15 * 6); s->big_probes_cap = n + 1; }
       rdk::PolyFrame f = *s->frame;
       f.probes = s->big_probes; f.pack = NULL;
@@ -1192,7 +1230,7 @@ void rd_detector_destroy(rd_detector *d) {
     for (int k = 0; k < 3 * RD_NBUDGETS; k++) if (s->gexec2[k]) RD_HIP(hipGraphExecDestroy(s->gexec2[k]));
     if (s->gz0) RD_HIP(hipGraphExecDestroy(s->gz0));
     for (int k = 0; k < 3 * RD_NBUDGETS; k++) if (s->gz2[k]) RD_HIP(hipGraphExecDestroy(s->gz2[k]));
-    slot_free(s);
+    slot_free(s, d->device);
   }
   free(d->slots);
   free(d->frames);
