@@ -1241,6 +1241,24 @@ void rd_detector_destroy(rd_detector *d) {
   free(d);
 }
 
+// a frame's way to the device: pieces copied into pinned memory (by the caller and whichever helper threads are awake), uploaded in order as they complete
+struct UploadJob { char *dst; const char *src; char *dev; size_t bytes, piece; hipStream_t st; bool nt; int n, uploaded; int ready[64]; };
+static void upload_copy_piece(void *ctx, int i) {
+  UploadJob *u = (UploadJob *)ctx;
+  const size_t o = (size_t)i * u->piece, m = u->bytes - o < u->piece ? u->bytes - o : u->piece;
+  if (u->nt) rd_copy_to_staging(u->dst + o, u->src + o, m); else memcpy(u->dst + o, u->src + o, m);
+  __atomic_store_n(&u->ready[i], 1, __ATOMIC_RELEASE);
+}
+static void upload_progress(void *ctx) {      // (caller's thread only)
+  UploadJob *u = (UploadJob *)ctx;
+  int e = u->uploaded;
+  while (e < u->n && __atomic_load_n(&u->ready[e], __ATOMIC_ACQUIRE)) e++;
+  if (e == u->uploaded) return;
+  const size_t o = (size_t)u->uploaded * u->piece, end = (size_t)e * u->piece < u->bytes ? (size_t)e * u->piece : u->bytes;
+  RD_HIP(hipMemcpyAsync(u->dev + o, u->dst + o, end - o, hipMemcpyHostToDevice, u->st));
+  u->uploaded = e;
+}
+
 long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_device) {
   if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_enqueue: bad handle\n");
   if (d->next_enqueue - d->next_poll >= d->nslots) exitf(-1, "rd_detector_enqueue: %d frames already in flight (poll first)\n", d->nslots);
@@ -1252,16 +1270,24 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
   const size_t bytes = (size_t)ws * d->ih;
   if (on_device) s->src = (const uint8_t *)frame;      // read where it lies (the caller keeps it valid until the frame's poll returned)
   else if (d->zb == 1) {
-    // a single frame: the copy into pinned memory and the upload in four pieces, so that a piece travels while the next is being copied
-    // (6 MB at 1920x1080: the copy alone takes a third of a millisecond of the caller's latency)
+    // a single frame: the copy into pinned memory and the upload in pieces, so that a piece travels while the next is being copied (6 MB at 1920x1080:
+    // the copy alone takes a fifth of a millisecond of the caller's latency).  With helper threads (armed here: the call that hands a frame over is followed by
+    // the poll that waits for one) the pieces are copied side by side and uploaded in order as they complete.
     static const bool nt_copy = getenv("RD_NT_COPY") ? atoi(getenv("RD_NT_COPY")) != 0 : true;
-    static const int npieces = getenv("RD_UPLOAD_PIECES") ? atoi(getenv("RD_UPLOAD_PIECES")) : 4;
-    const size_t piece = ((bytes + npieces - 1) / npieces + 4095) & ~(size_t)4095;
-    for (size_t o = 0; o < bytes; o += piece) {
-      const size_t m = bytes - o < piece ? bytes - o : piece;
-      if (nt_copy) rd_copy_to_staging((char *)s->h_bgr + o, (const char *)frame + o, m); else memcpy((char *)s->h_bgr + o, (const char *)frame + o, m);
-      RD_HIP(hipMemcpyAsync(s->bgr + o, (char *)s->h_bgr + o, m, hipMemcpyHostToDevice, s->st));
-    }
+    static const int npieces_env = getenv("RD_UPLOAD_PIECES") ? atoi(getenv("RD_UPLOAD_PIECES")) : 0;
+    static const bool par_copy = getenv("RD_PARALLEL_COPY") ? atoi(getenv("RD_PARALLEL_COPY")) != 0 : true;
+    const bool helpers = d->post_helpers > 0 && par_copy;
+    if (helpers) rd_post_helpers_arm();
+    int npieces = npieces_env > 0 ? npieces_env : (helpers ? 16 : 4);
+    if (npieces > 64) npieces = 64;
+    UploadJob u;
+    u.dst = (char *)s->h_bgr; u.src = (const char *)frame; u.dev = (char *)s->bgr; u.bytes = bytes; u.st = s->st; u.nt = nt_copy; u.uploaded = 0;
+    u.piece = ((bytes + npieces - 1) / npieces + 4095) & ~(size_t)4095;
+    u.n = (int)((bytes + u.piece - 1) / u.piece);
+    for (int i = 0; i < u.n; i++) u.ready[i] = 0;
+    rd_helpers_run(upload_copy_piece, &u, u.n, upload_progress);
+    upload_progress(&u);
+    if (u.uploaded != u.n) exitf(-1, "rd_detector_enqueue: internal error (pieces of the frame left behind)\n");
     s->src = s->bgr;
   } else { memcpy(s->h_bgr, frame, bytes); s->src = s->bgr; }
   if (d->zb > 1) {      // group mode: launched together with the other frames of its group, once that is full (or a poll needs one of them)

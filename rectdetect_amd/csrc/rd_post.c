@@ -153,36 +153,37 @@ static rect_t candidate_rect(const rdp_seg *sides, rdp_p2 centre, int iw, int ih
  * land in candidate order: the returned list does not depend on who computed what.  One frame at a time: a caller that finds the helpers
  * taken (another detector's poll) runs its candidates alone. */
 typedef struct { rdp_seg sides[4]; rdp_p2 centre; uint32_t status; rect_t out; } pose_job;
+typedef struct { pose_job *jobs; int iw, ih; double tan_aov; } pose_batch;
 
 static struct {
   pthread_mutex_t mu;             /* guards everything below */
   pthread_cond_t cv;
-  pthread_mutex_t owner;          /* the caller whose candidates the helpers work on */
+  pthread_mutex_t owner;          /* the caller whose jobs the helpers work on */
   pthread_t th[RD_POST_MAX_HELPERS];
   int nthreads, quit;
   unsigned arm_gen;               /* raised by every rd_post_helpers_arm */
-  pose_job *jobs; int njobs, next, done;
-  int iw, ih; double tan_aov;
+  rd_job_fn fn; void *ctx; int njobs, next, done;
   volatile int pending;           /* njobs - next, readable without the lock */
 } pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_MUTEX_INITIALIZER };
 
 static double mono_us(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
 
-/* claims and runs candidates until none is left; returns how many this thread ran */
-static int pool_work(void) {
+/* claims and runs jobs (in index order) until none is left; returns how many this thread ran */
+static int pool_work(rd_progress_fn progress) {
   int ran = 0;
   for (;;) {
     pthread_mutex_lock(&pool.mu);
     if (pool.next >= pool.njobs) { pthread_mutex_unlock(&pool.mu); return ran; }
-    pose_job *j = &pool.jobs[pool.next++];
+    const int idx = pool.next++;
     pool.pending = pool.njobs - pool.next;
-    const int iw = pool.iw, ih = pool.ih; const double tn = pool.tan_aov;
+    const rd_job_fn fn = pool.fn; void *ctx = pool.ctx;
     pthread_mutex_unlock(&pool.mu);
-    j->out = candidate_rect(j->sides, j->centre, iw, ih, tn, j->status);
+    fn(ctx, idx);
     ran++;
     pthread_mutex_lock(&pool.mu);
     pool.done++;
     pthread_mutex_unlock(&pool.mu);
+    if (progress) progress(ctx);
   }
 }
 
@@ -195,11 +196,13 @@ static void *pool_helper(void *arg) {
     seen = pool.arm_gen;
     if (pool.quit) { pthread_mutex_unlock(&pool.mu); return NULL; }
     pthread_mutex_unlock(&pool.mu);
-    /* armed: a caller is waiting for its frame - spin until its candidates appear (or RD_POST_SPIN_US have passed: a frame that takes
-     * longer than that is not one whose latency these threads can save).  A call of arm that arrives meanwhile is seen by the wait above. */
-    const double until = mono_us() + RD_POST_SPIN_US;
+    /* armed: a caller has work coming - spin until jobs appear, take part, and go on spinning (the same call brings the copy of a frame first and its
+     * candidates a millisecond later) until RD_POST_SPIN_US have passed since the last arm: a frame that takes longer than that is not one whose latency
+     * these threads can save.  A call of arm that arrives meanwhile extends the time. */
+    double until = mono_us() + RD_POST_SPIN_US;
     for (;;) {
-      if (pool.pending > 0) { if (pool_work() > 0) break; }
+      if (pool.pending > 0) pool_work(NULL);
+      else if (pool.arm_gen != seen) { seen = pool.arm_gen; until = mono_us() + RD_POST_SPIN_US; }      /* (racy read: a missed one is caught by the wait above) */
       else if (mono_us() > until) break;
       else __builtin_ia32_pause();
     }
@@ -226,25 +229,36 @@ void rd_post_helpers_arm(void) {
 
 int rd_post_helpers(void) { return pool.nthreads; }
 
-static void run_pose_jobs(pose_job *jobs, int n, int iw, int ih, double tanAOV) {
+void rd_helpers_run(rd_job_fn fn, void *ctx, int n, rd_progress_fn progress) {
   if (n > 1 && pool.nthreads > 0 && pthread_mutex_trylock(&pool.owner) == 0) {
     pthread_mutex_lock(&pool.mu);
-    pool.jobs = jobs; pool.njobs = n; pool.next = 0; pool.done = 0; pool.iw = iw; pool.ih = ih; pool.tan_aov = tanAOV;
+    pool.fn = fn; pool.ctx = ctx; pool.njobs = n; pool.next = 0; pool.done = 0;
     pool.pending = n;
     pthread_mutex_unlock(&pool.mu);
-    pool_work();
-    for (;;) {      /* candidates the helpers claimed: they are running them right now */
+    pool_work(progress);
+    for (;;) {      /* jobs the helpers claimed: they are running them right now */
       pthread_mutex_lock(&pool.mu);
       const int fin = pool.done == pool.njobs;
-      if (fin) { pool.njobs = 0; pool.next = 0; pool.pending = 0; pool.jobs = NULL; }
+      if (fin) { pool.njobs = 0; pool.next = 0; pool.pending = 0; pool.fn = NULL; pool.ctx = NULL; }
       pthread_mutex_unlock(&pool.mu);
       if (fin) break;
-      __builtin_ia32_pause();
+      if (progress) progress(ctx); else __builtin_ia32_pause();
     }
     pthread_mutex_unlock(&pool.owner);
+    if (progress) progress(ctx);
     return;
   }
-  for (int i = 0; i < n; i++) jobs[i].out = candidate_rect(jobs[i].sides, jobs[i].centre, iw, ih, tanAOV, jobs[i].status);
+  for (int i = 0; i < n; i++) { fn(ctx, i); if (progress) progress(ctx); }
+}
+
+static void pose_job_run(void *ctx, int i) {
+  pose_batch *b = (pose_batch *)ctx;
+  b->jobs[i].out = candidate_rect(b->jobs[i].sides, b->jobs[i].centre, b->iw, b->ih, b->tan_aov, b->jobs[i].status);
+}
+
+static void run_pose_jobs(pose_job *jobs, int n, int iw, int ih, double tanAOV) {
+  pose_batch b = { jobs, iw, ih, tanAOV };
+  rd_helpers_run(pose_job_run, &b, n, NULL);
 }
 
 typedef struct { int *v; int n, cap; } intlist;

@@ -17,6 +17,11 @@ void *rd_post_run(const void *segs, int max_records, const int *probes, int iw, 
 void rd_post_helpers_configure(int n);
 void rd_post_helpers_arm(void);
 int rd_post_helpers(void);
+/* fn(ctx, 0) .. fn(ctx, n - 1), each once, claimed in index order by the caller's thread and by whichever helpers are awake; returns when all have run.
+ * progress (may be NULL) is called on the CALLER's thread after each of its own jobs and while it waits for the helpers' last ones. */
+typedef void (*rd_job_fn)(void *ctx, int idx);
+typedef void (*rd_progress_fn)(void *ctx);
+void rd_helpers_run(rd_job_fn fn, void *ctx, int n, rd_progress_fn progress);
 /* memcpy into a staging buffer nobody on the host reads again (the DMA engine does): non-temporal stores - no read-for-ownership of the destination, the
  * caller's cache keeps its contents.  Falls back to memcpy without AVX2. */
 void rd_copy_to_staging(void *dst, const void *src, size_t n);
