@@ -1184,7 +1184,7 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   // streams of slot i mod 4) - a stream of its own would be time-sliced onto the same four hardware queues and stall frames
   // that have nothing to do with each other, while a queued frame keeps its queue busy as soon as its predecessor is done
   // (the host's turn-around between "frame polled" and "next frame enqueued" otherwise idles a quarter of the device).
-  const int nstreams = 4;
+  const int nstreams = getenv("RD_NSTREAMS") ? (atoi(getenv("RD_NSTREAMS")) < 1 ? 1 : (atoi(getenv("RD_NSTREAMS")) > 8 ? 8 : atoi(getenv("RD_NSTREAMS")))) : 4;      // (measurements only - 3 / 5 / 6 streams: 2776-2786 / 2746-2753 / 2827-2847 frames/s against 2881-2889 with four, one box)
   d->nstreams = nstreams < nslots ? nstreams : nslots;
   // Group mode: four frames per launch from twelve frame slots on (three groups: one being filled, two in flight), two from six on, eight from 32 on
   // (640x480: 9100 frames/s with 16 slots in groups of four, 11700 with 32 in groups of eight; 1080p: no difference);
@@ -1289,7 +1289,11 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
     upload_progress(&u);
     if (u.uploaded != u.n) exitf(-1, "rd_detector_enqueue: internal error (pieces of the frame left behind)\n");
     s->src = s->bgr;
-  } else { memcpy(s->h_bgr, frame, bytes); s->src = s->bgr; }
+  } else {      // (group mode: the group's frames are uploaded together when it is launched)
+    static const bool nt_copy_g = getenv("RD_NT_COPY") ? atoi(getenv("RD_NT_COPY")) != 0 : true;
+    if (nt_copy_g) rd_copy_to_staging(s->h_bgr, frame, bytes); else memcpy(s->h_bgr, frame, bytes);
+    s->src = s->bgr;
+  }
   if (d->zb > 1) {      // group mode: launched together with the other frames of its group, once that is full (or a poll needs one of them)
     const int si = (int)(s - d->slots);
     s->pending_dense = 1;
