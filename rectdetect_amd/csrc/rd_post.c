@@ -151,7 +151,9 @@ static rect_t candidate_rect(const rdp_seg *sides, rdp_p2 centre, int iw, int ih
  * the caller ARMS the helpers when it begins to wait for the device (rd_post_helpers_arm): they wake while the device is still busy and spin,
  * for a bounded time, until the candidates are published; then everybody - the caller included - claims candidates one by one.  Results
  * land in candidate order: the returned list does not depend on who computed what.  One frame at a time: a caller that finds the helpers
- * taken (another detector's poll) runs its candidates alone. */
+ * taken (another detector's poll) runs its candidates alone.
+ * The helpers live as long as the process (never joined; a child of fork() has none and runs everything on its caller's thread: the caller claims every
+ * job nobody else claims, so nothing ever waits for a helper that does not exist; the library is not meant to be unloaded while they exist). */
 typedef struct { rdp_seg sides[4]; rdp_p2 centre; uint32_t status; rect_t out; } pose_job;
 typedef struct { pose_job *jobs; int iw, ih; double tan_aov; } pose_batch;
 
