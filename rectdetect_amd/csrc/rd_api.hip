@@ -712,7 +712,9 @@ static const int kRoundBudgets[RD_NBUDGETS] = { 8, 10, 12, 14, 16, 18, 20 };
 
 static void run_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t st_over = NULL) {      // st_over (segment 1 only): another stream than the slot's
   hipStream_t lst = st_over ? st_over : s->st;
-  if (!d->use_graph || (seg == 2 && d->fork_poly && !d->graph_fork)) { frame_segment(d, s, ws, seg, lst); return; }
+  // (one or two frames in flight: kernel by kernel - the captured graph of the forked segment starts its second branch 170 us late, and the front segment, a straight
+  //  line of ten kernels, is no faster as a graph either: 1615-1623 against 1636-1652 frames/s two deep; RD_GRAPH_FORK=1 brings both graphs back)
+  if (!d->use_graph || (d->fork_poly && !d->graph_fork)) { frame_segment(d, s, ws, seg, lst); return; }
   hipGraphExec_t *ge = &s->gexec[seg];
   if (seg == 2) for (int k = 0; k < RD_NBUDGETS; k++) if (kRoundBudgets[k] == s->rounds) ge = &s->gexec2[k * 3 + (d->batch == 1 ? s->poly_mode : 0)];
   if (!*ge) {
