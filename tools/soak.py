@@ -18,8 +18,8 @@ for t in range(64):
     p = L.rd_device_alloc(a.nbytes); L.rd_upload(p, a.ctypes.data, a.nbytes); frames.append(p)
 
 
-def run(slots):
-    det = ra.Detector(iw, ih, nslots=slots, nworkers=1)
+def run(slots, workers=1):
+    det = ra.Detector(iw, ih, nslots=slots, nworkers=workers)
     out, infl = [], 0
     t0 = time.perf_counter()
     for i in range(nframes):
@@ -39,5 +39,6 @@ a, fa, ra_ = run(SL)
 b, fb, rb_ = run(SL)
 c, fc, rc_ = run(1)
 print("frames", nframes, "fps", round(fa), round(fb), round(fc), "round budget / repeats", ra_, rb_, rc_)
-print(SL, "slots twice identical:", a == b, "|", SL, "slots vs 1 slot identical:", a == c)
-sys.exit(0 if (a == b and a == c) else 1)
+d, fd, rd_ = run(2, 0)      # the reference's call shape: two frames in flight, the caller's thread post-processes - with the helper threads of rd_post.c
+print(SL, "slots twice identical:", a == b, "|", SL, "slots vs 1 slot identical:", a == c, "| vs 2 slots without workers (%d frames/s, %d helper threads) identical:" % (round(fd), L.rd_post_helpers()), a == d)
+sys.exit(0 if (a == b and a == c and a == d) else 1)
