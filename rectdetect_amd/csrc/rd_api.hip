@@ -1145,6 +1145,7 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   // frames in flight a frame spreads over two streams (polyline chain beside the blur chain: shortest latency); from three
   // frames on every frame keeps to one stream, so that four frames occupy the four queues (highest throughput).
   d->fork_poly = nslots <= 2 ? 1 : 0;
+  if (getenv("RD_FORK_POLY")) d->fork_poly = (atoi(getenv("RD_FORK_POLY")) != 0 && nslots <= 2) ? 1 : 0;      // (measurements: one stream per frame with one or two in flight as well)
   // One or two frames in flight and no worker threads = the reference's call sequence (executeOnce, enqueueTask / pollTask): the caller's thread runs the
   // post-process at the end of every frame's latency; helper threads share its pose estimations (rd_post.c), RD_POST_HELPERS=n overrides their number
   d->post_helpers = 0;
