@@ -157,9 +157,9 @@ def section_stream(R, rep):
 
 
 def section_streamlong(R, rep):
-    """the four long streams of the parity table (516 frames), rectangle lists only"""
+    """the long streams of the parity table (916 frames: 516 + round 5's two held-out streams), rectangle lists only"""
     rows = {}
-    for name in ("stream_1920x1080_s0_100", "stream_1920x1080_s7_100", "stream_1280x720_s1_300", "stream_3840x2160_s4_16"):
+    for name in ("stream_1920x1080_s0_100", "stream_1920x1080_s7_100", "stream_1280x720_s1_300", "stream_3840x2160_s4_16", "stream_1920x1080_s11_200", "stream_1920x1080_s12_200"):
         z = np.load(os.path.join(GOLDEN, name + ".npz"))
         iw, ih, seed, tan = int(z["iw"]), int(z["ih"]), int(z["seed"]), float(z["tan_aov"])
         d = Rect(R, iw, ih)
