@@ -32,7 +32,8 @@ ORDERS = STILL_ORDERS + [(0, 0, 5, 0), (64, 4, 3, 7), (16, 16, 3, 9), (128, 2, 3
 FRAMES = {"stream_1280x720_s1_300": [32, 161, 162], "stream_1920x1080_s0_100": [42, 55, 57, 70, 76, 90, 98], "stream_3840x2160_s4_16": [3, 7],
           "stream_1920x1080_s7_100": [0, 5, 63, 64, 71, 72],      # (the held-out stream of round 3: tools/stream_mismatch.py)
           # round 5's two held-out streams (generated after the round's last kernel change; 64 frames in flight)
-          "stream_1920x1080_s11_200": [0, 2, 12, 28, 31, 49, 112, 119, 155], "stream_1920x1080_s12_200": [14, 25, 26, 30, 39]}
+          "stream_1920x1080_s11_200": [0, 2, 12, 28, 31, 49, 112, 119, 155], "stream_1920x1080_s12_200": [14, 25, 26, 30, 39],
+          "stream_1280x720_s13_300": [112, 147, 158, 267, 277, 297]}
 PARALLEL = 8
 
 

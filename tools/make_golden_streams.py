@@ -28,7 +28,8 @@ CASES = {"stream_1920x1080_s0": (1920, 1080, 0, 16, 36.0), "stream_1280x720_s1":
          # round 3: a second 1920x1080 stream (another seed) that no design decision was made on - a held-out check of the region stages
          "stream_1920x1080_s7_100": (1920, 1080, 7, 100, 36.0),
          # round 5: two more 1920x1080 streams of other seeds, 200 frames each, generated after the last kernel change of the round - held out as well
-         "stream_1920x1080_s11_200": (1920, 1080, 11, 200, 36.0), "stream_1920x1080_s12_200": (1920, 1080, 12, 200, 36.0)}
+         "stream_1920x1080_s11_200": (1920, 1080, 11, 200, 36.0), "stream_1920x1080_s12_200": (1920, 1080, 12, 200, 36.0),
+         "stream_1280x720_s13_300": (1280, 720, 13, 300, 36.0)}      # (and a second 1280x720 stream at configs[2]'s length, another seed)
 DEFAULT = ["stream_1920x1080_s0", "stream_1280x720_s1", "stream_3840x2160_s4"]      # (the long ones by name: 6-10 minutes each)
 
 
