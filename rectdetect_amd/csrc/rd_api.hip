@@ -1351,9 +1351,20 @@ void *rd_detector_poll(rd_detector *d, double tanAOV) {
     }
   } else {
     if (d->post_helpers) rd_post_helpers_arm();      // (they wake while the device is still busy with the frame: rd_post.c)
-    RD_HIP(hipEventSynchronize(s->ev_done));
+    static const int trace_poll = getenv("RD_TRACE_POLL") ? atoi(getenv("RD_TRACE_POLL")) : 0;      // (1: timings, 2: wait by querying instead of hipEventSynchronize)
+    struct timespec t0, t1, t2, t3; clock_gettime(CLOCK_MONOTONIC, &t0);
+    if (trace_poll == 2) { while (hipEventQuery(s->ev_done) == hipErrorNotReady) __builtin_ia32_pause(); }
+    else RD_HIP(hipEventSynchronize(s->ev_done));
+    clock_gettime(CLOCK_MONOTONIC, &t1);
     slot_finish_device(d, s);
+    clock_gettime(CLOCK_MONOTONIC, &t2);
     r = slot_rectangles(d, s, tanAOV, &segs, &ns);
+    clock_gettime(CLOCK_MONOTONIC, &t3);
+    if (trace_poll) {
+      static double a, b, c; static int n;
+      a += (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3; b += (t2.tv_sec - t1.tv_sec) * 1e6 + (t2.tv_nsec - t1.tv_nsec) * 1e-3; c += (t3.tv_sec - t2.tv_sec) * 1e6 + (t3.tv_nsec - t2.tv_nsec) * 1e-3;
+      if (++n % 100 == 0) { fprintf(stderr, "poll: wait %.1f us, finish %.1f us, rectangles %.1f us (average of 100)\n", a / 100, b / 100, c / 100); a = b = c = 0; }
+    }
   }
   { float ms = 0.0f; if (hipEventElapsedTime(&ms, s->ev_begin, s->ev_done) == hipSuccess) { d->dev_us += (long)(ms * 1000.0f) / (s->group_n > 0 ? s->group_n : 1); d->dev_frames++; } }      // (a group's interval is shared by its frames: counted once)
   free(d->last_segs);
