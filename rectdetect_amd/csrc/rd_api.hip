@@ -279,6 +279,7 @@ cl_event oclpolyline_execute(oclpolyline_t *thiz, cl_mem lsList, int lsListSize,
 struct Slot {
   hipStream_t st;
   hipStream_t st2;                        // second stream of the slot: polyline stage, parallel to the region stages
+  int uploaded_early;                     // group mode, host frames: the upload was issued when the frame was handed over (ev_fork marks its end)
   int pooled_streams;                     // st / st2 come from the process-wide pool of high-priority streams and go back there
   int shares_streams;                     // st / st2 belong to another slot (see rd_detector_create)
   hipEvent_t ev_fork, ev_mm, ev_join;
@@ -357,6 +358,7 @@ struct rd_detector {
   int poly_overflows;                     // set once two frames in a row overflowed the single-launch polyline kernel: later frames go multi-launch
   int rounds_budget, need_hist[64]; unsigned need_pos; long budget_count[RD_NBUDGETS], need_count[21];
   int graph_fork;            // the forked segment (one or two frames in flight: polyline chain beside the blur / region chain) as a captured graph too
+  hipStream_t st_upload;     // group mode, host frames: the stream the frames travel on (created on first use, from the pool of high-priority streams)
   int post_helpers;          // helper threads armed by every poll (rd_post.c), 0 = none
   long host_enqueue_ns;      // wall time the caller spent inside rd_detector_enqueue
   long dev_us, dev_frames;   // sum over polled frames of (last kernel end - first kernel start) on the frame's stream, HIP events
@@ -825,7 +827,7 @@ static void group_launch(rd_detector *d, int g0) {
       Slot *s = &d->slots[i];
       if (!s->pending_dense) continue;
       s->pending_dense = 0;
-      if (s->src == s->bgr) RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, (size_t)s->ws * d->ih, hipMemcpyHostToDevice, s->st));
+      if (s->src == s->bgr) { if (s->uploaded_early) RD_HIP(hipStreamWaitEvent(s->st, s->ev_fork, 0)); else RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, (size_t)s->ws * d->ih, hipMemcpyHostToDevice, s->st)); }
       enqueue_frame(d, s, s->ws);
       slot_submitted(d, s);
     }
@@ -843,7 +845,7 @@ static void group_launch(rd_detector *d, int g0) {
   for (int i = 0; i < zb; i++) {
     Slot *s = &d->slots[g0 + i];
     s->pending_dense = 0;
-    if (s->src == s->bgr) RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, (size_t)ws * d->ih, hipMemcpyHostToDevice, st));
+    if (s->src == s->bgr) { if (s->uploaded_early) RD_HIP(hipStreamWaitEvent(st, s->ev_fork, 0)); else RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, (size_t)ws * d->ih, hipMemcpyHostToDevice, st)); }
     srcs[i] = s->src;
     RD_HIP(hipEventRecord(s->ev_begin, st));
   }
@@ -1235,6 +1237,7 @@ void rd_detector_destroy(rd_detector *d) {
     for (int k = 0; k < 3 * RD_NBUDGETS; k++) if (s->gz2[k]) RD_HIP(hipGraphExecDestroy(s->gz2[k]));
     slot_free(s, d->device);
   }
+  if (d->st_upload) { RD_HIP(hipStreamSynchronize(d->st_upload)); unpool_stream(d->device, d->st_upload); }
   free(d->slots);
   free(d->frames);
   dfree(d->prev_ring);
@@ -1296,6 +1299,17 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
     static const bool nt_copy_g = getenv("RD_NT_COPY") ? atoi(getenv("RD_NT_COPY")) != 0 : true;
     if (nt_copy_g) rd_copy_to_staging(s->h_bgr, frame, bytes); else memcpy(s->h_bgr, frame, bytes);
     s->src = s->bgr;
+    // The frame travels NOW, on a stream of the detector's own (high-priority pool: a hardware queue nobody computes on), not when its group is launched: eight uploads in
+    // front of a group's kernels kept that group's stream - a quarter of the device's queues - waiting for the copy engine for 1.6 of its 10.8 ms.  The group's stream
+    // waits for the event instead (group_launch).  RD_UPLOAD_EARLY=0: as before.
+    static const bool upload_early = getenv("RD_UPLOAD_EARLY") ? atoi(getenv("RD_UPLOAD_EARLY")) != 0 : true;
+    s->uploaded_early = 0;
+    if (upload_early) {
+      if (!d->st_upload) d->st_upload = pooled_stream(d->device);
+      RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, bytes, hipMemcpyHostToDevice, d->st_upload));
+      RD_HIP(hipEventRecord(s->ev_fork, d->st_upload));      // (the slot's fork event: unused by detectors that launch groups)
+      s->uploaded_early = 1;
+    }
   }
   if (d->zb > 1) {      // group mode: launched together with the other frames of its group, once that is full (or a poll needs one of them)
     const int si = (int)(s - d->slots);
