@@ -165,7 +165,7 @@ static struct {
   int nthreads, quit;
   unsigned arm_gen;               /* raised by every rd_post_helpers_arm */
   rd_job_fn fn; void *ctx; int njobs, next, done;
-  volatile int pending;           /* njobs - next, readable without the lock */
+  int pending;                    /* njobs - next; read without the lock by spinning helpers (relaxed atomics) */
 } pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_MUTEX_INITIALIZER };
 
 static double mono_us(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
@@ -177,7 +177,7 @@ static int pool_work(rd_progress_fn progress) {
     pthread_mutex_lock(&pool.mu);
     if (pool.next >= pool.njobs) { pthread_mutex_unlock(&pool.mu); return ran; }
     const int idx = pool.next++;
-    pool.pending = pool.njobs - pool.next;
+    __atomic_store_n(&pool.pending, pool.njobs - pool.next, __ATOMIC_RELAXED);
     const rd_job_fn fn = pool.fn; void *ctx = pool.ctx;
     pthread_mutex_unlock(&pool.mu);
     fn(ctx, idx);
@@ -203,8 +203,8 @@ static void *pool_helper(void *arg) {
      * these threads can save.  A call of arm that arrives meanwhile extends the time. */
     double until = mono_us() + RD_POST_SPIN_US;
     for (;;) {
-      if (pool.pending > 0) pool_work(NULL);
-      else if (pool.arm_gen != seen) { seen = pool.arm_gen; until = mono_us() + RD_POST_SPIN_US; }      /* (racy read: a missed one is caught by the wait above) */
+      if (__atomic_load_n(&pool.pending, __ATOMIC_RELAXED) > 0) pool_work(NULL);
+      else if (__atomic_load_n(&pool.arm_gen, __ATOMIC_RELAXED) != seen) { seen = __atomic_load_n(&pool.arm_gen, __ATOMIC_RELAXED); until = mono_us() + RD_POST_SPIN_US; }      /* (racy read: a missed one is caught by the wait above) */
       else if (mono_us() > until) break;
       else __builtin_ia32_pause();
     }
@@ -235,13 +235,13 @@ void rd_helpers_run(rd_job_fn fn, void *ctx, int n, rd_progress_fn progress) {
   if (n > 1 && pool.nthreads > 0 && pthread_mutex_trylock(&pool.owner) == 0) {
     pthread_mutex_lock(&pool.mu);
     pool.fn = fn; pool.ctx = ctx; pool.njobs = n; pool.next = 0; pool.done = 0;
-    pool.pending = n;
+    __atomic_store_n(&pool.pending, n, __ATOMIC_RELAXED);
     pthread_mutex_unlock(&pool.mu);
     pool_work(progress);
     for (;;) {      /* jobs the helpers claimed: they are running them right now */
       pthread_mutex_lock(&pool.mu);
       const int fin = pool.done == pool.njobs;
-      if (fin) { pool.njobs = 0; pool.next = 0; pool.pending = 0; pool.fn = NULL; pool.ctx = NULL; }
+      if (fin) { pool.njobs = 0; pool.next = 0; __atomic_store_n(&pool.pending, 0, __ATOMIC_RELAXED); pool.fn = NULL; pool.ctx = NULL; }
       pthread_mutex_unlock(&pool.mu);
       if (fin) break;
       if (progress) progress(ctx); else __builtin_ia32_pause();
