@@ -59,7 +59,7 @@ static void *prog_dl[NPROG];
 
 /* ---------------------------------------------------------------- trace */
 
-typedef struct { char name[96]; size_t gws[2]; int dim; } rdcl_launch_t;
+typedef struct { char name[96]; size_t gws[2]; int dim; uint64_t hash[16]; size_t bytes[16]; } rdcl_launch_t;
 typedef struct { char name[96]; int occurrence, argidx, ordinal; void *data; size_t size; int done; } rdcl_snap_t;
 
 static rdcl_launch_t *trace_buf = NULL;
@@ -72,6 +72,13 @@ void rdcl_trace_enable(int on) { trace_on = on; }
 int rdcl_trace_count(void) { return trace_n; }
 const char *rdcl_trace_name(int i) { return (i >= 0 && i < trace_n) ? trace_buf[i].name : ""; }
 size_t rdcl_trace_gws(int i, int d) { return (i >= 0 && i < trace_n && d >= 0 && d < 2) ? trace_buf[i].gws[d] : 0; }
+/* rdcl_hash_all(1): fingerprint and size of buffer argument `arg` of launch i right after it ran (size 0: not a buffer) */
+uint64_t rdcl_trace_hash(int i, int arg) { return (i >= 0 && i < trace_n && arg >= 0 && arg < 16) ? trace_buf[i].hash[arg] : 0; }
+size_t rdcl_trace_bytes(int i, int arg) { return (i >= 0 && i < trace_n && arg >= 0 && arg < 16) ? trace_buf[i].bytes[arg] : 0; }
+
+static size_t snap_limit = 0;      /* snapshots keep at most so many bytes of a buffer (0: all of it) */
+void rdcl_snapshot_limit(size_t bytes) { snap_limit = bytes; }
+void rdcl_zero_fill(int on) { (void)on; }      /* (the observer's switch, rdcl_observe.c: this device's buffers always start as zeros) */
 
 void rdcl_snapshot_clear(void) {
   for (int i = 0; i < nsnaps; i++) free(snaps[i].data);
@@ -292,39 +299,52 @@ static int order_applies(const struct _cl_kernel *k) {
   return 0;
 }
 
+
+/* ---------------------------------------------------------------- interventions for tests (none is on by default)
+ * rdcl_set_repeat(name, occurrence, extra): right after the `occurrence`-th launch of "<prog>:<kernel>" (counted since the last rdcl_trace_reset) the SAME launch - same
+ *   arguments, same work-item order - is run up to `extra` more times; rdcl_repeat_changed(i) = 32-bit words of the kernel's buffer arguments that extra launch i changed
+ *   (-1: not run; the extra launches stop after one that changed nothing - every later one would repeat it).  What it is for: is the reference's region merge settled after
+ *   its 8 launches (oclrect.c:325-331), and what does the reference return when the kernel is launched until it is?
+ * rdcl_skip_launches(on): launches become no-ops (the host side of the reference alone, on substituted read-backs).
+ * rdcl_substitute_reads(n, data, sizes): the next n clEnqueueReadBuffer calls return the given bytes instead of the buffer's (the caller's planes in place of the three
+ *   read-backs of genGPUTask, oclrect.c:371-376, so that the reference's own compiled executeCPUTask runs on them).
+ * rdcl_hash_all(on): every launch of the trace also records a 64-bit hash of each of its buffer arguments, taken right after it (rdcl_trace_hash). */
+#define MAXREPEAT 256
+static char repeat_name[96] = "";
+static int repeat_occ = -1, repeat_extra = 0, repeat_changed[MAXREPEAT];
+void rdcl_set_repeat(const char *name, int occurrence, int extra) {
+  snprintf(repeat_name, sizeof(repeat_name), "%s", name ? name : "");
+  repeat_occ = occurrence; repeat_extra = extra > MAXREPEAT ? MAXREPEAT : extra;
+  for (int i = 0; i < MAXREPEAT; i++) repeat_changed[i] = -1;
+}
+int rdcl_repeat_changed(int i) { return (i >= 0 && i < MAXREPEAT) ? repeat_changed[i] : -1; }
+static int skip_launches = 0;
+void rdcl_skip_launches(int on) { skip_launches = on; }
+#define MAXSUBST 8
+static const void *subst_data[MAXSUBST]; static size_t subst_size[MAXSUBST]; static int subst_n = 0, subst_at = 0;
+void rdcl_substitute_reads(int n, const void **data, const size_t *sizes) {
+  subst_n = n > MAXSUBST ? MAXSUBST : (n < 0 ? 0 : n); subst_at = 0;
+  for (int i = 0; i < subst_n; i++) { subst_data[i] = data[i]; subst_size[i] = sizes[i]; }
+}
+static int hash_all = 0;
+void rdcl_hash_all(int on) { hash_all = on; }
+static uint64_t hash_bytes(const void *p, size_t n) {      /* FNV-1a over 64-bit words (+ the tail bytes): a fingerprint, nothing more */
+  uint64_t h = 1469598103934665603ull;
+  const uint64_t *w = (const uint64_t *)p;
+  for (size_t i = 0; i < n / 8; i++) { h ^= w[i]; h *= 1099511628211ull; }
+  const unsigned char *b = (const unsigned char *)p + (n & ~(size_t)7);
+  for (size_t i = 0; i < (n & 7); i++) { h ^= b[i]; h *= 1099511628211ull; }
+  return h;
+}
+
 typedef void (*generic_fn)(int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
                            int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
                            float, float, float, float);
 
-cl_int clEnqueueNDRangeKernel(cl_command_queue q, cl_kernel k, cl_uint dim, const size_t *off, const size_t *gws,
-                              const size_t *lws, cl_uint nev, const cl_event *evl, cl_event *ev) {
-  (void)q; (void)off; (void)lws; (void)nev; (void)evl;
-  if (dim < 1 || dim > 2) return CL_INVALID_WORK_DIMENSION;
-
-  /* SysV x86-64: INTEGER-class parameters (ints, longs, pointers) go to rdi,rsi,rdx,rcx,r8,r9 and
-   * then to consecutive 8-byte stack slots in order; float parameters go to xmm0.. in order.  The two
-   * sequences are independent, so one generic signature covers every kernel (<=12 args, <=3 floats). */
-  int64_t ia[16]; float fa[4]; int ni = 0, nf = 0;
-  memset(ia, 0, sizeof(ia)); memset(fa, 0, sizeof(fa));
-  void *argptr[MAXARGS]; size_t argbytes[MAXARGS];
-  for (int i = 0; i < k->nargs; i++) {
-    argptr[i] = NULL; argbytes[i] = 0;
-    if (k->argsize[i] == 4 && (k->floatmask & (1u << i))) {
-      if (nf >= 4) return CL_INVALID_KERNEL_ARGS;
-      memcpy(&fa[nf++], &k->argval[i], 4);
-    } else if (k->argsize[i] == 4) {
-      int32_t v; memcpy(&v, &k->argval[i], 4);
-      ia[ni++] = v;
-    } else {
-      struct _cl_mem *m = find_mem(k->argval[i]);
-      if (m) { ia[ni++] = (int64_t)(intptr_t)m->data; argptr[i] = m->data; argbytes[i] = m->size; }
-      else ia[ni++] = (int64_t)k->argval[i];
-    }
-  }
-
+/* all work-items of one launch, in the order rdcl_set_order selected for this kernel */
+static void run_items(cl_kernel k, const int64_t *ia, const float *fa, size_t g0, size_t g1) {
   generic_fn fn = (generic_fn)k->fn;
   size_t *gid = k->prog.gid;
-  size_t g0 = gws[0], g1 = dim == 2 ? gws[1] : 1;
   gid[2] = 0;
 #define RUN_ITEM(X, Y) do { gid[0] = (X); gid[1] = (Y); \
       fn(ia[0], ia[1], ia[2], ia[3], ia[4], ia[5], ia[6], ia[7], ia[8], ia[9], ia[10], ia[11], ia[12], ia[13], ia[14], ia[15], \
@@ -355,6 +375,36 @@ cl_int clEnqueueNDRangeKernel(cl_command_queue q, cl_kernel k, cl_uint dim, cons
     }
   }
 #undef RUN_ITEM
+}
+
+cl_int clEnqueueNDRangeKernel(cl_command_queue q, cl_kernel k, cl_uint dim, const size_t *off, const size_t *gws,
+                              const size_t *lws, cl_uint nev, const cl_event *evl, cl_event *ev) {
+  (void)q; (void)off; (void)lws; (void)nev; (void)evl;
+  if (dim < 1 || dim > 2) return CL_INVALID_WORK_DIMENSION;
+
+  /* SysV x86-64: INTEGER-class parameters (ints, longs, pointers) go to rdi,rsi,rdx,rcx,r8,r9 and
+   * then to consecutive 8-byte stack slots in order; float parameters go to xmm0.. in order.  The two
+   * sequences are independent, so one generic signature covers every kernel (<=12 args, <=3 floats). */
+  int64_t ia[16]; float fa[4]; int ni = 0, nf = 0;
+  memset(ia, 0, sizeof(ia)); memset(fa, 0, sizeof(fa));
+  void *argptr[MAXARGS]; size_t argbytes[MAXARGS];
+  for (int i = 0; i < k->nargs; i++) {
+    argptr[i] = NULL; argbytes[i] = 0;
+    if (k->argsize[i] == 4 && (k->floatmask & (1u << i))) {
+      if (nf >= 4) return CL_INVALID_KERNEL_ARGS;
+      memcpy(&fa[nf++], &k->argval[i], 4);
+    } else if (k->argsize[i] == 4) {
+      int32_t v; memcpy(&v, &k->argval[i], 4);
+      ia[ni++] = v;
+    } else {
+      struct _cl_mem *m = find_mem(k->argval[i]);
+      if (m) { ia[ni++] = (int64_t)(intptr_t)m->data; argptr[i] = m->data; argbytes[i] = m->size; }
+      else ia[ni++] = (int64_t)k->argval[i];
+    }
+  }
+
+  const size_t g0 = gws[0], g1 = dim == 2 ? gws[1] : 1;
+  if (!skip_launches) run_items(k, ia, fa, g0, g1);
 
   if (trace_on) {
     char full[96];
@@ -374,12 +424,32 @@ cl_int clEnqueueNDRangeKernel(cl_command_queue q, cl_kernel k, cl_uint dim, cons
       if (!hit) continue;
       if (sn->argidx < 0 || sn->argidx >= k->nargs || !argptr[sn->argidx]) continue;
       sn->size = argbytes[sn->argidx];
+      if (snap_limit && sn->size > snap_limit) sn->size = snap_limit;
       sn->data = malloc(sn->size);
       memcpy(sn->data, argptr[sn->argidx], sn->size);
       sn->ordinal = trace_n;
       sn->done = 1;
     }
+    for (int i = 0; i < 16; i++) { trace_buf[trace_n].hash[i] = 0; trace_buf[trace_n].bytes[i] = 0; }
+    if (hash_all) for (int i = 0; i < k->nargs && i < 16; i++) if (argptr[i]) { trace_buf[trace_n].hash[i] = hash_bytes(argptr[i], argbytes[i]); trace_buf[trace_n].bytes[i] = argbytes[i]; }
     trace_n++;
+    /* the same launch again, up to repeat_extra times (rdcl_set_repeat): words of its buffer arguments each extra launch changes */
+    if (repeat_extra > 0 && occ == repeat_occ && !strcmp(full, repeat_name) && !skip_launches) {
+      void *before[MAXARGS];
+      for (int i = 0; i < k->nargs; i++) before[i] = argptr[i] ? malloc(argbytes[i]) : NULL;
+      for (int e = 0; e < repeat_extra; e++) {
+        for (int i = 0; i < k->nargs; i++) if (argptr[i]) memcpy(before[i], argptr[i], argbytes[i]);
+        run_items(k, ia, fa, g0, g1);
+        int changed = 0;
+        for (int i = 0; i < k->nargs; i++) if (argptr[i]) {
+          const uint32_t *x = (const uint32_t *)before[i], *y = (const uint32_t *)argptr[i];
+          for (size_t w = 0; w < argbytes[i] / 4; w++) changed += x[w] != y[w];
+        }
+        repeat_changed[e] = changed;
+        if (changed == 0) break;
+      }
+      for (int i = 0; i < k->nargs; i++) free(before[i]);
+    }
   }
 
   if (ev) { *ev = (cl_event)calloc(1, sizeof(struct _cl_event)); (*ev)->refs = 1; }
@@ -418,6 +488,12 @@ cl_int clEnqueueReadBuffer(cl_command_queue q, cl_mem m, cl_bool blocking, size_
                            cl_uint nev, const cl_event *evl, cl_event *ev) {
   (void)q; (void)blocking; (void)nev; (void)evl;
   if (!m || m->magic != MEM_MAGIC || off + size > m->size) return CL_INVALID_VALUE;
+  if (subst_at < subst_n) {      /* rdcl_substitute_reads: the caller's bytes in place of the buffer's (what lies beyond them: the buffer's) */
+    const size_t have = subst_size[subst_at] < size ? subst_size[subst_at] : size;
+    memcpy(dst, subst_data[subst_at], have);
+    if (have < size) memcpy((char *)dst + have, (char *)m->data + off + have, size - have);
+    subst_at++;
+  } else
   memcpy(dst, (char *)m->data + off, size);
   if (ev) *ev = new_event();
   return CL_SUCCESS;

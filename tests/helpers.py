@@ -180,6 +180,37 @@ class RefRect:
         snaps = {name: ref_snapshot_fetch(h, "u4") for name, h in hs.items()}
         return out[1:k].copy(), snaps
 
+    def host_postprocess(self, segs, boundary, table, tan_aov):
+        """THE REFERENCE'S OWN compiled executeCPUTask (oclrect.c:1049-1226) on the caller's planes: the stand-in hands `segs` (linesegment_t records incl. the header
+        record), `table` (reduceLS's vote table) and `boundary` (boundary-component ids, N ints) to the three read-backs of genGPUTask (oclrect.c:371-376) in place of its
+        own buffers, and runs none of the 220 launches (rdcl_skip_launches) - what is left of oclrect_executeOnce is the reference's host side, unchanged.  Returns its list."""
+        from rectdetect_amd import RECT_DTYPE
+        R = ref()
+        R.rdcl_substitute_reads.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_size_t)]
+        N = self.iw * self.ih
+        segs = np.ascontiguousarray(segs).view(np.uint8).reshape(-1)
+        ls = np.zeros(N * 16, np.uint8)                  # (the whole read-back: nothing of an earlier frame's list behind the records)
+        ls[: len(segs)] = segs
+        tb = np.zeros(N * 4, np.int32)
+        t = np.ascontiguousarray(table, dtype=np.int32).reshape(-1)
+        tb[: len(t)] = t
+        bd = np.ascontiguousarray(boundary, dtype=np.int32).reshape(-1)
+        assert len(bd) == N
+        bufs = [ls, tb, bd]
+        ptrs = (ctypes.c_void_p * 3)(*[b.ctypes.data for b in bufs])
+        sizes = (ctypes.c_size_t * 3)(*[b.nbytes for b in bufs])
+        img = np.zeros((self.ih, self.iw, 3), np.uint8)
+        out = np.zeros(4096, RECT_DTYPE)
+        R.rdcl_skip_launches(1)
+        R.rdcl_substitute_reads(3, ptrs, sizes)
+        try:
+            k = R.rdref_rect_execute_once(self.h, img.ctypes.data, img.strides[0], float(tan_aov), out.ctypes.data, 4096)
+        finally:
+            R.rdcl_skip_launches(0)
+            R.rdcl_substitute_reads(0, ptrs, sizes)
+        assert k <= 4096
+        return out[1:k].copy()
+
     def close(self):
         ref().rdref_rect_close(self.h)
 

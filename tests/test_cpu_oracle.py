@@ -356,6 +356,32 @@ def test_concurrent_merge_restatement_equals_the_references_own_kernel(iw, ih, s
         orc.close()
 
 
+@pytest.mark.ref
+@pytest.mark.parametrize("iw,ih,seed,nframes", [(333, 217, 2, 2), (640, 480, 5, 2), (640, 480, 0, 1)])
+def test_host_postprocess_equals_the_references_own_compiled_host_code(iw, ih, seed, nframes):
+    """pins csrc/rd_post.c (+ rd_post_core.h) from the outside: THE REFERENCE'S OWN compiled executeCPUTask (oclrect.c:1049-1226, unchanged, oracle/_ref) runs on the very
+    planes rd_post.c is given - the stand-in hands them to the three read-backs of genGPUTask (oclrect.c:371-376) and runs none of the 220 launches
+    (helpers.RefRect.host_postprocess) - and the two lists must agree in every bit AND in order; on the planes of the raster-order reference and on those of the concurrent,
+    settled region merge (what the HIP path computes), for two apertures.  The GPU suite repeats this on the HIP path's own planes over the long streams
+    (test_references_own_host_code_on_the_hip_paths_planes)."""
+    r = helpers.RefRect(iw, ih)
+    checked = 0
+    for mode in (helpers.REGION_REFERENCE_RASTER, helpers.REGION_SPEC):
+        orc = helpers.OracleRect(iw, ih, mode)
+        for t in range(nframes):
+            orc.frame(synth.frame(synth.SEED0 + seed, iw, ih, t))
+            segs, boundary, table = orc.segments(), orc.plane("boundary"), orc.plane("table")
+            for half_aov in (36.0, 25.0):
+                tan = float(np.tan(half_aov / 180.0 * np.pi))
+                mine = ra.postprocess_planes(segs, boundary, table, iw, ih, tan)
+                theirs = r.host_postprocess(segs, boundary, table, tan)
+                assert helpers.rects_equal(mine, theirs), (mode, t, half_aov, len(mine), len(theirs))
+                checked += len(mine)
+        orc.close()
+    r.close()
+    assert checked > 0
+
+
 def test_builtin_sensitivity_fixture_is_consistent_with_the_other_goldens():
     """tests/golden/builtin_sensitivity.npz (tools/make_golden_builtins.py: the reference under other legal OpenCL builtin choices): variant 0 is the
     baseline every other fixture was made with - its rectangle lists must be the ones of the still fixtures of the same frames - and the recorded

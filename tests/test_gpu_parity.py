@@ -1274,12 +1274,94 @@ def test_reference_stage_by_stage_on_the_real_opencl_device_against_the_oracle()
     print("reference on the OpenCL device stage by stage: 16 planes identical in every bit on", len(rep), "frames; after the merge:", {k: v["after_the_merge_differing_elements"] for k, v in summary.items()})
 
 
+def test_reference_polyline_stage_launch_by_launch_on_the_real_opencl_device():
+    """Pins the 47 kernels behind the merge masks as far as the reference is a function there.  tools/ref_launches_on_opencl.py runs the reference's
+    unchanged sources twice on nine frames up to 1920 x 1080 (three of them consecutive frames of the held-out stream stream_1920x1080_s12_200) - on the box's REAL OpenCL
+    device (goldens' arithmetic contract, the three loose builtins pinned, buffers zeroed like the stand-in's) and on the serial stand-in that generated every golden -
+    fingerprints every buffer argument after every one of the 220 launches on both sides, and compares the polyline stage's id planes and segment lists at ten check points up
+    to the permutation of ids that relabel_pass0 / mkpl_pass2 hand out through atomic counters in work-item order (the bijection is read off the id planes).
+    ASSERTED: the same 220 launches; every check point from the chains' ids (relabel_pass1) through the initial segments (mkpl_pass0b), six of the 15 split rounds (mkpl_pass3)
+    and the least-squares refinement (refine_pass2) is equal up to ids on every frame - i.e. everything in oclpolyline.cl that is a function of its input is computed by the
+    vendor's compiler on real hardware exactly as the goldens have it.  The one launch after which a canonicalised record may differ is refine_pass3 (H15: neighbouring segments
+    joined in place, in the device's order) - reported with the number of records and the largest end-point shift, not asserted."""
+    import json
+    import subprocess
+    import sys
+    so = os.path.join(helpers.ROOT, "oracle", "_ref", "librdref_ocl.so")
+    if not os.path.exists(so) or not helpers.have_ref():
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    opts = "-Wf,-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt -Wf,-include" + os.path.join(helpers.ROOT, "oracle", "refshim", "rdcl_pins.h")
+    p = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tools", "ref_launches_on_opencl.py"), "test"], cwd=helpers.ROOT, env=dict(os.environ, AMD_OCL_BUILD_OPTIONS_APPEND=opts, TMPDIR="/tmp"),
+                       capture_output=True, text=True, timeout=1500)
+    if p.returncode != 0:
+        pytest.skip("no usable OpenCL device for the reference here: " + (p.stderr or p.stdout)[-200:])
+    rep = json.load(open(os.path.join(helpers.ROOT, "gpurun_out", "ref_launches_opencl_test.json")))["frames"]
+    if any("error" in fr for fr in rep.values()):
+        pytest.skip("no usable OpenCL device for the reference here: " + str([fr["error"] for fr in rep.values() if "error" in fr])[:200])
+    assert len(rep) == 9 and sum("seed 12 1920x1080" in k for k in rep) == 3
+    summary = {}
+    for name, fr in rep.items():
+        assert fr["launches"] == 220 and not fr.get("launch_sequences_differ"), name
+        cps = fr["polyline_check_points"]
+        assert len(cps) == 10, (name, list(cps))
+        for title, c in cps.items():
+            if title.startswith("refine_pass3"):
+                continue
+            assert c["equal_up_to_ids"], (name, title, c)
+        assert fr["first_check_point_that_differs_up_to_ids"] in (None, "refine_pass3 (neighbouring segments joined, in place: H15)"), (name, fr["first_check_point_that_differs_up_to_ids"])
+        last = cps["refine_pass3 (neighbouring segments joined, in place: H15)"]
+        summary[name] = {"check_points_equal_up_to_ids": [t.split(" (")[0] for t, c in cps.items() if c["equal_up_to_ids"]], "ids_permuted_on_the_device": cps["mkpl_pass0b (initial segments)"]["ids_permuted"],
+                         "segments": last["records"][0], "refine_pass3_records_differing": last.get("records_differing"), "refine_pass3_largest_end_point_shift_px": last.get("largest_end_point_difference_px", 0.0),
+                         "launches_with_every_buffer_identical": fr["launches_with_every_buffer_argument_identical"], "rectangle_lists": fr["rectangles"]}
+    helpers.parity_report("the reference launch by launch on the box's OpenCL device against the reference on the serial stand-in (goldens' contract, pinned builtins, zeroed buffers)", "polyline stage", summary)
+    print("reference on the OpenCL device, polyline stage: equal up to ids through refine_pass2 on", len(rep), "frames; refine_pass3 (H15) moves",
+          {k: (v["refine_pass3_records_differing"], v["refine_pass3_largest_end_point_shift_px"]) for k, v in summary.items()})
+
+
+def test_references_own_host_code_on_the_hip_paths_planes():
+    """Pins the host post-process where the lists differ from the raster-order goldens: over the seven long streams, on EVERY frame whose rectangle
+    list is not the golden's in every bit and order, and on every fifth frame besides, the HIP path's own segment list, vote table and boundary plane are handed to THE
+    REFERENCE'S OWN compiled executeCPUTask (oclrect.c:1049-1226, unchanged: helpers.RefRect.host_postprocess - the stand-in substitutes them for the three read-backs of
+    genGPUTask and runs no launch): its list must be the HIP path's list in every bit AND in order.  So wherever a list differs from a golden, the difference is in the planes
+    (the region merge's order), never in rd_post.c."""
+    if not helpers.have_ref():
+        pytest.skip("oracle/_ref/librdref.so not built (needs /root/reference at build time)")
+    rows = {}
+    for name in ["stream_1920x1080_s12_200", "stream_1280x720_s13_300", "stream_1920x1080_s11_200", "stream_1920x1080_s0_100", "stream_1920x1080_s7_100", "stream_1280x720_s1_300", "stream_3840x2160_s4_16"]:
+        g = golden(name)
+        iw, ih, nframes, tan, seed = int(g["iw"]), int(g["ih"]), int(g["nframes"]), float(g["tan_aov"]), int(g["seed"])
+        N = iw * ih
+        det = ra.Detector(iw, ih, nslots=1)
+        r = helpers.RefRect(iw, ih)
+        deviating, others = [], 0
+        for t in range(nframes):
+            det.enqueue(synth.frame(seed, iw, ih, t))
+            rects = det.poll(tan)
+            differs = not helpers.rects_equal(rects, g[f"f{t}_rects"])
+            if not differs and t % 5:
+                continue
+            theirs = r.host_postprocess(det.last_segments(), det.plane("boundary"), det.plane("table", np.int32, (N * 4 // 5) * 5), tan)
+            assert helpers.rects_equal(rects, theirs), f"{name} frame {t}: the reference's own executeCPUTask returns another list on the HIP path's planes ({len(theirs)} against {len(rects)} rectangles)"
+            if differs:
+                deviating.append(t)
+            else:
+                others += 1
+        det.close()
+        r.close()
+        rows[name] = {"frames_whose_list_differs_from_the_golden_in_bits_or_order": deviating, "other_frames_checked": others}
+        print(name, ": the reference's own host code on the HIP path's planes returns the HIP path's list, bit for bit and in order, on the", len(deviating), "frames whose list differs from the raster-order golden", deviating, "and on", others, "others")
+    helpers.parity_report("the reference's own compiled executeCPUTask on the HIP path's planes", "lists identical in every bit and in order", rows)
+
+
 def test_reference_on_the_real_opencl_device_against_the_hip_path():
     """The one third-party execution of the reference this environment offers: its unchanged host C (oracle/_ref/librdref_ocl.so, built by `make -C oracle ref_ocl`) on the
-    box's OpenCL device - the MI355X through ROCm's OpenCL, the reference's .cl sources compiled at run time by the vendor's compiler - with contraction switched off and
-    correctly rounded divide / sqrt through the runtime's AMD_OCL_BUILD_OPTIONS_APPEND (the goldens' arithmetic contract; the reference's own options are empty,
-    i.e. contraction on), in a process of its own.  Compared with the HIP path on seven stills: the same number of rectangles, every rectangle within a pixel of one of the other
-    list - asserted - and how many lists / rectangles are identical in every bit - reported (the device's builtins and its work-item order are its own: DESIGN.md (c))."""
+    box's OpenCL device - the MI355X through ROCm's OpenCL, the reference's .cl sources compiled at run time by the vendor's compiler - under the goldens' arithmetic contract
+    (contraction off, correctly rounded divide / sqrt, the three loose builtins pinned: appended through the runtime's AMD_OCL_BUILD_OPTIONS_APPEND, the reference's sources and
+    options untouched; its own options are empty, i.e. contraction on), in a process of its own.  Compared with the HIP path on seven stills, rectangle by rectangle (each of
+    the HIP path's paired with the nearest of the device's).  ASSERTED: the same number of rectangles; every pair within the north_star's 1e-4 of a pixel on every corner -
+    except pairs that are reported BY NAME, of which there may be at most three among the ~60 and none further than 1e-2: what moves them is the device's work-item order in
+    the in-place kernels (labelMergeMain, despeckle2, refine_pass3 - the launch-by-launch test above shows refine_pass3 shifting segment end points by up to a few pixels on
+    this device, and the pose estimation is continuous in them).  Reported: lists / rectangles identical in every bit."""
     import subprocess
     import sys
     import tempfile
@@ -1289,30 +1371,40 @@ def test_reference_on_the_real_opencl_device_against_the_hip_path():
     specs = [(0, 640, 480, 0), (5, 640, 480, 0), (1, 1280, 720, 0), (0, 1920, 1080, 0), (0, 1920, 1080, 1), (0, 1920, 1080, 2), (7, 1920, 1080, 0)]
     with tempfile.TemporaryDirectory() as td:
         f = os.path.join(td, "ref.npz")
-        env = dict(os.environ, AMD_OCL_BUILD_OPTIONS_APPEND="-Wf,-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt")
-        p = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tools", "ref_on_opencl.py"), "dump", f] + [str(v) for sp in specs for v in sp], cwd=helpers.ROOT, env=env,
-                           capture_output=True, text=True, timeout=600)
+        opts = "-Wf,-ffp-contract=off -cl-fp32-correctly-rounded-divide-sqrt -Wf,-include" + os.path.join(helpers.ROOT, "oracle", "refshim", "rdcl_pins.h")
+        p = subprocess.run([sys.executable, os.path.join(helpers.ROOT, "tools", "ref_on_opencl.py"), "dump", f] + [str(v) for sp in specs for v in sp], cwd=helpers.ROOT,
+                           env=dict(os.environ, AMD_OCL_BUILD_OPTIONS_APPEND=opts), capture_output=True, text=True, timeout=600)
         if p.returncode != 0:
             pytest.skip("no usable OpenCL device for the reference here: " + (p.stderr or p.stdout)[-200:])
         with np.load(f) as z:
             ref = [z["f%d" % i].view(ra.RECT_DTYPE) if z["f%d" % i].dtype != ra.RECT_DTYPE else z["f%d" % i] for i in range(len(specs))]
     key = lambda r: r["c2"].tobytes() + r["c3"].tobytes() + r["value"].tobytes() + r["status"].tobytes()
-    rows, same_lists, same_rects, total = {}, 0, 0, 0
+    rows, same_lists, same_rects, total, beyond, one_ulp = {}, 0, 0, 0, [], []
     for (seed, iw, ih, t), want in zip(specs, ref):
+        name = "seed %d %dx%d t %d" % (seed, iw, ih, t)
         det = ra.Detector(iw, ih, nslots=1, nworkers=0)
         det.enqueue(synth.frame(synth.SEED0 + seed, iw, ih, t))
         got = det.poll(TAN36)
         det.close()
-        assert len(got) == len(want), (seed, iw, ih, t, len(got), len(want))
+        assert len(got) == len(want), (name, len(got), len(want))
         far = 0.0
-        for r in got:
-            far = max(far, float(np.abs(want["c2"] - r["c2"]).reshape(len(want), -1).max(1).min()) if len(want) else 0.0)
-        assert far <= 1.0, (seed, iw, ih, t, far)
+        for i, r in enumerate(got):
+            dist = float(np.abs(want["c2"] - r["c2"]).reshape(len(want), -1).max(1).min()) if len(want) else 0.0
+            far = max(far, dist)
+            # (the corners come from segment end points held in single precision: from x = 1024 on, one unit in the last place of an end point is 2^-13 = 1.22e-4 px - the
+            #  finest difference the reference's own data type can show there is already beyond the north_star's 1e-4, and refine_pass3's order on the device produces exactly that)
+            tol = max(1e-4, float(np.spacing(np.float32(np.abs(r["c2"]).max()))))
+            if dist > tol:
+                beyond.append({"frame": name, "rectangle": i, "corner_distance_px": dist})
+            elif dist > 1e-4:
+                one_ulp.append({"frame": name, "rectangle": i, "corner_distance_px": dist})
         ka, kb = {key(r) for r in got}, {key(r) for r in want}
         same_lists += ka == kb; same_rects += len(ka & kb); total += len(kb)
-        rows["seed %d %dx%d t %d" % (seed, iw, ih, t)] = {"rectangles": len(got), "bit_identical": len(ka & kb), "lists_bit_identical": ka == kb, "largest_corner_distance_px": far}
-    helpers.parity_report("the reference on the box's OpenCL device (contraction off, correctly rounded divide / sqrt) against the HIP path", "stills", dict(rows, lists_bit_identical=int(same_lists), rectangles_bit_identical="%d of %d" % (same_rects, total)))
-    print("reference on the OpenCL device vs HIP: %d of %d lists and %d of %d rectangles identical in every bit; all within a pixel" % (same_lists, len(specs), same_rects, total))
+        rows[name] = {"rectangles": len(got), "bit_identical": len(ka & kb), "lists_bit_identical": ka == kb, "largest_corner_distance_px": far}
+    helpers.parity_report("the reference on the box's OpenCL device (goldens' contract, pinned builtins) against the HIP path", "stills",
+                          dict(rows, lists_bit_identical=int(same_lists), rectangles_bit_identical="%d of %d" % (same_rects, total), rectangles_beyond_tolerance=beyond, rectangles_one_single_precision_ulp_apart_beyond_1e_4_px=one_ulp))
+    print("reference on the OpenCL device vs HIP: %d of %d lists and %d of %d rectangles identical in every bit; one single-precision ulp apart where that exceeds 1e-4 px: %s; beyond: %s" % (same_lists, len(specs), same_rects, total, one_ulp, beyond))
+    assert len(beyond) <= 3 and all(b["corner_distance_px"] <= 1e-2 for b in beyond), beyond
 
 
 def test_four_ranks_with_all_their_workers_keep_the_rate_of_one():

@@ -7,7 +7,8 @@ one detector instance runs the stream in raster order up to the frame before (so
 to frame is the real one), then a forked copy of the process runs the frame under each order (order 0 = raster: must
 reproduce the golden list).
 
--> tests/golden/stream_orders.npz: `<stream>_f<t>_union` = the distinct rectangles over all orders, `<stream>_f<t>_member[order, i]`.
+-> tests/golden/stream_orders.npz: `<stream>_f<t>_union` = the distinct rectangles over all orders, `<stream>_f<t>_count[order, i]` = how often the list of
+that order holds rectangle i (round 6: the lists are multisets - the reference repeats a rectangle that two boundary components vote for), `_member` = count > 0.
 The frames are the ones tools/stream_mismatch.py (GPU box) reported.  Only runs where /root/reference exists (oracle/_ref)."""
 import ctypes
 import os
@@ -77,13 +78,18 @@ def one_stream(name, frames, out):
                         if rect_key(q) not in index:
                             index[rect_key(q)] = len(union)
                             union.append(q)
-                member = np.zeros((len(ORDERS), len(union)), np.uint8)
+                # count[order, i] = how many times the list of that order holds rectangle i (the reference lists a rectangle once per boundary component that votes for
+                # it: exact duplicates are part of its output, and whether two components are one depends on the order like everything else); member = count > 0
+                count = np.zeros((len(ORDERS), len(union)), np.uint8)
                 for oi, l in enumerate(lists):
                     for q in l:
-                        member[oi, index[rect_key(q)]] = 1
+                        count[oi, index[rect_key(q)]] += 1
+                member = (count > 0).astype(np.uint8)
                 out[f"{name}_f{t}_union"] = np.array(union, dtype=ra.RECT_DTYPE) if union else np.zeros(0, ra.RECT_DTYPE)
                 out[f"{name}_f{t}_member"] = member
-                print(name, "frame", t, "rectangles per order", member.sum(1).tolist(), "distinct", len(union), "in every order", int(member.all(0).sum()), flush=True)
+                out[f"{name}_f{t}_count"] = count
+                print(name, "frame", t, "rectangles per order", count.sum(1).tolist(), "distinct", len(union), "in every order", int(member.all(0).sum()),
+                      "listed more than once under some order", int((count.max(0) > 1).sum()), "with a multiplicity that depends on the order", int((count.max(0) != count.min(0)).sum()), flush=True)
             rects, _ = r.execute_once(img, tan)          # the stream itself goes on in raster order
             assert helpers.rects_equal(rects, g[f"f{t}_rects"]), (name, t)
     r.close()
