@@ -263,8 +263,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--frames-per-step", type=int, default=512, help="frames of the stream resident in HBM and handed over per step (512 x 6.2 MB = 3.2 GB; 20 steps then run about 5 s)")
-    ap.add_argument("--slots", type=int, default=64, help="frames in flight per GPU (from three on: one stream per frame on four shared streams; from 6 / 12 / 32 on: groups of 2 / 4 / 8 frames per set of launches; 64 = two groups queued on each of the four streams, so that a stream never waits for the host to collect a group and hand over the next: 32 / 48 / 64 / 96 measured 2316-2329 / 2354 / 2373-2396 / 2402 frames/s on one box)")
+    ap.add_argument("--frames-per-step", type=int, default=512, help="frames of the stream resident in HBM and handed over per step (512 x 6.2 MB = 3.2 GB; 20 steps then run about 3.5 s)")
+    ap.add_argument("--slots", type=int, default=64, help="frames in flight per GPU (from three on: one stream per frame on four shared streams; from 6 / 12 / 32 on: groups of 2 / 4 / 8 frames per set of launches; 64 = two groups queued on each of the four streams, so that a stream never waits for the host to collect a group and hand over the next; 48 / 64 / 96 / 128 measured 2706-2717 / 2764-2782 / 2753-2754 / 2783-2810 frames/s on one box in round 5)")
     ap.add_argument("--host-frames", action="store_true", help="hand over host buffers (PCIe upload inside the timed region); not the headline value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="profiling runs only: skip the sequential verification pass and the host-frames pass (the line then says outputs_verified: null)")
@@ -332,6 +332,7 @@ def main():
             dframes.append(p)
 
     import zlib
+    pframes = []                 # the frames once more in pinned host memory (allocated for the host-frames pass only)
     results = []                 # rectangle lists in stream order (numpy arrays returned by poll)
     inflight = 0
     use_host = [args.host_frames]
@@ -349,7 +350,9 @@ def main():
             if inflight == slots:
                 results.append(d.poll(TAN_AOV))
                 inflight -= 1
-            if use_host[0]:
+            if use_host[0] == "pinned":
+                d.enqueue(pframes[i], ws=IW * 3, pinned=True)
+            elif use_host[0]:
                 d.enqueue(frames[i])
             else:
                 d.enqueue(dframes[i], ws=IW * 3, on_device=True)
@@ -414,7 +417,8 @@ def main():
         ctr = chk.plane("polyctr", np.int32, 64)
         rho = {"chain_pixels": int(ctr[0]), "chains": int(ctr[1]), "live_pixels": int(ctr[24]), "edge_density": round(float(ctr[0]) / (IW * IH), 5)}
         chk.close()
-        verify = {"outputs_verified": bool(len(timed_lists) == args.steps * F and digest(timed_lists) == digest(seq[args.warmup * F:])),
+        seq_digest = digest(seq[args.warmup * F:])
+        verify = {"outputs_verified": bool(len(timed_lists) == args.steps * F and digest(timed_lists) == seq_digest),
                   "rectangles_in_timed_frames": nrect, "rect_list_crc32": "%08x" % digest(timed_lists),
                   "against": "sequential pass of the same %d-frame stream, 1 frame in flight, no worker threads, outside the timed region" % len(seq)}
 
@@ -442,13 +446,35 @@ def main():
                               against=verify["against"] + " - on every rank, each against its own stream")
             # (2) the same work with host buffers handed over (memcpy into pinned memory + PCIe upload inside the timed region):
             #     SURVEY.md 8(d)'s "upload -> ... -> post-process" unit; reported beside the HBM-resident headline, never as `value`
+            #     - from the caller's PINNED memory, read in place by the copy engine (rd_detector_enqueue(..., RD_FRAME_HOST_PINNED): what a capture loop that allocates its
+            #       frames with allocatePinnedMemory / rd_host_alloc gets), and from pageable memory, copied by the caller's thread into the detector's staging pages first
+            #       (the reference's own oclrect.c:1256).  `value_host_frames` is the pinned one; both are printed, and the lists of both passes are checked.
             if world == 1 and not args.host_frames:
-                results.clear()
-                use_host[0] = True
-                timed(1)
-                th = timed(args.steps)
-                use_host[0] = False
-                host_rate = round(args.steps * F / th, 2)
+                import ctypes
+                host_passes = {}
+                for mode in ("pinned", "pageable"):
+                    if mode == "pinned":
+                        for a in frames:
+                            p = L.rd_host_alloc(a.nbytes)
+                            ctypes.memmove(p, a.ctypes.data, a.nbytes)
+                            pframes.append(p)
+                    results.clear()
+                    use_host[0] = "pinned" if mode == "pinned" else True
+                    c0 = [ra.lib().rd_detector_counter(det.h, k) for k in (18, 19)]
+                    timed(1)
+                    th = timed(args.steps)
+                    c1 = [ra.lib().rd_detector_counter(det.h, k) for k in (18, 19)]
+                    use_host[0] = False
+                    rate = round(args.steps * F / th, 2)
+                    host_passes[mode] = {"value": rate, "unit": "frames/s", "roofline_frac": round(rate * B_ALG_PER_PIXEL * N / HBM_PEAK, 4),
+                                         "frames_read_in_place_by_the_copy_engine": c1[0] - c0[0], "frames_copied_by_the_callers_thread_first": c1[1] - c0[1],
+                                         "outputs_verified": bool(len(results) == (1 + args.steps) * F and digest(results[F:]) == seq_digest)}
+                    if mode == "pinned":
+                        for p in pframes:
+                            L.rd_host_free(p)
+                        pframes.clear()
+                host_rate = host_passes["pinned"]["value"]
+                verify = dict(verify, outputs_verified=bool(verify["outputs_verified"] and all(h["outputs_verified"] for h in host_passes.values())))
         traffic, traffic_src = traffic_per_frame()
         out = {
             "metric": "%dx%d frames/sec" % (IW, IH), "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -458,9 +484,11 @@ def main():
                        "frames_per_step": F, "frames_in_flight": args.slots, "frames_per_launch": None if args.dry_run else det.frames_per_launch(), "input": "BGR u8 host buffers (PCIe upload timed)" if args.host_frames else "BGR u8 frames resident in HBM", "parallelism": "independent streams, one per GPU, no collective"},
             "ranks": per_rank,
             "value_definition": "frames resident in HBM when the timed region starts (bench contract); value_host_frames = the same work with host BGR buffers handed over, "
-                                "memcpy into pinned memory + PCIe upload inside the timed region (SURVEY.md 8(d)'s unit of work), same process, N=1 only",
+                                "PCIe upload inside the timed region (SURVEY.md 8(d)'s unit of work), same process, N=1 only: from the caller's pinned memory (read in place by the copy engine); "
+                                "host_frames.pageable = from pageable memory, copied by the caller's thread into pinned staging pages first, as the reference does",
             "value_host_frames": host_rate,
             "roofline_frac_host_frames": round(host_rate * B_ALG_PER_PIXEL * N / HBM_PEAK, 4) if host_rate else None,
+            "host_frames": None if not host_rate else dict(host_passes, value_host_frames_is="pinned"),
             "roofline": {"bound": "hbm", "kernel": "whole per-frame device pipeline (all stages, one stream per frame slot)",
                          "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4),
                          "algorithmic_bytes_per_frame": B_ALG_PER_PIXEL * N,

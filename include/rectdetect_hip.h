@@ -21,6 +21,8 @@ int rd_device_pci_bus_id(int ordinal, char *buf, int len);   /* "0000:c1:00.0" i
 /* device memory helpers for callers without a HIP binding of their own (tests, bench) */
 void *rd_device_alloc(size_t bytes);
 void rd_device_free(void *dptr);
+void *rd_host_alloc(size_t bytes);           /* pinned (page-locked) host memory: see RD_FRAME_HOST_PINNED */
+void rd_host_free(void *p);
 void rd_upload(void *dptr, const void *host, size_t bytes);
 void rd_download(void *host, const void *dptr, size_t bytes);
 
@@ -36,8 +38,21 @@ typedef struct rd_detector rd_detector;
 rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nworkers);
 void rd_detector_destroy(rd_detector *d);
 
-/* Enqueue one BGR frame (row stride ws bytes).  on_device != 0: `frame` is a device pointer that must stay valid
- * until the matching rd_detector_poll returned.  Returns the frame's sequence number. */
+/* Detectors with one or two frames in flight take their HIP streams from a process-wide cache (hardware queues of their own: DESIGN.md) and hand them back when they
+ * are destroyed, so that the next detector runs on the same queues.  This destroys the cached streams of `device` (-1: all devices); live detectors are not affected. */
+void rd_release_cached_streams(int device);
+
+/* Enqueue one BGR frame (row stride ws bytes).  Where the frame lies (`on_device`):
+ *   RD_FRAME_HOST (0)         host memory of any kind; copied before the call returns (the reference's oclrect_enqueueTask does the same, oclrect.c:1256), the caller may
+ *                             reuse the buffer at once
+ *   RD_FRAME_DEVICE (1)       a device pointer, read in place: must stay valid and unchanged until the matching rd_detector_poll returned
+ *   RD_FRAME_HOST_PINNED (2)  PINNED host memory (rd_host_alloc, allocatePinnedMemory of oclhelper.h, hipHostMalloc, or registered with hipHostRegister): the copy engine
+ *                             reads it in place - no copy by the caller's thread (6 MB per 1920x1080 frame) - so it must stay unchanged until the matching poll returned,
+ *                             like a device pointer; memory that is not pinned is refused (fatal)
+ * Returns the frame's sequence number. */
+#define RD_FRAME_HOST 0
+#define RD_FRAME_DEVICE 1
+#define RD_FRAME_HOST_PINNED 2
 long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_device);
 
 /* Result of the oldest frame not yet polled: malloc'd array of rect_t-compatible records (176 bytes each, element 0
@@ -64,8 +79,21 @@ int rd_detector_last_segments(rd_detector *d, void *dst, int max_records);
  * reference's capacity of 16N / 56 records; nothing is dropped); 11 / 12 = frames whose rectangles came from the device post-process (RD_DEVICE_POST=1:
  * candidate funnel + pose estimation in rd_k_post.hip) / from the host post-process; 13 = microseconds the worker threads spent in the
  * host post-process (sum over frames); 14 = frames whose small-region absorption (oclrect.cl:348-371) was finished by the slow path -
- * rounds over work lists until nothing changes - because they left more undecided pixels than the single-block tail holds (frames made of small regions) */
+ * rounds over work lists until nothing changes - because they left more undecided pixels than the single-block tail holds (frames made of small regions);
+ * 15 = frames per group launch; 16 / 17 = groups whose strong masks took one launch / one launch per frame; 18 = frames that travelled straight from the caller's pinned
+ * memory (RD_FRAME_HOST_PINNED), 19 = host frames copied into the detector's own pinned staging first (RD_FRAME_HOST) */
 long rd_detector_counter(rd_detector *d, int which);
+
+/* ---- Environment.  Everything is read when a detector is created (rd_detector_create / init_oclrect) and never again; an empty value counts as unset.
+ *   for users:   RD_DEVICE_POST=0|1      candidate funnel + pose estimation on the device (rd_k_post.hip) instead of the host threads (default: host, unless the process may
+ *                                        use no more than two cores)
+ *                RD_POST_HELPERS=n       helper threads that share a frame's pose estimations with the polling thread, reference-API shape only (default by core count, 0 = none)
+ *                RD_NO_GRAPH=1           plain launches instead of captured hipGraphs
+ *   test hooks:  RD_ZBATCH=k / RD_BATCH=k (frames per group launch / per set of sparse-stage launches), RD_REGION_ROUNDS_FIXED=8..20 and RD_BUDGET_CYCLE=n (launch budget of
+ *                the region merge pinned / cycling), RD_POLY_MULTILAUNCH, RD_POLY_FORCE_REDO, RD_ABSORB_FORCE_SLOW (the fallback paths for every frame), RD_MAXREC_DEV=n (small
+ *                probe buffers), RD_TEST_THRESHOLDS=a,b (strength thresholds), RD_STRONG_BY_FRAME (a group's strong masks frame by frame), RD_IIR_FORCE_FIX (every blur column
+ *                through the full-length path; read per call).  Each is driven by a test in tests/test_gpu_parity.py.
+ * Switches of experiments that were measured and not kept exist only in tuning builds (-DRD_TUNING, tools/variants.sh). */
 
 /* Test hook: copy an internal plane of the most recently completed frame to host memory.  Returns bytes written,
  * 0 for an unknown name.  Names: plab0 plab1 lblur vxy strength nms mask0 tidy label1 strsum edge500 smooth quant

@@ -52,6 +52,9 @@ def _declare(L):
         "rd_device_pci_bus_id": (ci, [ci, ctypes.c_char_p, ci]),
         "rd_device_alloc": (vp, [cz]),
         "rd_device_free": (None, [vp]),
+        "rd_host_alloc": (vp, [cz]),
+        "rd_host_free": (None, [vp]),
+        "rd_release_cached_streams": (None, [ci]),
         "rd_upload": (None, [vp, vp, cz]),
         "rd_download": (None, [vp, vp, cz]),
         "rd_detector_create": (vp, [ci, ci, ci, ci, ci]),
@@ -258,9 +261,11 @@ class Detector:
         if aperture is not None:      # tan(AOV / 2) of the polls to come (rd_detector_set_aperture): work ahead of the first poll can use it
             L.rd_detector_set_aperture(self.h, float(aperture))
 
-    def enqueue(self, frame, ws=None, on_device=False):
-        if on_device:
-            return lib().rd_detector_enqueue(self.h, frame, ws, 1)
+    def enqueue(self, frame, ws=None, on_device=False, pinned=False):
+        """frame: a numpy BGR image (copied before the call returns) - or, with on_device / pinned, the ADDRESS of a frame in device memory / in pinned host memory
+        (rd_host_alloc ...), which is read in place and must stay unchanged until the frame's poll returned"""
+        if on_device or pinned:
+            return lib().rd_detector_enqueue(self.h, frame, ws, 1 if on_device else 2)
         a = np.ascontiguousarray(frame)
         self._keep = a
         return lib().rd_detector_enqueue(self.h, a.ctypes.data, a.strides[0] if ws is None else ws, 0)

@@ -22,6 +22,17 @@ extern "C" {
 using rdrt::dptr;
 using rdrt::stream;
 
+// Environment switches.  A detector reads the ones include/rectdetect_hip.h lists ("Environment") when it is created - its behaviour never changes afterwards, and two
+// detectors of one process may differ.  The switches of experiments whose variant was measured and NOT kept (profiles/NOTES_r0*.md) exist in tuning builds only
+// (-DRD_TUNING, tools/variants.sh): in the product they are the constants below.
+static const char *rd_env(const char *name) { const char *v = getenv(name); return (v && *v) ? v : NULL; }
+static int rd_env_int(const char *name, int dflt) { const char *v = rd_env(name); return v ? atoi(v) : dflt; }
+#ifdef RD_TUNING
+#define RD_LAB_INT(name, dflt) rd_env_int(name, dflt)
+#else
+#define RD_LAB_INT(name, dflt) (dflt)
+#endif
+
 #define MAGIC_IMGUTIL 0xa640d893u
 #define MAGIC_POLYLINE 0x808f3801u
 #define MAGIC_RECT 0x808f3802u
@@ -348,6 +359,8 @@ struct rd_detector {
   // long as its slot's planes do (debug plane "strsum")
   int8_t *prev_ring; int nring;
   int t_edge, t_strong;                   // thresholds of the strength sums (500, 2500; RD_TEST_THRESHOLDS)
+  int strong_by_frame;                    // tests (RD_STRONG_BY_FRAME): the strong masks of a group frame by frame instead of in one launch
+  long n_strong_group, n_strong_by_frame; // groups whose strong masks took one launch / one launch per frame (rd_detector_counter 16 / 17)
   hipEvent_t last_strong; int have_last_strong;
   long next_enqueue, next_poll;
   long done_seq;                          // one more than the highest sequence number whose device work a worker has seen finished
@@ -369,6 +382,8 @@ struct rd_detector {
   // a stream that is capturing must not be synchronised.  launch_mu serialises captures against the launches of a repeat; repeats wait
   // on an event of their own (ev_redo), never on the stream.
   pthread_mutex_t launch_mu;
+  const void *pinned_lo, *pinned_hi;        // the last caller buffer that was verified to be pinned host memory (RD_FRAME_HOST_PINNED)
+  long n_frames_pinned, n_frames_copied;     // host frames that travelled straight from the caller's pinned memory / through the detector's own staging pages
   long n_truncated;          // frames with more segment records than the slots' probe buffers hold (maxrec_dev): probed again into a larger buffer
 };
 
@@ -419,7 +434,12 @@ static hipStream_t pooled_stream(int device) {
   pthread_mutex_lock(&stream_pool.mu);
   for (int i = 0; i < stream_pool.n; i++) if (stream_pool.dev[i] == device) { st = stream_pool.st[i]; stream_pool.st[i] = stream_pool.st[stream_pool.n - 1]; stream_pool.dev[i] = stream_pool.dev[stream_pool.n - 1]; stream_pool.n--; break; }
   pthread_mutex_unlock(&stream_pool.mu);
-  if (st) return st;
+  if (st) {      // (handed back idle - its last user synchronised it; one that reports an error instead is not handed out again)
+    const hipError_t e = hipStreamQuery(st);
+    if (e == hipSuccess || e == hipErrorNotReady) return st;
+    (void)hipGetLastError();
+    (void)hipStreamDestroy(st);
+  }
   int lo = 0, hi = 0;
   RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
   RD_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
@@ -433,13 +453,28 @@ static void unpool_stream(int device, hipStream_t st) {
   if (!room) RD_HIP(hipStreamDestroy(st));
 }
 
+// the pool's teardown, for a caller that wants the streams gone (they are otherwise kept until the process ends, at most 64 of them): destroys every pooled stream
+// of `device` (-1: of every device); streams in use by a live detector are not in the pool and are not touched
+extern "C" void rd_release_cached_streams(int device) {
+  hipStream_t gone[64]; int dev[64]; int n = 0;
+  pthread_mutex_lock(&stream_pool.mu);
+  for (int i = 0; i < stream_pool.n;) {
+    if (device < 0 || stream_pool.dev[i] == device) {
+      gone[n] = stream_pool.st[i]; dev[n] = stream_pool.dev[i]; n++;
+      stream_pool.st[i] = stream_pool.st[stream_pool.n - 1]; stream_pool.dev[i] = stream_pool.dev[stream_pool.n - 1]; stream_pool.n--;
+    } else i++;
+  }
+  pthread_mutex_unlock(&stream_pool.mu);
+  for (int i = 0; i < n; i++) { RD_HIP(hipSetDevice(dev[i])); RD_HIP(hipStreamSynchronize(gone[i])); RD_HIP(hipStreamDestroy(gone[i])); }
+}
+
 // A slot's stream for repeats and fetches (created on first use): from the runtime's high-priority pool of hardware queues.  As ordinary streams they share the
 // four queues of the default pool with the four streams that carry the groups, so a repeat - the oldest frame in flight, the one the caller waits for - stood in a queue
 // behind whole groups of later frames after all (the reason it has a stream of its own); with queues of their own: 2853 against 2776-2791 frames/s on one box
 // (RD_REDO_STREAM_PRIORITY=0: ordinary streams).  The group streams themselves stay in the default pool: moved to the high-priority pool they gain as much at 1920x1080
 // but a detector opened after another one was closed in the same process (bench.py's side configurations) then ran 10-16 % slower - not understood, not kept.
 static hipStream_t make_redo_stream() {
-  static const int prio = getenv("RD_REDO_STREAM_PRIORITY") ? atoi(getenv("RD_REDO_STREAM_PRIORITY")) : 1;
+  static const int prio = RD_LAB_INT("RD_REDO_STREAM_PRIORITY", 1);
   hipStream_t st = NULL;
   if (prio) { int lo = 0, hi = 0; RD_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi)); RD_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi)); }
   else RD_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
@@ -458,8 +493,9 @@ static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
     // chain (traced: two frames in flight ran 1.18 times as fast as one).  The streams of such a detector therefore come from the pool of another priority
     // level, where nothing else lives.  (Raising the number of queues for everybody - GPU_MAX_HW_QUEUES=8 - does the same for this path, 1420 -> 1590 frames/s, but
     // costs the group path, whose four streams are best served by four queues, 9 %.)
-    static const int fork_prio = getenv("RD_FORK_STREAM_PRIORITY") ? atoi(getenv("RD_FORK_STREAM_PRIORITY")) : 1;
-    if (d->fork_poly && fork_prio) {
+    static const int fork_prio = RD_LAB_INT("RD_FORK_STREAM_PRIORITY", 1);
+    const bool from_pool = fork_prio != 0;
+    if (d->fork_poly && from_pool) {
       s->st = pooled_stream(d->device);
       s->st2 = pooled_stream(d->device);
       s->pooled_streams = 1;
@@ -660,7 +696,7 @@ static void frame_segment(rd_detector *d, Slot *s, int ws, int seg, hipStream_t 
   //   2nd stream : junction counts of the filtered labels -> merge mask                      (oclrect.c:315-321)
   //                then the polyline stage, which needs nothing but the strong mask          (oclrect.c:361)
   // Inside a captured graph the streams become parallel branches.
-  static const int fork_order = getenv("RD_FORK_ORDER") ? atoi(getenv("RD_FORK_ORDER")) : 1;      // (0: polyline chain launched first, 1: after the region stage, 2: before it)
+  static const int fork_order = RD_LAB_INT("RD_FORK_ORDER", 1);      // (0: polyline chain launched first, 1: after the region stage, 2: before it)
   if (d->fork_poly) {      // (else: everything on the main stream, blur chain first)
     RD_HIP(hipEventRecord(s->ev_fork, st));
     RD_HIP(hipStreamWaitEvent(s->st2, s->ev_fork, 0));
@@ -853,15 +889,16 @@ static void group_launch(rd_detector *d, int g0) {
   run_group_segment(d, lead, zb, 0, st);
   // the strong masks: each frame's on top of its predecessor's (H1) - one launch for the group where its planes allow 16-byte accesses (the mask of the frame before
   // only decides sums that stand one below a threshold, and is then evaluated on the spot: k_strength_masks_group), else frame by frame
-  static const bool strong_by_frame = getenv("RD_STRONG_BY_FRAME") != NULL;
   if (d->have_last_strong) RD_HIP(hipStreamWaitEvent(st, d->last_strong, 0));      // (only the first frame waits for the group before - another stream - and only the last is waited for)
   bool consecutive = true;
   for (int i = 1; i < zb; i++) consecutive = consecutive && d->slots[g0 + i].seq == lead->seq + i;
-  if (!strong_by_frame && consecutive && rdk::strength_masks_group_fits(d->iw, lead->label1, d->prev_ring, lead->e8, d->slot_pitch) && (d->N & 3) == 0) {
+  if (!d->strong_by_frame && consecutive && rdk::strength_masks_group_fits(d->iw, lead->label1, d->prev_ring, lead->e8, d->slot_pitch) && (d->N & 3) == 0) {
     for (int i = 0; i < zb; i++) d->slots[g0 + i].prev_in = d->prev_ring + (size_t)(d->slots[g0 + i].seq % d->nring) * (size_t)d->N;
     rdk::strength_masks_group(st, d->prev_ring, lead->e8, lead->label1, lead->strsum, d->t_edge, d->t_strong, d->iw, d->ih, lead->strongbits, lead->seq, d->nring, zb, d->slot_pitch);
+    d->n_strong_group++;
   } else {
     for (int i = 0; i < zb; i++) frame_strong(d, &d->slots[g0 + i], st);
+    d->n_strong_by_frame++;
   }
   { Slot *s = &d->slots[g0 + zb - 1]; RD_HIP(hipEventRecord(s->ev_strong, st)); d->last_strong = s->ev_strong; d->have_last_strong = 1; }
   const int rounds = d->fixed_rounds ? d->fixed_rounds : __atomic_load_n(&d->rounds_budget, __ATOMIC_RELAXED);
@@ -941,7 +978,7 @@ static void slot_finish_device(rd_detector *d, Slot *s) {
     //  dispatch of the whole grid - then the definition's limit of 64)
     // (on a stream of the slot's own: the slot's regular stream is one of the four that carry the groups, and the repeat would wait there behind a whole group of
     //  other frames; nothing but this frame's result depends on it - the frame is finished, ev_done has been waited for)
-    static const bool redo_inline = getenv("RD_REDO_ON_MAIN_STREAM") != NULL;
+    static const bool redo_inline = RD_LAB_INT("RD_REDO_ON_MAIN_STREAM", 0) != 0;
     if (!s->st_redo && !redo_inline) s->st_redo = make_redo_stream();
     hipStream_t rst = redo_inline ? s->st : s->st_redo;
     for (int budget = 32; budget <= 64; budget *= 2) {
@@ -1126,18 +1163,18 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   d->magic = MAGIC_RECT; d->device = device; d->iw = iw; d->ih = ih; d->N = iw * ih; d->nslots = nslots; d->nworkers = nworkers;
   d->maxrec_dev = d->N * 16 / 56;
   if (d->maxrec_dev > 65536) d->maxrec_dev = 65536;      // the slots' probe buffers; frames with more records are probed again into a buffer that grows (slot_rectangles)
-  if (getenv("RD_MAXREC_DEV")) { const int m = atoi(getenv("RD_MAXREC_DEV")); if (m >= 16 && m < d->maxrec_dev) d->maxrec_dev = m; }      // (tests: exercise that path)
+  { const int m = rd_env_int("RD_MAXREC_DEV", 0); if (m >= 16 && m < d->maxrec_dev) d->maxrec_dev = m; }      // (tests: exercise that path)
   d->nring = nslots + 1;
   d->prev_ring = dnew<int8_t>((size_t)d->N * d->nring);
   RD_HIP(hipMemset(d->prev_ring, 0, (size_t)d->N * d->nring));
-  d->use_graph = getenv("RD_NO_GRAPH") ? 0 : 1;
-  d->graph_fork = getenv("RD_GRAPH_FORK") ? atoi(getenv("RD_GRAPH_FORK")) : 0;
-  d->poly_mode = getenv("RD_POLY_MULTILAUNCH") ? 0 : 1;      // (tests: the ~85-launch form for every frame)
-  d->force_redo = (getenv("RD_POLY_FORCE_REDO") ? 1 : 0) | (getenv("RD_ABSORB_FORCE_SLOW") ? 2 : 0);   // tests: every frame also takes the polyline / absorption fallback
+  d->use_graph = rd_env("RD_NO_GRAPH") ? 0 : 1;
+  d->graph_fork = RD_LAB_INT("RD_GRAPH_FORK", 0);
+  d->poly_mode = rd_env("RD_POLY_MULTILAUNCH") ? 0 : 1;      // (tests: the ~85-launch form for every frame)
+  d->force_redo = (rd_env("RD_POLY_FORCE_REDO") ? 1 : 0) | (rd_env("RD_ABSORB_FORCE_SLOW") ? 2 : 0);   // tests: every frame also takes the polyline / absorption fallback
   // candidate funnel + pose estimation on the device (rd_k_post.hip) instead of on one worker thread per frame slot: RD_DEVICE_POST=0|1 decides;
   // otherwise the host path - 0.3 ms of CPU time per 1080p frame, i.e. 0.6 of a core at 2000 frames/s: measured 2050 frames/s on 8 cores
   // as on 256, against 1830 for the device path - unless this process may run on one or two cores only
-  if (getenv("RD_DEVICE_POST")) d->device_post = atoi(getenv("RD_DEVICE_POST")) != 0;
+  if (rd_env("RD_DEVICE_POST")) d->device_post = rd_env_int("RD_DEVICE_POST", 0) != 0;
   else {
     cpu_set_t set;
     const int ncpu = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : 0;
@@ -1147,32 +1184,33 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   // frames in flight a frame spreads over two streams (polyline chain beside the blur chain: shortest latency); from three
   // frames on every frame keeps to one stream, so that four frames occupy the four queues (highest throughput).
   d->fork_poly = nslots <= 2 ? 1 : 0;
-  if (getenv("RD_FORK_POLY")) d->fork_poly = (atoi(getenv("RD_FORK_POLY")) != 0 && nslots <= 2) ? 1 : 0;      // (measurements: one stream per frame with one or two in flight as well)
+  if (RD_LAB_INT("RD_FORK_POLY", 1) == 0) d->fork_poly = 0;      // (measurements: one stream per frame with one or two in flight as well)
   // One or two frames in flight and no worker threads = the reference's call sequence (executeOnce, enqueueTask / pollTask): the caller's thread runs the
   // post-process at the end of every frame's latency; helper threads share its pose estimations (rd_post.c), RD_POST_HELPERS=n overrides their number
   d->post_helpers = 0;
   if (nworkers == 0 && nslots <= 2) {
     cpu_set_t set;
     const int ncpu = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : 0;
-    d->post_helpers = getenv("RD_POST_HELPERS") ? atoi(getenv("RD_POST_HELPERS")) : (ncpu >= 16 ? 4 : (ncpu >= 8 ? 2 : (ncpu >= 4 ? 1 : 0)));      // (1 / 3 / 5 / 7 helpers: 1.19 / 1.14-1.20 / 1.11 / 1.12-1.20 ms per executeOnce against 1.28 without)
+    d->post_helpers = rd_env_int("RD_POST_HELPERS", ncpu >= 16 ? 4 : (ncpu >= 8 ? 2 : (ncpu >= 4 ? 1 : 0)));      // (1 / 3 / 5 / 7 helpers: 1.19 / 1.14-1.20 / 1.11 / 1.12-1.20 ms per executeOnce against 1.28 without)
     if (d->post_helpers > 0) rd_post_helpers_configure(d->post_helpers);
   }
   // round budget of the region merge: what the last 64 frames needed + margin (8 / 12 / 16 / 20 launched rounds; the rounds after
   // the merge has settled are no-ops, but each still costs two launches of a thousand blocks), frames that turn out to need more
   // are repeated with all 20; RD_REGION_ROUNDS_FIXED=8|12|16|20 pins the budget (20: never repeat anything).
   d->fixed_rounds = 0;
-  if (getenv("RD_REGION_ROUNDS_FIXED")) { const int r = atoi(getenv("RD_REGION_ROUNDS_FIXED")); d->fixed_rounds = (r >= 8 && r <= 20 && !(r & 1)) ? r : 20; }
+  if (rd_env("RD_REGION_ROUNDS_FIXED")) { const int r = rd_env_int("RD_REGION_ROUNDS_FIXED", 20); d->fixed_rounds = (r >= 8 && r <= 20 && !(r & 1)) ? r : 20; }
   d->rounds_budget = 20;
   // The single-block polyline kernel holds 16 384 live chain pixels; a 1920x1080 frame of the synthetic streams has ~11 000, frames of 3 megapixels and
   // more are beyond it as a rule: their streams start on the multi-launch form instead of overflowing - and being repeated - until the two-overflow rule
   // below finds that out (3840x2160: 12 of the first 16 frames).  Smaller frames that overflow anyway are still caught by that rule.
   d->poly_overflows = (long)iw * ih > 3000000L ? 1 : 0;
   d->t_edge = 500; d->t_strong = 2500;      // oclrect.c:277-284, 307-313
-  if (getenv("RD_TEST_THRESHOLDS")) {      // tests only: other thresholds, so that many strength sums stand exactly one below one (where the mask of the frame before decides, H1)
+  if (rd_env("RD_TEST_THRESHOLDS")) {      // tests only: other thresholds, so that many strength sums stand exactly one below one (where the mask of the frame before decides, H1)
     int a = 0, b = 0;
-    if (sscanf(getenv("RD_TEST_THRESHOLDS"), "%d,%d", &a, &b) == 2 && a > 0 && b >= a) { d->t_edge = a; d->t_strong = b; }
+    if (sscanf(rd_env("RD_TEST_THRESHOLDS"), "%d,%d", &a, &b) == 2 && a > 0 && b >= a) { d->t_edge = a; d->t_strong = b; }
   }
-  d->budget_cycle = getenv("RD_BUDGET_CYCLE") ? atoi(getenv("RD_BUDGET_CYCLE")) : 0;      // tests: the launch budget changes every so many frames (12, 14, .. 20, 12, ..)
+  d->strong_by_frame = rd_env("RD_STRONG_BY_FRAME") ? 1 : 0;
+  d->budget_cycle = rd_env_int("RD_BUDGET_CYCLE", 0);      // tests: the launch budget changes every so many frames (12, 14, .. 20, 12, ..)
   pthread_mutex_init(&d->tan_mu, NULL); pthread_cond_init(&d->tan_cv, NULL);
   pthread_mutex_init(&d->launch_mu, NULL);
   d->slots = (Slot *)calloc((size_t)nslots, sizeof(Slot));
@@ -1180,7 +1218,7 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   // slots to keep the streams fed, and without it a batch is a barrier per group (measured 10 % slower than no batching) - else every
   // frame on its own; RD_BATCH=1..4 overrides (tests: batching with any slot count)
   d->batch = nslots >= 24 ? 8 : (nslots >= 12 ? 4 : 1);      // (these stages are latency-bound chains of gathers: eight frames take a launch as long as four)
-  if (getenv("RD_BATCH")) { const int b = atoi(getenv("RD_BATCH")); d->batch = b < 1 ? 1 : (b > RD_MAXB ? RD_MAXB : b); }
+  if (rd_env("RD_BATCH")) { const int b = rd_env_int("RD_BATCH", 1); d->batch = b < 1 ? 1 : (b > RD_MAXB ? RD_MAXB : b); }
   if (d->fork_poly || d->batch > nslots) d->batch = d->fork_poly ? 1 : nslots;
   d->frames = (rdk::PolyFrame *)calloc((size_t)nslots, sizeof(rdk::PolyFrame));
   d->deferred_slot = -1;
@@ -1189,14 +1227,14 @@ rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nwor
   // streams of slot i mod 4) - a stream of its own would be time-sliced onto the same four hardware queues and stall frames
   // that have nothing to do with each other, while a queued frame keeps its queue busy as soon as its predecessor is done
   // (the host's turn-around between "frame polled" and "next frame enqueued" otherwise idles a quarter of the device).
-  const int nstreams = getenv("RD_NSTREAMS") ? (atoi(getenv("RD_NSTREAMS")) < 1 ? 1 : (atoi(getenv("RD_NSTREAMS")) > 8 ? 8 : atoi(getenv("RD_NSTREAMS")))) : 4;      // (measurements only - 3 / 5 / 6 streams: 2776-2786 / 2746-2753 / 2827-2847 frames/s against 2881-2889 with four, one box)
+  const int nstreams = RD_LAB_INT("RD_NSTREAMS", 4) < 1 ? 1 : (RD_LAB_INT("RD_NSTREAMS", 4) > 8 ? 8 : RD_LAB_INT("RD_NSTREAMS", 4));      // (measurements only - 3 / 5 / 6 streams: 2776-2786 / 2746-2753 / 2827-2847 frames/s against 2881-2889 with four, one box)
   d->nstreams = nstreams < nslots ? nstreams : nslots;
   // Group mode: four frames per launch from twelve frame slots on (three groups: one being filled, two in flight), two from six on, eight from 32 on
   // (640x480: 9100 frames/s with 16 slots in groups of four, 11700 with 32 in groups of eight; 1080p: no difference);
   // RD_ZBATCH=k overrides (k frames per launch, 2..8; 0 / 1: off).
   d->zb = nslots >= 32 ? 8 : (nslots >= 12 ? 4 : (nslots >= 6 ? 2 : 1));      // (always at least three or four groups: one being filled, the others in flight on the four streams)
   if ((long long)iw * ih > 1920ll * 1088) d->zb = 1;      // (launches of larger frames fill the device on their own: 3840x2160 measured 1 % slower in groups)
-  if (getenv("RD_ZBATCH")) { const int z = atoi(getenv("RD_ZBATCH")); d->zb = z < 1 ? 1 : (z > RD_ZB_MAX ? RD_ZB_MAX : z); }
+  if (rd_env("RD_ZBATCH")) { const int z = rd_env_int("RD_ZBATCH", 1); d->zb = z < 1 ? 1 : (z > RD_ZB_MAX ? RD_ZB_MAX : z); }
   if (d->fork_poly || d->zb > nslots || nstreams <= 0) d->zb = 1;
   if (d->zb > 1) { d->batch = 1; d->defer = 0; }      // (a group's sparse stages follow its dense stages on the same stream)
   if (d->zb > 1) {
@@ -1274,14 +1312,32 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
   Slot *s = &d->slots[d->next_enqueue % d->nslots];
   s->seq = d->next_enqueue; s->ws = ws;
   const size_t bytes = (size_t)ws * d->ih;
-  if (on_device) s->src = (const uint8_t *)frame;      // read where it lies (the caller keeps it valid until the frame's poll returned)
+  if (on_device == RD_FRAME_DEVICE) s->src = (const uint8_t *)frame;      // read where it lies (the caller keeps it valid until the frame's poll returned)
+  else if (on_device == RD_FRAME_HOST_PINNED) {
+    // The caller's buffer is page-locked and stays as it is until the frame's poll: the copy engine takes it from there.  (The reference copies every frame into its own
+    // pinned page first, oclrect.c:1256 - 6 MB per 1920x1080 frame by the caller's thread, 16 GB/s at full rate on the thread that also launches everything.)
+    if (!(frame >= d->pinned_lo && (const char *)frame + bytes <= (const char *)d->pinned_hi)) {      // (one look per buffer, not per frame: a capture loop reuses its pages)
+      hipPointerAttribute_t at;
+      if (hipPointerGetAttributes(&at, frame) != hipSuccess || at.type != hipMemoryTypeHost) { (void)hipGetLastError(); exitf(-1, "rd_detector_enqueue: RD_FRAME_HOST_PINNED needs pinned host memory (rd_host_alloc, allocatePinnedMemory, hipHostMalloc, hipHostRegister); %p is not\n", frame); }
+      d->pinned_lo = frame; d->pinned_hi = (const char *)frame + bytes;
+    }
+    hipStream_t ust = s->st;
+    s->uploaded_early = 0;
+    if (d->zb > 1) { if (!d->st_upload) d->st_upload = pooled_stream(d->device); ust = d->st_upload; }      // (group mode: on the detector's upload stream, the group's stream waits for the event)
+    RD_HIP(hipMemcpyAsync(s->bgr, frame, bytes, hipMemcpyHostToDevice, ust));
+    if (d->zb > 1) { RD_HIP(hipEventRecord(s->ev_fork, ust)); s->uploaded_early = 1; }
+    s->src = s->bgr;
+    d->n_frames_pinned++;
+  }
+  else if (on_device != RD_FRAME_HOST) exitf(-1, "rd_detector_enqueue: on_device = %d (0: host memory, 1: device memory, 2: pinned host memory)\n", on_device);
   else if (d->zb == 1) {
+    d->n_frames_copied++;
     // a single frame: the copy into pinned memory and the upload in pieces, so that a piece travels while the next is being copied (6 MB at 1920x1080:
     // the copy alone takes a fifth of a millisecond of the caller's latency).  With helper threads (armed here: the call that hands a frame over is followed by
     // the poll that waits for one) the pieces are copied side by side and uploaded in order as they complete.
-    static const bool nt_copy = getenv("RD_NT_COPY") ? atoi(getenv("RD_NT_COPY")) != 0 : true;
-    static const int npieces_env = getenv("RD_UPLOAD_PIECES") ? atoi(getenv("RD_UPLOAD_PIECES")) : 0;
-    static const bool par_copy = getenv("RD_PARALLEL_COPY") ? atoi(getenv("RD_PARALLEL_COPY")) != 0 : true;
+    static const bool nt_copy = RD_LAB_INT("RD_NT_COPY", 1) != 0;
+    static const int npieces_env = RD_LAB_INT("RD_UPLOAD_PIECES", 0);
+    static const bool par_copy = RD_LAB_INT("RD_PARALLEL_COPY", 1) != 0;
     const bool helpers = d->post_helpers > 0 && par_copy;
     if (helpers) rd_post_helpers_arm();
     int npieces = npieces_env > 0 ? npieces_env : (helpers ? 16 : 4);
@@ -1296,13 +1352,14 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
     if (u.uploaded != u.n) exitf(-1, "rd_detector_enqueue: internal error (pieces of the frame left behind)\n");
     s->src = s->bgr;
   } else {      // (group mode: the group's frames are uploaded together when it is launched)
-    static const bool nt_copy_g = getenv("RD_NT_COPY") ? atoi(getenv("RD_NT_COPY")) != 0 : true;
+    d->n_frames_copied++;
+    static const bool nt_copy_g = RD_LAB_INT("RD_NT_COPY", 1) != 0;
     if (nt_copy_g) rd_copy_to_staging(s->h_bgr, frame, bytes); else memcpy(s->h_bgr, frame, bytes);
     s->src = s->bgr;
     // The frame travels NOW, on a stream of the detector's own (high-priority pool: a hardware queue nobody computes on), not when its group is launched: eight uploads in
     // front of a group's kernels kept that group's stream - a quarter of the device's queues - waiting for the copy engine for 1.6 of its 10.8 ms.  The group's stream
     // waits for the event instead (group_launch).  RD_UPLOAD_EARLY=0: as before.
-    static const bool upload_early = getenv("RD_UPLOAD_EARLY") ? atoi(getenv("RD_UPLOAD_EARLY")) != 0 : true;
+    static const bool upload_early = RD_LAB_INT("RD_UPLOAD_EARLY", 1) != 0;
     s->uploaded_early = 0;
     if (upload_early) {
       if (!d->st_upload) d->st_upload = pooled_stream(d->device);
@@ -1364,10 +1421,10 @@ void *rd_detector_poll(rd_detector *d, double tanAOV) {
       r = slot_rectangles(d, s, tanAOV, &segs, &ns);
     }
   } else {
-    if (d->post_helpers) rd_post_helpers_arm();      // (they wake while the device is still busy with the frame: rd_post.c)
-    static const int trace_poll = getenv("RD_TRACE_POLL") ? atoi(getenv("RD_TRACE_POLL")) : 0;      // (1: timings, 2: wait by querying instead of hipEventSynchronize)
+    if (d->post_helpers && !(s->post_mode && s->post_tan == tanAOV)) rd_post_helpers_arm();      // (they wake while the device is still busy with the frame: rd_post.c; not for a frame whose rectangles the device computes)
+    static const int trace_poll = RD_LAB_INT("RD_TRACE_POLL", 0);      // (1: timings, 2: wait by querying instead of hipEventSynchronize)
     struct timespec t0, t1, t2, t3; clock_gettime(CLOCK_MONOTONIC, &t0);
-    if (trace_poll == 2) { while (hipEventQuery(s->ev_done) == hipErrorNotReady) __builtin_ia32_pause(); }
+    if (trace_poll == 2) { while (hipEventQuery(s->ev_done) == hipErrorNotReady) sched_yield(); }
     else RD_HIP(hipEventSynchronize(s->ev_done));
     clock_gettime(CLOCK_MONOTONIC, &t1);
     slot_finish_device(d, s);
@@ -1419,6 +1476,10 @@ long rd_detector_counter(rd_detector *d, int which) {
   if (which == 13) return __atomic_load_n(&d->host_post_ns, __ATOMIC_RELAXED) / 1000;
   if (which == 14) return __atomic_load_n(&d->n_redo_absorb, __ATOMIC_RELAXED);
   if (which == 15) return d->zb;      // frames per group launch (1: every frame its own launches)
+  if (which == 18) return d->n_frames_pinned;
+  if (which == 19) return d->n_frames_copied;
+  if (which == 16) return d->n_strong_group;        // groups whose strong masks were ONE launch (k_strength_masks_group)
+  if (which == 17) return d->n_strong_by_frame;     // groups whose strong masks were evaluated frame by frame
   if (which >= 40 && which <= 60) return d->need_count[which - 40];      // frames whose region merge needed 0..20 launches (the one that changes nothing included; 20: or more)
   if (which == 1) return d->dev_us;
   if (which == 2) return d->dev_frames;
@@ -1514,7 +1575,7 @@ struct oclrect_t *init_oclrect(struct oclimgutil_t *oclimgutil, struct oclpolyli
   (void)oclimgutil; (void)oclpolyline; (void)context; (void)queue;
   struct oclrect_t *t = (struct oclrect_t *)calloc(1, sizeof(*t));
   t->magic = MAGIC_RECT; t->iw = iw; t->ih = ih;
-  t->det = rd_detector_create(device ? device->ordinal : rdrt::current_device(), iw, ih, 2, getenv("RD_API_WORKERS") ? atoi(getenv("RD_API_WORKERS")) : 0);   // two pages like oclrect.c:54
+  t->det = rd_detector_create(device ? device->ordinal : rdrt::current_device(), iw, ih, 2, RD_LAB_INT("RD_API_WORKERS", 0));   // two pages like oclrect.c:54
   return t;
 }
 

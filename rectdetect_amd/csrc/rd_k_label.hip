@@ -500,7 +500,9 @@ __global__ __launch_bounds__(256) void k_strength_masks(int *__restrict__ strong
 __device__ int strong_before(const int *label0, const int *str0, const int8_t *ring0, size_t zs, int zz, int q, int iw, int ih, int t_strong) {
   for (;;) {
     if (zz < 0) return (int)ring0[q];
-    const int l2 = *(const int *)((const char *)label0 + (size_t)zz * zs + (size_t)q * 4);
+    // (a word another block of this launch may be rewriting right now - filtered or not, it answers the same, see above: a relaxed atomic load of agent scope, so that the
+    //  race is a defined one and the load is neither hoisted nor served from a non-coherent path)
+    const int l2 = ld_agent((const int *)((const char *)label0 + (size_t)zz * zs + (size_t)q * 4));
     if (l2 <= 0) return 0;
     const int qy = q / iw, qx = q - qy * iw;
     if (!(qx > 0 && qy > 0 && qx < iw - 1 && qy < ih - 1)) return 1;      // (the frame's ring is never filtered)
@@ -510,7 +512,8 @@ __device__ int strong_before(const int *label0, const int *str0, const int8_t *r
     q = l2; zz--;           // the sum stands one below the threshold: the frame before decides, at this component's root
   }
 }
-__global__ __launch_bounds__(256) void k_strength_masks_group(int8_t *__restrict__ ring, int8_t *__restrict__ edge8, int *__restrict__ label, const int *__restrict__ str, int t_edge, int t_strong,
+// (label and ring without __restrict__: strong_before reads other frames' label words through an alias while blocks of this launch rewrite them)
+__global__ __launch_bounds__(256) void k_strength_masks_group(int8_t *ring, int8_t *__restrict__ edge8, int *label, const int *__restrict__ str, int t_edge, int t_strong,
                                                                int iw, int ih, unsigned long long *__restrict__ bits, long t0, int nring, size_t zs) {
   const int z = blockIdx.z;
   const int *label0 = label, *str0 = str;

@@ -12,6 +12,7 @@
 #define _GNU_SOURCE
 #include <math.h>
 #include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -157,15 +158,22 @@ static rect_t candidate_rect(const rdp_seg *sides, rdp_p2 centre, int iw, int ih
 typedef struct { rdp_seg sides[4]; rdp_p2 centre; uint32_t status; rect_t out; } pose_job;
 typedef struct { pose_job *jobs; int iw, ih; double tan_aov; } pose_batch;
 
+#if defined(__x86_64__) || defined(__i386__)
+#define RD_CPU_RELAX() __builtin_ia32_pause()
+#else
+#define RD_CPU_RELAX() __asm__ __volatile__("" ::: "memory")
+#endif
+
 static struct {
-  pthread_mutex_t mu;             /* guards everything below */
+  pthread_mutex_t mu;             /* guards everything below (the three words the spinning helpers read without it are written with atomic stores) */
   pthread_cond_t cv;
   pthread_mutex_t owner;          /* the caller whose jobs the helpers work on */
   pthread_t th[RD_POST_MAX_HELPERS];
-  int nthreads, quit;
-  unsigned arm_gen;               /* raised by every rd_post_helpers_arm */
+  int nthreads, quit;             /* nthreads: atomic (read by callers that do not hold the lock) */
+  unsigned arm_gen;               /* raised by every rd_post_helpers_arm; atomic */
   rd_job_fn fn; void *ctx; int njobs, next, done;
-  int pending;                    /* njobs - next; read without the lock by spinning helpers (relaxed atomics) */
+  int pending;                    /* njobs - next; atomic */
+  int atfork_registered;
 } pool = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_MUTEX_INITIALIZER };
 
 static double mono_us(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e6 + t.tv_nsec * 1e-3; }
@@ -194,45 +202,77 @@ static void *pool_helper(void *arg) {
   unsigned seen = 0;
   for (;;) {
     pthread_mutex_lock(&pool.mu);
-    while (pool.arm_gen == seen && !pool.quit) pthread_cond_wait(&pool.cv, &pool.mu);
-    seen = pool.arm_gen;
+    while (__atomic_load_n(&pool.arm_gen, __ATOMIC_RELAXED) == seen && !pool.quit) pthread_cond_wait(&pool.cv, &pool.mu);
+    seen = __atomic_load_n(&pool.arm_gen, __ATOMIC_RELAXED);
     if (pool.quit) { pthread_mutex_unlock(&pool.mu); return NULL; }
     pthread_mutex_unlock(&pool.mu);
-    /* armed: a caller has work coming - spin until jobs appear, take part, and go on spinning (the same call brings the copy of a frame first and its
-     * candidates a millisecond later) until RD_POST_SPIN_US have passed since the last arm: a frame that takes longer than that is not one whose latency
-     * these threads can save.  A call of arm that arrives meanwhile extends the time. */
-    double until = mono_us() + RD_POST_SPIN_US;
+    /* armed: a caller has work coming - spin until jobs appear, take part, and go on (the same call brings the copy of a frame first and its candidates a
+     * millisecond later) until RD_POST_SPIN_US have passed since the last arm: a frame that takes longer than that is not one whose latency these threads can
+     * save.  A call of arm that arrives meanwhile extends the time.  The first RD_POST_HOT_US are a tight spin; after that the thread offers its core to
+     * whoever wants it between two looks (sched_yield): on a busy machine an armed helper costs next to nothing, on an idle one it is what it is meant to be. */
+    const double armed = mono_us();
+    double until = armed + RD_POST_SPIN_US, hot = armed + RD_POST_HOT_US;
     for (;;) {
-      if (__atomic_load_n(&pool.pending, __ATOMIC_RELAXED) > 0) pool_work(NULL);
-      else if (__atomic_load_n(&pool.arm_gen, __ATOMIC_RELAXED) != seen) { seen = __atomic_load_n(&pool.arm_gen, __ATOMIC_RELAXED); until = mono_us() + RD_POST_SPIN_US; }      /* (racy read: a missed one is caught by the wait above) */
-      else if (mono_us() > until) break;
-      else __builtin_ia32_pause();
+      if (__atomic_load_n(&pool.pending, __ATOMIC_RELAXED) > 0) { pool_work(NULL); hot = mono_us() + RD_POST_HOT_US; }
+      else if (__atomic_load_n(&pool.arm_gen, __ATOMIC_RELAXED) != seen) { seen = __atomic_load_n(&pool.arm_gen, __ATOMIC_RELAXED); until = mono_us() + RD_POST_SPIN_US; }      /* (a change missed here is caught by the wait above) */
+      else {
+        const double now = mono_us();
+        if (now > until || __atomic_load_n(&pool.quit, __ATOMIC_RELAXED)) break;
+        if (now > hot) sched_yield(); else RD_CPU_RELAX();
+      }
     }
   }
+}
+
+/* the child of a fork() has none of the parent's threads: it starts with an empty pool (and fresh locks - a helper may have held one at the fork) and runs
+ * everything on its caller's thread until it configures helpers of its own */
+static void pool_after_fork_in_child(void) {
+  pthread_mutex_init(&pool.mu, NULL); pthread_cond_init(&pool.cv, NULL); pthread_mutex_init(&pool.owner, NULL);
+  __atomic_store_n(&pool.nthreads, 0, __ATOMIC_RELAXED);
+  pool.quit = 0; pool.fn = NULL; pool.ctx = NULL; pool.njobs = pool.next = pool.done = 0;
+  __atomic_store_n(&pool.pending, 0, __ATOMIC_RELAXED);
 }
 
 void rd_post_helpers_configure(int n) {
   if (n > RD_POST_MAX_HELPERS) n = RD_POST_MAX_HELPERS;
   pthread_mutex_lock(&pool.mu);
+  if (!pool.atfork_registered) { pthread_atfork(NULL, NULL, pool_after_fork_in_child); pool.atfork_registered = 1; }
   while (pool.nthreads < n) {
     if (pthread_create(&pool.th[pool.nthreads], NULL, pool_helper, NULL) != 0) break;
-    pool.nthreads++;
+    __atomic_store_n(&pool.nthreads, pool.nthreads + 1, __ATOMIC_RELEASE);
   }
   pthread_mutex_unlock(&pool.mu);
 }
 
-void rd_post_helpers_arm(void) {
-  if (pool.nthreads == 0) return;
+/* the helpers end with the library (dlclose, exit): asked to quit and joined, so that none of them is left running code that is about to be unmapped */
+void rd_post_helpers_shutdown(void) {
+  pthread_mutex_lock(&pool.owner);      /* (no frame's jobs in flight) */
   pthread_mutex_lock(&pool.mu);
-  pool.arm_gen++;
+  const int n = pool.nthreads;
+  __atomic_store_n(&pool.quit, 1, __ATOMIC_RELAXED);
+  pthread_cond_broadcast(&pool.cv);
+  pthread_mutex_unlock(&pool.mu);
+  for (int i = 0; i < n; i++) pthread_join(pool.th[i], NULL);
+  pthread_mutex_lock(&pool.mu);
+  __atomic_store_n(&pool.nthreads, 0, __ATOMIC_RELEASE);
+  pool.quit = 0;
+  pthread_mutex_unlock(&pool.mu);
+  pthread_mutex_unlock(&pool.owner);
+}
+__attribute__((destructor)) static void pool_at_unload(void) { if (__atomic_load_n(&pool.nthreads, __ATOMIC_ACQUIRE) > 0) rd_post_helpers_shutdown(); }
+
+void rd_post_helpers_arm(void) {
+  if (__atomic_load_n(&pool.nthreads, __ATOMIC_ACQUIRE) == 0) return;
+  pthread_mutex_lock(&pool.mu);
+  __atomic_store_n(&pool.arm_gen, pool.arm_gen + 1, __ATOMIC_RELAXED);
   pthread_cond_broadcast(&pool.cv);
   pthread_mutex_unlock(&pool.mu);
 }
 
-int rd_post_helpers(void) { return pool.nthreads; }
+int rd_post_helpers(void) { return __atomic_load_n(&pool.nthreads, __ATOMIC_ACQUIRE); }
 
 void rd_helpers_run(rd_job_fn fn, void *ctx, int n, rd_progress_fn progress) {
-  if (n > 1 && pool.nthreads > 0 && pthread_mutex_trylock(&pool.owner) == 0) {
+  if (n > 1 && __atomic_load_n(&pool.nthreads, __ATOMIC_ACQUIRE) > 0 && pthread_mutex_trylock(&pool.owner) == 0) {
     pthread_mutex_lock(&pool.mu);
     pool.fn = fn; pool.ctx = ctx; pool.njobs = n; pool.next = 0; pool.done = 0;
     __atomic_store_n(&pool.pending, n, __ATOMIC_RELAXED);
@@ -244,7 +284,7 @@ void rd_helpers_run(rd_job_fn fn, void *ctx, int n, rd_progress_fn progress) {
       if (fin) { pool.njobs = 0; pool.next = 0; __atomic_store_n(&pool.pending, 0, __ATOMIC_RELAXED); pool.fn = NULL; pool.ctx = NULL; }
       pthread_mutex_unlock(&pool.mu);
       if (fin) break;
-      if (progress) progress(ctx); else __builtin_ia32_pause();
+      if (progress) progress(ctx); else RD_CPU_RELAX();
     }
     pthread_mutex_unlock(&pool.owner);
     if (progress) progress(ctx);
@@ -270,6 +310,7 @@ static void il_push(intlist *l, int x) {
 }
 
 /* ------------------------------------------------------------------ the frame's way into pinned memory */
+#if defined(__x86_64__)
 #include <immintrin.h>
 __attribute__((target("avx2"))) static void copy_stream_avx2(char *d, const char *s, size_t n) {
   while (((uintptr_t)d & 31) && n) { *d++ = *s++; n--; }
@@ -285,10 +326,14 @@ __attribute__((target("avx2"))) static void copy_stream_avx2(char *d, const char
 
 void rd_copy_to_staging(void *dst, const void *src, size_t n) {
   static int avx2 = -1;
-  if (avx2 < 0) avx2 = __builtin_cpu_supports("avx2") ? 1 : 0;
-  if (avx2 && n >= 4096) copy_stream_avx2((char *)dst, (const char *)src, n);
+  int have = __atomic_load_n(&avx2, __ATOMIC_RELAXED);
+  if (have < 0) { have = __builtin_cpu_supports("avx2") ? 1 : 0; __atomic_store_n(&avx2, have, __ATOMIC_RELAXED); }
+  if (have && n >= 4096) copy_stream_avx2((char *)dst, (const char *)src, n);
   else memcpy(dst, src, n);
 }
+#else
+void rd_copy_to_staging(void *dst, const void *src, size_t n) { memcpy(dst, src, n); }
+#endif
 
 /* ------------------------------------------------------------------ rh:1049-1226 */
 

@@ -14,9 +14,12 @@ void *rd_post_run(const void *segs, int max_records, const int *probes, int iw, 
  * about to wait for a frame whose post-process it will run itself - the helpers wake and spin for at most RD_POST_SPIN_US microseconds. */
 #define RD_POST_MAX_HELPERS 7
 #define RD_POST_SPIN_US 2000.0
+#define RD_POST_HOT_US 300.0      /* of which a tight spin; then sched_yield between two looks */
 void rd_post_helpers_configure(int n);
 void rd_post_helpers_arm(void);
 int rd_post_helpers(void);
+/* asks the helpers to end and joins them (also run when the library is unloaded); configure() may start new ones afterwards */
+void rd_post_helpers_shutdown(void);
 /* fn(ctx, 0) .. fn(ctx, n - 1), each once, claimed in index order by the caller's thread and by whichever helpers are awake; returns when all have run.
  * progress (may be NULL) is called on the CALLER's thread after each of its own jobs and while it waits for the helpers' last ones. */
 typedef void (*rd_job_fn)(void *ctx, int idx);

@@ -70,6 +70,9 @@ int rd_device_pci_bus_id(int ordinal, char *buf, int len) {
 void rd_select_device(int ordinal) { enumerate(); if (ordinal < 0 || ordinal >= g_ndev) exitf(-1, "rd_select_device: no HIP device %d\n", ordinal); g_selected = ordinal; RD_HIP(hipSetDevice(ordinal)); }
 void *rd_device_alloc(size_t bytes) { void *p = NULL; RD_HIP(hipMalloc(&p, bytes ? bytes : 1)); return p; }
 void rd_device_free(void *dptr) { if (dptr) RD_HIP(hipFree(dptr)); }
+// pinned host memory for callers without a HIP binding of their own (frames handed over with rd_detector_enqueue(..., RD_FRAME_HOST_PINNED) travel straight from it)
+void *rd_host_alloc(size_t bytes) { void *p = NULL; RD_HIP(hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault)); return p; }
+void rd_host_free(void *p) { if (p) RD_HIP(hipHostFree(p)); }
 void rd_upload(void *dptr, const void *host, size_t bytes) { RD_HIP(hipMemcpy(dptr, host, bytes, hipMemcpyHostToDevice)); }
 void rd_download(void *host, const void *dptr, size_t bytes) { RD_HIP(hipMemcpy(host, dptr, bytes, hipMemcpyDeviceToHost)); }
 
