@@ -109,29 +109,46 @@ def device_bus_id(L, dev):
         return None
 
 
-def pin_to_gpu_cores(L, dev):
-    """One process per GPU runs the enqueue / poll loop plus one post-process worker thread per frame slot (9 threads); on the
-    8-GPU node (256 host cores, several NUMA nodes) keep them on the cores next to this rank's GPU.  Best effort: returns the
-    cpulist used, or None when the topology is not visible."""
+def parse_cpulist(spec):
+    """'0-15,128-143' -> {0..15, 128..143} (the kernel's cpulist format); ValueError on anything else"""
+    cpus = set()
+    for part in spec.strip().split(","):
+        lo, _, hi = part.partition("-")
+        lo, hi = int(lo), int(hi or lo)
+        if lo < 0 or hi < lo:
+            raise ValueError(spec)
+        cpus.update(range(lo, hi + 1))
+    return cpus
+
+
+def gpu_local_cpus(bus_id, sysfs_root="/sys"):
+    """the cores next to the GPU with PCI bus id `bus_id`: (the kernel's cpulist string, the set) from <sysfs>/bus/pci/devices/<bus id>/local_cpulist, or (None, None)"""
     try:
-        import ctypes
-        buf = ctypes.create_string_buffer(64)
-        if L.rd_device_pci_bus_id(dev, buf, 64) != 0:
-            return None
-        bus = buf.value.decode().lower()
-        with open("/sys/bus/pci/devices/%s/local_cpulist" % bus) as f:
+        with open(os.path.join(sysfs_root, "bus", "pci", "devices", bus_id.lower(), "local_cpulist")) as f:
             spec = f.read().strip()
-        cpus = set()
-        for part in spec.split(","):
-            lo, _, hi = part.partition("-")
-            cpus.update(range(int(lo), int(hi or lo) + 1))
-        cpus &= os.sched_getaffinity(0)
-        if len(cpus) < 2:
-            return None
-        os.sched_setaffinity(0, cpus)
-        return spec
-    except (OSError, ValueError, AttributeError):
+        return spec, parse_cpulist(spec)
+    except (OSError, ValueError):
+        return None, None
+
+
+def pin_to_gpu_cores(L, dev, sysfs_root="/sys"):
+    """One process per GPU runs the enqueue / poll loop plus one post-process worker thread per frame slot; on the 8-GPU node (256 host cores, several NUMA nodes) keep
+    them on the cores next to this rank's GPU.  Best effort: returns the cpulist used, or None when the topology is not visible (or leaves fewer than two of the cores
+    this process may use)."""
+    bus = device_bus_id(L, dev)
+    if not bus:
         return None
+    spec, cpus = gpu_local_cpus(bus, sysfs_root)
+    if not cpus:
+        return None
+    cpus &= os.sched_getaffinity(0)
+    if len(cpus) < 2:
+        return None
+    try:
+        os.sched_setaffinity(0, cpus)
+    except OSError:
+        return None
+    return spec
 
 
 def spawn_ranks(args):
@@ -266,6 +283,7 @@ def main():
     ap.add_argument("--frames-per-step", type=int, default=512, help="frames of the stream resident in HBM and handed over per step (512 x 6.2 MB = 3.2 GB; 20 steps then run about 3.5 s)")
     ap.add_argument("--slots", type=int, default=64, help="frames in flight per GPU (from three on: one stream per frame on four shared streams; from 6 / 12 / 32 on: groups of 2 / 4 / 8 frames per set of launches; 64 = two groups queued on each of the four streams, so that a stream never waits for the host to collect a group and hand over the next; 48 / 64 / 96 / 128 measured 2706-2717 / 2764-2782 / 2753-2754 / 2783-2810 frames/s on one box in round 5)")
     ap.add_argument("--host-frames", action="store_true", help="hand over host buffers (PCIe upload inside the timed region); not the headline value")
+    ap.add_argument("--host-mode", default="pageable", choices=["pageable", "pinned"], help="with --host-frames (profiling runs): pageable buffers, copied by the caller's thread first, or pinned ones, read in place")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="profiling runs only: skip the sequential verification pass and the host-frames pass (the line then says outputs_verified: null)")
     ap.add_argument("--dry-run", action="store_true", help="no GPU work: exercises sharding/aggregation only (CPU tests)")
@@ -333,9 +351,15 @@ def main():
 
     import zlib
     pframes = []                 # the frames once more in pinned host memory (allocated for the host-frames pass only)
+    if det is not None and args.host_frames and args.host_mode == "pinned":
+        import ctypes
+        for a in frames:
+            p = L.rd_host_alloc(a.nbytes)
+            ctypes.memmove(p, a.ctypes.data, a.nbytes)
+            pframes.append(p)
     results = []                 # rectangle lists in stream order (numpy arrays returned by poll)
     inflight = 0
-    use_host = [args.host_frames]
+    use_host = [("pinned" if args.host_mode == "pinned" else True) if args.host_frames else False]
 
     def step(d=None, slots=None):
         """one pass over the batch of F frames: every frame is handed to the detector; it is a stream, so the results of the

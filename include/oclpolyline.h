@@ -1,6 +1,6 @@
 /*
  * rectdetect-mi355x: polyline extraction API of the reference (reference oclpolyline.h:74-88), implemented in
- * rectdetect_amd/csrc/rd_polyline.hip on compacted edge pixels.
+ * rectdetect_amd/csrc/rd_k_poly.hip on compacted edge pixels.
  */
 #ifndef RD_COMPAT_OCLPOLYLINE_H
 #define RD_COMPAT_OCLPOLYLINE_H

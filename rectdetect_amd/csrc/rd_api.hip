@@ -878,10 +878,15 @@ static void group_launch(rd_detector *d, int g0) {
     lead->gz_ws = ws;
   }
   const uint8_t *srcs[RD_ZB_MAX];
+  // (frames that travelled when they were handed over did so one after the other on the detector's upload stream: the event of the LAST of them stands for all - one wait in
+  //  front of the group's kernels, not eight)
+  Slot *last_upload = NULL;
+  for (int i = 0; i < zb; i++) { Slot *s = &d->slots[g0 + i]; if (s->src == s->bgr && s->uploaded_early && (!last_upload || s->seq > last_upload->seq)) last_upload = s; }
+  if (last_upload) RD_HIP(hipStreamWaitEvent(st, last_upload->ev_fork, 0));
   for (int i = 0; i < zb; i++) {
     Slot *s = &d->slots[g0 + i];
     s->pending_dense = 0;
-    if (s->src == s->bgr) { if (s->uploaded_early) RD_HIP(hipStreamWaitEvent(st, s->ev_fork, 0)); else RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, (size_t)ws * d->ih, hipMemcpyHostToDevice, st)); }
+    if (s->src == s->bgr && !s->uploaded_early) RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, (size_t)ws * d->ih, hipMemcpyHostToDevice, st));
     srcs[i] = s->src;
     RD_HIP(hipEventRecord(s->ev_begin, st));
   }
@@ -1321,6 +1326,8 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
       if (hipPointerGetAttributes(&at, frame) != hipSuccess || at.type != hipMemoryTypeHost) { (void)hipGetLastError(); exitf(-1, "rd_detector_enqueue: RD_FRAME_HOST_PINNED needs pinned host memory (rd_host_alloc, allocatePinnedMemory, hipHostMalloc, hipHostRegister); %p is not\n", frame); }
       d->pinned_lo = frame; d->pinned_hi = (const char *)frame + bytes;
     }
+    // (The colour conversion reading the pinned buffer over PCIe itself, without the copy engine: 1985-2009 frames/s against 2656-2659 - the kernel then runs at the link's
+    //  rate, a millisecond per group, with its blocks resident all the while.  profiles/NOTES_r06.md.)
     hipStream_t ust = s->st;
     s->uploaded_early = 0;
     if (d->zb > 1) { if (!d->st_upload) d->st_upload = pooled_stream(d->device); ust = d->st_upload; }      // (group mode: on the detector's upload stream, the group's stream waits for the event)

@@ -54,3 +54,61 @@ def test_world_size_must_match_gpus():
     p = subprocess.run(cmd, cwd=helpers.ROOT, env=env, capture_output=True, text=True, timeout=240)
     assert p.returncode != 0
     assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_ranks_of_different_gpus_pin_to_different_cores(tmp_path):
+    """bench.py keeps each rank on the cores next to its GPU (gpu_local_cpus: <sysfs>/bus/pci/devices/<bus id>/local_cpulist).  On a fake sysfs tree of an 8-GPU node -
+    two sockets, four GPUs each, the kernel's cpulist format with SMT siblings in a second range - no two GPUs of different NUMA domains share a core, GPUs of one domain get the
+    same list, malformed or missing entries give (None, None) instead of a wrong set, and a real rank process pins itself to exactly that set."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(helpers.ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.parse_cpulist("0-3,8,10-11") == {0, 1, 2, 3, 8, 10, 11}
+    for bad in ("", "3-1", "a-b", "1,,2"):
+        try:
+            bench.parse_cpulist(bad)
+            raise AssertionError("accepted %r" % bad)
+        except ValueError:
+            pass
+    root = tmp_path / "sys"
+    lists = {}
+    for g in range(8):
+        bus = "0000:%02x:00.0" % (0x05 + 0x10 * g)
+        dom = g // 2                                    # four NUMA domains of 32 cores (+ their SMT siblings), two GPUs each
+        lists[bus] = "%d-%d,%d-%d" % (32 * dom, 32 * dom + 31, 128 + 32 * dom, 128 + 32 * dom + 31)
+        d = root / "bus" / "pci" / "devices" / bus
+        d.mkdir(parents=True)
+        (d / "local_cpulist").write_text(lists[bus] + "\n")
+    sets = {bus: bench.gpu_local_cpus(bus.upper(), str(root)) for bus in lists}      # (the runtime reports upper-case hex digits on some systems)
+    for bus, (spec_str, cpus) in sets.items():
+        assert spec_str == lists[bus] and len(cpus) == 64
+    buses = sorted(lists)
+    for i, a in enumerate(buses):
+        for b in buses[i + 1:]:
+            if lists[a] != lists[b]:
+                assert not (sets[a][1] & sets[b][1]), (a, b)
+    assert len({frozenset(v[1]) for v in sets.values()}) == 4
+    assert bench.gpu_local_cpus("0000:ff:00.0", str(root)) == (None, None)
+    (root / "bus" / "pci" / "devices" / "0000:05:00.0" / "local_cpulist").write_text("garbage\n")
+    assert bench.gpu_local_cpus("0000:05:00.0", str(root)) == (None, None)
+
+    # a rank process pins itself: a stand-in for the library that reports a bus id, a cpulist made of cores this process really has
+    class FakeLib:
+        def __init__(self, bus):
+            self.bus = bus
+
+        def rd_device_pci_bus_id(self, dev, buf, n):
+            buf.value = self.bus.encode()
+            return 0
+    have = sorted(os.sched_getaffinity(0))
+    if len(have) >= 4:
+        mine = have[1:3]
+        bus = "0000:15:00.0"
+        (root / "bus" / "pci" / "devices" / bus / "local_cpulist").write_text("%d-%d\n" % (mine[0], mine[1]) if mine[1] == mine[0] + 1 else "%d,%d\n" % tuple(mine))
+        before = os.sched_getaffinity(0)
+        try:
+            used = bench.pin_to_gpu_cores(FakeLib(bus), 0, str(root))
+            assert used is not None and os.sched_getaffinity(0) == set(mine)
+        finally:
+            os.sched_setaffinity(0, before)

@@ -882,7 +882,7 @@ def test_user_switches_change_nothing_but_the_way_there(monkeypatch):
         for t, ((r1, s1), (r2, s2)) in enumerate(zip(base, got)):
             assert helpers.rects_equal(r1, r2) and helpers.segments_equal(s1, s2), (env, t)
         if env.get("RD_POST_HELPERS") == "3":
-            assert helpers_now == 3
+            assert helpers_now >= 3      # (the pool is process-wide and never shrinks on its own: an earlier detector of this process may have asked for more)
         if env.get("RD_DEVICE_POST") == "1":
             assert on_device > 0, "RD_DEVICE_POST=1: the rectangles of (most) frames must come from the device"
 
@@ -1468,6 +1468,22 @@ def test_four_ranks_with_all_their_workers_keep_the_rate_of_one():
     helpers.parity_report("multi-process host side (one GPU shared)", "4 ranks x 64 frames in flight against 1 rank", {"frames_per_s_1_rank": one["value"], "frames_per_s_4_ranks_together": four["value"], "ratio": round(ratio, 3)})
     print("four ranks on one GPU: %.1f frames/s together, one rank alone %.1f (ratio %.3f)" % (four["value"], one["value"], ratio))
     assert ratio >= 0.9, (four["value"], one["value"])
+
+
+def test_eight_ranks_rehearsal_on_one_gpu():
+    """The node's shape as far as a one-GPU box can rehearse it: `bench.py --gpus 8 --share-gpus --slots 64` - EIGHT real per-GPU processes, each with
+    its own detector, 64 frames in flight and 64 worker threads (512 polling workers, eight enqueue loops, the gloo control plane), all on this box's only GPU and on one
+    socket's worth of host cores - must reach, together, at least 0.9 of what one such process reaches alone; every rank verifies its own lists."""
+    import sys
+    one = _bench_line([sys.executable, os.path.join(helpers.ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--frames-per-step", "256", "--no-cpu-baseline", "--no-configs"])
+    eight = _bench_line([sys.executable, os.path.join(helpers.ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--frames-per-step", "64", "--slots", "64", "--backend", "gloo", "--share-gpus",
+                         "--no-cpu-baseline", "--no-configs"], timeout=1500)
+    assert eight["n_gpus"] == 8 and eight["outputs_verified"] is True and all(r["outputs_verified"] is True for r in eight["ranks"])
+    assert len({r["pid"] for r in eight["ranks"]}) == 8 and len({r["stream_seed"] for r in eight["ranks"]}) == 8
+    ratio = eight["value"] / one["value"]
+    helpers.parity_report("multi-process host side (one GPU shared)", "8 ranks x 64 frames in flight against 1 rank", {"frames_per_s_1_rank": one["value"], "frames_per_s_8_ranks_together": eight["value"], "ratio": round(ratio, 3)})
+    print("eight ranks on one GPU: %.1f frames/s together, one rank alone %.1f (ratio %.3f)" % (eight["value"], one["value"], ratio))
+    assert ratio >= 0.9, (eight["value"], one["value"])
 
 
 def test_bench_refuses_more_ranks_than_devices():
