@@ -221,10 +221,29 @@ __global__ __launch_bounds__(64 * TY) void k_label_tile(int *__restrict__ label,
 // columns x = 64k-1 against their NE neighbour; lanes are consecutive pixels ALONG the border so that a lane whose
 // (label, neighbour label) pair equals its predecessor's can leave the union to that lane.
 // la, lb: label[p], label[q] (the tile roots: constant during this kernel unless roots themselves; any value when !want)
-__device__ __forceinline__ void border_union(int *label, int la, int lb, bool want) {
+// seen (optional): a block-wide table of the (tile root, tile root) pairs somebody in the block has already taken on (LB_SEEN 64-bit slots in LDS, all ~0 at the start): along
+// a border the background's runs alternate with the components that cross it, and every one of those runs asks for the SAME union of the two tiles' background roots - the
+// walks to the roots are the kernel's time (chains of dependent loads), so a pair is walked once per block, by the first lane that claims it.  (Whoever claims a pair carries
+// the union out before the kernel ends; unions commute and are idempotent, so it does not matter who.)
+#define LB_SEEN 512
+#ifndef LB_DEDUPE
+#define LB_DEDUPE 1
+#endif
+__device__ __forceinline__ void border_union(int *label, int la, int lb, bool want, unsigned long long *seen = nullptr) {
   if (!want) { la = -1; lb = -2; }
   const int pa = __shfl_up(la, 1), pb = __shfl_up(lb, 1);
-  if (want && !(__lane_id() > 0 && pa == la && pb == lb)) {
+  bool mine = want && !(__lane_id() > 0 && pa == la && pb == lb);
+  if (mine && seen != nullptr) {
+    const unsigned long long key = ((unsigned long long)(unsigned)la << 32) | (unsigned)lb;
+    unsigned h = ((unsigned)la * 2654435761u ^ (unsigned)lb * 40503u) >> 23;
+    for (int probe = 0; probe < 4; probe++) {
+      const unsigned long long was = atomicCAS(&seen[h], ~0ull, key);
+      if (was == key) { mine = false; break; }      // somebody of this block is on it
+      if (was == ~0ull) break;                       // claimed
+      h = (h + 1) & (LB_SEEN - 1);
+    }                                                // (a crowded neighbourhood: just do it)
+  }
+  if (mine) {
     int a = la, b = lb;
     for (;;) {
       // both walks to the roots together: they are chains of dependent loads (the background's tile roots form chains as long as a row of tiles until
@@ -248,6 +267,14 @@ __device__ __forceinline__ void border_union(int *label, int la, int lb, bool wa
 // (both kinds of border in one launch - unions commute: the first `hblocks` blocks take the horizontal borders)
 __global__ __launch_bounds__(256) void k_label_border(int *label, const int *__restrict__ pix, int bgc, int iw, int ih, int hblocks, size_t zs) {
   RD_ZSHIFT(zs, label, pix);
+#if LB_DEDUPE
+  __shared__ unsigned long long seen_tab[LB_SEEN];
+  for (int i = threadIdx.x; i < LB_SEEN; i += 256) seen_tab[i] = ~0ull;
+  __syncthreads();
+  unsigned long long *const seen = seen_tab;
+#else
+  unsigned long long *const seen = nullptr;
+#endif
   const bool horizontal = (int)blockIdx.x < hblocks;
   const int t = (horizontal ? blockIdx.x : blockIdx.x - hblocks) * blockDim.x + threadIdx.x;
   if (horizontal) {
@@ -266,9 +293,9 @@ __global__ __launch_bounds__(256) void k_label_border(int *label, const int *__r
     // (the labels of all three candidate pairs are requested together: clamped addresses, used only where wanted)
     const int pc = in ? p : 0;
     const int l0 = label[pc], ln = label[in ? p - iw : 0], lnw = label[(in && x > 0) ? p - iw - 1 : 0], lne = label[(in && x < iw - 1) ? p - iw + 1 : 0];
-    border_union(label, l0, ln, nSame && !(wSame && nwSame));
-    border_union(label, l0, lnw, !nSame && nwSame && !wSame);
-    border_union(label, l0, lne, !nSame && neSame && !eSame);
+    border_union(label, l0, ln, nSame && !(wSame && nwSame), seen);
+    border_union(label, l0, lnw, !nSame && nwSame && !wSame, seen);
+    border_union(label, l0, lne, !nSame && neSame && !eSame, seen);
   } else {
     const int nb = (iw - 1) / LT_W;              // border columns
     const int y = t % ih, k = t / ih;
@@ -283,8 +310,8 @@ __global__ __launch_bounds__(256) void k_label_border(int *label, const int *__r
     const int pc = in ? p : 0;
     const int l0 = label[pc], lw = label[in ? p - 1 : 0], lnw = label[(in && y > 0) ? p - iw - 1 : 0];
     const int ll0 = label[in ? p - 1 : 0], llne = label[(in && y > 0) ? p - 1 - iw + 1 : 0];
-    border_union(label, l0, lw, wSame);
-    border_union(label, l0, lnw, nwSame && !nSame && !wSame);
+    border_union(label, l0, lw, wSame, seen);
+    border_union(label, l0, lnw, nwSame && !nSame && !wSame, seen);
     // the pixel left of the border and its NE neighbour (x, y-1)
     const int pl = p - 1;
     const int vl = in ? pix[pl] : bgc;
@@ -292,7 +319,7 @@ __global__ __launch_bounds__(256) void k_label_border(int *label, const int *__r
     const bool lne = actl && pix[pl - iw + 1] == vl;
     const bool ln = actl && pix[pl - iw] == vl;
     const bool le = actl && pix[pl + 1] == vl;
-    border_union(label, ll0, llne, lne && !ln && !le);
+    border_union(label, ll0, llne, lne && !ln && !le, seen);
   }
 }
 
