@@ -85,7 +85,7 @@ def cpu_baseline():
                       "the reference's kernels run one work-item at a time on the serial OpenCL shim" % (P, wall)}
 
 
-TRAFFIC_FILE = os.path.join("profiles", "r05_traffic.json")
+TRAFFIC_FILE = os.path.join("profiles", "r06_traffic.json")
 
 
 def traffic_per_frame():
