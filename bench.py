@@ -244,35 +244,53 @@ def side_config(ra, L, label, iw, ih, seed, nframes, slots, dev, min_seconds=1.5
 def reference_api_config(ra, frames, dev, min_seconds=1.5):
     """The path the reference's own programs take, through the reference's own C API on host buffers (upload inside): vidrect.cpp:159-205 keeps TWO
     frames in flight with oclrect_enqueueTask / oclrect_pollTask; rect.cpp:105 calls oclrect_executeOnce per frame.  The headline `value` needs the
-    rectdetect_hip.h detector with 32 frames in flight - an application that keeps the reference's call sequence gets these rates instead."""
+    rectdetect_hip.h detector with 64 frames in flight - an application that keeps the reference's call sequence gets these rates instead.  Each shape twice: frames in
+    pageable memory (what cv::Mat hands over: copied by the caller's thread, as the reference does) and in page-locked memory from the reference's own allocatePinnedMemory
+    (oclhelper.h; read in place by the copy engine, the call still returns only when the buffer may be reused)."""
     ctx = ra.Context(dev)
     det = ra.RectDetector(ctx, IW, IH)
-    n = len(frames)
-    for k in range(8):      # (graph capture, round budget)
-        det.execute_once(frames[k % n], TAN_AOV)
-    lat, t_end, k = [], time.perf_counter() + min_seconds, 0
-    while time.perf_counter() < t_end or k < 16:
-        t0 = time.perf_counter()
-        det.execute_once(frames[k % n], TAN_AOV)
-        lat.append(time.perf_counter() - t0)
-        k += 1
-    lat.sort()
-    once = {"workload": "oclrect_executeOnce per 1920x1080 frame, host buffers (rect.cpp:105)", "frame": "%dx%d" % (IW, IH), "frames": k, "frames_in_flight": 1,
-            "value": round(k / sum(lat), 2), "unit": "frames/s", "latency_ms_median": round(1e3 * lat[len(lat) // 2], 3), "latency_ms_p90": round(1e3 * lat[(len(lat) * 9) // 10], 3),
-            "roofline_frac": round(k / sum(lat) * B_ALG_PER_PIXEL * IW * IH / HBM_PEAK, 4)}
-    det.enqueue(frames[0])
-    k, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < min_seconds or k < 32:
-        det.enqueue(frames[(k + 1) % n])      # vidrect.cpp:159-172: the next frame is handed over, then the one before it is polled
+    rows = []
+    for memory in ("pageable", "pinned"):
+        fr = frames[:16] if memory == "pageable" else [ctx.pinned_copy(f) for f in frames[:16]]
+        n = len(fr)
+        pinned0 = ra.lib().rd_detector_counter(_api_detector(det), 18)
+        for k in range(8):      # (graph capture, round budget)
+            det.execute_once(fr[k % n], TAN_AOV)
+        lat, t_end, k = [], time.perf_counter() + min_seconds, 0
+        while time.perf_counter() < t_end or k < 16:
+            t0 = time.perf_counter()
+            det.execute_once(fr[k % n], TAN_AOV)
+            lat.append(time.perf_counter() - t0)
+            k += 1
+        lat.sort()
+        once = {"workload": "oclrect_executeOnce per 1920x1080 frame, %s host buffers (rect.cpp:105)" % memory, "frame": "%dx%d" % (IW, IH), "frames": k, "frames_in_flight": 1, "host_memory": memory,
+                "value": round(k / sum(lat), 2), "unit": "frames/s", "latency_ms_median": round(1e3 * lat[len(lat) // 2], 3), "latency_ms_p90": round(1e3 * lat[(len(lat) * 9) // 10], 3),
+                "roofline_frac": round(k / sum(lat) * B_ALG_PER_PIXEL * IW * IH / HBM_PEAK, 4)}
+        det.enqueue(fr[0])
+        k, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < min_seconds or k < 32:
+            det.enqueue(fr[(k + 1) % n])      # vidrect.cpp:159-172: the next frame is handed over, then the one before it is polled
+            det.poll(TAN_AOV)
+            k += 1
+        dt = time.perf_counter() - t0
         det.poll(TAN_AOV)
-        k += 1
-    dt = time.perf_counter() - t0
-    det.poll(TAN_AOV)
-    two = {"workload": "oclrect_enqueueTask / oclrect_pollTask, two 1920x1080 frames in flight, host buffers (what vidrect.cpp:159-205 gets)", "frame": "%dx%d" % (IW, IH),
-           "frames": k, "frames_in_flight": 2, "value": round(k / dt, 2), "unit": "frames/s", "roofline_frac": round(k / dt * B_ALG_PER_PIXEL * IW * IH / HBM_PEAK, 4)}
+        two = {"workload": "oclrect_enqueueTask / oclrect_pollTask, two 1920x1080 frames in flight, %s host buffers (what vidrect.cpp:159-205 gets)" % memory, "frame": "%dx%d" % (IW, IH), "host_memory": memory,
+               "frames": k, "frames_in_flight": 2, "value": round(k / dt, 2), "unit": "frames/s", "roofline_frac": round(k / dt * B_ALG_PER_PIXEL * IW * IH / HBM_PEAK, 4)}
+        took = ra.lib().rd_detector_counter(_api_detector(det), 18) - pinned0
+        two["frames_read_in_place_by_the_copy_engine"] = once["frames_read_in_place_by_the_copy_engine"] = bool(took > 0)
+        rows += [two, once]
+        if memory == "pinned":
+            for f in fr:
+                ctx.free_pinned(f)
     det.close()
     ctx.close()
-    return [two, once]
+    return rows
+
+
+def _api_detector(rect_detector):
+    """the rd_detector behind an oclrect_t (struct oclrect_t { uint32_t magic; rd_detector *det; ... }: rd_api.hip) - for its counters"""
+    import ctypes
+    return ctypes.cast(rect_detector.h + 8, ctypes.POINTER(ctypes.c_void_p))[0]
 
 
 def main():

@@ -76,6 +76,8 @@ def _declare(L):
         # reference API (oclhelper.h / raw cl*)
         "simpleGetDevice": (vp, [ci]),
         "simpleCreateContext": (vp, [vp]),
+        "allocatePinnedMemory": (vp, [cz, vp, vp]),
+        "freePinnedMemory": (None, [vp, vp, vp]),
         "clCreateCommandQueue": (vp, [vp, vp, ctypes.c_ulong, vp]),
         "clReleaseCommandQueue": (ci, [vp]),
         "clReleaseContext": (ci, [vp]),
@@ -169,6 +171,17 @@ class Context:
         if rc != 0:
             raise RuntimeError("clEnqueueReadBuffer failed: %d" % rc)
         return out
+
+    def pinned_copy(self, array):
+        """a copy of `array` in page-locked host memory from the reference's own allocator (oclhelper.h: allocatePinnedMemory) as a numpy array; free with free_pinned()"""
+        a = np.ascontiguousarray(array)
+        p = lib().allocatePinnedMemory(a.nbytes, self.context, self.queue)
+        out = np.ctypeslib.as_array((ctypes.c_uint8 * a.nbytes).from_address(p)).view(a.dtype).reshape(a.shape)
+        out[...] = a
+        return out
+
+    def free_pinned(self, array):
+        lib().freePinnedMemory(array.ctypes.data, self.context, self.queue)
 
     def release(self, *mems):
         for m in mems:

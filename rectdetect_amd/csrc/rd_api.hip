@@ -296,6 +296,7 @@ struct Slot {
   hipEvent_t ev_fork, ev_mm, ev_join;
   hipEvent_t ev_begin, ev_done, ev_strong;   // ev_begin/ev_done carry timestamps: device time of the frame (rd_detector_counter)
   hipEvent_t ev_redo;                        // end of a repeated part of the frame (slot_finish_device)
+  hipEvent_t ev_upload;                      // one or two frames in flight: the copy engine has read a host frame it took straight from the caller's pinned buffer
   hipStream_t st_redo;                       // created on first use: the slow absorption path (frame_absorb_slow), fetches of long lists
   int *big_probes; int big_probes_cap;       // probes of a frame with more segments than `probes` holds (grows on demand)
   const int8_t *prev_in;                  // the strong mask this slot's frame read (plane of rd_detector::prev_ring)
@@ -383,6 +384,7 @@ struct rd_detector {
   // on an event of their own (ev_redo), never on the stream.
   pthread_mutex_t launch_mu;
   const void *pinned_lo, *pinned_hi;        // the last caller buffer that was verified to be pinned host memory (RD_FRAME_HOST_PINNED)
+  const void *probed[2]; int probed_pinned[2];      // RD_FRAME_HOST, one or two frames in flight: the last two frame pointers asked about (a loop alternates between its two pages) and the answer
   long n_frames_pinned, n_frames_copied;     // host frames that travelled straight from the caller's pinned memory / through the detector's own staging pages
   long n_truncated;          // frames with more segment records than the slots' probe buffers hold (maxrec_dev): probed again into a larger buffer
 };
@@ -511,6 +513,7 @@ static void slot_alloc(rd_detector *d, Slot *s, Slot *share) {
   RD_HIP(hipEventCreate(&s->ev_done));
   RD_HIP(hipEventCreateWithFlags(&s->ev_strong, hipEventDisableTiming));
   RD_HIP(hipEventCreateWithFlags(&s->ev_redo, hipEventDisableTiming));
+  RD_HIP(hipEventCreateWithFlags(&s->ev_upload, hipEventDisableTiming));
   RD_HIP(hipEventCreateWithFlags(&s->ev_dense, hipEventDisableTiming));
   { PlaneAlloc A = { d->arena ? d->arena + (size_t)(s - d->slots) * d->slot_pitch : NULL, 0, d->arena ? 1 : 0 }; slot_planes(d, s, A); }
   s->ps = rdk::poly_scratch_create(d->iw, d->ih);
@@ -547,7 +550,7 @@ static void slot_free(Slot *s, int device) {
   RD_HIP(hipHostFree(s->h_bgr)); RD_HIP(hipHostFree(s->h_pack));
   dfree(s->post_scratch); if (s->h_post) RD_HIP(hipHostFree(s->h_post));
   RD_HIP(hipEventDestroy(s->ev_begin)); RD_HIP(hipEventDestroy(s->ev_done)); RD_HIP(hipEventDestroy(s->ev_strong));
-  RD_HIP(hipEventDestroy(s->ev_fork)); RD_HIP(hipEventDestroy(s->ev_mm)); RD_HIP(hipEventDestroy(s->ev_join)); RD_HIP(hipEventDestroy(s->ev_redo)); RD_HIP(hipEventDestroy(s->ev_dense));
+  RD_HIP(hipEventDestroy(s->ev_fork)); RD_HIP(hipEventDestroy(s->ev_mm)); RD_HIP(hipEventDestroy(s->ev_join)); RD_HIP(hipEventDestroy(s->ev_redo)); RD_HIP(hipEventDestroy(s->ev_dense)); RD_HIP(hipEventDestroy(s->ev_upload));
   if (s->st_redo) RD_HIP(hipStreamDestroy(s->st_redo));
   dfree(s->big_probes);
   if (!s->shares_streams) {
@@ -1308,6 +1311,17 @@ static void upload_progress(void *ctx) {      // (caller's thread only)
   u->uploaded = e;
 }
 
+// is this host buffer page-locked (allocatePinnedMemory of oclhelper.h, rd_host_alloc, hipHostMalloc, hipHostRegister)?  One question to the runtime per buffer, not per frame.
+static bool host_buffer_is_pinned(rd_detector *d, const void *frame) {
+  for (int k = 0; k < 2; k++) if (d->probed[k] == frame) return d->probed_pinned[k] != 0;
+  hipPointerAttribute_t at;
+  const bool pinned = hipPointerGetAttributes(&at, frame) == hipSuccess && at.type == hipMemoryTypeHost;
+  if (!pinned) (void)hipGetLastError();
+  d->probed[1] = d->probed[0]; d->probed_pinned[1] = d->probed_pinned[0];
+  d->probed[0] = frame; d->probed_pinned[0] = pinned ? 1 : 0;
+  return pinned;
+}
+
 long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_device) {
   if (!d || d->magic != MAGIC_RECT) exitf(-1, "rd_detector_enqueue: bad handle\n");
   if (d->next_enqueue - d->next_poll >= d->nslots) exitf(-1, "rd_detector_enqueue: %d frames already in flight (poll first)\n", d->nslots);
@@ -1317,6 +1331,7 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
   Slot *s = &d->slots[d->next_enqueue % d->nslots];
   s->seq = d->next_enqueue; s->ws = ws;
   const size_t bytes = (size_t)ws * d->ih;
+  Slot *wait_upload = NULL;
   if (on_device == RD_FRAME_DEVICE) s->src = (const uint8_t *)frame;      // read where it lies (the caller keeps it valid until the frame's poll returned)
   else if (on_device == RD_FRAME_HOST_PINNED) {
     // The caller's buffer is page-locked and stays as it is until the frame's poll: the copy engine takes it from there.  (The reference copies every frame into its own
@@ -1337,6 +1352,17 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
     d->n_frames_pinned++;
   }
   else if (on_device != RD_FRAME_HOST) exitf(-1, "rd_detector_enqueue: on_device = %d (0: host memory, 1: device memory, 2: pinned host memory)\n", on_device);
+  else if (d->zb == 1 && host_buffer_is_pinned(d, frame)) {
+    // The reference's call shape (oclrect_enqueueTask / executeOnce) on a buffer that happens to be page-locked - allocatePinnedMemory of oclhelper.h hands such memory out
+    // (oclhelper.c:837-851, poly.cpp:68-69): the copy engine reads it in place, nothing is copied by the caller's thread, and the frame's kernels are launched behind the
+    // transfer at once.  The reference's contract - the caller may reuse the buffer as soon as the call returns (oclrect.c:1256 copies it) - is kept by returning only when
+    // the engine has read it: waited for at the END of this call (enqueue_done), after the frame's ~45 launches, by which time it has long happened (6 MB in 0.12 ms).
+    RD_HIP(hipMemcpyAsync(s->bgr, frame, bytes, hipMemcpyHostToDevice, s->st));
+    RD_HIP(hipEventRecord(s->ev_upload, s->st));
+    s->src = s->bgr;
+    wait_upload = s;
+    d->n_frames_pinned++;
+  }
   else if (d->zb == 1) {
     d->n_frames_copied++;
     // a single frame: the copy into pinned memory and the upload in pieces, so that a piece travels while the next is being copied (6 MB at 1920x1080:
@@ -1399,6 +1425,7 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
       } else sparse_flush(d, si);
     }
   }
+  if (wait_upload) RD_HIP(hipEventSynchronize(wait_upload->ev_upload));      // (the caller may touch its buffer again)
   { struct timespec ts1; clock_gettime(CLOCK_MONOTONIC, &ts1); d->host_enqueue_ns += (ts1.tv_sec - ts0.tv_sec) * 1000000000L + (ts1.tv_nsec - ts0.tv_nsec); }
   return d->next_enqueue++;
 }

@@ -430,6 +430,61 @@ def test_reference_api_pipelined_equals_single_shot(ctx):
         assert helpers.rects_equal(x, y)
 
 
+def test_reference_api_on_page_locked_buffers_keeps_the_copy_contract(ctx):
+    """A frame handed to oclrect_enqueueTask / oclrect_executeOnce in page-locked memory - the reference's own allocatePinnedMemory (oclhelper.h) hands such memory out - is read in
+    place by the copy engine instead of being copied by the caller's thread first.  The reference's contract stays: the caller may REUSE the buffer the moment the call returns
+    (oclrect.c:1256 copies it) - here the same pinned buffer is overwritten with the next frame right after every enqueue, two frames in flight, and every list must be the one the
+    pageable path returns; the counters say which way the frames went; and the detector extension's RD_FRAME_HOST_PINNED gives the same lists with 8 frames in flight."""
+    iw, ih, n = 640, 480, 10
+    frames = [synth.frame(synth.SEED0 + 14, iw, ih, t) for t in range(n)]
+    a = ra.RectDetector(ctx, iw, ih)
+    want = [a.execute_once(f, TAN36) for f in frames]
+    a.close()
+    det_of = lambda r: ctypes_cast_detector(r)
+    b = ra.RectDetector(ctx, iw, ih)
+    buf = ctx.pinned_copy(frames[0])
+    got = []
+    b.enqueue(buf)
+    for t in range(1, n):
+        buf[...] = frames[t]          # the buffer of the frame in flight is overwritten at once
+        b.enqueue(buf)
+        got.append(b.poll(TAN36))
+    got.append(b.poll(TAN36))
+    assert ra.lib().rd_detector_counter(det_of(b), 18) == n and ra.lib().rd_detector_counter(det_of(b), 19) == 0, "the frames must have travelled straight from the pinned buffer"
+    once = []
+    for f in frames[:3]:
+        buf[...] = f
+        once.append(b.execute_once(buf, TAN36))
+    b.close()
+    for t, (x, y) in enumerate(zip(want, got)):
+        assert helpers.rects_equal(x, y), t
+    c = ra.RectDetector(ctx, iw, ih)
+    for t, y in enumerate(once):
+        assert helpers.rects_equal(c.execute_once(frames[t], TAN36), y), t
+    assert ra.lib().rd_detector_counter(det_of(c), 18) == 0 and ra.lib().rd_detector_counter(det_of(c), 19) == 3      # (pageable numpy memory: copied first)
+    c.close()
+    # the detector extension: RD_FRAME_HOST_PINNED, eight in flight, every frame a buffer of its own that stays untouched until its poll
+    bufs = [ctx.pinned_copy(f) for f in frames]
+    d = ra.Detector(iw, ih, nslots=8, nworkers=1)
+    lists, k = [], 0
+    for p in bufs:
+        if k - len(lists) == 8: lists.append(d.poll(TAN36))
+        d.enqueue(p.ctypes.data, ws=iw * 3, pinned=True); k += 1
+    while len(lists) < k: lists.append(d.poll(TAN36))
+    assert ra.lib().rd_detector_counter(d.h, 18) == n
+    d.close()
+    for t, (x, y) in enumerate(zip(want, lists)):
+        assert helpers.rects_equal(x, y), t
+    for p in bufs + [buf]:
+        ctx.free_pinned(p)
+
+
+def ctypes_cast_detector(rect_detector):
+    """the rd_detector behind an oclrect_t (struct oclrect_t { uint32_t magic; rd_detector *det; ... }, rd_api.hip): for its counters"""
+    import ctypes
+    return ctypes.cast(rect_detector.h + 8, ctypes.POINTER(ctypes.c_void_p))[0]
+
+
 def test_device_resident_frames_and_stride(ctx):
     """frames already in HBM, row stride larger than 3*iw"""
     iw, ih = 333, 217
