@@ -614,7 +614,7 @@ static void frame_regions(rd_detector *d, Slot *s, hipStream_t st_over = NULL) {
   rdk::despeckle2(st, s->region, s->region0, d2scratch, s->rsize, 16, iw, ih, 1, s->scratch2 + N + 64);   // (status words: they travel to the host with the round flags)
 
   // region boundaries and their components (oclrect.c:340-342)
-  rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, iw, ih, s->table, s->claim, s->tlist);   // (also undoes the previous frame's vote-table entries)
+  rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, iw, ih, s->table, s->claim, s->tlist, 1, 0, RD_BOUNDARY_FLATTEN);   // (also undoes the previous frame's vote-table entries)
 }
 
 // votes and probes of a frame whose regions were computed again (a frame whose rectangles the device computes gets them again as well,
@@ -638,7 +638,7 @@ static void frame_absorb_slow(rd_detector *d, Slot *s) {
   if (!s->st_redo) s->st_redo = make_redo_stream();
   hipStream_t st = s->st_redo;
   rdk::despeckle2_slow(st, s->region, s->region0, s->d2s, s->rsize, 16, d->iw, d->ih);
-  rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, d->iw, d->ih, s->table, s->claim, s->tlist);
+  rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, d->iw, d->ih, s->table, s->claim, s->tlist, 1, 0, RD_BOUNDARY_FLATTEN);
   redo_votes(d, s, st);
   RD_HIP(hipStreamSynchronize(st));
   s->h_ctr[52] = 0;
@@ -829,7 +829,7 @@ static void group_segment(rd_detector *d, Slot *s, int nz, int seg, hipStream_t 
   rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mmbits, s->strongbits, iw, ih, s->rounds, s->rsize, &marked, nz, zs);
   rdk::region_size(st, s->rsize, s->region0, N, s->d2s + N, marked, nz, zs);
   rdk::despeckle2(st, s->region, s->region0, s->d2s, s->rsize, 16, iw, ih, 1, s->scratch2 + N + 64, nz, zs);
-  rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, iw, ih, s->table, s->claim, s->tlist, nz, zs);
+  rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, iw, ih, s->table, s->claim, s->tlist, nz, zs, RD_BOUNDARY_FLATTEN);
   rdk::polyline(st, s->frame, nz, N * 16, 1, 4.0f, 20, iw, ih, s->poly_mode);
   frames_votes(d, s->frame, nz, st, 1, 0);
 }
@@ -1547,6 +1547,7 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
       // (launches of a test tap: under the lock that keeps launches out of another thread's graph capture)
       pthread_mutex_lock(&d->launch_mu);
       if (!strcmp(name, "lsid")) rdk::polyline_ids(s->st, s->frame, 1, (int)N);   // not part of the frame path: built from the compact state
+      if (!strcmp(name, "boundary") && !RD_BOUNDARY_FLATTEN) rdk::label8_flatten(s->st, s->boundary, (int)N);   // the frame path leaves the components as a forest (its few readers walk): flattened here, where the plane is looked at
       if ((!strcmp(name, "plab1") || !strcmp(name, "vxy") || !strcmp(name, "strength")) && front_is_fused(d))
         frames_grad_nms(d, s, s->st, 1, 0, 1);      // these never leave the chip on the frame path: the same kernel again, writing them out (the blurred planes are intact)
       pthread_mutex_unlock(&d->launch_mu);

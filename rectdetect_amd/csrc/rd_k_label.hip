@@ -627,14 +627,21 @@ void label8_tidy(hipStream_t s, int *label, int *mask0, int *tidy, const float *
 }
 
 // region boundaries (oclrect.cl:373-390) marked into `marks` and their 8-connected components labelled into `label`
-void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih, int *vt_table, int *vt_claim, int *vt_list, int nz, size_t zs) {
+void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih, int *vt_table, int *vt_claim, int *vt_list, int nz, size_t zs, int flatten) {
   hipLaunchKernelGGL((k_label_tile<1, LT_TY1>), dim3(rd_tile_blocks(cdiv(iw, LT_W), cdiv(ih, LT_H), nz)), dim3(64, LT_TY1), 0, s, label, region, -1, iw, ih, marks, (const float *)nullptr, (int *)nullptr, (int *)nullptr, zs, rd_gdim(cdiv(iw, LT_W), cdiv(ih, LT_H), nz));
   const int nh = ((ih - 1) / LT_H) * iw, nv = ((iw - 1) / LT_W) * ih;
   const int hb = cdiv(nh, 256), vb = cdiv(nv, 256);
   if (hb + vb > 0) hipLaunchKernelGGL(k_label_border, dim3(hb + vb, 1, nz), dim3(256), 0, s, label, (const int *)marks, -1, iw, ih, hb, zs);
+  // flatten != 0: every pixel walks to its component's root (phase 3).  The frame path leaves the forest as it is - the plane's few readers walk themselves (rd_k_rect.hip:
+  // boundary_root) - and then only the vote tables' clean-up, which rode on that launch, is left: one block
   const int n = iw * ih;
+  int g = flatten ? cdiv(n, 256 * 4) : 1;
+  hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g, 1, nz), dim3(256), 0, s, label, flatten ? n : 0, vt_table, vt_claim, vt_list, zs);
+}
+// phase 3 alone, on a plane label8_boundary(..., flatten = 0) left as a forest (the debug plane "boundary")
+void label8_flatten(hipStream_t s, int *label, int n) {
   int g = cdiv(n, 256 * 4);
-  hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g, 1, nz), dim3(256), 0, s, label, n, vt_table, vt_claim, vt_list, zs);
+  hipLaunchKernelGGL(k_label_flatten, dim3(g < 1 ? 1 : g), dim3(256), 0, s, label, n, (int *)nullptr, (int *)nullptr, (int *)nullptr, (size_t)0);
 }
 
 void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int iw, int ih, const int8_t *add, int flatten, int nz, size_t zs) {

@@ -1677,6 +1677,15 @@ __device__ __forceinline__ void tlist_append(int *tlist, bool first, unsigned sl
 
 // (the three vote kernels and the sampling kernel work on frame blockIdx.z of a batch: see rdk::PolyFrame)
 #define RD_VFRAME const rdk::PolyFrame &FRM = FRS.f[blockIdx.z]; const rdk::PolyScratch &s = FRM.ps; (void)s
+// -DRD_BOUNDARY_FLATTEN=0 (tuning builds, rd_kernels.h): the boundary-component plane arrives as the union-find forest the border kernel left (a pixel holds its tile's root,
+// tile roots point towards the component's smallest pixel), and its readers - the 7x7 windows of the chain pixels, the 15 probes per segment - walk to the roots themselves.
+__device__ __forceinline__ int boundary_root(const int *__restrict__ boundary, int l) {
+#if !RD_BOUNDARY_FLATTEN
+  if (l > 0) { int n = boundary[l]; while (n != l) { l = n; n = boundary[l]; } }
+#endif
+  return l;
+}
+
 __global__ __launch_bounds__(1024) void k_reduce_clean(const rdk::PolyFrames FRS) {
   RD_VFRAME;
   int *table = FRM.table, *claim = FRM.claim, *tlist = FRM.tlist;
@@ -1716,6 +1725,19 @@ __global__ __launch_bounds__(256) void k_reduce_claim(const rdk::PolyFrames FRS,
       const int xx = x + k % 7 - 3, yy = y + k / 7 - 3;
       win[k] = (act && xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? boundary[yy * iw + xx] : 0;
     }
+#if !RD_BOUNDARY_FLATTEN
+    {   // the cells' walks to their components' roots take their steps together (most cells hold -1 or a root already)
+      int nx[49];
+      bool moving = false;
+#pragma unroll
+      for (int k = 0; k < 49; k++) { nx[k] = win[k] > 0 ? boundary[win[k]] : win[k]; moving = moving || nx[k] != win[k]; }
+      while (__any(moving)) {
+        moving = false;
+#pragma unroll
+        for (int k = 0; k < 49; k++) if (nx[k] != win[k]) { win[k] = nx[k]; nx[k] = boundary[win[k]]; moving = moving || nx[k] != win[k]; }
+      }
+    }
+#endif
     int floor = 0;
     bool more = true;
     while (__any(more)) {               // one pass for all but a few pixels
@@ -1845,7 +1867,7 @@ __global__ __launch_bounds__(256) void k_reduce_box(const rdk::PolyFrames FRS, i
 #pragma unroll
     for (int k = 0; k < 49; k++) {
       const int xx = x + k % 7 - 3, yy = y + k / 7 - 3;
-      win[k] = (xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? boundary[yy * iw + xx] : 0;
+      win[k] = boundary_root(boundary, (xx >= 0 && xx < iw && yy >= 0 && yy < ih) ? boundary[yy * iw + xx] : 0);
     }
     int floor = 0;
     bool more = true;
@@ -1907,7 +1929,7 @@ __global__ void k_sample_segments(const rdk::PolyFrames FRS, int max_records, in
   int segid = 0;
   if (ls[i].polyid != 0) {
     int sx, sy;
-    if (rdp_probe_pixel(ls[i].x0, ls[i].y0, ls[i].x1, ls[i].y1, k, iw, ih, &sx, &sy)) segid = boundary[sx + sy * iw];
+    if (rdp_probe_pixel(ls[i].x0, ls[i].y0, ls[i].x1, ls[i].y1, k, iw, ih, &sx, &sy)) segid = boundary_root(boundary, boundary[sx + sy * iw]);
   }
   int v[6] = { segid, 0, 0, 0, 0, 0 };
   if (segid > 0) {

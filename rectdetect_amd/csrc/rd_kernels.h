@@ -63,7 +63,14 @@ void rand_i(hipStream_t s, int *out, uint64_t seed, int n);
 // 8-connected components of equal `pix` value, pixels equal to bgc -> -1, label = smallest pixel index
 void label8(hipStream_t s, int *label, const int *pix, int bgc, int iw, int ih, int skip_flatten = 0);   // label = smallest index of the 8-connected component of equal value, -1 for bgc; skip_flatten: the final walk to the roots is left to calc_strength(flatten = 1)
 void label8_tidy(hipStream_t s, int *label, int *mask0, int *tidy, const float *nms, int *zero_plane, int iw, int ih, int skip_flatten = 0, int nz = 1, size_t zs = 0);   // rect_tidy + label8(tidy, background -1) in the same tile kernel
-void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih, int *vt_table = nullptr, int *vt_claim = nullptr, int *vt_list = nullptr, int nz = 1, size_t zs = 0);   // mark_boundary + label8(marks, background -1) with the marking fused into the tile kernel
+// flatten = 0: the component plane is left as the union-find forest of the tile and border kernels and its readers - votes, probes - walk to the roots themselves
+// (-DRD_BOUNDARY_FLATTEN=0, tuning builds).  Built in round 6, lists identical, and NOT the default: k_label_flatten 5.6 -> 0.9 us per frame, but the 7x7 windows of
+// k_reduce_claim then walk (7.6 -> 14.4 us) - 2883-2899 against 2879-2892 frames/s, nothing.  profiles/NOTES_r06.md.
+#ifndef RD_BOUNDARY_FLATTEN
+#define RD_BOUNDARY_FLATTEN 1
+#endif
+void label8_boundary(hipStream_t s, int *label, int *marks, const int *region, int iw, int ih, int *vt_table = nullptr, int *vt_claim = nullptr, int *vt_list = nullptr, int nz = 1, size_t zs = 0, int flatten = 1);
+void label8_flatten(hipStream_t s, int *label, int n);      // phase 3 alone, later (debug plane)   // mark_boundary + label8(marks, background -1) with the marking fused into the tile kernel
 // add (optional): a plane whose non-zero elements are added to out element by element in the same launch (out = zeros + add + sums)
 void calc_strength(hipStream_t s, int *out, const float *edge, int *label, int iw, int ih, const int8_t *add = nullptr, int flatten = 0, int nz = 1, size_t zs = 0);   // add (optional): a 0/1 byte plane added to the sums (H1)
 void filter_strength(hipStream_t s, int *label, const int *str, int thre, int iw, int ih);
