@@ -295,6 +295,7 @@ struct Slot {
   int shares_streams;                     // st / st2 belong to another slot (see rd_detector_create)
   hipEvent_t ev_fork, ev_mm, ev_join;
   hipEvent_t ev_begin, ev_done, ev_strong;   // ev_begin/ev_done carry timestamps: device time of the frame (rd_detector_counter)
+  hipEvent_t watch_begin, watch_done;        // the events that bracket the frame in flight: the slot's own, or - a frame of a group launch - the ones of the group's first slot
   hipEvent_t ev_redo;                        // end of a repeated part of the frame (slot_finish_device)
   hipEvent_t ev_upload;                      // one or two frames in flight: the copy engine has read a host frame it took straight from the caller's pinned buffer
   hipStream_t st_redo;                       // created on first use: the slow absorption path (frame_absorb_slow), fetches of long lists
@@ -778,6 +779,7 @@ static void enqueue_frame(rd_detector *d, Slot *s, int ws) {
     s->graph_ws = ws;
   }
   RD_HIP(hipEventRecord(s->ev_begin, s->st));
+  s->watch_begin = s->ev_begin; s->watch_done = s->ev_done;
   s->group_n = 1;
   rdk::bgr2plab_transposed(s->st, s->plab0, s->tr, s->src, d->iw, d->ih, ws);
   run_segment(d, s, ws, 0);
@@ -861,12 +863,21 @@ static void group_launch(rd_detector *d, int g0) {
   int cnt = 0, same_ws = 1;
   for (int i = g0; i < g0 + zb && i < d->nslots; i++) { Slot *s = &d->slots[i]; if (s->pending_dense) { cnt++; if (s->ws != d->slots[g0].ws) same_ws = 0; } }
   if (cnt == 0) return;
+  // Host frames travelled when they were handed over, one after the other on the detector's upload stream (rd_detector_enqueue).  The launching thread waits for that
+  // stream here - at most for the transfer just issued, 0.1 ms, on a thread that has nothing else to do until the next group completes - and what the host has seen
+  // complete needs no ordering on the device: no event.  Round 6 found the 7-8 % that host frames cost against frames resident in HBM in exactly two places: an event
+  // recorded after every upload (a record is a system-scope release, a write-back of the device's caches, 2 900 times a second in the middle of everybody's kernels:
+  // 2671-2698 frames/s with it, 2886-2901 without) and - pinned frames, whose hand-over takes microseconds - eight transfers queued on the copy engine at once
+  // (2701-2723 against 2849-2884 with one at a time).  profiles/NOTES_r06.md.
+  bool travelled = false;
+  for (int i = g0; i < g0 + zb && i < d->nslots; i++) { Slot *s = &d->slots[i]; if (s->pending_dense && s->src == s->bgr && s->uploaded_early) travelled = true; }
+  if (travelled) RD_HIP(hipStreamSynchronize(d->st_upload));
   if (cnt < zb || !same_ws) {
     for (int i = g0; i < g0 + zb && i < d->nslots; i++) {
       Slot *s = &d->slots[i];
       if (!s->pending_dense) continue;
       s->pending_dense = 0;
-      if (s->src == s->bgr) { if (s->uploaded_early) RD_HIP(hipStreamWaitEvent(s->st, s->ev_fork, 0)); else RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, (size_t)s->ws * d->ih, hipMemcpyHostToDevice, s->st)); }
+      if (s->src == s->bgr) { if (s->uploaded_early) { /* arrived: waited for above */ } else RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, (size_t)s->ws * d->ih, hipMemcpyHostToDevice, s->st)); }
       enqueue_frame(d, s, s->ws);
       slot_submitted(d, s);
     }
@@ -880,18 +891,16 @@ static void group_launch(rd_detector *d, int g0) {
     for (int k = 0; k < 3 * RD_NBUDGETS; k++) if (lead->gz2[k]) { RD_HIP(hipGraphExecDestroy(lead->gz2[k])); lead->gz2[k] = NULL; }
     lead->gz_ws = ws;
   }
+  static const bool one_event = RD_LAB_INT("RD_GROUP_ONE_EVENT", 1) != 0;
   const uint8_t *srcs[RD_ZB_MAX];
-  // (frames that travelled when they were handed over did so one after the other on the detector's upload stream: the event of the LAST of them stands for all - one wait in
-  //  front of the group's kernels, not eight)
-  Slot *last_upload = NULL;
-  for (int i = 0; i < zb; i++) { Slot *s = &d->slots[g0 + i]; if (s->src == s->bgr && s->uploaded_early && (!last_upload || s->seq > last_upload->seq)) last_upload = s; }
-  if (last_upload) RD_HIP(hipStreamWaitEvent(st, last_upload->ev_fork, 0));
   for (int i = 0; i < zb; i++) {
     Slot *s = &d->slots[g0 + i];
     s->pending_dense = 0;
     if (s->src == s->bgr && !s->uploaded_early) RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, (size_t)ws * d->ih, hipMemcpyHostToDevice, st));
     srcs[i] = s->src;
-    RD_HIP(hipEventRecord(s->ev_begin, st));
+    // (ONE pair of events brackets the group - its frames start and end together -, not one per frame: every record is a release fence in the stream)
+    if (i == 0 || !one_event) RD_HIP(hipEventRecord(s->ev_begin, st));
+    s->watch_begin = one_event ? lead->ev_begin : s->ev_begin; s->watch_done = one_event ? lead->ev_done : s->ev_done;
   }
   rdk::bgr2plab_transposed(st, lead->plab0, lead->tr, srcs, d->iw, d->ih, ws, zb, d->slot_pitch);
   run_group_segment(d, lead, zb, 0, st);
@@ -924,7 +933,7 @@ static void group_launch(rd_detector *d, int g0) {
   for (int i = 0; i < zb; i++) {
     Slot *s = &d->slots[g0 + i];
     s->post_mode = with_post; s->post_tan = tn; s->group_n = zb;
-    RD_HIP(hipEventRecord(s->ev_done, st));
+    if (i == 0 || !one_event) RD_HIP(hipEventRecord(s->ev_done, st));
   }
   rdrt::check_launch("rect frames, group launch");
   for (int i = 0; i < zb; i++) slot_submitted(d, &d->slots[g0 + i]);
@@ -960,6 +969,7 @@ static void sparse_launch(rd_detector *d, int a, int b) {
     s->post_mode = with_post; s->post_tan = tn;
     s->poly_mode = pm;
     RD_HIP(hipEventRecord(s->ev_done, st));
+    s->watch_done = s->ev_done;
     s->pending_sparse = 0;
   }
   rdrt::check_launch("rect frames, sparse stages");
@@ -1146,7 +1156,7 @@ static void *slot_worker(void *arg) {
       const long window = 2L * (d->zb > 1 ? d->zb : 4);
       while (!s->quit && s->seq >= __atomic_load_n(&d->done_seq, __ATOMIC_RELAXED) + window) { struct timespec ts = { 0, 250000 }; nanosleep(&ts, NULL); }
     }
-    wait_event_outside_captures(d, s->ev_done);
+    wait_event_outside_captures(d, s->watch_done);
     { long cur = __atomic_load_n(&d->done_seq, __ATOMIC_RELAXED); while (cur < s->seq + 1 && !__atomic_compare_exchange_n(&d->done_seq, &cur, s->seq + 1, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { } }
     void *segs = NULL; int ns = 0;
     slot_finish_device(d, s);
@@ -1345,9 +1355,10 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
     //  rate, a millisecond per group, with its blocks resident all the while.  profiles/NOTES_r06.md.)
     hipStream_t ust = s->st;
     s->uploaded_early = 0;
-    if (d->zb > 1) { if (!d->st_upload) d->st_upload = pooled_stream(d->device); ust = d->st_upload; }      // (group mode: on the detector's upload stream, the group's stream waits for the event)
+    if (d->zb > 1) { if (!d->st_upload) d->st_upload = pooled_stream(d->device); ust = d->st_upload; }      // (group mode: on the detector's upload stream, from the high-priority pool; an ordinary stream shares a hardware queue with a group's: 2786-2796 frames/s, the caller waiting 0.35 ms per frame)
+    if (d->zb > 1) RD_HIP(hipStreamSynchronize(ust));      // (one transfer in the copy engine's queue at a time: the caller waits for the frame before - 0.1 ms where it used to copy for 0.16 - see group_launch)
     RD_HIP(hipMemcpyAsync(s->bgr, frame, bytes, hipMemcpyHostToDevice, ust));
-    if (d->zb > 1) { RD_HIP(hipEventRecord(s->ev_fork, ust)); s->uploaded_early = 1; }
+    if (d->zb > 1) s->uploaded_early = 1;      // (no event here: group_launch records ONE behind the uploads of all its frames - see there)
     s->src = s->bgr;
     d->n_frames_pinned++;
   }
@@ -1397,8 +1408,7 @@ long rd_detector_enqueue(rd_detector *d, const void *frame, int ws, int on_devic
     if (upload_early) {
       if (!d->st_upload) d->st_upload = pooled_stream(d->device);
       RD_HIP(hipMemcpyAsync(s->bgr, s->h_bgr, bytes, hipMemcpyHostToDevice, d->st_upload));
-      RD_HIP(hipEventRecord(s->ev_fork, d->st_upload));      // (the slot's fork event: unused by detectors that launch groups)
-      s->uploaded_early = 1;
+      s->uploaded_early = 1;      // (no event here: group_launch records ONE behind the uploads of all its frames)
     }
   }
   if (d->zb > 1) {      // group mode: launched together with the other frames of its group, once that is full (or a poll needs one of them)
@@ -1458,8 +1468,8 @@ void *rd_detector_poll(rd_detector *d, double tanAOV) {
     if (d->post_helpers && !(s->post_mode && s->post_tan == tanAOV)) rd_post_helpers_arm();      // (they wake while the device is still busy with the frame: rd_post.c; not for a frame whose rectangles the device computes)
     static const int trace_poll = RD_LAB_INT("RD_TRACE_POLL", 0);      // (1: timings, 2: wait by querying instead of hipEventSynchronize)
     struct timespec t0, t1, t2, t3; clock_gettime(CLOCK_MONOTONIC, &t0);
-    if (trace_poll == 2) { while (hipEventQuery(s->ev_done) == hipErrorNotReady) sched_yield(); }
-    else RD_HIP(hipEventSynchronize(s->ev_done));
+    if (trace_poll == 2) { while (hipEventQuery(s->watch_done) == hipErrorNotReady) sched_yield(); }
+    else RD_HIP(hipEventSynchronize(s->watch_done));
     clock_gettime(CLOCK_MONOTONIC, &t1);
     slot_finish_device(d, s);
     clock_gettime(CLOCK_MONOTONIC, &t2);
@@ -1471,7 +1481,7 @@ void *rd_detector_poll(rd_detector *d, double tanAOV) {
       if (++n % 100 == 0) { fprintf(stderr, "poll: wait %.1f us, finish %.1f us, rectangles %.1f us (average of 100)\n", a / 100, b / 100, c / 100); a = b = c = 0; }
     }
   }
-  { float ms = 0.0f; if (hipEventElapsedTime(&ms, s->ev_begin, s->ev_done) == hipSuccess) { d->dev_us += (long)(ms * 1000.0f) / (s->group_n > 0 ? s->group_n : 1); d->dev_frames++; } }      // (a group's interval is shared by its frames: counted once)
+  { float ms = 0.0f; if (hipEventElapsedTime(&ms, s->watch_begin, s->watch_done) == hipSuccess) { d->dev_us += (long)(ms * 1000.0f) / (s->group_n > 0 ? s->group_n : 1); d->dev_frames++; } }      // (a group's interval is shared by its frames: counted once)
   free(d->last_segs);
   d->last_segs = segs; d->last_nsegs = ns;
   d->last_polled_slot = si;
