@@ -50,6 +50,8 @@ def main():
             out[f"f{t}_rects"] = rects
             out[f"f{t}_segments"] = snaps["lslist"][: 14 * (n + 1)].view(ra.LS_DTYPE)
             print(name, "frame", t, "rects", len(rects), "segments", n, flush=True)
+            if os.environ.get("RD_GOLDEN_PREFIXES") and (t + 1) % 50 == 0 and t + 1 < nframes:      # (long runs: the stream so far, as a fixture of its own length, in case the run is cut short)
+                np.savez_compressed(os.path.join(os.environ["RD_GOLDEN_PREFIXES"], "%s_first%d.npz" % (name, t + 1)), **dict(out, nframes=t + 1))
         r.close()
         np.savez_compressed(os.path.join(helpers.GOLDEN, name + ".npz"), **out)
 
