@@ -34,8 +34,12 @@ FRAMES = {"stream_1280x720_s1_300": [32, 161, 162], "stream_1920x1080_s0_100": [
           "stream_1920x1080_s7_100": [0, 5, 63, 64, 71, 72],      # (the held-out stream of round 3: tools/stream_mismatch.py)
           # round 5's two held-out streams (generated after the round's last kernel change; 64 frames in flight)
           "stream_1920x1080_s11_200": [0, 2, 12, 28, 31, 49, 112, 119, 155], "stream_1920x1080_s12_200": [14, 25, 26, 30, 39],
-          "stream_1280x720_s13_300": [112, 147, 158, 267, 277, 297]}
-PARALLEL = 8
+          "stream_1280x720_s13_300": [112, 147, 158, 267, 277, 297],
+          # round 6's held-out streams: the frames whose multiset of rectangles under the concurrent, settled merge differs from the raster order's and whose merge had not settled
+          # within the reference's 8 launches (tests/golden/*_settled.npz against the raster-order goldens)
+          "stream_3840x2160_s4_32": [17, 19, 23, 25, 27, 30], "stream_1920x1080_s21_300": [139, 185],
+          "stream_1920x1080_s22_300": [4, 74, 118, 159, 179, 195, 229, 237, 285]}
+PARALLEL = int(os.environ.get("RD_ORDERS_PARALLEL", "8"))
 
 
 def one_stream(name, frames, out):
