@@ -34,7 +34,7 @@ typedef struct rd_detector rd_detector;
  * 1-2 frames in flight: a frame spreads over two HIP streams (shortest latency); from 3 on: one stream per frame, and frames
  * beyond the fourth queue up on the same four streams (the device runs four hardware queues side by side).  From 6 slots on the
  * frames of two consecutive slots, from 12 on of four, from 32 on of eight, run as ONE set of launches (group launches: a frame waits until its group is
- * full or a poll asks for it - then it is launched on its own); 16 gives the highest rate ("Execution"). */
+ * full or a poll asks for it - then it is launched on its own); 64 is what bench.py runs ("Data layout in HBM, execution"). */
 rd_detector *rd_detector_create(int device, int iw, int ih, int nslots, int nworkers);
 void rd_detector_destroy(rd_detector *d);
 

@@ -38,7 +38,8 @@ FRAMES = {"stream_1280x720_s1_300": [32, 161, 162], "stream_1920x1080_s0_100": [
           # round 6's held-out streams: the frames whose multiset of rectangles under the concurrent, settled merge differs from the raster order's and whose merge had not settled
           # within the reference's 8 launches (tests/golden/*_settled.npz against the raster-order goldens)
           "stream_3840x2160_s4_32": [17, 19, 23, 25, 27, 30], "stream_1920x1080_s21_300": [139, 185],
-          "stream_1920x1080_s22_300": [4, 74, 118, 159, 179, 195, 229, 237, 285]}
+          "stream_1920x1080_s22_300": [4, 74, 118, 159, 179, 195, 229, 237, 285],
+          "stream_1920x1080_s23_300": [99, 116, 119, 130, 244, 269], "stream_1920x1080_s24_300": [8, 27, 43, 208]}
 PARALLEL = int(os.environ.get("RD_ORDERS_PARALLEL", "8"))
 
 
