@@ -73,7 +73,7 @@ int rd_detector_last_segments(rd_detector *d, void *dst, int max_records);
 /* counters since creation: which 0 = frames whose polyline stage did not fit the single-launch kernel's on-chip tables and
  * was repeated with the multi-launch path (same results, slower); 1 = device microseconds summed over the polled frames
  * (HIP events on the frame's stream: first kernel start to last copy end, so concurrent frames overlap); 2 = frames in that sum; 3 = host microseconds spent inside rd_detector_enqueue;
- * 4 = frames whose region merge had not settled within their launch budget and were repeated with more launches (32, then 64);
+ * 4 = frames whose region merge had not settled within their launch budget and were repeated with more launches (32, then 64, then 128); 6 = frames still changing after 128 (none so far);
  * 5 = the current launch budget of the region merge (8, 10, .. 20); 20..26 = frames launched with a budget of 8 / 10 / .. / 20; 40 + k = frames whose merge needed k launches;
  * 10 = frames with more line segments than a slot's probe buffer holds (65535), whose probes were taken again into a larger buffer (the list keeps the
  * reference's capacity of 16N / 56 records; nothing is dropped); 11 / 12 = frames whose rectangles came from the device post-process (RD_DEVICE_POST=1:

@@ -55,7 +55,7 @@ void rdo_region_size(int *out, const int *label, int n);
 void rdo_despeckle2(int *label, const int *size, int thre, int iw, int ih);
 void rdo_mark_boundary(int *out, const int *in, int iw, int ih);
 /* the reference's region merge with concurrent work-items: what the HIP path reproduces (SPEC, see rd_oracle.c) */
-#define RDO_REGION_MAX_LAUNCHES 64
+#define RDO_REGION_MAX_LAUNCHES 128      /* (round 6: a 3840x2160 frame of the held-out stream needs 86) */
 int rdo_region_concurrent(int *label, const int *pix, const int *mask, const int *edge, int iw, int ih, int launches);
 int rdo_despeckle2_jacobi_k(int *label, const int *size, int thre, int iw, int ih, int *nsmall, int max_rounds);
 void rdo_reduce_ls(int *table, const int *boundary, const int *lsid, int iw, int ih, int nentry);

@@ -387,6 +387,7 @@ struct rd_detector {
   const void *pinned_lo, *pinned_hi;        // the last caller buffer that was verified to be pinned host memory (RD_FRAME_HOST_PINNED)
   const void *probed[2]; int probed_pinned[2];      // RD_FRAME_HOST, one or two frames in flight: the last two frame pointers asked about (a loop alternates between its two pages) and the answer
   long n_frames_pinned, n_frames_copied;     // host frames that travelled straight from the caller's pinned memory / through the detector's own staging pages
+  long n_unsettled;          // frames whose region merge was still changing after RD_REGION_MAX_LAUNCHES launches (none on any fixture)
   long n_truncated;          // frames with more segment records than the slots' probe buffers hold (maxrec_dev): probed again into a larger buffer
 };
 
@@ -612,7 +613,7 @@ static void frame_regions(rd_detector *d, Slot *s, hipStream_t st_over = NULL) {
   rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mmbits, s->strongbits, iw, ih, s->rounds,
                     s->rsize, &marked);   // H2: the sizes start from the junction counts (evaluated by the first kernel)
   rdk::region_size(st, s->rsize, s->region0, N, d2scratch + N, marked);      // (also strips the rounds' marks from the labels)
-  rdk::despeckle2(st, s->region, s->region0, d2scratch, s->rsize, 16, iw, ih, 1, s->scratch2 + N + 64);   // (status words: they travel to the host with the round flags)
+  rdk::despeckle2(st, s->region, s->region0, d2scratch, s->rsize, 16, iw, ih, 1, s->scratch2 + N + RD_REGION_STATUS_AT);   // (status words: they travel to the host with the round flags)
 
   // region boundaries and their components (oclrect.c:340-342)
   rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, iw, ih, s->table, s->claim, s->tlist, 1, 0, RD_BOUNDARY_FLATTEN);   // (also undoes the previous frame's vote-table entries)
@@ -830,7 +831,7 @@ static void group_segment(rd_detector *d, Slot *s, int nz, int seg, hipStream_t 
   int marked = 0;
   rdk::region_merge(st, s->region0, s->scratch2, (const int *)s->quant, s->mmbits, s->strongbits, iw, ih, s->rounds, s->rsize, &marked, nz, zs);
   rdk::region_size(st, s->rsize, s->region0, N, s->d2s + N, marked, nz, zs);
-  rdk::despeckle2(st, s->region, s->region0, s->d2s, s->rsize, 16, iw, ih, 1, s->scratch2 + N + 64, nz, zs);
+  rdk::despeckle2(st, s->region, s->region0, s->d2s, s->rsize, 16, iw, ih, 1, s->scratch2 + N + RD_REGION_STATUS_AT, nz, zs);
   rdk::label8_boundary(st, s->boundary, s->boundarysrc, s->region, iw, ih, s->table, s->claim, s->tlist, nz, zs, RD_BOUNDARY_FLATTEN);
   rdk::polyline(st, s->frame, nz, N * 16, 1, 4.0f, 20, iw, ih, s->poly_mode);
   frames_votes(d, s->frame, nz, st, 1, 0);
@@ -993,13 +994,13 @@ static void slot_fetch(Slot *s, void *dst, const void *src, size_t bytes);
 static void slot_finish_device(rd_detector *d, Slot *s) {
   if (s->rounds <= 20 && s->h_ctr[32 + s->rounds - 1] != 0) {   // the region merge was still changing in its last launch: again with as many launches as it takes
     // (32 first - the frames that exceed a budget of 12-14 need 13-20 as a rule, and every launch after the settling one still costs a
-    //  dispatch of the whole grid - then the definition's limit of 64)
+    //  dispatch of the whole grid - then 64, then the definition's limit of RD_REGION_MAX_LAUNCHES = 128)
     // (on a stream of the slot's own: the slot's regular stream is one of the four that carry the groups, and the repeat would wait there behind a whole group of
     //  other frames; nothing but this frame's result depends on it - the frame is finished, ev_done has been waited for)
     static const bool redo_inline = RD_LAB_INT("RD_REDO_ON_MAIN_STREAM", 0) != 0;
     if (!s->st_redo && !redo_inline) s->st_redo = make_redo_stream();
     hipStream_t rst = redo_inline ? s->st : s->st_redo;
-    for (int budget = 32; budget <= 64; budget *= 2) {
+    for (int budget = 32; budget <= RD_REGION_MAX_LAUNCHES; budget *= 2) {
       s->rounds = budget;
       pthread_mutex_lock(&d->launch_mu);
       frame_regions(d, s, rst);
@@ -1008,8 +1009,9 @@ static void slot_finish_device(rd_detector *d, Slot *s) {
       pthread_mutex_unlock(&d->launch_mu);
       wait_event_outside_captures(d, s->ev_redo);
       int still = 0;
-      if (budget < 64) slot_fetch(s, &still, s->scratch2 + d->N + budget - 1, sizeof(int));      // the flag of the budget's last launch
+      slot_fetch(s, &still, s->scratch2 + d->N + budget - 1, sizeof(int));      // the flag of the budget's last launch
       if (!still) break;
+      if (budget == RD_REGION_MAX_LAUNCHES) __atomic_add_fetch(&d->n_unsettled, 1, __ATOMIC_RELAXED);      // (the definition's limit: the frame keeps what that many launches made of it - counter 6)
     }
     __atomic_add_fetch(&d->n_redo_rounds, 1, __ATOMIC_RELAXED);
   }
@@ -1520,6 +1522,7 @@ long rd_detector_counter(rd_detector *d, int which) {
   if (which == 13) return __atomic_load_n(&d->host_post_ns, __ATOMIC_RELAXED) / 1000;
   if (which == 14) return __atomic_load_n(&d->n_redo_absorb, __ATOMIC_RELAXED);
   if (which == 15) return d->zb;      // frames per group launch (1: every frame its own launches)
+  if (which == 6) return __atomic_load_n(&d->n_unsettled, __ATOMIC_RELAXED);
   if (which == 18) return d->n_frames_pinned;
   if (which == 19) return d->n_frames_copied;
   if (which == 16) return d->n_strong_group;        // groups whose strong masks were ONE launch (k_strength_masks_group)
@@ -1549,7 +1552,7 @@ size_t rd_detector_debug_plane(rd_detector *d, const char *name, void *dst, size
     { "nms", s->nms, N * 4 }, { "mask0", s->nms, N * 4 }, { "tidy", s->tidy, N * 4 }, { "label1", s->label1, N * 4 }, { "strsum", s->strsum, N * 4 },
     { "edge500", s->e8, N }, { "smooth", s->smooth, N * 4 }, { "quant", s->quant, N * 4 }, { "strong", s->strongbits, (size_t)((d->iw + 63) / 64) * d->ih * 8 }, { "junction", s->strongbits, (size_t)((d->iw + 63) / 64) * d->ih * 8 },
     { "mergemask", s->mmbits, (size_t)((d->iw + 63) / 64) * d->ih * 8 }, /* (bit planes: handed out as int planes by the branch below) */ { "region", s->region, N * 4 }, { "region0", s->region0, N * 4 }, { "rsize", s->rsize, N * 4 }, { "boundarysrc", s->boundarysrc, N * 4 },
-    { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 }, { "polyctr", rdk::poly_scratch_counters(s->ps), 64 * 4 }, { "iirflags", s->flags, 16 * 4 }, { "d2work", s->d2s + N, 16 * 4 }, { "absorb", s->scratch2 + N + 64, 8 * 4 },
+    { "boundary", s->boundary, N * 4 }, { "lsid", s->lsid, N * 4 }, { "table", s->table, (N * 4 / 5) * 5 * 4 }, { "lslist", s->lslist, N * 16 }, { "polyctr", rdk::poly_scratch_counters(s->ps), 64 * 4 }, { "iirflags", s->flags, 16 * 4 }, { "d2work", s->d2s + N, 16 * 4 }, { "absorb", s->scratch2 + N + RD_REGION_STATUS_AT, 8 * 4 },
   };
   for (size_t i = 0; i < sizeof(tab) / sizeof(tab[0]); i++)
     if (!strcmp(tab[i].n, name)) {

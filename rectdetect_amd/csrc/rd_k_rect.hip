@@ -528,7 +528,8 @@ __global__ __launch_bounds__(256) void k_mm_gather(unsigned long long *__restric
 // Also written: one byte per pixel telling from which of its 4 neighbours the pixel may adopt a label in every launch (rc:308-326 - colours,
 // merge mask and edges do not change): bit0 up, bit1 left, bit2 right, bit3 down, bit4 processed; 0 for frame-border pixels.
 // The labels leave as the words of k_region_round (label << 3, no mark) in both planes its launches alternate between.
-#define RR_NFLAGS 96                    // ints in front of the allow bytes: [0, 64) one flag per launch of the merge, [64, 72) status words of the absorption
+#define RR_NFLAGS (RD_REGION_STATUS_AT + 32)      // ints in front of the allow bytes: [0, RD_REGION_MAX_LAUNCHES) one flag per launch of the merge, [RD_REGION_STATUS_AT, + 8) status words of the absorption
+static_assert(RD_REGION_STATUS_AT >= RD_REGION_MAX_LAUNCHES && RR_NFLAGS <= 256, "k_region_init clears the flag words with one block of 256 threads");
 #ifndef RI_ROWS
 #define RI_ROWS 32
 #endif
@@ -1918,7 +1919,7 @@ __global__ void k_sample_segments(const rdk::PolyFrames FRS, int max_records, in
   if (pack) {
     if (t < 32) pack[t] = polyctr[t];
     else if (t < 52) pack[t] = rflags[t - 32];        // (the flags of the first 20 launches of the region merge)
-    else if (t < 60) pack[t] = rflags[64 + t - 52];   // (the status words of the absorption)
+    else if (t < 60) pack[t] = rflags[RD_REGION_STATUS_AT + t - 52];   // (the status words of the absorption)
     if (t < 14) pack[64 + t] = ((const int *)ls)[t];        // header record
   }
   const int i = t / 15 + 1, k = t % 15;
@@ -1978,7 +1979,7 @@ void merge_mask(hipStream_t s, unsigned long long *out, const unsigned long long
 // *marked <- 1: `label` holds the rounds' words (label << 3 | mark), which region_size turns into plain labels.
 void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const unsigned long long *mask, const unsigned long long *edge, int iw, int ih, int ROUNDS, int *size_out, int *marked, int nz, size_t zs) {
   const int n = iw * ih;
-  if (ROUNDS < 2 || (ROUNDS & 1) || ROUNDS > 64) { fprintf(stderr, "region_merge: the number of launches must be even, 2..64 (got %d)\n", ROUNDS); abort(); }
+  if (ROUNDS < 2 || (ROUNDS & 1) || ROUNDS > RD_REGION_MAX_LAUNCHES) { fprintf(stderr, "region_merge: the number of launches must be even, 2..%d (got %d)\n", RD_REGION_MAX_LAUNCHES, ROUNDS); abort(); }
   int *flags = scratch + n;
   u64 *allow = (u64 *)(((uintptr_t)(flags + RR_NFLAGS) + 7) & ~(uintptr_t)7);      // ceil(ih / 8) * iw words: the allow bytes of 8 rows per column (k_region_init)
   int *A = label, *B = scratch + 2 * (size_t)n;   // the two planes of the rounds; the result is in A

@@ -39,7 +39,9 @@ FRAMES = {"stream_1280x720_s1_300": [32, 161, 162], "stream_1920x1080_s0_100": [
           # within the reference's 8 launches (tests/golden/*_settled.npz against the raster-order goldens)
           "stream_3840x2160_s4_32": [17, 19, 23, 25, 27, 30], "stream_1920x1080_s21_300": [139, 185],
           "stream_1920x1080_s22_300": [4, 74, 118, 159, 179, 195, 229, 237, 285],
-          "stream_1920x1080_s23_300": [99, 116, 119, 130, 244, 269], "stream_1920x1080_s24_300": [8, 27, 43, 208]}
+          "stream_1920x1080_s23_300": [99, 116, 119, 130, 244, 269], "stream_1920x1080_s24_300": [8, 27, 43, 208],
+          # (configs[3] at SURVEY.md 8(d)'s length; its first 32 frames are stream_3840x2160_s4_32: frames 17 .. 30 are copied from there)
+          "stream_3840x2160_s4_100": [33, 35, 37, 38, 41, 47, 48, 50, 51, 53, 56, 59, 67, 72, 75, 78, 81, 85, 87, 88, 89, 92, 95, 97, 98]}
 PARALLEL = int(os.environ.get("RD_ORDERS_PARALLEL", "8"))
 
 

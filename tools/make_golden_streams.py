@@ -34,7 +34,7 @@ CASES = {"stream_1920x1080_s0": (1920, 1080, 0, 16, 36.0), "stream_1280x720_s1":
          # change: held out like the streams of round 5
          "stream_1920x1080_s21_300": (1920, 1080, 21, 300, 36.0), "stream_1920x1080_s22_300": (1920, 1080, 22, 300, 36.0),
          "stream_1920x1080_s23_300": (1920, 1080, 23, 300, 36.0), "stream_1920x1080_s24_300": (1920, 1080, 24, 300, 36.0),
-         "stream_3840x2160_s4_32": (3840, 2160, 4, 32, 36.0)}
+         "stream_3840x2160_s4_32": (3840, 2160, 4, 32, 36.0), "stream_3840x2160_s4_100": (3840, 2160, 4, 100, 36.0)}      # (100: SURVEY.md 8(d)'s t = 0..99)
 DEFAULT = ["stream_1920x1080_s0", "stream_1280x720_s1", "stream_3840x2160_s4"]      # (the long ones by name: 6-10 minutes each)
 
 
