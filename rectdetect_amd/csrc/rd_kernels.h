@@ -100,7 +100,7 @@ void region_merge(hipStream_t s, int *label, int *scratch, const int *pix, const
                   int *size_out, int *marked, int nz = 1, size_t zs = 0);
 void region_size(hipStream_t s, int *out, int *label, int n, int *zero_me, int marked = 0, int nz = 1, size_t zs = 0);   // accumulates into out; zero_me (optional): an int to clear on the way
 #define RD_D2_SCRATCH_INTS(N) (5 * (size_t)(N) + 64)
-// The region merge is launched until a launch changes nothing - at most RD_REGION_MAX_LAUNCHES times (the definition's limit, oracle/rd_oracle.h: RDO_REGION_MAX_LAUNCHES).  Its
+// The region merge is launched until a launch changes nothing - at most RD_REGION_MAX_LAUNCHES times (the definition's limit: DESIGN.md, "Region stages").  Its
 // flag words (one per launch) are followed by the status words of the absorption at RD_REGION_STATUS_AT.  (Round 6: 128 - one 3840x2160 frame of the held-out stream needs 86,
 // two 1920x1080 frames 49; the limit had been 64.)
 #define RD_REGION_MAX_LAUNCHES 128
